@@ -1,0 +1,254 @@
+"""ctypes binding of oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module, and only to check (or time, as the CPU baseline) -- never as a
+fallback of the product path.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+MAX_IMAGES = 8
+MAX_THRESH = 8
+
+
+class FeatCfg(C.Structure):
+    _fields_ = [
+        ("n_rimg", C.c_int), ("rimg", C.c_void_p * MAX_IMAGES), ("rbins", C.c_int * MAX_IMAGES),
+        ("rlo", C.c_double * MAX_IMAGES), ("rhi", C.c_double * MAX_IMAGES),
+        ("n_rlimg", C.c_int), ("rlimg", C.c_void_p * MAX_IMAGES), ("rlbins", C.c_int * MAX_IMAGES),
+        ("rllo", C.c_double * MAX_IMAGES), ("rlhi", C.c_double * MAX_IMAGES),
+        ("n_bimg", C.c_int), ("bimg", C.c_void_p * MAX_IMAGES), ("bbins", C.c_int * MAX_IMAGES),
+        ("blo", C.c_double * MAX_IMAGES), ("bhi", C.c_double * MAX_IMAGES),
+        ("pb", C.c_void_p), ("n_thr", C.c_int), ("thr", C.c_double * MAX_THRESH),
+        ("norm_area", C.c_double), ("norm_len", C.c_double),
+        ("use_log", C.c_int), ("use_simple", C.c_int),
+    ]
+
+
+class Forest(C.Structure):
+    _fields_ = [
+        ("nrnodes", C.c_int), ("ntree", C.c_int), ("nclass", C.c_int),
+        ("xbestsplit", C.c_void_p), ("treemap", C.c_void_p), ("nodestatus", C.c_void_p),
+        ("nodeclass", C.c_void_p), ("bestvar", C.c_void_p), ("orig_labels", C.c_void_p),
+        ("predict_label", C.c_int),
+    ]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("hmt_oracle.cc", "hmt_oracle.hpp")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.orc_rag_build.restype = C.c_void_p
+        L.orc_rag_num_regions.restype = C.c_int64
+        L.orc_rag_num_pairs.restype = C.c_int64
+        L.orc_merge_order_pb.restype = C.c_int64
+        L.orc_merge_order_bc.restype = C.c_int64
+        L.orc_bc_feat.restype = C.c_int64
+        L.orc_pre_merge.restype = C.c_int64
+        L.orc_gen_tree.restype = C.c_int64
+        L.orc_forest_predict.restype = C.c_double
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _dims(shape):
+    """numpy shape (z,y,x) or (y,x) -> (dim, int64[3] as x,y,z)."""
+    dim = len(shape)
+    d = np.ones(3, dtype=np.int64)
+    d[:dim] = shape[::-1]
+    return dim, d
+
+
+def synth(shape, S, G, seed=0x9E3779B97F4A7C15, variant=0):
+    """Synthetic supervoxels + pb. shape is numpy order (z,y,x) / (y,x)."""
+    dim, d = _dims(shape)
+    labels = np.empty(shape, dtype=np.uint32)
+    pb = np.empty(shape, dtype=np.float32)
+    rc = lib().orc_synth(C.c_int(dim), _p(d), C.c_int(S), C.c_int(G), C.c_uint64(seed), C.c_int(variant),
+                         _p(labels), _p(pb))
+    assert rc == 0
+    return labels, pb
+
+
+def make_cfg(pb, rb=(), r=(), rl=(), b=(), thr=(0.2, 0.5, 0.8), norm_area=1.0, norm_len=1.0,
+             use_log=False, use_simple=False):
+    """rb/r/rl/b: lists of (image, bins, lo, hi).  Mirrors prepareImages (hmt_util.hxx:17-56)."""
+    cfg = FeatCfg()
+    keep = [pb]
+    rimgs = list(rb) + list(r)
+    bimgs = list(rb) + list(b)
+    for name, lst in (("r", rimgs), ("rl", list(rl)), ("b", bimgs)):
+        setattr(cfg, "n_%simg" % name, len(lst))
+        for i, (img, bins, lo, hi) in enumerate(lst):
+            assert img.dtype == np.float32 and img.flags.c_contiguous
+            keep.append(img)
+            getattr(cfg, "%simg" % name)[i] = img.ctypes.data
+            getattr(cfg, "%sbins" % name)[i] = bins
+            getattr(cfg, "%slo" % name)[i] = lo
+            getattr(cfg, "%shi" % name)[i] = hi
+    cfg.pb = pb.ctypes.data
+    cfg.n_thr = len(thr)
+    for i, t in enumerate(thr):
+        cfg.thr[i] = t
+    cfg.norm_area, cfg.norm_len = norm_area, norm_len
+    cfg.use_log, cfg.use_simple = int(use_log), int(use_simple)
+    cfg._keep = keep
+    return cfg
+
+
+def make_forest(arrays, predict_label=-1):
+    """arrays: dict with xbestsplit[ntree,nrnodes] f64, treemap[ntree,nrnodes,2] i32, nodestatus, nodeclass,
+    bestvar [ntree,nrnodes] i32, orig_labels[nclass] i32."""
+    f = Forest()
+    xb = np.ascontiguousarray(arrays["xbestsplit"], dtype=np.float64)
+    tm = np.ascontiguousarray(arrays["treemap"], dtype=np.int32)
+    ns = np.ascontiguousarray(arrays["nodestatus"], dtype=np.int32)
+    nc = np.ascontiguousarray(arrays["nodeclass"], dtype=np.int32)
+    bv = np.ascontiguousarray(arrays["bestvar"], dtype=np.int32)
+    ol = np.ascontiguousarray(arrays["orig_labels"], dtype=np.int32)
+    f.ntree, f.nrnodes = xb.shape
+    f.nclass = ol.size
+    f.xbestsplit, f.treemap, f.nodestatus = xb.ctypes.data, tm.ctypes.data, ns.ctypes.data
+    f.nodeclass, f.bestvar, f.orig_labels = nc.ctypes.data, bv.ctypes.data, ol.ctypes.data
+    f.predict_label = predict_label
+    f._keep = (xb, tm, ns, nc, bv, ol)
+    return f
+
+
+class Rag:
+    def __init__(self, labels, mask=None, only_contour=False):
+        labels = np.ascontiguousarray(labels, dtype=np.uint32)
+        self.shape = labels.shape
+        self.dim, d = _dims(labels.shape)
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, dtype=np.uint32)
+        self.h = C.c_void_p(lib().orc_rag_build(C.c_int(self.dim), _p(d), _p(labels), _p(mask),
+                                                C.c_int(int(only_contour))))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_rag_free(self.h)
+            self.h = None
+
+    @property
+    def num_regions(self):
+        return lib().orc_rag_num_regions(self.h)
+
+    @property
+    def num_pairs(self):
+        return lib().orc_rag_num_pairs(self.h)
+
+    def regions(self):
+        n = self.num_regions
+        lab = np.empty(n, np.uint32); npts = np.empty(n, np.int64); nb = np.empty(n, np.int64)
+        lib().orc_rag_regions(self.h, _p(lab), _p(npts), _p(nb))
+        return lab, npts, nb
+
+    def pairs(self):
+        n = self.num_pairs
+        a = np.empty(n, np.uint32); b = np.empty(n, np.uint32); c = np.empty(n, np.int64)
+        lib().orc_rag_pairs(self.h, _p(a), _p(b), _p(c))
+        return a, b, c
+
+    def region_iter_order(self):
+        lab = np.empty(self.num_regions, np.uint32)
+        lib().orc_rag_region_iter_order(self.h, _p(lab))
+        return lab
+
+    def pair_stats(self, img):
+        n = self.num_pairs
+        out = [np.empty(n, np.float64) for _ in range(4)]
+        lib().orc_rag_pair_stats(self.h, _p(img), *[_p(o) for o in out])
+        return out
+
+    def region_stats(self, img):
+        n = self.num_regions
+        out = [np.empty(n, np.float64) for _ in range(4)]
+        lo = np.empty((n, 3), np.int64); hi = np.empty((n, 3), np.int64)
+        lib().orc_rag_region_stats(self.h, _p(img), *[_p(o) for o in out], _p(lo), _p(hi))
+        return out + [lo, hi]
+
+    def dump(self, pb, type, update_region, path):
+        rc = lib().orc_rag_dump(self.h, _p(pb), C.c_int(type), C.c_int(int(update_region)), path.encode())
+        assert rc == 0
+
+    def merge_order_pb(self, pb, type=1, update_region=False):
+        cap = max(self.num_regions, 1)
+        order = np.empty((cap, 3), np.uint32); sal = np.empty(cap, np.float64)
+        n = lib().orc_merge_order_pb(self.h, _p(pb), C.c_int(type), C.c_int(int(update_region)), _p(order),
+                                     _p(sal), C.c_int64(cap))
+        if n < 0:
+            raise RuntimeError("orc_merge_order_pb failed: %d" % n)
+        return order[:n].copy(), sal[:n].copy()
+
+    def merge_order_bc(self, cfg, forest=None, stub_index=31, want_feats=False):
+        cap = max(self.num_regions, 1)
+        order = np.empty((cap, 3), np.uint32); sal = np.empty(cap, np.float64)
+        d = lib().orc_feat_dim(C.c_int(self.dim), C.byref(cfg))
+        feats = np.empty((cap, d), np.float64) if want_feats else None
+        nev = C.c_int64(0)
+        n = lib().orc_merge_order_bc(self.h, C.byref(cfg), C.byref(forest) if forest is not None else None,
+                                     C.c_int(stub_index), _p(order), _p(sal), _p(feats), C.c_int64(cap),
+                                     C.byref(nev))
+        if n < 0:
+            raise RuntimeError("orc_merge_order_bc failed: %d" % n)
+        self.n_feat_evals = nev.value
+        if want_feats:
+            return order[:n].copy(), sal[:n].copy(), feats[:n].copy()
+        return order[:n].copy(), sal[:n].copy()
+
+    def bc_feat(self, cfg, order):
+        order = np.ascontiguousarray(order, dtype=np.uint32)
+        d = lib().orc_feat_dim(C.c_int(self.dim), C.byref(cfg))
+        feats = np.empty((len(order), d), np.float64)
+        n = lib().orc_bc_feat(self.h, C.byref(cfg), _p(order), C.c_int64(len(order)), _p(feats))
+        if n < 0:
+            raise RuntimeError("orc_bc_feat failed")
+        return feats
+
+    def pre_merge(self, pb, size_thresholds, rpb_threshold):
+        cap = max(self.num_regions, 1)
+        order = np.empty((cap, 3), np.uint32); sal = np.empty(cap, np.float64)
+        st = np.asarray(size_thresholds, dtype=np.int32)
+        n = lib().orc_pre_merge(self.h, _p(pb), _p(st), C.c_int(len(st)), C.c_double(rpb_threshold), _p(order),
+                                _p(sal), C.c_int64(cap))
+        if n < 0:
+            raise RuntimeError("orc_pre_merge failed")
+        return order[:n].copy(), sal[:n].copy()
+
+
+def feat_dim(dim, cfg):
+    return lib().orc_feat_dim(C.c_int(dim), C.byref(cfg))
+
+
+def forest_predict(forest, x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    return lib().orc_forest_predict(C.byref(forest), _p(x), C.c_int(x.size))
+
+
+def gen_tree(order):
+    order = np.ascontiguousarray(order, dtype=np.uint32)
+    cap = 2 * len(order) + 1
+    lab = np.empty(cap, np.uint32)
+    par = np.empty(cap, np.int32); c0 = np.empty(cap, np.int32); c1 = np.empty(cap, np.int32)
+    n = lib().orc_gen_tree(_p(order), C.c_int64(len(order)), _p(lab), _p(par), _p(c0), _p(c1), C.c_int64(cap))
+    assert n >= 0
+    return lab[:n], par[:n], c0[:n], c1[:n]
