@@ -1,0 +1,385 @@
+// glia_amd/csrc/api.cpp -- C ABI of libglia_hmt.so (see include/glia_hmt.h for the reference
+// operators each entry point replaces).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <mutex>
+
+#include "hmt_internal.hpp"
+
+namespace glia {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+static float ceil_f32(double d) {   // smallest float >= d
+  if (std::isinf(d) || std::isnan(d)) return (float)d;
+  float f = (float)d;
+  if ((double)f < d) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
+  return f;
+}
+static float floor_f32(double d) {  // largest float <= d
+  if (std::isinf(d) || std::isnan(d)) return (float)d;
+  float f = (float)d;
+  if ((double)f > d) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
+  return f;
+}
+static uint32_t next_pow2(uint64_t v) {
+  uint64_t p = 1;
+  while (p < v) p <<= 1;
+  return (uint32_t)std::min<uint64_t>(p, 1ull << 31);
+}
+
+// util/image_stats.hxx:17-22: bounds[0] = interval (range.first ignored), bounds[i] = bounds[i-1] + interval
+HistSpec make_hist_spec(int bins, double lo, double hi) {
+  HistSpec h;
+  h.bins = bins;
+  double interval = (hi - lo) / bins;
+  double b = 0.0;
+  for (int i = 0; i < GLIA_HMT_MAX_BINS; ++i) {
+    if (i < bins) { b = (i == 0) ? interval : b + interval; h.fb[i] = ceil_f32(b); }
+    else h.fb[i] = std::numeric_limits<float>::infinity();
+  }
+  h.lo_f = floor_f32(lo);
+  h.hi_f = ceil_f32(hi);
+  return h;
+}
+
+}  // namespace glia
+
+using namespace glia;
+
+struct glia_hmt_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  // accumulation hash tables (kept clean between builds: compaction clears what it consumes)
+  uint32_t rcap = 0, pcap = 0;
+  uint32_t* rkeys = nullptr; uint32_t* rrec = nullptr;
+  unsigned long long* pkeys = nullptr; uint32_t* prec = nullptr;
+  uint32_t* flags = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  uint32_t hint_rcap = 0, hint_pcap = 0;
+};
+
+struct glia_hmt_rag {
+  glia_hmt_ctx* ctx = nullptr;
+  int dim = 3;
+  int64_t dims[3] = {1, 1, 1};
+  bool only_contour = false;
+  int bins = 0, nthr = 0;
+  RagArrays arr;
+  double pass_ms = 0, alg_bytes = 0;
+  double ms_table = 0, ms_init = 0, ms_loop = 0;
+  int64_t n_scored = 0;
+  glia_hmt_feat_config cfg;
+  bool has_cfg = false;
+};
+
+static int free_tables(glia_hmt_ctx* c) {
+  if (c->rkeys) GLIA_HIP_TRY(hipFree(c->rkeys));
+  if (c->rrec) GLIA_HIP_TRY(hipFree(c->rrec));
+  if (c->pkeys) GLIA_HIP_TRY(hipFree(c->pkeys));
+  if (c->prec) GLIA_HIP_TRY(hipFree(c->prec));
+  c->rkeys = nullptr; c->rrec = nullptr; c->pkeys = nullptr; c->prec = nullptr;
+  c->rcap = c->pcap = 0;
+  return GLIA_HMT_OK;
+}
+
+static int ensure_tables(glia_hmt_ctx* c, uint32_t rcap, uint32_t pcap) {
+  if (rcap <= c->rcap && pcap <= c->pcap) return GLIA_HMT_OK;
+  rcap = std::max(rcap, c->rcap);
+  pcap = std::max(pcap, c->pcap);
+  int rc = free_tables(c);
+  if (rc) return rc;
+  GLIA_HIP_TRY(hipMalloc(&c->rkeys, sizeof(uint32_t) * (size_t)rcap));
+  GLIA_HIP_TRY(hipMalloc(&c->rrec, sizeof(uint32_t) * kRegionWords * (size_t)rcap));
+  GLIA_HIP_TRY(hipMalloc(&c->pkeys, sizeof(unsigned long long) * (size_t)pcap));
+  GLIA_HIP_TRY(hipMalloc(&c->prec, sizeof(uint32_t) * kPairWords * (size_t)pcap));
+  GLIA_HIP_TRY(hipMemsetAsync(c->rkeys, 0, sizeof(uint32_t) * (size_t)rcap, c->stream));
+  GLIA_HIP_TRY(hipMemsetAsync(c->rrec, 0, sizeof(uint32_t) * kRegionWords * (size_t)rcap, c->stream));
+  GLIA_HIP_TRY(hipMemsetAsync(c->pkeys, 0, sizeof(unsigned long long) * (size_t)pcap, c->stream));
+  GLIA_HIP_TRY(hipMemsetAsync(c->prec, 0, sizeof(uint32_t) * kPairWords * (size_t)pcap, c->stream));
+  c->rcap = rcap;
+  c->pcap = pcap;
+  return GLIA_HMT_OK;
+}
+
+static int clear_tables(glia_hmt_ctx* c) {
+  GLIA_HIP_TRY(hipMemsetAsync(c->rkeys, 0, sizeof(uint32_t) * (size_t)c->rcap, c->stream));
+  GLIA_HIP_TRY(hipMemsetAsync(c->rrec, 0, sizeof(uint32_t) * kRegionWords * (size_t)c->rcap, c->stream));
+  GLIA_HIP_TRY(hipMemsetAsync(c->pkeys, 0, sizeof(unsigned long long) * (size_t)c->pcap, c->stream));
+  GLIA_HIP_TRY(hipMemsetAsync(c->prec, 0, sizeof(uint32_t) * kPairWords * (size_t)c->pcap, c->stream));
+  return GLIA_HMT_OK;
+}
+
+extern "C" {
+
+const char* glia_hmt_last_error(void) { return g_err.c_str(); }
+const char* glia_hmt_version(void) { return "glia_hmt 0.1 (gfx950)"; }
+
+int glia_hmt_ctx_create(int device, void* hip_stream, glia_hmt_ctx** out) {
+  if (!out) { set_error("ctx_create: out is NULL"); return GLIA_HMT_ERR_ARG; }
+  int n = 0;
+  GLIA_HIP_TRY(hipGetDeviceCount(&n));
+  if (device < 0 || device >= n) { set_error("ctx_create: no such HIP device"); return GLIA_HMT_ERR_ARG; }
+  GLIA_HIP_TRY(hipSetDevice(device));
+  glia_hmt_ctx* c = new glia_hmt_ctx;
+  c->device = device;
+  if (hip_stream) c->stream = (hipStream_t)hip_stream;
+  else { GLIA_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+  GLIA_HIP_TRY(hipMalloc(&c->flags, 64));
+  GLIA_HIP_TRY(hipMemsetAsync(c->flags, 0, 64, c->stream));
+  GLIA_HIP_TRY(hipEventCreate(&c->ev0));
+  GLIA_HIP_TRY(hipEventCreate(&c->ev1));
+  *out = c;
+  return GLIA_HMT_OK;
+}
+
+void glia_hmt_ctx_destroy(glia_hmt_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  (void)free_tables(c);
+  if (c->flags) (void)hipFree(c->flags);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int glia_hmt_ctx_sync(glia_hmt_ctx* c) {
+  if (!c) return GLIA_HMT_ERR_ARG;
+  GLIA_HIP_TRY(hipStreamSynchronize(c->stream));
+  return GLIA_HMT_OK;
+}
+
+int glia_hmt_ctx_set_table_hint(glia_hmt_ctx* c, int64_t expected_regions, int64_t expected_pairs) {
+  if (!c) return GLIA_HMT_ERR_ARG;
+  c->hint_rcap = expected_regions > 0 ? next_pow2((uint64_t)expected_regions * 2) : 0;
+  c->hint_pcap = expected_pairs > 0 ? next_pow2((uint64_t)expected_pairs * 2) : 0;
+  return GLIA_HMT_OK;
+}
+
+int glia_hmt_synth(glia_hmt_ctx* c, int dim, const int64_t dims[3], int S, int G, uint64_t seed, int variant,
+                   uint32_t* d_labels, float* d_pb) {
+  if (!c || !dims || !d_labels || !d_pb || (dim != 2 && dim != 3) || S <= 0 || G <= 0) {
+    set_error("synth: invalid argument");
+    return GLIA_HMT_ERR_ARG;
+  }
+  GLIA_HIP_TRY(hipSetDevice(c->device));
+  int64_t N = dims[0] * dims[1] * (dim == 3 ? dims[2] : 1);
+  uint32_t* d_truth = nullptr;
+  GLIA_HIP_TRY(hipMalloc(&d_truth, sizeof(uint32_t) * (size_t)N));
+  int rc = launch_synth(dim, dims, S, G, seed, variant, d_labels, d_truth, d_pb, c->stream);
+  if (rc == GLIA_HMT_OK) GLIA_HIP_TRY(hipStreamSynchronize(c->stream));
+  GLIA_HIP_TRY(hipFree(d_truth));
+  return rc;
+}
+
+int glia_hmt_rag_build(glia_hmt_ctx* c, int dim, const int64_t dims[3], const uint32_t* d_labels,
+                       const uint32_t* d_mask, int only_contour, const float* d_pb,
+                       const glia_hmt_feat_config* cfg, glia_hmt_rag** out) {
+  if (!c || !dims || !d_labels || !out || (dim != 2 && dim != 3)) {
+    set_error("rag_build: invalid argument");
+    return GLIA_HMT_ERR_ARG;
+  }
+  if (d_mask) { set_error("rag_build: mask images are not supported yet"); return GLIA_HMT_ERR_UNSUPPORTED; }
+  const int64_t nx = dims[0], ny = dims[1], nz = dim == 3 ? dims[2] : 1;
+  if (nx <= 0 || ny <= 0 || nz <= 0 || nx >= (1ll << 31) || ny >= (1ll << 31) || nz >= (1ll << 31)) {
+    set_error("rag_build: bad dimensions");
+    return GLIA_HMT_ERR_ARG;
+  }
+  GLIA_HIP_TRY(hipSetDevice(c->device));
+  const float* img = d_pb;
+  int bins = 8;
+  double lo = 0.0, hi = 1.0;
+  int nthr = 0;
+  double thr[GLIA_HMT_MAX_THRESH] = {0, 0, 0, 0};
+  if (cfg) {
+    // first implementation: one image volume shared by every list (the --rbi pb configuration of SURVEY.md 8d)
+    const glia_hmt_image* ref = nullptr;
+    auto check = [&](const glia_hmt_image* lst, int n) -> bool {
+      for (int i = 0; i < n; ++i) {
+        if (!ref) ref = &lst[i];
+        if (lst[i].d_image != ref->d_image || lst[i].bins != ref->bins || lst[i].lo != ref->lo || lst[i].hi != ref->hi)
+          return false;
+      }
+      return true;
+    };
+    if (cfg->n_region < 0 || cfg->n_rlabel < 0 || cfg->n_boundary < 0 || cfg->n_region > GLIA_HMT_MAX_IMAGES ||
+        cfg->n_rlabel > GLIA_HMT_MAX_IMAGES || cfg->n_boundary > GLIA_HMT_MAX_IMAGES ||
+        cfg->n_thresholds < 0 || cfg->n_thresholds > GLIA_HMT_MAX_THRESH) {
+      set_error("rag_build: feature configuration out of range");
+      return GLIA_HMT_ERR_ARG;
+    }
+    bool same = check(cfg->region, cfg->n_region) && check(cfg->rlabel, cfg->n_rlabel) &&
+                check(cfg->boundary, cfg->n_boundary);
+    if (!same || cfg->n_region > 1 || cfg->n_rlabel > 1 || cfg->n_boundary > 1 ||
+        (ref && cfg->d_pb && ref->d_image != cfg->d_pb)) {
+      set_error("rag_build: only a single image volume shared by --pb/--rbi is supported yet");
+      return GLIA_HMT_ERR_UNSUPPORTED;
+    }
+    img = cfg->d_pb ? cfg->d_pb : (ref ? ref->d_image : d_pb);
+    if (ref) { bins = ref->bins; lo = ref->lo; hi = ref->hi; }
+    nthr = cfg->n_thresholds;
+    for (int i = 0; i < nthr; ++i) thr[i] = cfg->thresholds[i];
+  }
+  if (!img) { set_error("rag_build: no image volume given"); return GLIA_HMT_ERR_ARG; }
+  if (bins < 1 || bins > GLIA_HMT_MAX_BINS || !(hi > lo)) {
+    set_error("rag_build: histogram bins must be 1..16 and hi > lo");
+    return GLIA_HMT_ERR_ARG;
+  }
+
+  const int64_t N = nx * ny * nz;
+  uint32_t rcap = c->hint_rcap ? c->hint_rcap : next_pow2(std::max<int64_t>(1 << 12, N / 128));
+  uint32_t pcap = c->hint_pcap ? c->hint_pcap : next_pow2(std::max<int64_t>(1 << 14, N / 32));
+
+  glia_hmt_rag* rag = new glia_hmt_rag;
+  rag->ctx = c; rag->dim = dim; rag->dims[0] = nx; rag->dims[1] = ny; rag->dims[2] = nz;
+  rag->only_contour = only_contour != 0;
+  rag->bins = bins; rag->nthr = nthr;
+  if (cfg) { rag->cfg = *cfg; rag->has_cfg = true; }
+
+  for (int attempt = 0;; ++attempt) {
+    int rc = ensure_tables(c, rcap, pcap);
+    if (rc) { delete rag; return rc; }
+    AccParams p;
+    p.lab = d_labels; p.img = img;
+    p.nx = nx; p.ny = ny; p.nz = nz; p.dim = dim;
+    p.nbx = (int)((nx + kRowX - 1) / kRowX);
+    p.nby = (int)((ny + kRows - 1) / kRows);
+    p.nbz = (int)((nz + kTZ - 1) / kTZ);
+    p.hist = make_hist_spec(bins, lo, hi);
+    p.nthr = nthr;
+    for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) p.thr_f[i] = i < nthr ? ceil_f32(thr[i]) : std::numeric_limits<float>::infinity();
+    p.rkeys = c->rkeys; p.rrec = c->rrec; p.rmask = c->rcap - 1;
+    p.pkeys = c->pkeys; p.prec = c->prec; p.pmask = c->pcap - 1;
+    p.flags = c->flags;
+    if ((int64_t)p.nbx * p.nby * p.nbz >= (1ll << 31)) { delete rag; set_error("rag_build: volume too large"); return GLIA_HMT_ERR_ARG; }
+    hipError_t e = hipEventRecord(c->ev0, c->stream);
+    if (e == hipSuccess) { rc = launch_accumulate(p, c->stream); e = hipEventRecord(c->ev1, c->stream); }
+    if (e != hipSuccess) { delete rag; set_error(hipGetErrorString(e)); return GLIA_HMT_ERR_HIP; }
+    if (rc) { delete rag; return rc; }
+    uint32_t flags[2] = {0, 0};
+    e = hipMemcpyAsync(flags, c->flags, sizeof(flags), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { delete rag; set_error(std::string("rag_build: ") + hipGetErrorString(e)); return GLIA_HMT_ERR_HIP; }
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    rag->pass_ms = ms;
+    rag->alg_bytes = (double)N * 8.0;
+    if (flags[0] || flags[1]) {
+      // a table filled up: drop the partial result, grow and redo the pass
+      if (attempt >= 6) { delete rag; set_error("rag_build: hash tables keep overflowing"); return GLIA_HMT_ERR_HIP; }
+      (void)hipMemsetAsync(c->flags, 0, 64, c->stream);
+      rc = clear_tables(c);
+      if (rc) { delete rag; return rc; }
+      if (flags[0]) rcap = c->rcap * 4;
+      if (flags[1]) pcap = c->pcap * 4;
+      continue;
+    }
+    rc = compact_tables(p, c->rcap, c->pcap, &rag->arr, c->stream);
+    if (rc) { delete rag; return rc; }
+    break;
+  }
+  *out = rag;
+  return GLIA_HMT_OK;
+}
+
+void glia_hmt_rag_free(glia_hmt_rag* r) {
+  if (!r) return;
+  (void)hipSetDevice(r->ctx->device);
+  (void)hipFree(r->arr.d_rlabel); (void)hipFree(r->arr.d_rrec);
+  (void)hipFree(r->arr.d_pa); (void)hipFree(r->arr.d_pb); (void)hipFree(r->arr.d_prec);
+  delete r;
+}
+
+int64_t glia_hmt_rag_num_regions(const glia_hmt_rag* r) { return r ? r->arr.R : -1; }
+int64_t glia_hmt_rag_num_pairs(const glia_hmt_rag* r) { return r ? r->arr.P : -1; }
+
+int glia_hmt_rag_last_pass(const glia_hmt_rag* r, double* ms, double* bytes) {
+  if (!r) return GLIA_HMT_ERR_ARG;
+  if (ms) *ms = r->pass_ms;
+  if (bytes) *bytes = r->alg_bytes;
+  return GLIA_HMT_OK;
+}
+
+static double dword(const uint32_t* w) { double d; std::memcpy(&d, w, 8); return d; }
+
+int glia_hmt_rag_export_regions(const glia_hmt_rag* r, uint32_t* h_label, int64_t* h_count, int64_t* h_border,
+                                int64_t* h_lo, int64_t* h_hi, double* h_sum, double* h_sumsq, double* h_min,
+                                double* h_max, int64_t* h_hist, int64_t* h_first) {
+  if (!r) return GLIA_HMT_ERR_ARG;
+  GLIA_HIP_TRY(hipSetDevice(r->ctx->device));
+  const int64_t R = r->arr.R;
+  std::vector<uint32_t> lab(R), rec((size_t)R * kRegionWords);
+  if (R) {
+    GLIA_HIP_TRY(hipMemcpy(lab.data(), r->arr.d_rlabel, sizeof(uint32_t) * R, hipMemcpyDeviceToHost));
+    GLIA_HIP_TRY(hipMemcpy(rec.data(), r->arr.d_rrec, sizeof(uint32_t) * kRegionWords * R, hipMemcpyDeviceToHost));
+  }
+  for (int64_t i = 0; i < R; ++i) {
+    const uint32_t* w = &rec[(size_t)i * kRegionWords];
+    if (h_label) h_label[i] = lab[i];
+    if (h_count) h_count[i] = w[R_CNT];
+    if (h_border) h_border[i] = w[R_BORDER];
+    for (int d = 0; d < 3; ++d) {
+      if (h_lo) h_lo[3 * i + d] = (int64_t)(0x7fffffffu - w[R_LO + d]);
+      if (h_hi) h_hi[3 * i + d] = (int64_t)w[R_HI + d] - 1;
+    }
+    if (h_sum) h_sum[i] = dword(&w[R_SUM]);
+    if (h_sumsq) h_sumsq[i] = dword(&w[R_SQ]);
+    if (h_min) h_min[i] = (double)ord_float(~w[R_MIN]);
+    if (h_max) h_max[i] = (double)ord_float(w[R_MAX]);
+    if (h_hist) for (int b = 0; b < r->bins; ++b) h_hist[i * r->bins + b] = w[R_HIST + b];
+    if (h_first) { unsigned long long f; std::memcpy(&f, &w[R_FIRST], 8); h_first[i] = (int64_t)~f; }
+  }
+  return GLIA_HMT_OK;
+}
+
+int glia_hmt_rag_export_pairs(const glia_hmt_rag* r, uint32_t* h_a, uint32_t* h_b, int64_t* h_count, double* h_sum,
+                              double* h_sumsq, double* h_min, double* h_max, int64_t* h_hist, int64_t* h_thr) {
+  if (!r) return GLIA_HMT_ERR_ARG;
+  GLIA_HIP_TRY(hipSetDevice(r->ctx->device));
+  const int64_t P = r->arr.P;
+  std::vector<uint32_t> a(P), b(P), rec((size_t)P * kPairWords);
+  if (P) {
+    GLIA_HIP_TRY(hipMemcpy(a.data(), r->arr.d_pa, sizeof(uint32_t) * P, hipMemcpyDeviceToHost));
+    GLIA_HIP_TRY(hipMemcpy(b.data(), r->arr.d_pb, sizeof(uint32_t) * P, hipMemcpyDeviceToHost));
+    GLIA_HIP_TRY(hipMemcpy(rec.data(), r->arr.d_prec, sizeof(uint32_t) * kPairWords * P, hipMemcpyDeviceToHost));
+  }
+  for (int64_t i = 0; i < P; ++i) {
+    const uint32_t* w = &rec[(size_t)i * kPairWords];
+    if (h_a) h_a[i] = a[i];
+    if (h_b) h_b[i] = b[i];
+    if (h_count) h_count[i] = w[P_CNT];
+    if (h_sum) h_sum[i] = dword(&w[P_SUM]);
+    if (h_sumsq) h_sumsq[i] = dword(&w[P_SQ]);
+    if (h_min) h_min[i] = (double)ord_float(~w[P_MIN]);
+    if (h_max) h_max[i] = (double)ord_float(w[P_MAX]);
+    if (h_hist) for (int k = 0; k < r->bins; ++k) h_hist[i * r->bins + k] = w[P_HIST + k];
+    if (h_thr) for (int k = 0; k < r->nthr; ++k) h_thr[i * r->nthr + k] = w[P_THR + k];
+  }
+  return GLIA_HMT_OK;
+}
+
+int glia_hmt_merge_order_pb(glia_hmt_ctx* c, glia_hmt_rag* rag, int type, uint32_t* h_order, double* h_sal,
+                            int64_t capacity, int64_t* n_merges) {
+  (void)c; (void)rag; (void)type; (void)h_order; (void)h_sal; (void)capacity; (void)n_merges;
+  set_error("merge_order_pb: not implemented yet");
+  return GLIA_HMT_ERR_UNSUPPORTED;
+}
+
+int glia_hmt_last_merge_timing(const glia_hmt_rag* r, double* ms_table, double* ms_init, double* ms_loop,
+                               int64_t* n_scored) {
+  if (!r) return GLIA_HMT_ERR_ARG;
+  if (ms_table) *ms_table = r->ms_table;
+  if (ms_init) *ms_init = r->ms_init;
+  if (ms_loop) *ms_loop = r->ms_loop;
+  if (n_scored) *n_scored = r->n_scored;
+  return GLIA_HMT_OK;
+}
+
+}  // extern "C"

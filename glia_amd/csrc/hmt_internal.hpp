@@ -1,0 +1,93 @@
+// glia_amd/csrc/hmt_internal.hpp -- shared definitions of the HIP implementation (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/glia_hmt.h"
+
+namespace glia {
+
+void set_error(const std::string& msg);
+#define GLIA_HIP_TRY(expr)                                                                       \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess) {                                                                      \
+      ::glia::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                      \
+      return GLIA_HMT_ERR_HIP;                                                                   \
+    }                                                                                            \
+  } while (0)
+
+// ---- accumulation tile geometry -------------------------------------------------------------
+constexpr int kVX = 4;            // voxels per lane along x (one 16-byte load)
+constexpr int kWave = 64;
+constexpr int kRowX = kWave * kVX;  // 256 voxels of one row per wave
+constexpr int kRows = 8;          // waves (= y rows) per workgroup
+constexpr int kThreads = kRows * kWave;
+constexpr int kTZ = 32;           // planes a workgroup marches through; kTZ*kVX <= 255 (8-bit run counters)
+
+// ---- record layouts (32-bit words).  All zero == "empty": minima / lower bounds are stored
+// complemented so that every reduction is an add or an unsigned max and tables initialise by memset.
+// region record
+constexpr int R_CNT = 0, R_BORDER = 1, R_LO = 2 /*3: 0x7fffffff-lo*/, R_HI = 5 /*3: hi+1*/, R_SUM = 8 /*f64*/,
+              R_SQ = 10 /*f64*/, R_MIN = 12 /*~ord*/, R_MAX = 13 /*ord*/, R_FIRST = 14 /*u64 ~idx*/, R_HIST = 16;
+constexpr int kRegionWords = 32;
+// directed pair record
+constexpr int P_CNT = 0, P_MIN = 1, P_MAX = 2, P_THR = 4 /*4*/, P_SUM = 8, P_SQ = 10, P_HIST = 12;
+constexpr int kPairWordsLds = 28;   // LDS stride
+constexpr int kPairWords = 32;      // global stride (128-byte lines)
+
+constexpr int kLdsRegionSlots = 128;
+constexpr int kLdsPairSlots = 512;
+
+struct HistSpec {
+  int bins;
+  float fb[GLIA_HMT_MAX_BINS];  // smallest float >= bounds[i] (util/image_stats.hxx:17-22), +inf padded
+  float lo_f;                   // largest float <= range.first   (val >  lo  <=> val >  lo_f ; val <= lo <=> val <= lo_f)
+  float hi_f;                   // smallest float >= range.second (val <  hi  <=> val <  hi_f)
+};
+
+struct AccParams {
+  const uint32_t* lab;
+  const float* img;
+  int64_t nx, ny, nz;
+  int dim;
+  int nbx, nby, nbz;
+  HistSpec hist;
+  int nthr;
+  float thr_f[GLIA_HMT_MAX_THRESH];  // smallest float >= threshold (val >= thr <=> val >= thr_f)
+  uint32_t* rkeys;                   // label + 1, 0 = empty
+  uint32_t* rrec;
+  uint32_t rmask;
+  unsigned long long* pkeys;         // ((a+1) << 32) | (b+1), 0 = empty
+  uint32_t* prec;
+  uint32_t pmask;
+  uint32_t* flags;                   // [0] region table full, [1] pair table full
+};
+
+// compact, sorted RAG as produced by the edge-table step
+struct RagArrays {
+  int64_t R = 0, P = 0;       // regions, directed pairs
+  uint32_t* d_rlabel = nullptr;   // [R] ascending
+  uint32_t* d_rrec = nullptr;     // [R][kRegionWords]
+  uint32_t* d_pa = nullptr;       // [P] label a (ascending (a,b))
+  uint32_t* d_pb = nullptr;       // [P]
+  uint32_t* d_prec = nullptr;     // [P][kPairWords]
+};
+
+int launch_accumulate(const AccParams& p, hipStream_t stream);
+int launch_synth(int dim, const int64_t dims[3], int S, int G, uint64_t seed, int variant, uint32_t* d_labels,
+                 uint32_t* d_truth_tmp, float* d_pb, hipStream_t stream);
+int compact_tables(const AccParams& p, uint32_t rcap, uint32_t pcap, RagArrays* out, hipStream_t stream);
+
+__host__ __device__ inline uint32_t float_ord(float f) {
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__host__ __device__ inline float ord_float(uint32_t o) {
+  uint32_t u = o ^ ((o >> 31) ? 0x80000000u : 0xFFFFFFFFu);
+  return __builtin_bit_cast(float, u);
+}
+
+}  // namespace glia

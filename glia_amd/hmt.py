@@ -1,0 +1,214 @@
+"""Host-side mirror of GLIA's HMT operators over the C ABI (include/glia_hmt.h).
+
+Names follow the reference: RegionMap ~ TRegionMap(image, mask, onlyContour) (type/region_map.hxx:38-40),
+merge_order_pb ~ hmt/main_merge_order_pb.cxx.  Volumes are torch CUDA tensors (device memory plumbing
+only) in numpy axis order (z, y, x).  No CPU path exists here.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libglia_hmt.so")
+
+MAX_IMAGES, MAX_BINS, MAX_THRESH = 8, 16, 4
+
+
+class HmtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("glia_hmt error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Image(C.Structure):
+    _fields_ = [("d_image", C.c_void_p), ("bins", C.c_int), ("lo", C.c_double), ("hi", C.c_double)]
+
+
+class FeatConfig(C.Structure):
+    _fields_ = [
+        ("n_region", C.c_int), ("region", Image * MAX_IMAGES),
+        ("n_rlabel", C.c_int), ("rlabel", Image * MAX_IMAGES),
+        ("n_boundary", C.c_int), ("boundary", Image * MAX_IMAGES),
+        ("d_pb", C.c_void_p), ("n_thresholds", C.c_int), ("thresholds", C.c_double * MAX_THRESH),
+        ("normalizing_area", C.c_double), ("normalizing_length", C.c_double),
+        ("use_log_shape", C.c_int), ("use_simple_features", C.c_int),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Loads libglia_hmt.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise ImportError("glia_amd/libglia_hmt.so is missing: run `python -c 'import __graft_entry__ as g; "
+                              "g.build()'` (hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = C.CDLL(_SO)
+        L.glia_hmt_last_error.restype = C.c_char_p
+        L.glia_hmt_version.restype = C.c_char_p
+        L.glia_hmt_rag_num_regions.restype = C.c_int64
+        L.glia_hmt_rag_num_pairs.restype = C.c_int64
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise HmtError(rc, lib().glia_hmt_last_error().decode())
+
+
+def _dims(shape):
+    dim = len(shape)
+    d = (C.c_int64 * 3)(1, 1, 1)
+    for i, n in enumerate(shape[::-1]):
+        d[i] = n
+    return dim, d
+
+
+def _np(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    def __init__(self, device=0, stream=None):
+        self.h = C.c_void_p()
+        _check(lib().glia_hmt_ctx_create(C.c_int(device), C.c_void_p(stream) if stream else None, C.byref(self.h)))
+        self.device = device
+
+    def close(self):
+        if self.h:
+            lib().glia_hmt_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _check(lib().glia_hmt_ctx_sync(self.h))
+
+    def set_table_hint(self, regions, pairs):
+        _check(lib().glia_hmt_ctx_set_table_hint(self.h, C.c_int64(regions), C.c_int64(pairs)))
+
+    def synth(self, shape, S, G, seed=0x9E3779B97F4A7C15, variant=0):
+        """Synthetic supervoxels + pb on the device; returns torch tensors (labels i32 view, pb)."""
+        import torch
+        dim, d = _dims(shape)
+        dev = torch.device("cuda", self.device)
+        labels = torch.empty(shape, dtype=torch.int32, device=dev)   # uint32 payload
+        pb = torch.empty(shape, dtype=torch.float32, device=dev)
+        _check(lib().glia_hmt_synth(self.h, C.c_int(dim), d, C.c_int(S), C.c_int(G), C.c_uint64(seed),
+                                    C.c_int(variant), C.c_void_p(labels.data_ptr()), C.c_void_p(pb.data_ptr())))
+        return labels, pb
+
+
+def make_config(pb, rb=(), r=(), rl=(), b=(), thresholds=(0.2, 0.5, 0.8), normalizing_area=1.0,
+                normalizing_length=1.0, use_log_shape=False, use_simple_features=False):
+    """Builds the image lists the way prepareImages does (hmt/hmt_util.hxx:17-56).
+    rb/r/rl/b: sequences of (device tensor, bins, lo, hi)."""
+    cfg = FeatConfig()
+    keep = [pb]
+
+    def fill(arr, lst):
+        for i, (img, bins, lo, hi) in enumerate(lst):
+            keep.append(img)
+            arr[i].d_image = img.data_ptr()
+            arr[i].bins, arr[i].lo, arr[i].hi = bins, lo, hi
+        return len(lst)
+
+    cfg.n_region = fill(cfg.region, list(rb) + list(r))
+    cfg.n_rlabel = fill(cfg.rlabel, list(rl))
+    cfg.n_boundary = fill(cfg.boundary, list(rb) + list(b))
+    cfg.d_pb = pb.data_ptr()
+    cfg.n_thresholds = len(thresholds)
+    for i, t in enumerate(thresholds):
+        cfg.thresholds[i] = t
+    cfg.normalizing_area, cfg.normalizing_length = normalizing_area, normalizing_length
+    cfg.use_log_shape, cfg.use_simple_features = int(use_log_shape), int(use_simple_features)
+    cfg._keep = keep
+    return cfg
+
+
+class RegionMap:
+    """Device-resident region adjacency structure with sufficient statistics.
+    Mirrors TRegionMap(image, mask, onlyContour) (type/region_map.hxx:38-40)."""
+
+    def __init__(self, ctx, labels, pb=None, mask=None, only_contour=False, cfg=None):
+        assert labels.is_cuda and labels.is_contiguous() and labels.element_size() == 4
+        self.ctx = ctx
+        self.shape = tuple(labels.shape)
+        self.dim, d = _dims(self.shape)
+        self._keep = (labels, pb, mask, cfg)
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        _check(lib().glia_hmt_rag_build(
+            ctx.h, C.c_int(self.dim), d, C.c_void_p(labels.data_ptr()),
+            C.c_void_p(mask.data_ptr()) if mask is not None else None, C.c_int(int(only_contour)),
+            C.c_void_p(pb.data_ptr()) if pb is not None else None,
+            C.byref(cfg) if cfg is not None else None, C.byref(self.h)))
+        self.bins = cfg.region[0].bins if cfg is not None and cfg.n_region else \
+            (cfg.boundary[0].bins if cfg is not None and cfg.n_boundary else 8)
+        self.nthr = cfg.n_thresholds if cfg is not None else 0
+
+    def close(self):
+        if self.h:
+            lib().glia_hmt_rag_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def num_regions(self):
+        return lib().glia_hmt_rag_num_regions(self.h)
+
+    @property
+    def num_pairs(self):
+        return lib().glia_hmt_rag_num_pairs(self.h)
+
+    def last_pass(self):
+        ms, by = C.c_double(), C.c_double()
+        _check(lib().glia_hmt_rag_last_pass(self.h, C.byref(ms), C.byref(by)))
+        return ms.value, by.value
+
+    def regions(self):
+        n = self.num_regions
+        out = dict(label=np.empty(n, np.uint32), count=np.empty(n, np.int64), border=np.empty(n, np.int64),
+                   lo=np.empty((n, 3), np.int64), hi=np.empty((n, 3), np.int64), sum=np.empty(n), sumsq=np.empty(n),
+                   min=np.empty(n), max=np.empty(n), hist=np.empty((n, self.bins), np.int64),
+                   first=np.empty(n, np.int64))
+        _check(lib().glia_hmt_rag_export_regions(self.h, *[_np(out[k]) for k in (
+            "label", "count", "border", "lo", "hi", "sum", "sumsq", "min", "max", "hist", "first")]))
+        return out
+
+    def pairs(self):
+        n = self.num_pairs
+        out = dict(a=np.empty(n, np.uint32), b=np.empty(n, np.uint32), count=np.empty(n, np.int64), sum=np.empty(n),
+                   sumsq=np.empty(n), min=np.empty(n), max=np.empty(n), hist=np.empty((n, self.bins), np.int64),
+                   thr=np.empty((n, max(self.nthr, 1)), np.int64))
+        _check(lib().glia_hmt_rag_export_pairs(self.h, *[_np(out[k]) for k in (
+            "a", "b", "count", "sum", "sumsq", "min", "max", "hist")], _np(out["thr"]) if self.nthr else None))
+        return out
+
+    def merge_order_pb(self, type=1):
+        """hmt/main_merge_order_pb.cxx: type 1 = median, 2 = mean.  Returns (order[n,3] uint32, saliency[n])."""
+        cap = max(self.num_regions, 1)
+        order = np.empty((cap, 3), np.uint32)
+        sal = np.empty(cap, np.float64)
+        n = C.c_int64(0)
+        _check(lib().glia_hmt_merge_order_pb(self.ctx.h, self.h, C.c_int(type), _np(order), _np(sal), C.c_int64(cap),
+                                             C.byref(n)))
+        return order[:n.value].copy(), sal[:n.value].copy()
+
+    def last_merge_timing(self):
+        a, b, c, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+        _check(lib().glia_hmt_last_merge_timing(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
+        return dict(ms_table=a.value, ms_init=b.value, ms_loop=c.value, n_edges_scored=n.value)

@@ -1,0 +1,125 @@
+/* include/glia_hmt.h -- C ABI of the MI355X-native HMT hot path (libglia_hmt.so).
+ *
+ * Drop-in boundary for GLIA's hierarchical-merge-tree path (code/hmt + the L1/L2 types it
+ * drives).  GLIA has no FFI/plugin registry: its operator API is header templates whose
+ * behaviour is injected through lambdas, plus CLIs and file formats.  Each
+ * entry point below therefore replaces one reference operator together with the fixed set
+ * of lambdas the reference's own callers pass to it; the citation names file:line under
+ * /root/reference/code/.
+ *
+ * Conventions: plain C, opaque handles, int status (0 = ok, <0 = error, message via
+ * glia_hmt_last_error()); never exits the process (the reference's perr() does,
+ * glia_base.hxx:66-69).  Pointers prefixed d_ are DEVICE (HBM) pointers on the context's
+ * GPU, h_ are host pointers.  Volumes are dense, x fastest: index = x + nx*(y + ny*z),
+ * labels uint32 (glia_base.hxx:43), images float (:44), features double (:45).
+ * A handle is not thread-safe; all work of a context is ordered on its HIP stream.
+ */
+#ifndef GLIA_HMT_H
+#define GLIA_HMT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLIA_HMT_OK 0
+#define GLIA_HMT_ERR_ARG (-1)          /* invalid argument */
+#define GLIA_HMT_ERR_HIP (-2)          /* HIP runtime error */
+#define GLIA_HMT_ERR_UNSUPPORTED (-3)  /* valid in the reference, not implemented here yet */
+#define GLIA_HMT_ERR_CAPACITY (-4)     /* caller-provided output buffer too small */
+#define GLIA_HMT_ERR_SALIENCY (-5)     /* "Error: invalid boundary saliency..." (util/struct_merge.hxx:58-59) */
+#define GLIA_HMT_ERR_IO (-6)           /* file could not be read / malformed */
+
+#define GLIA_HMT_MAX_IMAGES 8
+#define GLIA_HMT_MAX_BINS 16
+#define GLIA_HMT_MAX_THRESH 4
+
+typedef struct glia_hmt_ctx glia_hmt_ctx;
+typedef struct glia_hmt_rag glia_hmt_rag;
+typedef struct glia_hmt_forest glia_hmt_forest;
+
+const char* glia_hmt_last_error(void);
+const char* glia_hmt_version(void);
+
+/* Context: device + stream + reusable workspaces.  hip_stream may be NULL (own stream) or a
+ * hipStream_t the caller owns (e.g. torch.cuda.current_stream().cuda_stream). */
+int glia_hmt_ctx_create(int device, void* hip_stream, glia_hmt_ctx** out);
+void glia_hmt_ctx_destroy(glia_hmt_ctx* ctx);
+int glia_hmt_ctx_sync(glia_hmt_ctx* ctx);
+/* Optional sizing hint for the accumulation hash tables (0 = derive from the volume size; they grow and
+ * the pass is redone if they fill up). */
+int glia_hmt_ctx_set_table_hint(glia_hmt_ctx* ctx, int64_t expected_regions, int64_t expected_pairs);
+
+/* Image + histogram spec: one ImageHistPair of hmt/bc_feat.hxx:29-43. */
+typedef struct {
+  const float* d_image;
+  int bins;            /* --rbb/--rlb/--rb/--bb, <= GLIA_HMT_MAX_BINS */
+  double lo, hi;       /* histogram range (--rbl/--rbu ...) */
+} glia_hmt_image;
+
+/* Feature configuration = the image lists prepareImages builds (hmt/hmt_util.hxx:17-56: an --rbi
+ * image is appended to BOTH the region and the boundary list) plus the scalar flags of
+ * hmt/main_merge_order_bc.cxx:172-242. */
+typedef struct {
+  int n_region;  glia_hmt_image region[GLIA_HMT_MAX_IMAGES];         /* rImages  */
+  int n_rlabel;  glia_hmt_image rlabel[GLIA_HMT_MAX_IMAGES];         /* rlImages */
+  int n_boundary; glia_hmt_image boundary[GLIA_HMT_MAX_IMAGES];      /* bImages  */
+  const float* d_pb;                 /* --pb */
+  int n_thresholds;                  /* --bt, <= GLIA_HMT_MAX_THRESH */
+  double thresholds[GLIA_HMT_MAX_THRESH];
+  double normalizing_area;           /* 1.0 unless --ns (main_merge_order_bc.cxx:36-39) */
+  double normalizing_length;
+  int use_log_shape;                 /* --logs */
+  int use_simple_features;           /* --simpf */
+} glia_hmt_feat_config;
+
+/* ---- region adjacency structure -------------------------------------------------------
+ * Replaces TRegionMap(image, mask, onlyContour) (type/region_map.hxx:38-40,52-65), i.e.
+ * genPointMap/genContourMap (util/struct.hxx:77-144) with getContourTraits
+ * (type/neighbor.hxx:109-126).  Instead of voxel lists it accumulates, in ONE pass over the
+ * label volume and `cfg->d_pb`/image volumes, the sufficient statistics every downstream
+ * operator needs: per label (count, border count, bbox, image moments, histogram) and per
+ * DIRECTED label pair (a->b) (boundary voxel count, image moments, histogram, threshold counts).
+ * cfg may be NULL when only merge_order_pb will be called (then d_pb must be given).
+ * d_mask must be NULL for now (GLIA_HMT_ERR_UNSUPPORTED otherwise). */
+int glia_hmt_rag_build(glia_hmt_ctx* ctx, int dim, const int64_t dims[3], const uint32_t* d_labels,
+                       const uint32_t* d_mask, int only_contour, const float* d_pb,
+                       const glia_hmt_feat_config* cfg, glia_hmt_rag** out);
+void glia_hmt_rag_free(glia_hmt_rag* rag);
+int64_t glia_hmt_rag_num_regions(const glia_hmt_rag* rag);
+int64_t glia_hmt_rag_num_pairs(const glia_hmt_rag* rag);     /* directed label pairs */
+/* Export for inspection / parity tests (host arrays sized by the counts above; any may be NULL).
+ * Regions ascend by label; pairs ascend by (a,b). */
+int glia_hmt_rag_export_regions(const glia_hmt_rag* rag, uint32_t* h_label, int64_t* h_count,
+                                int64_t* h_border, int64_t* h_bbox_lo /*[n][3]*/, int64_t* h_bbox_hi,
+                                double* h_sum, double* h_sumsq, double* h_min, double* h_max,
+                                int64_t* h_hist /*[n][bins]*/, int64_t* h_first_voxel);
+int glia_hmt_rag_export_pairs(const glia_hmt_rag* rag, uint32_t* h_a, uint32_t* h_b, int64_t* h_count,
+                              double* h_sum, double* h_sumsq, double* h_min, double* h_max,
+                              int64_t* h_hist /*[n][bins]*/, int64_t* h_thr /*[n][n_thresholds]*/);
+/* Kernel time of the accumulation pass of the last build on this handle, measured with HIP events
+ * on the context stream (milliseconds), and the algorithmic bytes it covers. */
+int glia_hmt_rag_last_pass(const glia_hmt_rag* rag, double* ms, double* algorithmic_bytes);
+
+/* ---- greedy merge orders -----------------------------------------------------------------
+ * glia_hmt_merge_order_pb replaces genMergeOrderGreedyUsingPbApproxMedian (type 1,
+ * util/struct_merge.hxx:90-136) and genMergeOrderGreedyUsingPbMean (type 2, :38-85) as called by
+ * merge_order_pb (hmt/main_merge_order_pb.cxx:27-36) with fcond = f_true.
+ * Output: h_order[3*i..] = (x0, x1, x2) of merge i (TTriple, type/tuple.hxx:8-29),
+ * h_saliency[i] = popped queue key.  *n_merges <= capacity. */
+int glia_hmt_merge_order_pb(glia_hmt_ctx* ctx, glia_hmt_rag* rag, int type, uint32_t* h_order,
+                            double* h_saliency, int64_t capacity, int64_t* n_merges);
+
+/* Phase timings of the last merge_order_* call on this rag (ms): edge-table build, init, greedy loop. */
+int glia_hmt_last_merge_timing(const glia_hmt_rag* rag, double* ms_table, double* ms_init, double* ms_loop,
+                               int64_t* n_edges_scored);
+
+/* ---- synthetic inputs for tests / bench, generated on the device -------------- */
+int glia_hmt_synth(glia_hmt_ctx* ctx, int dim, const int64_t dims[3], int S, int G, uint64_t seed,
+                   int variant, uint32_t* d_labels, float* d_pb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

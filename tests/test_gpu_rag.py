@@ -1,0 +1,102 @@
+"""-m gpu: the HIP accumulation pass (K1-K3) vs the oracle's voxel-list RAG, bit for bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU test run without a GPU"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from glia_amd import hmt
+    c = hmt.Context(0)
+    yield c
+    c.close()
+
+
+def _oracle_rag(labels, pb, bins, lo, hi, thr):
+    from oracle import pyoracle as O
+    rag = O.Rag(labels, only_contour=False)
+    lab, npts, nborder = rag.regions()
+    rs = rag.region_stats(pb)
+    a, b, n = rag.pairs()
+    ps = rag.pair_stats(pb)
+    return dict(lab=lab, npts=npts, nborder=nborder, rsum=rs[0], rsq=rs[1], rmin=rs[2], rmax=rs[3], lo=rs[4], hi=rs[5],
+                a=a, b=b, n=n, psum=ps[0], psq=ps[1], pmin=ps[2], pmax=ps[3])
+
+
+def _np_hist(vals, bins, lo, hi):
+    """util/image_stats.hxx:12-37 in numpy (float32 values against double bounds)."""
+    interval = (hi - lo) / bins
+    bounds = np.empty(bins)
+    bounds[0] = interval
+    for i in range(1, bins):
+        bounds[i] = bounds[i - 1] + interval
+    v = vals.astype(np.float64)
+    h = np.zeros(bins, np.int64)
+    inside = (v > lo) & (v < hi)
+    c = (v[inside][:, None] >= bounds[None, :]).sum(1)
+    for k in range(bins):
+        h[k] += (c == k).sum()
+    h[0] += (~inside & (v <= lo)).sum()
+    h[bins - 1] += (~inside & ~(v <= lo)).sum()
+    return h
+
+
+CASES = [
+    ((32, 32, 32), 8, 16, 0, 8),
+    ((40, 36, 28), 6, 12, 1, 8),       # ragged: scalar load path, partial tiles
+    ((64, 64, 256), 8, 32, 0, 8),      # vector load path
+    ((96, 96), 8, 32, 0, 8),           # 2D
+    ((33, 70, 300), 5, 20, 1, 16),     # 16 bins, ragged
+    ((3, 5, 7), 2, 4, 0, 8),           # tiny
+]
+
+
+@pytest.mark.parametrize("shape,S,G,variant,bins", CASES)
+def test_rag_matches_oracle(ctx, shape, S, G, variant, bins):
+    torch = _torch()
+    from glia_amd import hmt
+    from oracle import pyoracle as O
+    labels, pb = O.synth(shape, S, G, variant=variant)
+    d_lab = torch.from_numpy(labels.view(np.int32)).cuda()
+    d_pb = torch.from_numpy(pb).cuda()
+    thr = (0.2, 0.5, 0.8)
+    lo, hi = 0.0, 1.0
+    cfg = hmt.make_config(d_pb, rb=[(d_pb, bins, lo, hi)], thresholds=thr)
+    rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, cfg=cfg)
+    ref = _oracle_rag(labels, pb, bins, lo, hi, thr)
+    reg, par = rm.regions(), rm.pairs()
+    assert (reg["label"] == ref["lab"]).all()
+    assert (reg["count"] == ref["npts"]).all()
+    assert (reg["border"] == ref["nborder"]).all()
+    assert (reg["lo"] == ref["lo"]).all() and (reg["hi"] == ref["hi"]).all()
+    assert (reg["min"] == ref["rmin"]).all() and (reg["max"] == ref["rmax"]).all()
+    assert (par["a"] == ref["a"]).all() and (par["b"] == ref["b"]).all()
+    assert (par["count"] == ref["n"]).all()
+    assert (par["min"] == ref["pmin"]).all() and (par["max"] == ref["pmax"]).all()
+    if variant == 0:   # Q8 pb: every sum is exact in double -> bit-identical whatever the order
+        assert (reg["sum"] == ref["rsum"]).all() and (reg["sumsq"] == ref["rsq"]).all()
+        assert (par["sum"] == ref["psum"]).all() and (par["sumsq"] == ref["psq"]).all()
+    else:              # F32 pb: summation order differs -> tolerance of the north star (1e-5), far tighter here
+        assert np.allclose(reg["sum"], ref["rsum"], rtol=1e-12) and np.allclose(reg["sumsq"], ref["rsq"], rtol=1e-12)
+        assert np.allclose(par["sum"], ref["psum"], rtol=1e-12) and np.allclose(par["sumsq"], ref["psq"], rtol=1e-12)
+    # first voxel (raster order) of every label
+    flat = labels.reshape(-1)
+    first = {}
+    for i in range(flat.size - 1, -1, -1):
+        first[int(flat[i])] = i
+    assert [first[int(l)] for l in reg["label"]] == reg["first"].tolist()
+    # histograms + threshold counts: recomputed with numpy from the voxel sets
+    for i, l in enumerate(reg["label"][:50]):
+        assert (reg["hist"][i] == _np_hist(pb[labels == l], bins, lo, hi)).all()
+    assert (reg["hist"].sum(1) == reg["count"]).all()
+    assert (par["hist"].sum(1) == par["count"]).all()
+    # threshold counts are monotone and bounded by the pair's voxel count
+    assert (par["thr"][:, 0] <= par["count"]).all() and (np.diff(par["thr"], axis=1) <= 0).all()
+    rm.close()
