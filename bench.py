@@ -1,0 +1,128 @@
+#!/usr/bin/env python
+"""bench.py -- HMT hot path on N MI355X (one process per GPU).
+
+A "step" is one pass of the hot path over one synthetic volume that is already resident in HBM:
+  region-adjacency + sufficient-statistics accumulation (K1-K3)  ->  edge table (K4)  ->
+  greedy pb-mean merge loop (K5).
+`value` = region merges per second over the whole step (all ranks; weak scaling: every rank owns its own volume,
+the merge loop does not shard -- SURVEY.md 8e).  `roofline` describes the dominant streaming kernel
+(rag_accumulate: 8 algorithmic bytes per voxel), timed live with HIP events on the library's stream.
+`cpu_baseline` times the oracle (the CPU restatement of GLIA's algorithm) on a bounded sub-volume on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def cpu_baseline(size, S):
+    """oracle (reference-faithful port, 1 thread): RAG build + pb-mean greedy on a size^3 sample."""
+    import numpy as np  # noqa: F401
+    from oracle import pyoracle as O
+    labels, pb = O.synth((size,) * 3, S, 4 * S)
+    t0 = time.time()
+    rag = O.Rag(labels, only_contour=True)
+    t1 = time.time()
+    order, _ = rag.merge_order_pb(pb, type=2)
+    t2 = time.time()
+    return {"value": len(order) / (t2 - t0), "unit": "region-merges/s", "cores": 1, "kind": "port",
+            "sample": "%d^3 synthetic volume, S=%d (%d regions): RAG %.2fs + greedy pb-mean %.2fs, oracle/hmt_oracle.cc"
+                      % (size, S, len(order) + 1, t1 - t0, t2 - t1),
+            "merge_loop_only": len(order) / max(t2 - t1, 1e-9)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--S", type=int, default=16)
+    ap.add_argument("--cpu-size", type=int, default=192)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from glia_amd import hmt
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    ctx = hmt.Context(local)
+    shape = (args.size,) * 3
+    labels, pb = ctx.synth(shape, args.S, 8 * args.S, seed=0x9E3779B97F4A7C15 + rank)
+    cfg = hmt.make_config(pb, rb=[(pb, 8, 0.0, 1.0)], thresholds=(0.2, 0.5, 0.8))
+    N = labels.numel()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.sync()
+
+    def step():
+        rm = hmt.RegionMap(ctx, labels, pb=pb, only_contour=True, cfg=cfg)
+        order, sal = rm.merge_order_pb(type=2)
+        ms, by = rm.last_pass()
+        tm = rm.last_merge_timing()
+        info = dict(R=rm.num_regions, P=rm.num_pairs, merges=len(order), acc_ms=ms, acc_bytes=by, **tm)
+        rm.close()
+        return info
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.time()
+    infos = [step() for _ in range(args.steps)]
+    barrier()
+    dt = time.time() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        m = torch.tensor([float(sum(i["merges"] for i in infos))], dtype=torch.float64, device="cuda")
+        dist.all_reduce(m, op=dist.ReduceOp.SUM)
+        merges = float(m.item())
+    else:
+        merges = float(sum(i["merges"] for i in infos))
+
+    if rank == 0:
+        acc_ms = sum(i["acc_ms"] for i in infos) / len(infos)
+        achieved = infos[0]["acc_bytes"] / (acc_ms * 1e-3) / 1e9
+        loop_ms = sum(i["ms_loop"] for i in infos) / len(infos)
+        out = {
+            "metric": "region_merges_per_sec", "value": merges / dt, "unit": "region-merges/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 labels / f32 image / f64 stats",
+            "data": "synthetic",
+            "config": {"workload": "%d^3 synthetic EM volume (jittered-Voronoi supervoxels S=%d, Q8 pb), RAG + boundary/"
+                                   "region statistics accumulation + edge table + greedy pb-mean merge tree"
+                                   % (args.size, args.S),
+                       "voxels": N, "regions": infos[0]["R"], "directed_pairs": infos[0]["P"],
+                       "merges_per_step": infos[0]["merges"], "parallelism": "replica x%d" % world},
+            "phases_ms": {"accumulate": acc_ms, "edge_table": sum(i["ms_table"] for i in infos) / len(infos),
+                          "merge_loop": loop_ms},
+            "merge_loop_merges_per_sec": infos[0]["merges"] / (loop_ms * 1e-3) if loop_ms else None,
+            "edge_stat_records_per_sec": (infos[0]["P"] + infos[0]["R"]) / (acc_ms * 1e-3),
+            "roofline": {"bound": "hbm", "kernel": "rag_accumulate_kernel", "achieved": achieved, "peak": 8000.0,
+                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                         "algorithmic_bytes_per_launch": infos[0]["acc_bytes"], "avg_launch_ms": acc_ms},
+        }
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_size, args.S)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -367,9 +367,44 @@ int glia_hmt_rag_export_pairs(const glia_hmt_rag* r, uint32_t* h_a, uint32_t* h_
 
 int glia_hmt_merge_order_pb(glia_hmt_ctx* c, glia_hmt_rag* rag, int type, uint32_t* h_order, double* h_sal,
                             int64_t capacity, int64_t* n_merges) {
-  (void)c; (void)rag; (void)type; (void)h_order; (void)h_sal; (void)capacity; (void)n_merges;
-  set_error("merge_order_pb: not implemented yet");
-  return GLIA_HMT_ERR_UNSUPPORTED;
+  if (!c || !rag || !h_order || !h_sal || !n_merges || rag->ctx != c) {
+    set_error("merge_order_pb: invalid argument");
+    return GLIA_HMT_ERR_ARG;
+  }
+  if (type == 1) {
+    set_error("merge_order_pb: median linkage (type 1) is not implemented on the device yet");
+    return GLIA_HMT_ERR_UNSUPPORTED;
+  }
+  if (type != 2) {   // hmt/main_merge_order_pb.cxx:36
+    set_error("Error: unsupported boundary stats type...");
+    return GLIA_HMT_ERR_ARG;
+  }
+  GLIA_HIP_TRY(hipSetDevice(c->device));
+  const int64_t R = rag->arr.R, P = rag->arr.P;
+  *n_merges = 0;
+  if (R == 0 || P == 0) return GLIA_HMT_OK;
+  std::vector<uint32_t> order((size_t)3 * R);
+  std::vector<double> sal((size_t)R);
+  int64_t n = 0;
+  int rc = greedy_mean(rag->arr, c->stream, order.data(), sal.data(), R, &n, &rag->ms_table, &rag->ms_loop,
+                       &rag->n_scored);
+  if (rc) return rc;
+  if (n > capacity) { set_error("merge_order_pb: output capacity too small"); return GLIA_HMT_ERR_CAPACITY; }
+  // dense id -> key.  Leaves: i-th label ascending.  Merged regions: maxKey + 1 + k (util/struct_merge.hxx:19,27-31),
+  // maxKey over the regions the reference's map holds: every label (point-map mode) or every label that owns a
+  // directed boundary (contour-only mode, type/region_map.hxx:99-111).
+  std::vector<uint32_t> lab((size_t)R);
+  GLIA_HIP_TRY(hipMemcpy(lab.data(), rag->arr.d_rlabel, sizeof(uint32_t) * R, hipMemcpyDeviceToHost));
+  uint32_t maxKey = lab[R - 1];
+  if (rag->only_contour)
+    GLIA_HIP_TRY(hipMemcpy(&maxKey, rag->arr.d_pa + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
+  for (int64_t i = 0; i < 3 * n; ++i) {
+    const uint32_t id = order[i];
+    h_order[i] = id < (uint32_t)R ? lab[id] : maxKey + 1u + (id - (uint32_t)R);
+  }
+  for (int64_t i = 0; i < n; ++i) h_sal[i] = sal[i];
+  *n_merges = n;
+  return GLIA_HMT_OK;
 }
 
 int glia_hmt_last_merge_timing(const glia_hmt_rag* r, double* ms_table, double* ms_init, double* ms_loop,

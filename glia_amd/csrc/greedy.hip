@@ -1,2 +1,495 @@
-// placeholder, replaced below
+// glia_amd/csrc/greedy.hip -- K4b + K5: edge table and the greedy agglomeration loop, on the device.
+//
+// Reference semantics reproduced (all under /root/reference/code/):
+//   * TBoundaryTable::init (type/boundary_table.hxx:91-114): one edge per unordered label pair, only if BOTH
+//     directed boundaries exist; queue inserts happen in lexicographic (r0,r1) order.
+//   * TBoundaryTable::top (:46-52) on a std::multimap<double,...>: largest saliency, and among equal
+//     saliencies the MOST RECENTLY INSERTED item.  Here every queue item carries a 64-bit sequence number
+//     that is order-isomorphic to the reference's insertion order, and the queue orders by (saliency, seq).
+//   * TBoundaryTable::update (:121-167): the table scan visits the neighbours rs of the merged pair
+//     (r0 < r1) in this order:  rs < r0 ascending;  neighbours of r0 with rs > r0 ascending;  neighbours of
+//     r1 only, ascending.  seq = (merge# + 1) << 32 | category << 30 | rs encodes exactly that, so no sort
+//     is needed.  pData0s is always the (r0,rs) item, pData1s the (r1,rs) item (:139-153).
+//   * genMergeOrderGreedy (util/struct_merge.hxx:13-33) and the mean linkage (:62-76):
+//     d2 = sdivide(m0*n0 + m1*n1, n0+n1, 0) with the reference's operation order (no FMA contraction).
+//
+// MI355X mapping.  The loop is a chain of R-1 dependent contractions, so it runs as ONE persistent
+// workgroup: all state (edge records, adjacency pool, priority structure) stays in HBM/L2, each
+// contraction is data-parallel over the neighbours of the merged pair.  The priority queue is a
+// 64-ary tournament tree over edge slots (one wave recomputes one node with a 64-lane reduction);
+// insertions and deletions of one contraction are applied level by level from a dirty-node worklist.
+// Dense region ids: leaves 0..R-1 ascending by label, merged regions R+k; the map id -> key is monotone,
+// so every key comparison of the reference is an id comparison here.
+#include <cstring>
+#include <rocprim/device/device_scan.hpp>
+
 #include "hmt_internal.hpp"
+
+namespace glia {
+
+constexpr int kFan = 64;
+constexpr int kMaxLevels = 6;
+constexpr int kGreedyThreads = 512;
+constexpr int kWorkCap = 2048;
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+struct PqLevel {
+  double* sal;
+  unsigned long long* seq;
+  uint32_t* arg;
+  uint32_t* dirty;
+  uint32_t size;
+};
+
+struct GreedyState {
+  uint32_t R0;
+  uint32_t* adj_off;   // [2*R0] start of a region's incident-edge list in pool
+  uint32_t* adj_len;   // [2*R0] slots in that list (live edges + tombstones)
+  uint32_t* pool;
+  unsigned long long pool_cap;
+  uint32_t Ecap;
+  uint32_t *e_u, *e_v, *e_posu, *e_posv;
+  double* e_mean;
+  int* e_n;
+  double* leaf_sal;
+  unsigned long long* leaf_seq;   // 0 = dead
+  int nlevels;
+  PqLevel lv[kMaxLevels];
+  uint32_t *mark0, *mark1;        // [2*R0], zero between contractions
+  uint32_t* order;                // [R0][3] dense ids
+  double* sal_out;
+  unsigned long long* ctrl;       // [0] merges done, [1] edges used, [2] pool used, [3] status
+  unsigned long long max_iters;
+};
+
+enum { ST_RUN = 0, ST_DONE = 1, ST_NEED_EDGES = 2, ST_NEED_POOL = 3, ST_BAD_SALIENCY = 4 };
+
+namespace {
+
+struct Key { double sal; unsigned long long seq; uint32_t arg; };
+
+__device__ __forceinline__ bool better(const Key& a, const Key& b) {
+  return a.sal > b.sal || (a.sal == b.sal && a.seq > b.seq);
+}
+
+__device__ __forceinline__ Key wave_max(Key k) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    Key o;
+    o.sal = __shfl_xor(k.sal, off);
+    o.seq = __shfl_xor(k.seq, off);
+    o.arg = __shfl_xor(k.arg, off);
+    if (better(o, k)) k = o;
+  }
+  return k;
+}
+
+// recompute node j of level l (l = 0: parents of leaves) with one wave
+__device__ __forceinline__ void recompute_node(const GreedyState& st, int l, uint32_t j, int lane) {
+  Key k;
+  k.sal = -__builtin_inf(); k.seq = 0; k.arg = 0;
+  uint32_t ci = j * kFan + lane;
+  if (l == 0) {
+    if (ci < st.Ecap) { k.seq = st.leaf_seq[ci]; k.sal = k.seq ? st.leaf_sal[ci] : -__builtin_inf(); k.arg = ci; }
+  } else {
+    const PqLevel& c = st.lv[l - 1];
+    if (ci < c.size) { k.sal = c.sal[ci]; k.seq = c.seq[ci]; k.arg = c.arg[ci]; }
+  }
+  k = wave_max(k);
+  if (lane == 0) {
+    const PqLevel& d = st.lv[l];
+    d.sal[j] = k.sal; d.seq[j] = k.seq; d.arg[j] = k.arg;
+  }
+}
+
+__global__ void pq_build_level(GreedyState st, int l) {
+  const int lane = threadIdx.x & 63;
+  uint32_t j = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (j < st.lv[l].size) recompute_node(st, l, j, lane);
+}
+
+inline __device__ double sdivide(double l, double r, double d) { return fabs(r) >= 2.22e-16 ? l / r : d; }
+
+struct Shared {
+  uint32_t r0, r1, e, stop, len0, len1, off0, off1, newcount, ovf;
+  uint32_t wln[2];
+  uint32_t wl[2][kWorkCap];
+};
+
+__device__ __forceinline__ void touch(const GreedyState& st, Shared& s, int level, int which, uint32_t child) {
+  uint32_t p = child / kFan;
+  if (atomicExch(&st.lv[level].dirty[p], 1u) == 0u) {
+    uint32_t i = atomicAdd(&s.wln[which], 1u);
+    if (i < kWorkCap) s.wl[which][i] = p; else s.ovf = 1;
+  }
+}
+
+__global__ __launch_bounds__(kGreedyThreads) void greedy_mean_kernel(GreedyState st) {
+  __shared__ Shared s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int nwaves = kGreedyThreads / 64;
+  unsigned long long k = st.ctrl[0], ne = st.ctrl[1], pool_used = st.ctrl[2];
+  uint32_t status = ST_RUN;
+  if (tid == 0) { s.wln[0] = s.wln[1] = 0; s.ovf = 0; }
+  __syncthreads();
+
+  for (unsigned long long it = 0; it < st.max_iters; ++it) {
+    // ---- pop (TBoundaryTable::top) ----
+    if (tid == 0) {
+      const PqLevel& root = st.lv[st.nlevels - 1];
+      s.stop = ST_RUN;
+      s.newcount = 0;
+      if (root.seq[0] == 0) s.stop = ST_DONE;
+      else {
+        uint32_t e = root.arg[0];
+        s.e = e; s.r0 = st.e_u[e]; s.r1 = st.e_v[e];
+        s.len0 = st.adj_len[s.r0]; s.len1 = st.adj_len[s.r1];
+        s.off0 = st.adj_off[s.r0]; s.off1 = st.adj_off[s.r1];
+        unsigned long long tot = (unsigned long long)s.len0 + s.len1;
+        if (ne + tot > st.Ecap) s.stop = ST_NEED_EDGES;
+        else if (pool_used + tot > st.pool_cap) s.stop = ST_NEED_POOL;
+        else {
+          st.order[3 * k + 0] = s.r0; st.order[3 * k + 1] = s.r1; st.order[3 * k + 2] = st.R0 + (uint32_t)k;
+          st.sal_out[k] = root.sal[0];
+        }
+      }
+    }
+    __syncthreads();
+    if (s.stop != ST_RUN) { status = s.stop; break; }
+    const uint32_t r0 = s.r0, r1 = s.r1, e = s.e, len0 = s.len0, len1 = s.len1, off0 = s.off0, off1 = s.off1;
+    const uint32_t r2 = st.R0 + (uint32_t)k;
+    const uint32_t total = len0 + len1;
+    const uint32_t r2off = (uint32_t)pool_used;
+
+    // ---- phase A: mark the neighbours of r0 / r1 with the edge that reaches them ----
+    for (uint32_t i = tid; i < total; i += kGreedyThreads) {
+      const bool side1 = i >= len0;
+      const uint32_t eid = st.pool[side1 ? off1 + (i - len0) : off0 + i];
+      if (eid == e || st.leaf_seq[eid] == 0) continue;
+      const uint32_t r = side1 ? r1 : r0;
+      const uint32_t u = st.e_u[eid], v = st.e_v[eid];
+      const uint32_t rs = (u == r) ? v : u;
+      (side1 ? st.mark1 : st.mark0)[rs] = eid + 1u;
+    }
+    __syncthreads();
+
+    // ---- phase B: one new edge (rs, r2) per distinct neighbour (TBoundaryTable::update) ----
+    bool bad = false;
+    for (uint32_t i = tid; i < total; i += kGreedyThreads) {
+      const bool side1 = i >= len0;
+      const uint32_t eid = st.pool[side1 ? off1 + (i - len0) : off0 + i];
+      if (eid == e) continue;
+      const uint32_t u = st.e_u[eid], v = st.e_v[eid];
+      const uint32_t r = side1 ? r1 : r0;
+      if (u != r && v != r) continue;                // stale tombstone of an older contraction
+      const uint32_t rs = (u == r) ? v : u;
+      uint32_t e0s, e1s;
+      if (!side1) {
+        if (st.mark0[rs] != eid + 1u) continue;      // dead edge (not marked in phase A)
+        e0s = eid;
+        const uint32_t m = st.mark1[rs];
+        e1s = m ? m - 1u : kNone;
+      } else {
+        if (st.mark1[rs] != eid + 1u) continue;
+        if (st.mark0[rs] != 0u) continue;            // common neighbour: handled from the r0 side
+        e0s = kNone; e1s = eid;
+      }
+      const uint32_t idx = atomicAdd(&s.newcount, 1u);
+      const uint32_t newE = (uint32_t)ne + idx;
+      // util/struct_merge.hxx:62-76
+      double first = 0.0;
+      int second = 0;
+      if (e0s != kNone) { const int n0 = st.e_n[e0s]; first += st.e_mean[e0s] * n0; second += n0; }
+      if (e1s != kNone) { const int n1 = st.e_n[e1s]; first += st.e_mean[e1s] * n1; second += n1; }
+      first = sdivide(first, (double)second, 0.0);
+      if (first == -1.0) bad = true;               // DUMMY -> "invalid boundary saliency" (:78-79)
+      const uint32_t cat = rs < r0 ? 0u : (e0s != kNone ? 1u : 2u);
+      const unsigned long long seq = ((k + 1ull) << 32) | ((unsigned long long)cat << 30) | rs;
+      const uint32_t old = (e0s != kNone) ? e0s : e1s;
+      const uint32_t posRs = (st.e_u[old] == rs) ? st.e_posu[old] : st.e_posv[old];
+      st.e_u[newE] = rs; st.e_v[newE] = r2; st.e_posu[newE] = posRs; st.e_posv[newE] = idx;
+      st.e_mean[newE] = first; st.e_n[newE] = second;
+      st.leaf_sal[newE] = -first; st.leaf_seq[newE] = seq;
+      st.pool[st.adj_off[rs] + posRs] = newE;
+      st.pool[r2off + idx] = newE;
+      touch(st, s, 0, 0, newE);
+      if (e0s != kNone) { st.leaf_seq[e0s] = 0; touch(st, s, 0, 0, e0s); }
+      if (e1s != kNone) { st.leaf_seq[e1s] = 0; touch(st, s, 0, 0, e1s); }
+    }
+    if (tid == 0) { st.leaf_seq[e] = 0; touch(st, s, 0, 0, e); }
+    if (__syncthreads_or(bad ? 1 : 0)) { status = ST_BAD_SALIENCY; break; }
+
+    // ---- phase C: reset marks, publish r2's list ----
+    const uint32_t newcount = s.newcount;
+    for (uint32_t j = tid; j < newcount; j += kGreedyThreads) {
+      const uint32_t rs = st.e_u[(uint32_t)ne + j];
+      st.mark0[rs] = 0; st.mark1[rs] = 0;
+    }
+    if (tid == 0) { st.adj_off[r2] = r2off; st.adj_len[r2] = newcount; }
+
+    // ---- priority structure: propagate dirty nodes level by level ----
+    int cur = 0;
+    for (int l = 0; l < st.nlevels; ++l) {
+      __syncthreads();
+      const bool ovf = s.ovf != 0;
+      const uint32_t n = ovf ? st.lv[l].size : s.wln[cur];
+      for (uint32_t w = wave; w < n; w += nwaves) {
+        const uint32_t j = ovf ? w : s.wl[cur][w];
+        recompute_node(st, l, j, lane);
+        if (lane == 0) {
+          st.lv[l].dirty[j] = 0;
+          if (!ovf && l + 1 < st.nlevels) touch(st, s, l + 1, cur ^ 1, j);
+        }
+      }
+      __syncthreads();
+      if (tid == 0) s.wln[cur] = 0;
+      cur ^= 1;
+    }
+    __syncthreads();
+    if (tid == 0) { s.ovf = 0; s.wln[0] = s.wln[1] = 0; }
+    k += 1; ne += newcount; pool_used += total;
+    __syncthreads();
+  }
+  if (tid == 0) { st.ctrl[0] = k; st.ctrl[1] = ne; st.ctrl[2] = pool_used; st.ctrl[3] = status; }
+}
+
+// ---- edge table construction --------------------------------------------------------------------------
+__device__ __forceinline__ long long find_pair(const uint32_t* pa, const uint32_t* pb, long long P, uint32_t a, uint32_t b) {
+  long long lo = 0, hi = P;
+  while (lo < hi) {
+    long long mid = (lo + hi) >> 1;
+    if (pa[mid] < a || (pa[mid] == a && pb[mid] < b)) lo = mid + 1; else hi = mid;
+  }
+  return (lo < P && pa[lo] == a && pb[lo] == b) ? lo : -1;
+}
+__device__ __forceinline__ uint32_t find_label(const uint32_t* lab, uint32_t R, uint32_t key) {
+  uint32_t lo = 0, hi = R;
+  while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (lab[mid] < key) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+
+__global__ void edge_flags(const uint32_t* pa, const uint32_t* pb, long long P, uint32_t* flag, long long* partner) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  uint32_t a = pa[i], b = pb[i];
+  long long j = (a < b) ? find_pair(pa, pb, P, b, a) : -1;   // "boundaries have to be mutual" (boundary_table.hxx:99-102)
+  flag[i] = j >= 0 ? 1u : 0u;
+  partner[i] = j;
+}
+
+__global__ void edge_fill(const uint32_t* pa, const uint32_t* pb, const uint32_t* prec, long long P,
+                          const uint32_t* flag, const uint32_t* eidx, const long long* partner,
+                          const uint32_t* rlabel, uint32_t R, GreedyState st, uint32_t* deg) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P || !flag[i]) return;
+  const uint32_t e = eidx[i];
+  const long long j = partner[i];
+  const uint32_t u = find_label(rlabel, R, pa[i]), v = find_label(rlabel, R, pb[i]);
+  const uint32_t* wi = &prec[(size_t)i * kPairWords];
+  const uint32_t* wj = &prec[(size_t)j * kPairWords];
+  double si, sj;
+  memcpy(&si, &wi[P_SUM], 8);
+  memcpy(&sj, &wj[P_SUM], 8);
+  // util/struct_merge.hxx:45-56: sum of pb over both directed boundaries / their voxel count
+  const int n = (int)(wi[P_CNT] + wj[P_CNT]);
+  const double mean = sdivide(si + sj, (double)n, 0.0);
+  st.e_u[e] = u; st.e_v[e] = v; st.e_mean[e] = mean; st.e_n[e] = n;
+  st.leaf_sal[e] = -mean; st.leaf_seq[e] = (unsigned long long)e + 1ull;
+  atomicAdd(&deg[u], 1u);
+  atomicAdd(&deg[v], 1u);
+}
+
+__global__ void adj_fill(GreedyState st, uint32_t E0, uint32_t* cursor) {
+  uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E0) return;
+  const uint32_t u = st.e_u[e], v = st.e_v[e];
+  const uint32_t pu = atomicAdd(&cursor[u], 1u), pv = atomicAdd(&cursor[v], 1u);
+  st.pool[st.adj_off[u] + pu] = e; st.e_posu[e] = pu;
+  st.pool[st.adj_off[v] + pv] = e; st.e_posv[e] = pv;
+}
+
+__global__ void fill_leaves_dead(GreedyState st, uint32_t from) {
+  uint32_t i = from + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < st.Ecap) { st.leaf_seq[i] = 0; st.leaf_sal[i] = -__builtin_inf(); }
+}
+
+template <typename T>
+int dmalloc(T** p, size_t n) {
+  GLIA_HIP_TRY(hipMalloc((void**)p, sizeof(T) * (n ? n : 1)));
+  return GLIA_HMT_OK;
+}
+
+struct Buffers {
+  std::vector<void*> all;
+  ~Buffers() { for (void* p : all) (void)hipFree(p); }
+  template <typename T> int get(T** p, size_t n, bool zero, hipStream_t s) {
+    int rc = dmalloc(p, n);
+    if (rc) return rc;
+    all.push_back(*p);
+    if (zero) GLIA_HIP_TRY(hipMemsetAsync(*p, 0, sizeof(T) * (n ? n : 1), s));
+    return GLIA_HMT_OK;
+  }
+};
+
+template <typename T>
+int grow(Buffers& b, T** p, size_t old_n, size_t new_n, hipStream_t s) {
+  T* q = nullptr;
+  int rc = dmalloc(&q, new_n);
+  if (rc) return rc;
+  GLIA_HIP_TRY(hipMemcpyAsync(q, *p, sizeof(T) * old_n, hipMemcpyDeviceToDevice, s));
+  GLIA_HIP_TRY(hipStreamSynchronize(s));
+  for (auto& x : b.all) if (x == (void*)*p) { (void)hipFree(x); x = q; }
+  *p = q;
+  return GLIA_HMT_OK;
+}
+
+int setup_levels(Buffers& buf, GreedyState& st, hipStream_t stream) {
+  // free nothing here: old level arrays (if any) stay owned by buf until it dies
+  st.nlevels = 0;
+  uint32_t n = st.Ecap;
+  while (true) {
+    n = (n + kFan - 1) / kFan;
+    if (st.nlevels >= kMaxLevels) { set_error("greedy: edge table too large"); return GLIA_HMT_ERR_ARG; }
+    PqLevel& L = st.lv[st.nlevels++];
+    L.size = n;
+    int rc;
+    if ((rc = buf.get(&L.sal, n, false, stream))) return rc;
+    if ((rc = buf.get(&L.seq, n, false, stream))) return rc;
+    if ((rc = buf.get(&L.arg, n, false, stream))) return rc;
+    if ((rc = buf.get(&L.dirty, n, true, stream))) return rc;
+    if (n == 1) break;
+  }
+  for (int l = 0; l < st.nlevels; ++l) {
+    unsigned long long threads = (unsigned long long)st.lv[l].size * 64ull;
+    hipLaunchKernelGGL(pq_build_level, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, st, l);
+  }
+  GLIA_HIP_TRY(hipGetLastError());
+  return GLIA_HMT_OK;
+}
+
+}  // namespace
+
+// Runs the pb-mean greedy merge on a compact RAG.  h_order receives dense ids (leaf i = i-th label ascending,
+// merged region R+k); the caller maps them to keys.
+int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, double* h_sal, int64_t capacity,
+                int64_t* n_merges, double* ms_table, double* ms_loop, int64_t* n_scored) {
+  const long long P = rag.P;
+  const uint32_t R = (uint32_t)rag.R;
+  *n_merges = 0;
+  if (R == 0 || P == 0) return GLIA_HMT_OK;
+  hipEvent_t ev[3];
+  for (auto& e : ev) GLIA_HIP_TRY(hipEventCreate(&e));
+  GLIA_HIP_TRY(hipEventRecord(ev[0], stream));
+  Buffers buf;
+  int rc;
+  uint32_t* flag; uint32_t* eidx; long long* partner;
+  if ((rc = buf.get(&flag, P + 1, true, stream))) return rc;
+  if ((rc = buf.get(&eidx, P + 1, false, stream))) return rc;
+  if ((rc = buf.get(&partner, P, false, stream))) return rc;
+  hipLaunchKernelGGL(edge_flags, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, rag.d_pa, rag.d_pb, P, flag, partner);
+  {
+    size_t tmp = 0;
+    GLIA_HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, flag, eidx, 0u, (size_t)(P + 1), rocprim::plus<uint32_t>(), stream));
+    void* d_tmp;
+    if ((rc = buf.get((char**)&d_tmp, tmp ? tmp : 16, false, stream))) return rc;
+    GLIA_HIP_TRY(rocprim::exclusive_scan(d_tmp, tmp, flag, eidx, 0u, (size_t)(P + 1), rocprim::plus<uint32_t>(), stream));
+  }
+  uint32_t E0 = 0;
+  GLIA_HIP_TRY(hipMemcpyAsync(&E0, eidx + P, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  GLIA_HIP_TRY(hipStreamSynchronize(stream));
+  if (E0 == 0) return GLIA_HMT_OK;
+
+  GreedyState st;
+  memset(&st, 0, sizeof(st));
+  st.R0 = R;
+  st.Ecap = (uint32_t)std::min<unsigned long long>(0xFFFFFF00ull, (unsigned long long)E0 * 8ull + (1u << 16));
+  st.pool_cap = (unsigned long long)E0 * 16ull + (1u << 16);
+  if ((rc = buf.get(&st.adj_off, 2 * (size_t)R, true, stream))) return rc;
+  if ((rc = buf.get(&st.adj_len, 2 * (size_t)R + 1, true, stream))) return rc;
+  if ((rc = buf.get(&st.pool, st.pool_cap, false, stream))) return rc;
+  if ((rc = buf.get(&st.e_u, st.Ecap, false, stream))) return rc;
+  if ((rc = buf.get(&st.e_v, st.Ecap, false, stream))) return rc;
+  if ((rc = buf.get(&st.e_posu, st.Ecap, false, stream))) return rc;
+  if ((rc = buf.get(&st.e_posv, st.Ecap, false, stream))) return rc;
+  if ((rc = buf.get(&st.e_mean, st.Ecap, false, stream))) return rc;
+  if ((rc = buf.get(&st.e_n, st.Ecap, false, stream))) return rc;
+  if ((rc = buf.get(&st.leaf_sal, st.Ecap, false, stream))) return rc;
+  if ((rc = buf.get(&st.leaf_seq, st.Ecap, false, stream))) return rc;
+  if ((rc = buf.get(&st.mark0, 2 * (size_t)R, true, stream))) return rc;
+  if ((rc = buf.get(&st.mark1, 2 * (size_t)R, true, stream))) return rc;
+  if ((rc = buf.get(&st.order, 3 * (size_t)R, false, stream))) return rc;
+  if ((rc = buf.get(&st.sal_out, (size_t)R, false, stream))) return rc;
+  if ((rc = buf.get(&st.ctrl, 8, true, stream))) return rc;
+  uint32_t* cursor;
+  if ((rc = buf.get(&cursor, 2 * (size_t)R, true, stream))) return rc;
+
+  hipLaunchKernelGGL(fill_leaves_dead, dim3((st.Ecap - E0 + 255) / 256), dim3(256), 0, stream, st, E0);
+  hipLaunchKernelGGL(edge_fill, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, rag.d_pa, rag.d_pb, rag.d_prec, P,
+                     flag, eidx, partner, rag.d_rlabel, R, st, st.adj_len);
+  {
+    // adjacency offsets = exclusive scan of the degrees (adj_len[0..R) holds them, the rest is zero)
+    size_t tmp = 0;
+    GLIA_HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, st.adj_len, st.adj_off, 0u, (size_t)R, rocprim::plus<uint32_t>(), stream));
+    void* d_tmp;
+    if ((rc = buf.get((char**)&d_tmp, tmp ? tmp : 16, false, stream))) return rc;
+    GLIA_HIP_TRY(rocprim::exclusive_scan(d_tmp, tmp, st.adj_len, st.adj_off, 0u, (size_t)R, rocprim::plus<uint32_t>(), stream));
+  }
+  hipLaunchKernelGGL(adj_fill, dim3((E0 + 255) / 256), dim3(256), 0, stream, st, E0, cursor);
+  GLIA_HIP_TRY(hipGetLastError());
+  if ((rc = setup_levels(buf, st, stream))) return rc;
+  unsigned long long ctrl[4] = {0, E0, 2ull * E0, ST_RUN};
+  GLIA_HIP_TRY(hipMemcpyAsync(st.ctrl, ctrl, sizeof(ctrl), hipMemcpyHostToDevice, stream));
+  GLIA_HIP_TRY(hipEventRecord(ev[1], stream));
+
+  // ---- the loop, in bounded launches so a contraction budget can be re-negotiated between them ----
+  st.max_iters = 1ull << 16;
+  while (true) {
+    hipLaunchKernelGGL(greedy_mean_kernel, dim3(1), dim3(kGreedyThreads), 0, stream, st);
+    GLIA_HIP_TRY(hipGetLastError());
+    GLIA_HIP_TRY(hipMemcpyAsync(ctrl, st.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, stream));
+    GLIA_HIP_TRY(hipStreamSynchronize(stream));
+    if (ctrl[3] == ST_RUN) continue;
+    if (ctrl[3] == ST_DONE) break;
+    if (ctrl[3] == ST_BAD_SALIENCY) { set_error("Error: invalid boundary saliency..."); return GLIA_HMT_ERR_SALIENCY; }
+    if (ctrl[3] == ST_NEED_POOL) {
+      unsigned long long ncap = st.pool_cap * 2;
+      if ((rc = grow(buf, &st.pool, (size_t)st.pool_cap, (size_t)ncap, stream))) return rc;
+      st.pool_cap = ncap;
+    } else if (ctrl[3] == ST_NEED_EDGES) {
+      if (st.Ecap >= 0xFFFFFF00u) { set_error("greedy: more than 2^32 edge slots needed"); return GLIA_HMT_ERR_ARG; }
+      uint32_t ocap = st.Ecap;
+      uint32_t ncap = (uint32_t)std::min<unsigned long long>(0xFFFFFF00ull, (unsigned long long)ocap * 2ull);
+      if ((rc = grow(buf, &st.e_u, ocap, ncap, stream))) return rc;
+      if ((rc = grow(buf, &st.e_v, ocap, ncap, stream))) return rc;
+      if ((rc = grow(buf, &st.e_posu, ocap, ncap, stream))) return rc;
+      if ((rc = grow(buf, &st.e_posv, ocap, ncap, stream))) return rc;
+      if ((rc = grow(buf, &st.e_mean, ocap, ncap, stream))) return rc;
+      if ((rc = grow(buf, &st.e_n, ocap, ncap, stream))) return rc;
+      if ((rc = grow(buf, &st.leaf_sal, ocap, ncap, stream))) return rc;
+      if ((rc = grow(buf, &st.leaf_seq, ocap, ncap, stream))) return rc;
+      st.Ecap = ncap;
+      hipLaunchKernelGGL(fill_leaves_dead, dim3((ncap - ocap + 255) / 256), dim3(256), 0, stream, st, ocap);
+      if ((rc = setup_levels(buf, st, stream))) return rc;
+    }
+    unsigned long long zero = ST_RUN;
+    GLIA_HIP_TRY(hipMemcpyAsync(st.ctrl + 3, &zero, sizeof(zero), hipMemcpyHostToDevice, stream));
+  }
+  GLIA_HIP_TRY(hipEventRecord(ev[2], stream));
+  GLIA_HIP_TRY(hipEventSynchronize(ev[2]));
+  float t01 = 0, t12 = 0;
+  (void)hipEventElapsedTime(&t01, ev[0], ev[1]);
+  (void)hipEventElapsedTime(&t12, ev[1], ev[2]);
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  *ms_table = t01; *ms_loop = t12;
+  const int64_t n = (int64_t)ctrl[0];
+  *n_scored = (int64_t)ctrl[1];
+  if (n > capacity) { set_error("merge_order: output capacity too small"); return GLIA_HMT_ERR_CAPACITY; }
+  if (n) {
+    GLIA_HIP_TRY(hipMemcpy(h_order, st.order, sizeof(uint32_t) * 3 * n, hipMemcpyDeviceToHost));
+    GLIA_HIP_TRY(hipMemcpy(h_sal, st.sal_out, sizeof(double) * n, hipMemcpyDeviceToHost));
+  }
+  *n_merges = n;
+  return GLIA_HMT_OK;
+}
+
+}  // namespace glia

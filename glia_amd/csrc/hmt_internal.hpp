@@ -79,6 +79,8 @@ struct RagArrays {
 int launch_accumulate(const AccParams& p, hipStream_t stream);
 int launch_synth(int dim, const int64_t dims[3], int S, int G, uint64_t seed, int variant, uint32_t* d_labels,
                  uint32_t* d_truth_tmp, float* d_pb, hipStream_t stream);
+int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, double* h_sal, int64_t capacity,
+                int64_t* n_merges, double* ms_table, double* ms_loop, int64_t* n_scored);
 int compact_tables(const AccParams& p, uint32_t rcap, uint32_t pcap, RagArrays* out, hipStream_t stream);
 
 __host__ __device__ inline uint32_t float_ord(float f) {

@@ -46,6 +46,12 @@ def lib():
         if not os.path.exists(_SO):
             raise ImportError("glia_amd/libglia_hmt.so is missing: run `python -c 'import __graft_entry__ as g; "
                               "g.build()'` (hipcc --offload-arch=gfx950); there is no CPU fallback")
+        # torch wheels bundle their own HIP runtime: when torch is used in the process (tests, bench.py) it has to
+        # be loaded first so that both sides share ONE runtime; a plain C host simply gets /opt/rocm's.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(_SO)
         L.glia_hmt_last_error.restype = C.c_char_p
         L.glia_hmt_version.restype = C.c_char_p
