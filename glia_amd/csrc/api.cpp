@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <mutex>
@@ -258,18 +259,23 @@ int glia_hmt_rag_build(glia_hmt_ctx* c, int dim, const int64_t dims[3], const ui
     p.rkeys = c->rkeys; p.rrec = c->rrec; p.rmask = c->rcap - 1;
     p.pkeys = c->pkeys; p.prec = c->prec; p.pmask = c->pcap - 1;
     p.flags = c->flags;
+    { const char* dbg = getenv("GLIA_HMT_DEBUG"); p.debug = dbg ? (uint32_t)strtoul(dbg, nullptr, 0) : 0u; }
     if ((int64_t)p.nbx * p.nby * p.nbz >= (1ll << 31)) { delete rag; set_error("rag_build: volume too large"); return GLIA_HMT_ERR_ARG; }
     hipError_t e = hipEventRecord(c->ev0, c->stream);
     if (e == hipSuccess) { rc = launch_accumulate(p, c->stream); e = hipEventRecord(c->ev1, c->stream); }
     if (e != hipSuccess) { delete rag; set_error(hipGetErrorString(e)); return GLIA_HMT_ERR_HIP; }
     if (rc) { delete rag; return rc; }
-    uint32_t flags[2] = {0, 0};
+    uint32_t flags[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     e = hipMemcpyAsync(flags, c->flags, sizeof(flags), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { delete rag; set_error(std::string("rag_build: ") + hipGetErrorString(e)); return GLIA_HMT_ERR_HIP; }
     float ms = 0;
     (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
     rag->pass_ms = ms;
+    if (p.debug & 16) {
+      fprintf(stderr, "[glia_hmt debug] region flushes %u (lds-miss %u), pair flushes %u (lds-miss %u)\n", flags[2], flags[4], flags[3], flags[5]);
+      (void)hipMemsetAsync(c->flags, 0, 64, c->stream);
+    }
     rag->alg_bytes = (double)N * 8.0;
     if (flags[0] || flags[1]) {
       // a table filled up: drop the partial result, grow and redo the pass

@@ -64,6 +64,7 @@ struct AccParams {
   uint32_t* prec;
   uint32_t pmask;
   uint32_t* flags;                   // [0] region table full, [1] pair table full
+  uint32_t debug;                    // ablation switches for profiling builds (GLIA_HMT_DEBUG), 0 in production
 };
 
 // compact, sorted RAG as produced by the edge-table step

@@ -190,15 +190,19 @@ __device__ __forceinline__ void write_pair(uint32_t* rec, const PairRun<BINS>& r
 
 template <int BINS>
 __device__ __forceinline__ void flush_region(Lds& s, const AccParams& p, const RegionRun<BINS>& r, int y) {
+  if (p.debug & 16) atomicAdd(&p.flags[2], 1u);
   int slot = lds_region_slot(s, r.key);
   if (slot >= 0) { write_region<BINS>(&s.rrec[slot * kRegionWords], r, y); return; }
+  if (p.debug & 16) atomicAdd(&p.flags[4], 1u);
   int g = global_region_slot(p, r.key);     // LDS table saturated: straight to HBM (slow, still exact)
   if (g >= 0) write_region<BINS>(&p.rrec[(size_t)g * kRegionWords], r, y);
 }
 template <int BINS>
 __device__ __forceinline__ void flush_pair(Lds& s, const AccParams& p, const PairRun<BINS>& r) {
+  if (p.debug & 16) atomicAdd(&p.flags[3], 1u);
   int slot = lds_pair_slot(s, r.key);
   if (slot >= 0) { write_pair<BINS>(&s.prec[slot * kPairWordsLds], r, p.nthr); return; }
+  if (p.debug & 16) atomicAdd(&p.flags[5], 1u);
   int g = global_pair_slot(p, r.key);
   if (g >= 0) write_pair<BINS>(&p.prec[(size_t)g * kPairWords], r, p.nthr);
 }
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(kThreads, 4) void rag_accumulate_kernel(const AccPa
 #pragma unroll
     for (int i = 0; i < kVX; ++i) {
       const int64_t x = x0 + i;
-      if (!(rowOk && x < nx)) continue;
+      if (!(rowOk && x < nx) || (p.debug & 4)) continue;
       const uint32_t L = Lc.v[i];
       const uint32_t xm = (i == 0) ? left : Lc.v[i > 0 ? i - 1 : 0];
       const uint32_t xp = (i == kVX - 1) ? right : Lc.v[i < kVX - 1 ? i + 1 : kVX - 1];
@@ -310,7 +314,7 @@ __global__ __launch_bounds__(kThreads, 4) void rag_accumulate_kernel(const AccPa
 
       const uint32_t rkey = L + 1u;
       if (rkey != rr.key) {
-        if (rr.key) flush_region<BINS>(s, p, rr, (int)y);
+        if (rr.key && !(p.debug & 1)) flush_region<BINS>(s, p, rr, (int)y);
         rr.key = rkey; rr.m.reset(); rr.border = 0;
         rr.xlo = rr.xhi = (int)x; rr.zlo = (int)z;
         rr.first = (unsigned long long)(z * sz + y * sy + x);
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(kThreads, 4) void rag_accumulate_kernel(const AccPa
       if (boundary) {
         const unsigned long long pkey = ((unsigned long long)rkey << 32) | (unsigned long long)(b + 1u);
         if (pkey != pr.key) {
-          if (pr.key) flush_pair<BINS>(s, p, pr);
+          if (pr.key && !(p.debug & 2)) flush_pair<BINS>(s, p, pr);
           pr.key = pkey; pr.m.reset(); pr.thr = 0;
         }
         pr.m.add(v, bin);
@@ -339,6 +343,7 @@ __global__ __launch_bounds__(kThreads, 4) void rag_accumulate_kernel(const AccPa
   if (pr.key) flush_pair<BINS>(s, p, pr);
   __syncthreads();
 
+  if (p.debug & 8) return;
   // ---- fold the workgroup's LDS tables into the global tables ----
   for (int i = tid; i < kLdsRegionSlots + kLdsPairSlots; i += kThreads) {
     int g = -1;
