@@ -250,8 +250,8 @@ int glia_hmt_rag_build(glia_hmt_ctx* c, int dim, const int64_t dims[3], const ui
     AccParams p;
     p.lab = d_labels; p.img = img;
     p.nx = nx; p.ny = ny; p.nz = nz; p.dim = dim;
-    p.nbx = (int)((nx + kRowX - 1) / kRowX);
-    p.nby = (int)((ny + kRows - 1) / kRows);
+    p.nbx = (int)((nx + kTileX - 1) / kTileX);
+    p.nby = (int)((ny + kTileY - 1) / kTileY);
     p.nbz = (int)((nz + kTZ - 1) / kTZ);
     p.hist = make_hist_spec(bins, lo, hi);
     p.nthr = nthr;
@@ -272,8 +272,8 @@ int glia_hmt_rag_build(glia_hmt_ctx* c, int dim, const int64_t dims[3], const ui
     float ms = 0;
     (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
     rag->pass_ms = ms;
-    if (p.debug & 16) {
-      fprintf(stderr, "[glia_hmt debug] region flushes %u (lds-miss %u), pair flushes %u (lds-miss %u)\n", flags[2], flags[4], flags[3], flags[5]);
+    if (p.debug & 32) {
+      fprintf(stderr, "[glia_hmt debug] region runs %u (lds-miss %u), pair runs %u (lds-miss %u), drains %u\n", flags[2], flags[4], flags[3], flags[5], flags[6]);
       (void)hipMemsetAsync(c->flags, 0, 64, c->stream);
     }
     rag->alg_bytes = (double)N * 8.0;

@@ -20,12 +20,17 @@ void set_error(const std::string& msg);
   } while (0)
 
 // ---- accumulation tile geometry -------------------------------------------------------------
-constexpr int kVX = 4;            // voxels per lane along x (one 16-byte load)
-constexpr int kWave = 64;
-constexpr int kRowX = kWave * kVX;  // 256 voxels of one row per wave
-constexpr int kRows = 8;          // waves (= y rows) per workgroup
-constexpr int kThreads = kRows * kWave;
-constexpr int kTZ = 32;           // planes a workgroup marches through; kTZ*kVX <= 255 (8-bit run counters)
+constexpr int kVX = 4;             // voxels per lane along x (one 16-byte load)
+#ifndef GLIA_LANES_PER_ROW
+#define GLIA_LANES_PER_ROW 16
+#endif
+constexpr int kLanesPerRow = GLIA_LANES_PER_ROW;       // 16: wave = 4 rows x 64 voxels; 64: wave = 1 row x 256 voxels
+constexpr int kRowsPerWave = 64 / kLanesPerRow;
+constexpr int kTileWaves = 8;
+constexpr int kTileX = kLanesPerRow * kVX;
+constexpr int kTileY = kTileWaves * kRowsPerWave;
+constexpr int kThreads = kTileWaves * 64;
+constexpr int kTZ = 32;            // planes a workgroup marches through; kTZ*kVX <= 255 (8-bit run counters)
 
 // ---- record layouts (32-bit words).  All zero == "empty": minima / lower bounds are stored
 // complemented so that every reduction is an add or an unsigned max and tables initialise by memset.
@@ -35,11 +40,8 @@ constexpr int R_CNT = 0, R_BORDER = 1, R_LO = 2 /*3: 0x7fffffff-lo*/, R_HI = 5 /
 constexpr int kRegionWords = 32;
 // directed pair record
 constexpr int P_CNT = 0, P_MIN = 1, P_MAX = 2, P_THR = 4 /*4*/, P_SUM = 8, P_SQ = 10, P_HIST = 12;
-constexpr int kPairWordsLds = 28;   // LDS stride
 constexpr int kPairWords = 32;      // global stride (128-byte lines)
 
-constexpr int kLdsRegionSlots = 128;
-constexpr int kLdsPairSlots = 512;
 
 struct HistSpec {
   int bins;

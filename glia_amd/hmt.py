@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libglia_hmt.so")
+_SO = os.environ.get("GLIA_HMT_LIB", os.path.join(_HERE, "libglia_hmt.so"))   # override: kernel experiments only
 
 MAX_IMAGES, MAX_BINS, MAX_THRESH = 8, 16, 4
 
