@@ -8,6 +8,8 @@
 #include <limits>
 #include <mutex>
 
+#include "bc_features.hpp"
+#include "forest.hpp"
 #include "hmt_internal.hpp"
 
 namespace glia {
@@ -409,6 +411,121 @@ int glia_hmt_merge_order_pb(glia_hmt_ctx* c, glia_hmt_rag* rag, int type, uint32
     h_order[i] = id < (uint32_t)R ? lab[id] : maxKey + 1u + (id - (uint32_t)R);
   }
   for (int64_t i = 0; i < n; ++i) h_sal[i] = sal[i];
+  *n_merges = n;
+  return GLIA_HMT_OK;
+}
+
+static int upload_forest(const HostForest& hf, glia_hmt_forest* f, int slot, hipStream_t stream) {
+  double* d_split = nullptr;
+  int4* d_meta = nullptr;
+  GLIA_HIP_TRY(hipMalloc(&d_split, sizeof(double) * hf.split.size()));
+  f->allocs.push_back(d_split);
+  GLIA_HIP_TRY(hipMalloc(&d_meta, sizeof(int) * hf.meta.size()));
+  f->allocs.push_back(d_meta);
+  GLIA_HIP_TRY(hipMemcpyAsync(d_split, hf.split.data(), sizeof(double) * hf.split.size(), hipMemcpyHostToDevice, stream));
+  GLIA_HIP_TRY(hipMemcpyAsync(d_meta, hf.meta.data(), sizeof(int) * hf.meta.size(), hipMemcpyHostToDevice, stream));
+  GLIA_HIP_TRY(hipStreamSynchronize(stream));
+  f->dc.f[slot].ntree = hf.ntree; f->dc.f[slot].nrnodes = hf.nrnodes;
+  f->dc.f[slot].split = d_split; f->dc.f[slot].meta = d_meta;
+  if (hf.max_var > f->max_var) f->max_var = hf.max_var;
+  return GLIA_HMT_OK;
+}
+
+int glia_hmt_forest_load(glia_hmt_ctx* c, int n_models, const char* const* paths, int predict_label,
+                         const double* dist, glia_hmt_forest** out) {
+  if (!c || !paths || !out || (n_models != 1 && n_models != 3)) {
+    set_error("forest_load: one model, or three models with distributor arguments, expected");
+    return GLIA_HMT_ERR_ARG;
+  }
+  if (n_models == 3 && !dist) { set_error("Error: model distributor needs 3 arguments..."); return GLIA_HMT_ERR_ARG; }
+  GLIA_HIP_TRY(hipSetDevice(c->device));
+  glia_hmt_forest* f = new glia_hmt_forest;
+  f->device = c->device;
+  memset(&f->dc, 0, sizeof(f->dc));
+  f->dc.kind = 0; f->dc.n_models = n_models;
+  if (dist) { f->dc.dim0 = (int)dist[0]; f->dc.dim1 = (int)dist[1]; f->dc.threshold = dist[2]; }
+  for (int i = 0; i < n_models; ++i) {
+    HostForest hf;
+    int rc = load_forest_file(paths[i], predict_label, &hf);
+    if (rc == GLIA_HMT_OK && i > 0 && hf.ntree != f->dc.f[0].ntree) {
+      set_error("forest_load: ensemble members with different tree counts are not supported");
+      rc = GLIA_HMT_ERR_UNSUPPORTED;
+    }
+    if (rc == GLIA_HMT_OK) rc = upload_forest(hf, f, i, c->stream);
+    if (rc) { glia_hmt_forest_free(f); return rc; }
+  }
+  *out = f;
+  return GLIA_HMT_OK;
+}
+
+int glia_hmt_forest_stub(glia_hmt_ctx* c, int feature_index, glia_hmt_forest** out) {
+  if (!c || !out || feature_index < 0) { set_error("forest_stub: invalid argument"); return GLIA_HMT_ERR_ARG; }
+  glia_hmt_forest* f = new glia_hmt_forest;
+  f->device = c->device;
+  memset(&f->dc, 0, sizeof(f->dc));
+  f->dc.kind = 1; f->dc.n_models = 1; f->dc.stub_index = feature_index; f->max_var = feature_index;
+  *out = f;
+  return GLIA_HMT_OK;
+}
+
+void glia_hmt_forest_free(glia_hmt_forest* f) {
+  if (!f) return;
+  (void)hipSetDevice(f->device);
+  for (void* p : f->allocs) (void)hipFree(p);
+  delete f;
+}
+
+static bool make_bc_cfg(const glia_hmt_rag* rag, BcCfg* c) {
+  if (!rag->has_cfg) return false;
+  const glia_hmt_feat_config& g = rag->cfg;
+  c->D = rag->dim; c->T = g.n_thresholds; c->bins = rag->bins;
+  c->n_region = g.n_region; c->n_rlabel = g.n_rlabel; c->n_boundary = g.n_boundary;
+  c->use_log = g.use_log_shape; c->use_simple = g.use_simple_features;
+  c->norm_area = g.normalizing_area; c->norm_len = g.normalizing_length;
+  c->rfdim = bc_rf_dim(*c); c->bfdim = bc_bf_dim(*c); c->fdim = bc_feat_dim(*c);
+  return true;
+}
+
+int glia_hmt_feat_dim(const glia_hmt_rag* rag) {
+  BcCfg c;
+  if (!rag || !make_bc_cfg(rag, &c)) return -1;
+  return c.fdim;
+}
+
+int glia_hmt_merge_order_bc(glia_hmt_ctx* c, glia_hmt_rag* rag, const glia_hmt_forest* forest, uint32_t* h_order,
+                            double* h_sal, double* h_feats, int64_t capacity, int64_t* n_merges) {
+  if (!c || !rag || !forest || !h_order || !h_sal || !n_merges || rag->ctx != c) {
+    set_error("merge_order_bc: invalid argument");
+    return GLIA_HMT_ERR_ARG;
+  }
+  BcCfg cfg;
+  if (!make_bc_cfg(rag, &cfg) || rag->only_contour) {
+    set_error("merge_order_bc: the region map must be built with a feature configuration and with region points");
+    return GLIA_HMT_ERR_ARG;
+  }
+  if (forest->max_var >= cfg.fdim) { set_error("merge_order_bc: the classifier reads features beyond the vector"); return GLIA_HMT_ERR_ARG; }
+  GLIA_HIP_TRY(hipSetDevice(c->device));
+  const int64_t R = rag->arr.R;
+  *n_merges = 0;
+  if (R == 0 || rag->arr.P == 0) return GLIA_HMT_OK;
+  std::vector<uint32_t> order((size_t)3 * R);
+  std::vector<double> sal((size_t)R);
+  std::vector<double> feats;
+  if (h_feats) feats.resize((size_t)R * cfg.fdim);
+  int64_t n = 0;
+  int rc = greedy_bc(rag->arr, cfg, forest->dc, c->stream, order.data(), sal.data(), h_feats ? feats.data() : nullptr, R, &n,
+                     &rag->ms_table, &rag->ms_init, &rag->ms_loop, &rag->n_scored);
+  if (rc) return rc;
+  if (n > capacity) { set_error("merge_order_bc: output capacity too small"); return GLIA_HMT_ERR_CAPACITY; }
+  std::vector<uint32_t> lab((size_t)R);
+  GLIA_HIP_TRY(hipMemcpy(lab.data(), rag->arr.d_rlabel, sizeof(uint32_t) * R, hipMemcpyDeviceToHost));
+  const uint32_t maxKey = lab[R - 1];
+  for (int64_t i = 0; i < 3 * n; ++i) {
+    const uint32_t id = order[i];
+    h_order[i] = id < (uint32_t)R ? lab[id] : maxKey + 1u + (id - (uint32_t)R);
+  }
+  for (int64_t i = 0; i < n; ++i) h_sal[i] = sal[i];
+  if (h_feats) memcpy(h_feats, feats.data(), sizeof(double) * (size_t)n * cfg.fdim);
   *n_merges = n;
   return GLIA_HMT_OK;
 }

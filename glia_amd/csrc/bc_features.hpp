@@ -1,0 +1,241 @@
+// glia_amd/csrc/bc_features.hpp -- K6: boundary-classifier feature vector from sufficient statistics (device).
+//
+// The reference re-walks the voxels of r0, r1 and r0 u r1 for every candidate edge
+// (hmt/main_merge_order_bc.cxx:54-95, 98 % of its run time).  Every feature is a function of
+// mergeable statistics -- counts, f64 sums, min/max, integer histograms, bounding boxes, thresholded counts --
+// so here a feature vector costs O(D_f) flops.  Formulas follow, operation for operation (device code is built
+// with -ffp-contract=off):
+//   RegionShapeFeats::generate            type/feat.hxx:71-90     alg::getBoundingBox  alg/geometry.hxx:21-39
+//   ImageRegionShapeFeats::generate       type/feat.hxx:485-502
+//   ImageLabelFeats / ImageRealFeats      type/feat.hxx:632-638, 706-737   hist: util/image_stats.hxx:41-52
+//   stats::entropy / distL1 / distX2      util/stats.hxx:145-152, 155-163, 177-185
+//   RegionShapeDiffFeats / IntraDiffFeats type/feat.hxx:124-132, 176-186, 567-589
+//   ImageDiffFeats                        type/feat.hxx:663-669, 801-810
+//   RegionFeats / BoundaryFeats layout    hmt/bc_feat.hxx:69-77, 156-167, 232-238;  log(): feat.hxx:46-52,...
+//   selectFeatures                        hmt/bc_feat.hxx:247-279
+#pragma once
+#include "hmt_internal.hpp"
+
+namespace glia {
+
+constexpr int kMaxFeat = 160;   // 11+4T+7+3+5 + 3*(4+D+2T+5+1+5) with D=3, T=4
+
+// statistics of a set of boundary voxels (a commutative monoid under combine)
+struct EStats {
+  uint32_t n;
+  uint32_t thr[GLIA_HMT_MAX_THRESH];
+  float mn, mx;          // +inf / -inf when n == 0
+  double sum, sq;
+  uint32_t hist[GLIA_HMT_MAX_BINS];
+};
+// statistics of the voxels of a region
+struct PStats {
+  uint32_t n, border;
+  int lo[3], hi[3];
+  float mn, mx;
+  double sum, sq;
+  uint32_t hist[GLIA_HMT_MAX_BINS];
+};
+
+__host__ __device__ inline void estats_clear(EStats& s) {
+  s.n = 0;
+  for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) s.thr[i] = 0;
+  s.mn = __builtin_inff(); s.mx = -__builtin_inff(); s.sum = 0.0; s.sq = 0.0;
+  for (int i = 0; i < GLIA_HMT_MAX_BINS; ++i) s.hist[i] = 0;
+}
+__host__ __device__ inline void estats_add(EStats& a, const EStats& b) {
+  a.n += b.n;
+  for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) a.thr[i] += b.thr[i];
+  a.mn = b.mn < a.mn ? b.mn : a.mn; a.mx = b.mx > a.mx ? b.mx : a.mx;
+  a.sum += b.sum; a.sq += b.sq;
+  for (int i = 0; i < GLIA_HMT_MAX_BINS; ++i) a.hist[i] += b.hist[i];
+}
+// additive part only (counts and sums); min/max untouched
+__host__ __device__ inline void estats_sub_additive(EStats& a, const EStats& b) {
+  a.n -= b.n;
+  for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) a.thr[i] -= b.thr[i];
+  a.sum -= b.sum; a.sq -= b.sq;
+  for (int i = 0; i < GLIA_HMT_MAX_BINS; ++i) a.hist[i] -= b.hist[i];
+}
+__host__ __device__ inline void pstats_add(PStats& a, const PStats& b) {
+  a.n += b.n; a.border += b.border;
+  for (int i = 0; i < 3; ++i) { a.lo[i] = b.lo[i] < a.lo[i] ? b.lo[i] : a.lo[i]; a.hi[i] = b.hi[i] > a.hi[i] ? b.hi[i] : a.hi[i]; }
+  a.mn = b.mn < a.mn ? b.mn : a.mn; a.mx = b.mx > a.mx ? b.mx : a.mx;
+  a.sum += b.sum; a.sq += b.sq;
+  for (int i = 0; i < GLIA_HMT_MAX_BINS; ++i) a.hist[i] += b.hist[i];
+}
+
+struct BcCfg {
+  int D, T, bins;
+  int n_region, n_rlabel, n_boundary;   // 0 or 1 each: all lists share one image volume (see rag_build)
+  int use_log, use_simple;
+  double norm_area, norm_len;
+  int rfdim, bfdim, fdim;
+};
+
+__host__ __device__ inline int bc_rf_dim(const BcCfg& c) { return 4 + c.D + 2 * c.T + 5 * c.n_region + c.n_rlabel + 5 * c.n_boundary; }
+__host__ __device__ inline int bc_bf_dim(const BcCfg& c) { return 11 + 4 * c.T + 7 * c.n_region + 3 * c.n_rlabel + 5 * c.n_boundary; }
+__host__ __device__ inline int bc_feat_dim(const BcCfg& c) {
+  return c.use_simple ? 5 + c.n_boundary + 4 * c.n_region + 2 * c.n_rlabel : bc_bf_dim(c) + 3 * bc_rf_dim(c);
+}
+
+namespace feat {
+
+__device__ inline double sdiv(double l, double r, double d) { return fabs(r) >= 2.22e-16 ? l / r : d; }
+__device__ inline double slog(double x, double d) { return x > 0.0 ? log(x) : d; }
+__device__ inline double ssqrt(double x, double d) { return x >= 0.0 ? sqrt(x) : d; }
+
+// histogram -> entropy (normalised by the set's voxel count), also returns the normalised histogram
+__device__ inline double hist_entropy(const uint32_t* hc, uint32_t n, int bins, double* h) {
+  double ent = 0.0;
+  for (int i = 0; i < bins; ++i) {
+    double p = n ? hc[i] / (double)n : 0.0;
+    h[i] = p;
+    if (!(fabs(p - 0.0) < 2.22e-16)) ent -= p * log2(p);
+  }
+  return ent;
+}
+
+// the five ImageFeats numbers (entropy, mean, std, min, max) of a voxel set
+struct ImgFeats { double entropy, mean, stddev, mn, mx; };
+__device__ inline ImgFeats image_feats(const uint32_t* hc, uint32_t n, double sum, double sq, float mn, float mx, int bins,
+                                       double* h) {
+  ImgFeats f;
+  f.entropy = hist_entropy(hc, n, bins, h);
+  f.mean = 0.0; f.stddev = 0.0; f.mn = 0.0; f.mx = 0.0;
+  const int ni = (int)n;
+  if (ni != 0) {
+    f.mean = sum / ni;
+    f.stddev = ssqrt(sq / ni - f.mean * f.mean, 0.0);
+    f.mn = (double)mn; f.mx = (double)mx;
+  }
+  return f;
+}
+
+// RegionFeats of one region: p = its voxels, b = its un-cancelled boundary set.  Writes rfdim doubles to out and
+// the pieces BoundaryFeats needs to `aux` (area, perim after normalisation + region-image feats + histograms).
+struct RegionAux {
+  double area, perim;
+  ImgFeats rimg, rlimg;
+  double rh[GLIA_HMT_MAX_BINS];
+};
+
+__device__ inline void region_feats(const BcCfg& c, const PStats& p, const EStats& b, double* out, RegionAux& aux) {
+  const int D = c.D, T = c.T;
+  double area = (double)p.n;
+  double perim = (double)((unsigned long long)b.n + (unsigned long long)p.border);
+  double compactness = sdiv(pow(perim, (double)D / (D - 1)), area, 0.0);
+  area = sdiv(area, c.norm_area, 0.0);
+  perim = sdiv(perim, c.norm_len, 0.0);
+  double bboxArea = 1.0;
+  double bboxSize[3];
+  for (int i = 0; i < D; ++i) {
+    double bb = (double)(unsigned long long)(p.hi[i] - p.lo[i]);
+    bboxSize[i] = sdiv(bb, c.norm_len, 0.0);
+    bboxArea *= bb;
+  }
+  bboxArea = sdiv(bboxArea, c.norm_area, 0.0);
+  int k = 0;
+  out[k++] = area; out[k++] = perim; out[k++] = compactness; out[k++] = bboxArea;
+  for (int i = 0; i < D; ++i) out[k++] = bboxSize[i];
+  for (int i = 0; i < T; ++i) out[k++] = sdiv((double)b.thr[i], c.norm_len, 0.0);
+  for (int i = 0; i < T; ++i) out[k++] = sdiv((double)b.thr[i], (double)b.n, 0.0);
+  aux.area = area; aux.perim = perim;
+  double htmp[GLIA_HMT_MAX_BINS];
+  if (c.n_region) {
+    aux.rimg = image_feats(p.hist, p.n, p.sum, p.sq, p.mn, p.mx, c.bins, aux.rh);
+    out[k++] = aux.rimg.entropy; out[k++] = aux.rimg.mean; out[k++] = aux.rimg.stddev; out[k++] = aux.rimg.mn; out[k++] = aux.rimg.mx;
+  }
+  if (c.n_rlabel) {
+    aux.rlimg.entropy = hist_entropy(p.hist, p.n, c.bins, aux.rh);
+    out[k++] = aux.rlimg.entropy;
+  }
+  if (c.n_boundary) {
+    ImgFeats f = image_feats(b.hist, b.n, b.sum, b.sq, b.mn, b.mx, c.bins, htmp);
+    out[k++] = f.entropy; out[k++] = f.mean; out[k++] = f.stddev; out[k++] = f.mn; out[k++] = f.mx;
+  }
+}
+
+__device__ inline void region_log(const BcCfg& c, double* rf) {    // feat.hxx:46-52, 463-467
+  rf[0] = slog(rf[0], 0.0); rf[1] = slog(rf[1], 0.0); rf[3] = slog(rf[3], 0.0);
+  for (int i = 0; i < c.D; ++i) rf[4 + i] = slog(rf[4 + i], 0.0);
+  for (int i = 0; i < c.T; ++i) rf[4 + c.D + i] = slog(rf[4 + c.D + i], 0.0);
+}
+
+// BoundaryFeats from the shared boundary set `sh` and the two (area-ordered) regions
+__device__ inline void boundary_feats(const BcCfg& c, const EStats& sh, const RegionAux& a0, const RegionAux& a1, double* out) {
+  const int T = c.T;
+  int k = 0;
+  const double areaDiff = fabs(a0.area - a1.area);
+  out[k++] = areaDiff; out[k++] = sdiv(areaDiff, a0.area, 0.0); out[k++] = sdiv(areaDiff, a1.area, 0.0);
+  const double perimDiff = fabs(a0.perim - a1.perim);
+  out[k++] = perimDiff; out[k++] = sdiv(perimDiff, a0.perim, 0.0); out[k++] = sdiv(perimDiff, a1.perim, 0.0);
+  const double bl = sdiv(ceil(sh.n / 2.0), c.norm_len, 0.0);
+  out[k++] = bl; out[k++] = sdiv(bl, a0.area, 0.0); out[k++] = sdiv(bl, a1.area, 0.0);
+  out[k++] = sdiv(bl, a0.perim, 0.0); out[k++] = sdiv(bl, a1.perim, 0.0);
+  double vbl[GLIA_HMT_MAX_THRESH];
+  for (int i = 0; i < T; ++i) { vbl[i] = sdiv(ceil(sh.thr[i] / 2.0), c.norm_len, 0.0); out[k++] = vbl[i]; }
+  for (int i = 0; i < T; ++i) out[k++] = sdiv(vbl[i], bl, 0.0);
+  for (int i = 0; i < T; ++i) out[k++] = sdiv(vbl[i], a0.perim, 0.0);
+  for (int i = 0; i < T; ++i) out[k++] = sdiv(vbl[i], a1.perim, 0.0);
+  if (c.n_region || c.n_rlabel) {
+    double l1 = 0.0, x2 = 0.0;
+    for (int i = 0; i < c.bins; ++i) {
+      const double d = a0.rh[i] - a1.rh[i];
+      l1 += fabs(d);
+      x2 += (d * d) / (a0.rh[i] + a1.rh[i] + 2.22e-16);
+    }
+    if (c.n_region) {
+      out[k++] = l1; out[k++] = x2; out[k++] = fabs(a0.rimg.entropy - a1.rimg.entropy);
+      out[k++] = fabs(a0.rimg.mean - a1.rimg.mean); out[k++] = fabs(a0.rimg.stddev - a1.rimg.stddev);
+      out[k++] = fabs(a0.rimg.mn - a1.rimg.mn); out[k++] = fabs(a0.rimg.mx - a1.rimg.mx);
+    }
+    if (c.n_rlabel) {
+      const double e0 = c.n_region ? a0.rimg.entropy : a0.rlimg.entropy, e1 = c.n_region ? a1.rimg.entropy : a1.rlimg.entropy;
+      out[k++] = l1; out[k++] = x2; out[k++] = fabs(e0 - e1);
+    }
+  }
+  if (c.n_boundary) {
+    double htmp[GLIA_HMT_MAX_BINS];
+    ImgFeats f = image_feats(sh.hist, sh.n, sh.sum, sh.sq, sh.mn, sh.mx, c.bins, htmp);
+    out[k++] = f.entropy; out[k++] = f.mean; out[k++] = f.stddev; out[k++] = f.mn; out[k++] = f.mx;
+  }
+}
+
+__device__ inline void boundary_log(const BcCfg& c, double* bf) {   // feat.hxx:103-106, 148-155, 531-539
+  bf[0] = slog(bf[0], 0.0); bf[3] = slog(bf[3], 0.0); bf[6] = slog(bf[6], 0.0);
+  for (int i = 0; i < c.T; ++i) bf[11 + i] = slog(bf[11 + i], 0.0);
+}
+
+// The whole vector of hmt/main_merge_order_bc.cxx:54-95.  (p0,b0) / (p1,b1) are the regions in the orientation
+// the reference passes them (reg0, reg1), (p2,b2) the scratch-merged region, sh their shared boundary.
+__device__ inline void bc_features(const BcCfg& c, const PStats& p0, const EStats& b0, const PStats& p1, const EStats& b1,
+                                   const PStats& p2, const EStats& b2, const EStats& sh, double* out) {
+  double rf0[48], rf1[48], rf2[48], bf[48];
+  RegionAux a0, a1, a2;
+  region_feats(c, p0, b0, rf0, a0);
+  region_feats(c, p1, b1, rf1, a1);
+  region_feats(c, p2, b2, rf2, a2);
+  // keep region 0 area <= region 1 area (main_merge_order_bc.cxx:77-80)
+  const bool swap = a0.area > a1.area;
+  const double* x1 = swap ? rf1 : rf0;
+  const double* x2 = swap ? rf0 : rf1;
+  boundary_feats(c, sh, swap ? a1 : a0, swap ? a0 : a1, bf);
+  if (c.use_log) { boundary_log(c, bf); region_log(c, rf0); region_log(c, rf1); region_log(c, rf2); }
+  int k = 0;
+  if (c.use_simple) {   // hmt/bc_feat.hxx:247-279
+    out[k++] = x1[0]; out[k++] = x2[0]; out[k++] = x1[1]; out[k++] = x2[1]; out[k++] = bf[6];
+    const int bimg = 11 + 4 * c.T + 7 * c.n_region + 3 * c.n_rlabel;
+    if (c.n_boundary) out[k++] = bf[bimg + 1];
+    if (c.n_region) { const int r = 11 + 4 * c.T; out[k++] = bf[r + 3]; out[k++] = bf[r + 0]; out[k++] = bf[r + 1]; out[k++] = bf[r + 2]; }
+    if (c.n_rlabel) { const int r = 11 + 4 * c.T + 7 * c.n_region; out[k++] = bf[r + 0]; out[k++] = bf[r + 1]; }
+    return;
+  }
+  for (int i = 0; i < c.bfdim; ++i) out[k++] = bf[i];
+  for (int i = 0; i < c.rfdim; ++i) out[k++] = x1[i];
+  for (int i = 0; i < c.rfdim; ++i) out[k++] = x2[i];
+  for (int i = 0; i < c.rfdim; ++i) out[k++] = rf2[i];
+}
+
+}  // namespace feat
+}  // namespace glia

@@ -1,0 +1,39 @@
+// glia_amd/csrc/forest.hpp -- boundary classifier objects (alg/rf.hxx:10-122).
+#pragma once
+#include "hmt_internal.hpp"
+
+namespace glia {
+
+struct HostForest {
+  int ntree = 0, nrnodes = 0, nclass = 0, max_var = 0;
+  std::vector<double> split;   // [ntree][nrnodes]
+  std::vector<int> meta;       // [ntree][nrnodes][4] = {var (0-based), left, right (0-based), vote (-1 = internal node)}
+};
+
+struct DeviceForest {
+  int ntree, nrnodes;
+  const double* split;
+  const int4* meta;
+};
+
+// What fBcPred evaluates (hmt/main_merge_order_bc.cxx:127-137): one forest, or three forests behind a
+// ThresholdModelDistributor (type/function.hxx:71-85), or -- diagnostics only -- 1 - x[index].
+struct DeviceClassifier {
+  int kind;              // 0 = forest(s), 1 = feature stub
+  int n_models;          // 1 or 3
+  DeviceForest f[3];
+  int dim0, dim1;
+  double threshold;
+  int stub_index;
+};
+
+int load_forest_file(const char* path, int predict_label, HostForest* out);
+
+}  // namespace glia
+
+struct glia_hmt_forest {
+  int device = 0;
+  glia::DeviceClassifier dc;
+  std::vector<void*> allocs;
+  int max_var = 0;
+};

@@ -23,23 +23,39 @@
 #include <cstring>
 #include <rocprim/device/device_scan.hpp>
 
-#include "hmt_internal.hpp"
+#include "greedy_common.hpp"
 
 namespace glia {
 
-constexpr int kFan = 64;
-constexpr int kMaxLevels = 6;
-constexpr int kGreedyThreads = 512;
-constexpr int kWorkCap = 2048;
-constexpr uint32_t kNone = 0xFFFFFFFFu;
+__global__ void pq_build_level_kernel(PqTree t, int l) {
+  const int lane = threadIdx.x & 63;
+  uint32_t j = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (j < t.lv[l].size) pq_recompute_node(t, l, j, lane);
+}
 
-struct PqLevel {
-  double* sal;
-  unsigned long long* seq;
-  uint32_t* arg;
-  uint32_t* dirty;
-  uint32_t size;
-};
+// (re)allocates the tree levels above t.nleaves leaves and builds them from the current leaf keys
+int pq_setup(DeviceBuffers& buf, PqTree& t, hipStream_t stream) {
+  t.nlevels = 0;
+  uint32_t n = t.nleaves;
+  while (true) {
+    n = (n + kFan - 1) / kFan;
+    if (t.nlevels >= kMaxLevels) { set_error("greedy: edge table too large"); return GLIA_HMT_ERR_ARG; }
+    PqLevel& L = t.lv[t.nlevels++];
+    L.size = n;
+    int rc;
+    if ((rc = buf.get(&L.sal, n, false, stream))) return rc;
+    if ((rc = buf.get(&L.seq, n, false, stream))) return rc;
+    if ((rc = buf.get(&L.arg, n, false, stream))) return rc;
+    if ((rc = buf.get(&L.dirty, n, true, stream))) return rc;
+    if (n == 1) break;
+  }
+  for (int l = 0; l < t.nlevels; ++l) {
+    unsigned long long threads = (unsigned long long)t.lv[l].size * 64ull;
+    hipLaunchKernelGGL(pq_build_level_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, t, l);
+  }
+  GLIA_HIP_TRY(hipGetLastError());
+  return GLIA_HMT_OK;
+}
 
 struct GreedyState {
   uint32_t R0;
@@ -51,10 +67,7 @@ struct GreedyState {
   uint32_t *e_u, *e_v, *e_posu, *e_posv;
   double* e_mean;
   int* e_n;
-  double* leaf_sal;
-  unsigned long long* leaf_seq;   // 0 = dead
-  int nlevels;
-  PqLevel lv[kMaxLevels];
+  PqTree pq;
   uint32_t *mark0, *mark1;        // [2*R0], zero between contractions
   uint32_t* order;                // [R0][3] dense ids
   double* sal_out;
@@ -62,67 +75,13 @@ struct GreedyState {
   unsigned long long max_iters;
 };
 
-enum { ST_RUN = 0, ST_DONE = 1, ST_NEED_EDGES = 2, ST_NEED_POOL = 3, ST_BAD_SALIENCY = 4 };
 
 namespace {
 
-struct Key { double sal; unsigned long long seq; uint32_t arg; };
-
-__device__ __forceinline__ bool better(const Key& a, const Key& b) {
-  return a.sal > b.sal || (a.sal == b.sal && a.seq > b.seq);
-}
-
-__device__ __forceinline__ Key wave_max(Key k) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    Key o;
-    o.sal = __shfl_xor(k.sal, off);
-    o.seq = __shfl_xor(k.seq, off);
-    o.arg = __shfl_xor(k.arg, off);
-    if (better(o, k)) k = o;
-  }
-  return k;
-}
-
-// recompute node j of level l (l = 0: parents of leaves) with one wave
-__device__ __forceinline__ void recompute_node(const GreedyState& st, int l, uint32_t j, int lane) {
-  Key k;
-  k.sal = -__builtin_inf(); k.seq = 0; k.arg = 0;
-  uint32_t ci = j * kFan + lane;
-  if (l == 0) {
-    if (ci < st.Ecap) { k.seq = st.leaf_seq[ci]; k.sal = k.seq ? st.leaf_sal[ci] : -__builtin_inf(); k.arg = ci; }
-  } else {
-    const PqLevel& c = st.lv[l - 1];
-    if (ci < c.size) { k.sal = c.sal[ci]; k.seq = c.seq[ci]; k.arg = c.arg[ci]; }
-  }
-  k = wave_max(k);
-  if (lane == 0) {
-    const PqLevel& d = st.lv[l];
-    d.sal[j] = k.sal; d.seq[j] = k.seq; d.arg[j] = k.arg;
-  }
-}
-
-__global__ void pq_build_level(GreedyState st, int l) {
-  const int lane = threadIdx.x & 63;
-  uint32_t j = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (j < st.lv[l].size) recompute_node(st, l, j, lane);
-}
-
-inline __device__ double sdivide(double l, double r, double d) { return fabs(r) >= 2.22e-16 ? l / r : d; }
-
 struct Shared {
-  uint32_t r0, r1, e, stop, len0, len1, off0, off1, newcount, ovf;
-  uint32_t wln[2];
-  uint32_t wl[2][kWorkCap];
+  uint32_t r0, r1, e, stop, len0, len1, off0, off1, newcount;
+  PqWork pq;
 };
-
-__device__ __forceinline__ void touch(const GreedyState& st, Shared& s, int level, int which, uint32_t child) {
-  uint32_t p = child / kFan;
-  if (atomicExch(&st.lv[level].dirty[p], 1u) == 0u) {
-    uint32_t i = atomicAdd(&s.wln[which], 1u);
-    if (i < kWorkCap) s.wl[which][i] = p; else s.ovf = 1;
-  }
-}
 
 __global__ __launch_bounds__(kGreedyThreads) void greedy_mean_kernel(GreedyState st) {
   __shared__ Shared s;
@@ -130,13 +89,13 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_mean_kernel(GreedyState
   constexpr int nwaves = kGreedyThreads / 64;
   unsigned long long k = st.ctrl[0], ne = st.ctrl[1], pool_used = st.ctrl[2];
   uint32_t status = ST_RUN;
-  if (tid == 0) { s.wln[0] = s.wln[1] = 0; s.ovf = 0; }
+  if (tid == 0) { s.pq.wln[0] = s.pq.wln[1] = 0; s.pq.ovf = 0; }
   __syncthreads();
 
   for (unsigned long long it = 0; it < st.max_iters; ++it) {
     // ---- pop (TBoundaryTable::top) ----
     if (tid == 0) {
-      const PqLevel& root = st.lv[st.nlevels - 1];
+      const PqLevel& root = st.pq.lv[st.pq.nlevels - 1];
       s.stop = ST_RUN;
       s.newcount = 0;
       if (root.seq[0] == 0) s.stop = ST_DONE;
@@ -165,7 +124,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_mean_kernel(GreedyState
     for (uint32_t i = tid; i < total; i += kGreedyThreads) {
       const bool side1 = i >= len0;
       const uint32_t eid = st.pool[side1 ? off1 + (i - len0) : off0 + i];
-      if (eid == e || st.leaf_seq[eid] == 0) continue;
+      if (eid == e || st.pq.leaf_seq[eid] == 0) continue;
       const uint32_t r = side1 ? r1 : r0;
       const uint32_t u = st.e_u[eid], v = st.e_v[eid];
       const uint32_t rs = (u == r) ? v : u;
@@ -209,14 +168,14 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_mean_kernel(GreedyState
       const uint32_t posRs = (st.e_u[old] == rs) ? st.e_posu[old] : st.e_posv[old];
       st.e_u[newE] = rs; st.e_v[newE] = r2; st.e_posu[newE] = posRs; st.e_posv[newE] = idx;
       st.e_mean[newE] = first; st.e_n[newE] = second;
-      st.leaf_sal[newE] = -first; st.leaf_seq[newE] = seq;
+      st.pq.leaf_sal[newE] = -first; st.pq.leaf_seq[newE] = seq;
       st.pool[st.adj_off[rs] + posRs] = newE;
       st.pool[r2off + idx] = newE;
-      touch(st, s, 0, 0, newE);
-      if (e0s != kNone) { st.leaf_seq[e0s] = 0; touch(st, s, 0, 0, e0s); }
-      if (e1s != kNone) { st.leaf_seq[e1s] = 0; touch(st, s, 0, 0, e1s); }
+      pq_touch(st.pq, s.pq, 0, 0, newE);
+      if (e0s != kNone) { st.pq.leaf_seq[e0s] = 0; pq_touch(st.pq, s.pq, 0, 0, e0s); }
+      if (e1s != kNone) { st.pq.leaf_seq[e1s] = 0; pq_touch(st.pq, s.pq, 0, 0, e1s); }
     }
-    if (tid == 0) { st.leaf_seq[e] = 0; touch(st, s, 0, 0, e); }
+    if (tid == 0) { st.pq.leaf_seq[e] = 0; pq_touch(st.pq, s.pq, 0, 0, e); }
     if (__syncthreads_or(bad ? 1 : 0)) { status = ST_BAD_SALIENCY; break; }
 
     // ---- phase C: reset marks, publish r2's list ----
@@ -228,46 +187,13 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_mean_kernel(GreedyState
     if (tid == 0) { st.adj_off[r2] = r2off; st.adj_len[r2] = newcount; }
 
     // ---- priority structure: propagate dirty nodes level by level ----
-    int cur = 0;
-    for (int l = 0; l < st.nlevels; ++l) {
-      __syncthreads();
-      const bool ovf = s.ovf != 0;
-      const uint32_t n = ovf ? st.lv[l].size : s.wln[cur];
-      for (uint32_t w = wave; w < n; w += nwaves) {
-        const uint32_t j = ovf ? w : s.wl[cur][w];
-        recompute_node(st, l, j, lane);
-        if (lane == 0) {
-          st.lv[l].dirty[j] = 0;
-          if (!ovf && l + 1 < st.nlevels) touch(st, s, l + 1, cur ^ 1, j);
-        }
-      }
-      __syncthreads();
-      if (tid == 0) s.wln[cur] = 0;
-      cur ^= 1;
-    }
-    __syncthreads();
-    if (tid == 0) { s.ovf = 0; s.wln[0] = s.wln[1] = 0; }
+    pq_propagate<kGreedyThreads>(st.pq, s.pq, tid);
     k += 1; ne += newcount; pool_used += total;
-    __syncthreads();
   }
   if (tid == 0) { st.ctrl[0] = k; st.ctrl[1] = ne; st.ctrl[2] = pool_used; st.ctrl[3] = status; }
 }
 
 // ---- edge table construction --------------------------------------------------------------------------
-__device__ __forceinline__ long long find_pair(const uint32_t* pa, const uint32_t* pb, long long P, uint32_t a, uint32_t b) {
-  long long lo = 0, hi = P;
-  while (lo < hi) {
-    long long mid = (lo + hi) >> 1;
-    if (pa[mid] < a || (pa[mid] == a && pb[mid] < b)) lo = mid + 1; else hi = mid;
-  }
-  return (lo < P && pa[lo] == a && pb[lo] == b) ? lo : -1;
-}
-__device__ __forceinline__ uint32_t find_label(const uint32_t* lab, uint32_t R, uint32_t key) {
-  uint32_t lo = 0, hi = R;
-  while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (lab[mid] < key) lo = mid + 1; else hi = mid; }
-  return lo;
-}
-
 __global__ void edge_flags(const uint32_t* pa, const uint32_t* pb, long long P, uint32_t* flag, long long* partner) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
@@ -294,7 +220,7 @@ __global__ void edge_fill(const uint32_t* pa, const uint32_t* pb, const uint32_t
   const int n = (int)(wi[P_CNT] + wj[P_CNT]);
   const double mean = sdivide(si + sj, (double)n, 0.0);
   st.e_u[e] = u; st.e_v[e] = v; st.e_mean[e] = mean; st.e_n[e] = n;
-  st.leaf_sal[e] = -mean; st.leaf_seq[e] = (unsigned long long)e + 1ull;
+  st.pq.leaf_sal[e] = -mean; st.pq.leaf_seq[e] = (unsigned long long)e + 1ull;
   atomicAdd(&deg[u], 1u);
   atomicAdd(&deg[v], 1u);
 }
@@ -308,63 +234,9 @@ __global__ void adj_fill(GreedyState st, uint32_t E0, uint32_t* cursor) {
   st.pool[st.adj_off[v] + pv] = e; st.e_posv[e] = pv;
 }
 
-__global__ void fill_leaves_dead(GreedyState st, uint32_t from) {
+__global__ void fill_leaves_dead(PqTree t, uint32_t from) {
   uint32_t i = from + blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < st.Ecap) { st.leaf_seq[i] = 0; st.leaf_sal[i] = -__builtin_inf(); }
-}
-
-template <typename T>
-int dmalloc(T** p, size_t n) {
-  GLIA_HIP_TRY(hipMalloc((void**)p, sizeof(T) * (n ? n : 1)));
-  return GLIA_HMT_OK;
-}
-
-struct Buffers {
-  std::vector<void*> all;
-  ~Buffers() { for (void* p : all) (void)hipFree(p); }
-  template <typename T> int get(T** p, size_t n, bool zero, hipStream_t s) {
-    int rc = dmalloc(p, n);
-    if (rc) return rc;
-    all.push_back(*p);
-    if (zero) GLIA_HIP_TRY(hipMemsetAsync(*p, 0, sizeof(T) * (n ? n : 1), s));
-    return GLIA_HMT_OK;
-  }
-};
-
-template <typename T>
-int grow(Buffers& b, T** p, size_t old_n, size_t new_n, hipStream_t s) {
-  T* q = nullptr;
-  int rc = dmalloc(&q, new_n);
-  if (rc) return rc;
-  GLIA_HIP_TRY(hipMemcpyAsync(q, *p, sizeof(T) * old_n, hipMemcpyDeviceToDevice, s));
-  GLIA_HIP_TRY(hipStreamSynchronize(s));
-  for (auto& x : b.all) if (x == (void*)*p) { (void)hipFree(x); x = q; }
-  *p = q;
-  return GLIA_HMT_OK;
-}
-
-int setup_levels(Buffers& buf, GreedyState& st, hipStream_t stream) {
-  // free nothing here: old level arrays (if any) stay owned by buf until it dies
-  st.nlevels = 0;
-  uint32_t n = st.Ecap;
-  while (true) {
-    n = (n + kFan - 1) / kFan;
-    if (st.nlevels >= kMaxLevels) { set_error("greedy: edge table too large"); return GLIA_HMT_ERR_ARG; }
-    PqLevel& L = st.lv[st.nlevels++];
-    L.size = n;
-    int rc;
-    if ((rc = buf.get(&L.sal, n, false, stream))) return rc;
-    if ((rc = buf.get(&L.seq, n, false, stream))) return rc;
-    if ((rc = buf.get(&L.arg, n, false, stream))) return rc;
-    if ((rc = buf.get(&L.dirty, n, true, stream))) return rc;
-    if (n == 1) break;
-  }
-  for (int l = 0; l < st.nlevels; ++l) {
-    unsigned long long threads = (unsigned long long)st.lv[l].size * 64ull;
-    hipLaunchKernelGGL(pq_build_level, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, st, l);
-  }
-  GLIA_HIP_TRY(hipGetLastError());
-  return GLIA_HMT_OK;
+  if (i < t.nleaves) { t.leaf_seq[i] = 0; t.leaf_sal[i] = -__builtin_inf(); }
 }
 
 }  // namespace
@@ -380,7 +252,7 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
   hipEvent_t ev[3];
   for (auto& e : ev) GLIA_HIP_TRY(hipEventCreate(&e));
   GLIA_HIP_TRY(hipEventRecord(ev[0], stream));
-  Buffers buf;
+  DeviceBuffers buf;
   int rc;
   uint32_t* flag; uint32_t* eidx; long long* partner;
   if ((rc = buf.get(&flag, P + 1, true, stream))) return rc;
@@ -413,8 +285,8 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
   if ((rc = buf.get(&st.e_posv, st.Ecap, false, stream))) return rc;
   if ((rc = buf.get(&st.e_mean, st.Ecap, false, stream))) return rc;
   if ((rc = buf.get(&st.e_n, st.Ecap, false, stream))) return rc;
-  if ((rc = buf.get(&st.leaf_sal, st.Ecap, false, stream))) return rc;
-  if ((rc = buf.get(&st.leaf_seq, st.Ecap, false, stream))) return rc;
+  if ((rc = buf.get(&st.pq.leaf_sal, st.Ecap, false, stream))) return rc;
+  if ((rc = buf.get(&st.pq.leaf_seq, st.Ecap, false, stream))) return rc;
   if ((rc = buf.get(&st.mark0, 2 * (size_t)R, true, stream))) return rc;
   if ((rc = buf.get(&st.mark1, 2 * (size_t)R, true, stream))) return rc;
   if ((rc = buf.get(&st.order, 3 * (size_t)R, false, stream))) return rc;
@@ -423,7 +295,7 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
   uint32_t* cursor;
   if ((rc = buf.get(&cursor, 2 * (size_t)R, true, stream))) return rc;
 
-  hipLaunchKernelGGL(fill_leaves_dead, dim3((st.Ecap - E0 + 255) / 256), dim3(256), 0, stream, st, E0);
+  hipLaunchKernelGGL(fill_leaves_dead, dim3((st.Ecap - E0 + 255) / 256), dim3(256), 0, stream, st.pq, E0);
   hipLaunchKernelGGL(edge_fill, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, rag.d_pa, rag.d_pb, rag.d_prec, P,
                      flag, eidx, partner, rag.d_rlabel, R, st, st.adj_len);
   {
@@ -436,7 +308,7 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
   }
   hipLaunchKernelGGL(adj_fill, dim3((E0 + 255) / 256), dim3(256), 0, stream, st, E0, cursor);
   GLIA_HIP_TRY(hipGetLastError());
-  if ((rc = setup_levels(buf, st, stream))) return rc;
+  if ((rc = pq_setup(buf, st.pq, stream))) return rc;
   unsigned long long ctrl[4] = {0, E0, 2ull * E0, ST_RUN};
   GLIA_HIP_TRY(hipMemcpyAsync(st.ctrl, ctrl, sizeof(ctrl), hipMemcpyHostToDevice, stream));
   GLIA_HIP_TRY(hipEventRecord(ev[1], stream));
@@ -453,23 +325,23 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
     if (ctrl[3] == ST_BAD_SALIENCY) { set_error("Error: invalid boundary saliency..."); return GLIA_HMT_ERR_SALIENCY; }
     if (ctrl[3] == ST_NEED_POOL) {
       unsigned long long ncap = st.pool_cap * 2;
-      if ((rc = grow(buf, &st.pool, (size_t)st.pool_cap, (size_t)ncap, stream))) return rc;
+      if ((rc = buf.grow(&st.pool, (size_t)st.pool_cap, (size_t)ncap, stream))) return rc;
       st.pool_cap = ncap;
     } else if (ctrl[3] == ST_NEED_EDGES) {
       if (st.Ecap >= 0xFFFFFF00u) { set_error("greedy: more than 2^32 edge slots needed"); return GLIA_HMT_ERR_ARG; }
       uint32_t ocap = st.Ecap;
       uint32_t ncap = (uint32_t)std::min<unsigned long long>(0xFFFFFF00ull, (unsigned long long)ocap * 2ull);
-      if ((rc = grow(buf, &st.e_u, ocap, ncap, stream))) return rc;
-      if ((rc = grow(buf, &st.e_v, ocap, ncap, stream))) return rc;
-      if ((rc = grow(buf, &st.e_posu, ocap, ncap, stream))) return rc;
-      if ((rc = grow(buf, &st.e_posv, ocap, ncap, stream))) return rc;
-      if ((rc = grow(buf, &st.e_mean, ocap, ncap, stream))) return rc;
-      if ((rc = grow(buf, &st.e_n, ocap, ncap, stream))) return rc;
-      if ((rc = grow(buf, &st.leaf_sal, ocap, ncap, stream))) return rc;
-      if ((rc = grow(buf, &st.leaf_seq, ocap, ncap, stream))) return rc;
-      st.Ecap = ncap;
-      hipLaunchKernelGGL(fill_leaves_dead, dim3((ncap - ocap + 255) / 256), dim3(256), 0, stream, st, ocap);
-      if ((rc = setup_levels(buf, st, stream))) return rc;
+      if ((rc = buf.grow(&st.e_u, ocap, ncap, stream))) return rc;
+      if ((rc = buf.grow(&st.e_v, ocap, ncap, stream))) return rc;
+      if ((rc = buf.grow(&st.e_posu, ocap, ncap, stream))) return rc;
+      if ((rc = buf.grow(&st.e_posv, ocap, ncap, stream))) return rc;
+      if ((rc = buf.grow(&st.e_mean, ocap, ncap, stream))) return rc;
+      if ((rc = buf.grow(&st.e_n, ocap, ncap, stream))) return rc;
+      if ((rc = buf.grow(&st.pq.leaf_sal, ocap, ncap, stream))) return rc;
+      if ((rc = buf.grow(&st.pq.leaf_seq, ocap, ncap, stream))) return rc;
+      st.Ecap = ncap; st.pq.nleaves = ncap;
+      hipLaunchKernelGGL(fill_leaves_dead, dim3((ncap - ocap + 255) / 256), dim3(256), 0, stream, st.pq, ocap);
+      if ((rc = pq_setup(buf, st.pq, stream))) return rc;
     }
     unsigned long long zero = ST_RUN;
     GLIA_HIP_TRY(hipMemcpyAsync(st.ctrl + 3, &zero, sizeof(zero), hipMemcpyHostToDevice, stream));

@@ -1,0 +1,699 @@
+// glia_amd/csrc/greedy_bc.hip -- K5/K6/K7 for the classifier linkage: greedy agglomeration where every new
+// edge gets a feature vector and a boundary-classifier score, on the device.
+//
+// Reference semantics reproduced (all under /root/reference/code/):
+//   * genMergeOrderGreedyUsingBoundaryClassifier (util/struct_merge_bc.hxx:10-43): saliency of an edge =
+//     classifier(features(r0, r1, r0 u r1, shared boundary)); regions ARE merged (updateRegion = true).
+//   * TRegion::merge (type/region.hxx:66-75): a merged region's boundary set is the union of its leaves' DIRECTED
+//     boundary entries minus every MUTUAL pair (a->b, b->a) whose two leaves are both inside; a non-mutual
+//     entry is never cancelled.  So  B(R) = Bn(R) + Bm(R):  Bn = all non-mutual out-entries of R's leaves (only
+//     ever grows), Bm = mutual entries to leaves outside R (lives on the table edges of R).
+//   * getBoundary / boundaryWith (util/struct.hxx:10-16, type/region.hxx:42-51): the shared boundary of R0,R1 =
+//     entries (a->x) of R0 whose target leaf x is in R1 AND still owns an un-cancelled entry there, plus the
+//     symmetric set.  A mutual entry's target always qualifies; a non-mutual entry's target x qualifies iff x
+//     has a non-mutual out-entry of its own or a mutual partner outside its region ("alive").
+//   * TBoundaryTable (type/boundary_table.hxx): only MUTUAL leaf pairs start as table edges (:99-102); update
+//     creates (rs,r2) iff (r0,rs) or (r1,rs) is a table edge (:127-156).  Directed-only adjacencies are kept
+//     here as non-table records so that their entries are found when a later contraction makes the pair a
+//     table edge.  Tie rule / visit order: see greedy.hip.
+//   * feature vector and orientation: bc_features.hpp; initial edges are passed to fBcFeat in the orientation
+//     in which TBoundaryTable::init meets them, i.e. the region that comes first in the unordered_map
+//     iteration order of the region map (rank[] is computed on the host by replaying the reference's insertion
+//     sequences through the same libstdc++ container); updated edges are passed as (rs, r2).
+//
+// MI355X mapping: one persistent workgroup (the contraction chain is sequential); per contraction the new
+// records are built data-parallel, features are computed one thread per new edge into a workspace, and the
+// forest is evaluated with (edge, tree) pairs spread over the whole workgroup.
+#include <algorithm>
+#include <cstring>
+#include <unordered_map>
+#include <rocprim/device/device_scan.hpp>
+
+#include "bc_features.hpp"
+#include "forest.hpp"
+#include "greedy_common.hpp"
+
+namespace glia {
+
+constexpr int kBcThreads = 1024;
+constexpr int kChunk = 256;     // new edges scored per round
+
+struct BcState {
+  uint32_t R0;
+  // regions [2*R0]
+  PStats* pts;
+  EStats* Bn;          // non-mutual out-entries of the region's leaves
+  EStats* Bt;          // additive totals of the whole boundary set (min/max fields unused)
+  float* Bmn; float* Bmx;   // min / max over the whole boundary set
+  uint32_t* parent;    // merge forest (find -> current region of a leaf)
+  uint32_t* adj_off; uint32_t* adj_len; uint32_t* pool; unsigned long long pool_cap;
+  // records [Ecap]
+  uint32_t Ecap;
+  uint32_t *e_u, *e_v, *e_posu, *e_posv;
+  uint8_t *e_alive, *e_table, *e_orient;    // orient: 1 = features take (u, v), 0 = (v, u)
+  EStats* e_A;         // mutual entries, both directions
+  EStats* e_NA;        // always-alive non-mutual entries, both directions
+  float* e_dir;        // [Ecap][4]  mutual u->v min,max ; v->u min,max
+  uint32_t *e_fhead, *e_ftail;   // fragile non-mutual leaf entries (linked through le_next), kNone = empty
+  PqTree pq;
+  // leaf entries [P] (directed label pairs, ascending (a,b))
+  long long P;
+  uint32_t *le_src, *le_dst;     // dense leaf ids
+  EStats* le_stats;
+  uint32_t* le_next;
+  uint8_t* le_mutual;
+  uint32_t* le_start;            // [R0+1] first out-entry of each leaf
+  uint32_t* nm_out;              // [R0] non-mutual out-entries per leaf
+  uint32_t *mark0, *mark1;       // [2*R0]
+  uint32_t* order; double* sal_out; double* feats_out;
+  double* featbuf;               // [kChunk][fdim]
+  unsigned long long* ctrl;
+  unsigned long long max_iters;
+  BcCfg cfg;
+  DeviceClassifier clf;
+};
+
+namespace {
+
+__device__ __forceinline__ uint32_t find_root(const BcState& st, uint32_t x) {
+  uint32_t p = st.parent[x];
+  while (p != x) {
+    const uint32_t g = st.parent[p];
+    if (g != p) st.parent[x] = g;    // path halving (benign race: only ever points to an ancestor)
+    x = p; p = g;
+  }
+  return x;
+}
+
+// does leaf x still own an un-cancelled boundary entry inside its region?
+__device__ bool leaf_alive(const BcState& st, uint32_t x) {
+  if (st.nm_out[x]) return true;
+  const uint32_t rx = find_root(st, x);
+  for (uint32_t i = st.le_start[x]; i < st.le_start[x + 1]; ++i)
+    if (st.le_mutual[i] && find_root(st, st.le_dst[i]) != rx) return true;
+  return false;
+}
+
+// min / max over region r's boundary set without the mutual entries it sends along record `skip`
+__device__ void excl_minmax(const BcState& st, uint32_t r, uint32_t skip, float& mn, float& mx) {
+  mn = st.Bn[r].mn; mx = st.Bn[r].mx;
+  const uint32_t off = st.adj_off[r], len = st.adj_len[r];
+  for (uint32_t i = 0; i < len; ++i) {
+    const uint32_t e = st.pool[off + i];
+    if (e == skip || !st.e_alive[e]) continue;
+    const float* d = &st.e_dir[(size_t)e * 4 + (st.e_u[e] == r ? 0 : 2)];
+    mn = fminf(mn, d[0]); mx = fmaxf(mx, d[1]);
+  }
+}
+
+// feature vector of record rec (regions `first`, `second` in the reference's orientation)
+__device__ void edge_features(const BcState& st, uint32_t first, uint32_t second, uint32_t rec, float ex0mn, float ex0mx,
+                              float ex1mn, float ex1mx, double* out) {
+  EStats b0 = st.Bt[first], b1 = st.Bt[second];
+  b0.mn = st.Bmn[first]; b0.mx = st.Bmx[first];
+  b1.mn = st.Bmn[second]; b1.mx = st.Bmx[second];
+  PStats p2 = st.pts[first];
+  pstats_add(p2, st.pts[second]);
+  EStats b2 = st.Bt[first];
+  estats_add(b2, st.Bt[second]);
+  estats_sub_additive(b2, st.e_A[rec]);
+  b2.mn = fminf(ex0mn, ex1mn); b2.mx = fmaxf(ex0mx, ex1mx);
+  EStats sh = st.e_A[rec];
+  estats_add(sh, st.e_NA[rec]);
+  for (uint32_t f = st.e_fhead[rec]; f != kNone; f = st.le_next[f])
+    if (leaf_alive(st, st.le_dst[f])) estats_add(sh, st.le_stats[f]);
+  feat::bc_features(st.cfg, st.pts[first], b0, st.pts[second], b1, p2, b2, sh, out);
+}
+
+__device__ __forceinline__ int forest_vote(const DeviceForest& f, int tree, const double* x) {
+  const size_t base = (size_t)tree * f.nrnodes;
+  int k = 0;
+  for (int step = 0; step < f.nrnodes; ++step) {        // bounded: a malformed tree cannot hang the device
+    const int4 m = f.meta[base + k];
+    if (m.w >= 0) return m.w;
+    k = (x[m.x] <= f.split[base + k]) ? m.y : m.z;
+  }
+  return 0;
+}
+__device__ __forceinline__ int pick_model(const DeviceClassifier& c, const double* x) {
+  if (c.n_models == 1) return 0;
+  if (x[c.dim1] < c.threshold) return 0;                // type/function.hxx:80-84
+  if (x[c.dim0] < c.threshold) return 1;
+  return 2;
+}
+__device__ double classify_serial(const DeviceClassifier& c, const double* x) {
+  if (c.kind == 1) return 1.0 - x[c.stub_index];
+  const DeviceForest& f = c.f[pick_model(c, x)];
+  int votes = 0;
+  for (int t = 0; t < f.ntree; ++t) votes += forest_vote(f, t, x);
+  return (double)votes / (double)f.ntree;               // ml/rf/rf.hxx:366-369
+}
+
+// ---- initialisation kernels ---------------------------------------------------------------------------
+__global__ void bc_leaf_entries(BcState st, const uint32_t* pa, const uint32_t* pb, const uint32_t* prec,
+                                const uint32_t* rlabel, long long* partner, int bins, int nthr) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= st.P) return;
+  const uint32_t a = pa[i], b = pb[i];
+  const long long j = find_pair(pa, pb, st.P, b, a);
+  partner[i] = j;
+  st.le_mutual[i] = j >= 0;
+  const uint32_t src = find_label(rlabel, st.R0, a), dst = find_label(rlabel, st.R0, b);
+  st.le_src[i] = src; st.le_dst[i] = dst; st.le_next[i] = kNone;
+  const uint32_t* w = &prec[(size_t)i * kPairWords];
+  EStats s;
+  estats_clear(s);
+  s.n = w[P_CNT];
+  for (int t = 0; t < nthr; ++t) s.thr[t] = w[P_THR + t];
+  s.mn = ord_float(~w[P_MIN]); s.mx = ord_float(w[P_MAX]);
+  memcpy(&s.sum, &w[P_SUM], 8); memcpy(&s.sq, &w[P_SQ], 8);
+  for (int k = 0; k < bins; ++k) s.hist[k] = w[P_HIST + k];
+  st.le_stats[i] = s;
+  if (j < 0) atomicAdd(&st.nm_out[src], 1u);
+  if (i == 0 || pa[i - 1] != a) st.le_start[src] = (uint32_t)i;
+  if (i == st.P - 1) st.le_start[st.R0] = (uint32_t)st.P;
+}
+
+// leaves without any out-entry: le_start must still be monotone (fill gaps from the right)
+__global__ void bc_fix_starts(BcState st) {
+  if (blockIdx.x || threadIdx.x) return;
+  uint32_t next = (uint32_t)st.P;
+  for (long long r = (long long)st.R0 - 1; r >= 0; --r) {
+    if (st.le_start[r] == kNone) st.le_start[r] = next; else next = st.le_start[r];
+  }
+}
+
+__global__ void bc_leaf_regions(BcState st, const uint32_t* rrec, int bins) {
+  uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= st.R0) return;
+  const uint32_t* w = &rrec[(size_t)r * kRegionWords];
+  PStats p;
+  p.n = w[R_CNT]; p.border = w[R_BORDER];
+  for (int d = 0; d < 3; ++d) { p.lo[d] = (int)(0x7fffffffu - w[R_LO + d]); p.hi[d] = (int)w[R_HI + d] - 1; }
+  p.mn = ord_float(~w[R_MIN]); p.mx = ord_float(w[R_MAX]);
+  memcpy(&p.sum, &w[R_SUM], 8); memcpy(&p.sq, &w[R_SQ], 8);
+  for (int k = 0; k < GLIA_HMT_MAX_BINS; ++k) p.hist[k] = k < bins ? w[R_HIST + k] : 0;
+  st.pts[r] = p;
+  EStats bn, bt;
+  estats_clear(bn); estats_clear(bt);
+  for (uint32_t i = st.le_start[r]; i < st.le_start[r + 1]; ++i) {
+    estats_add(bt, st.le_stats[i]);
+    if (!st.le_mutual[i]) estats_add(bn, st.le_stats[i]);
+  }
+  st.Bn[r] = bn; st.Bt[r] = bt; st.Bmn[r] = bt.mn; st.Bmx[r] = bt.mx;
+  st.parent[r] = r;
+}
+
+__global__ void bc_record_flags(BcState st, const uint32_t* pa, const uint32_t* pb, uint32_t* flag) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= st.P) return;
+  // one record per unordered leaf pair: owned by the (a<b) entry when it exists, else by the lone (a>b) entry
+  flag[i] = (pa[i] < pb[i] || !st.le_mutual[i]) ? 1u : 0u;
+}
+
+__global__ void bc_record_fill(BcState st, const uint32_t* flag, const uint32_t* eidx, const long long* partner,
+                               const uint32_t* rank, uint32_t* deg) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= st.P || !flag[i]) return;
+  const uint32_t e = eidx[i];
+  const uint32_t src = st.le_src[i], dst = st.le_dst[i];
+  const uint32_t u = src < dst ? src : dst, v = src < dst ? dst : src;
+  st.e_u[e] = u; st.e_v[e] = v; st.e_alive[e] = 1;
+  st.e_orient[e] = rank[u] < rank[v] ? 1 : 0;
+  EStats A, NA;
+  estats_clear(A); estats_clear(NA);
+  float* d = &st.e_dir[(size_t)e * 4];
+  d[0] = d[2] = __builtin_inff(); d[1] = d[3] = -__builtin_inff();
+  st.e_fhead[e] = st.e_ftail[e] = kNone;
+  const long long j = partner[i];
+  if (j >= 0) {            // mutual pair: i = (u -> v), j = (v -> u)
+    const EStats& si = st.le_stats[i];
+    const EStats& sj = st.le_stats[j];
+    A = si; estats_add(A, sj);
+    d[0] = si.mn; d[1] = si.mx; d[2] = sj.mn; d[3] = sj.mx;
+    st.e_table[e] = 1;
+    st.pq.leaf_seq[e] = (unsigned long long)i + 1ull;      // lexicographic (u,v) order of the table edges
+  } else {
+    st.e_table[e] = 0;
+    if (st.nm_out[dst]) NA = st.le_stats[i];
+    else { st.e_fhead[e] = st.e_ftail[e] = (uint32_t)i; }
+  }
+  st.e_A[e] = A; st.e_NA[e] = NA;
+  atomicAdd(&deg[u], 1u);
+  atomicAdd(&deg[v], 1u);
+}
+
+__global__ void bc_adj_fill(BcState st, uint32_t E0, uint32_t* cursor) {
+  uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E0) return;
+  const uint32_t u = st.e_u[e], v = st.e_v[e];
+  const uint32_t pu = atomicAdd(&cursor[u], 1u), pv = atomicAdd(&cursor[v], 1u);
+  st.pool[st.adj_off[u] + pu] = e; st.e_posu[e] = pu;
+  st.pool[st.adj_off[v] + pv] = e; st.e_posv[e] = pv;
+}
+
+__global__ void bc_init_dead(BcState st, uint32_t from) {
+  uint32_t i = from + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < st.Ecap) { st.pq.leaf_seq[i] = 0; st.pq.leaf_sal[i] = -__builtin_inf(); st.e_alive[i] = 0; st.e_table[i] = 0; }
+}
+
+// initFb + initFsal of every initial table edge (util/struct_merge_bc.hxx:18-27)
+__global__ void bc_init_score(BcState st, uint32_t E0) {
+  uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E0 || !st.e_table[e]) return;
+  const uint32_t u = st.e_u[e], v = st.e_v[e];
+  const uint32_t first = st.e_orient[e] ? u : v, second = st.e_orient[e] ? v : u;
+  float a, b, c, d;
+  excl_minmax(st, first, e, a, b);
+  excl_minmax(st, second, e, c, d);
+  double x[kMaxFeat];
+  edge_features(st, first, second, e, a, b, c, d, x);
+  st.pq.leaf_sal[e] = classify_serial(st.clf, x);
+}
+
+// ---- the loop ----------------------------------------------------------------------------------------------
+struct BcShared {
+  uint32_t r0, r1, e, stop, len0, len1, off0, off1, newcount;
+  unsigned long long best_mn, best_mx, second_mn, second_mx;    // ord(value) << 32 | record, over r2's new records
+  uint32_t ex[4];
+  int votes[kChunk];
+  int model[kChunk];
+  PqWork pq;
+};
+
+__global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
+  __shared__ BcShared s;
+  const int tid = threadIdx.x;
+  unsigned long long k = st.ctrl[0], ne = st.ctrl[1], pool_used = st.ctrl[2];
+  uint32_t status = ST_RUN;
+  const int fdim = st.cfg.fdim;
+  if (tid == 0) { s.pq.wln[0] = s.pq.wln[1] = 0; s.pq.ovf = 0; }
+  __syncthreads();
+
+  for (unsigned long long it = 0; it < st.max_iters; ++it) {
+    if (tid == 0) {
+      const PqLevel& root = st.pq.lv[st.pq.nlevels - 1];
+      s.stop = ST_RUN; s.newcount = 0;
+      s.best_mn = s.second_mn = ~0ull; s.best_mx = s.second_mx = 0ull;
+      s.ex[0] = s.ex[2] = 0xFFFFFFFFu; s.ex[1] = s.ex[3] = 0u;
+      if (root.seq[0] == 0) s.stop = ST_DONE;
+      else {
+        const uint32_t e = root.arg[0];
+        s.e = e; s.r0 = st.e_u[e]; s.r1 = st.e_v[e];
+        s.len0 = st.adj_len[s.r0]; s.len1 = st.adj_len[s.r1];
+        s.off0 = st.adj_off[s.r0]; s.off1 = st.adj_off[s.r1];
+        const unsigned long long tot = (unsigned long long)s.len0 + s.len1;
+        if (ne + tot > st.Ecap) s.stop = ST_NEED_EDGES;
+        else if (pool_used + tot > st.pool_cap) s.stop = ST_NEED_POOL;
+        else {
+          st.order[3 * k + 0] = s.r0; st.order[3 * k + 1] = s.r1; st.order[3 * k + 2] = st.R0 + (uint32_t)k;
+          st.sal_out[k] = root.sal[0];
+        }
+      }
+    }
+    __syncthreads();
+    if (s.stop != ST_RUN) { status = s.stop; break; }
+    const uint32_t r0 = s.r0, r1 = s.r1, e = s.e, len0 = s.len0, len1 = s.len1, off0 = s.off0, off1 = s.off1;
+    const uint32_t r2 = st.R0 + (uint32_t)k;
+    const uint32_t total = len0 + len1;
+    const uint32_t r2off = (uint32_t)pool_used;
+
+    // ---- optional: the feature vector the popped edge was scored with (main_merge_order_bc.cxx:148-157) ----
+    if (st.feats_out) {
+      for (uint32_t i = tid; i < total; i += kBcThreads) {
+        const bool side1 = i >= len0;
+        const uint32_t r = side1 ? r1 : r0;
+        const uint32_t eid = st.pool[side1 ? off1 + (i - len0) : off0 + i];
+        if (eid == e || !st.e_alive[eid]) continue;
+        const float* d = &st.e_dir[(size_t)eid * 4 + (st.e_u[eid] == r ? 0 : 2)];
+        atomicMin(&s.ex[side1 ? 2 : 0], float_ord(d[0]));
+        atomicMax(&s.ex[side1 ? 3 : 1], float_ord(d[1]));
+      }
+      __syncthreads();
+      if (tid == 0) {
+        float m0 = fminf(st.Bn[r0].mn, ord_float(s.ex[0])), x0 = fmaxf(st.Bn[r0].mx, ord_float(s.ex[1]));
+        float m1 = fminf(st.Bn[r1].mn, ord_float(s.ex[2])), x1 = fmaxf(st.Bn[r1].mx, ord_float(s.ex[3]));
+        double x[kMaxFeat];
+        if (st.e_orient[e]) edge_features(st, r0, r1, e, m0, x0, m1, x1, x);
+        else edge_features(st, r1, r0, e, m1, x1, m0, x0, x);
+        for (int i = 0; i < fdim; ++i) st.feats_out[(size_t)k * fdim + i] = x[i];
+      }
+      __syncthreads();
+    }
+
+    // ---- the merged region (TRegionMap::merge, type/region_map.hxx:113-118) ----
+    if (tid == 0) {
+      PStats p = st.pts[r0];
+      pstats_add(p, st.pts[r1]);
+      st.pts[r2] = p;
+      EStats bn = st.Bn[r0];
+      estats_add(bn, st.Bn[r1]);
+      st.Bn[r2] = bn;
+      EStats bt = st.Bt[r0];
+      estats_add(bt, st.Bt[r1]);
+      estats_sub_additive(bt, st.e_A[e]);
+      st.Bt[r2] = bt;
+      st.parent[r0] = r2; st.parent[r1] = r2; st.parent[r2] = r2;
+      st.e_alive[e] = 0; st.pq.leaf_seq[e] = 0; pq_touch(st.pq, s.pq, 0, 0, e);
+    }
+    // ---- phase A: mark the neighbours of r0 / r1 with the record that reaches them ----
+    for (uint32_t i = tid; i < total; i += kBcThreads) {
+      const bool side1 = i >= len0;
+      const uint32_t eid = st.pool[side1 ? off1 + (i - len0) : off0 + i];
+      if (eid == e || !st.e_alive[eid]) continue;
+      const uint32_t r = side1 ? r1 : r0;
+      const uint32_t u = st.e_u[eid], v = st.e_v[eid];
+      const uint32_t rs = (u == r) ? v : u;
+      (side1 ? st.mark1 : st.mark0)[rs] = eid + 1u;
+    }
+    __syncthreads();
+
+    // ---- phase B: one new record (rs, r2) per distinct neighbour ----
+    for (uint32_t i = tid; i < total; i += kBcThreads) {
+      const bool side1 = i >= len0;
+      const uint32_t eid = st.pool[side1 ? off1 + (i - len0) : off0 + i];
+      if (eid == e) continue;
+      const uint32_t u = st.e_u[eid], v = st.e_v[eid];
+      const uint32_t r = side1 ? r1 : r0;
+      if (u != r && v != r) continue;
+      const uint32_t rs = (u == r) ? v : u;
+      uint32_t e0s, e1s;
+      if (!side1) {
+        if (st.mark0[rs] != eid + 1u) continue;
+        e0s = eid;
+        const uint32_t m = st.mark1[rs];
+        e1s = m ? m - 1u : kNone;
+      } else {
+        if (st.mark1[rs] != eid + 1u) continue;
+        if (st.mark0[rs] != 0u) continue;
+        e0s = kNone; e1s = eid;
+      }
+      const uint32_t idx = atomicAdd(&s.newcount, 1u);
+      const uint32_t newE = (uint32_t)ne + idx;
+      EStats A, NA;
+      estats_clear(A); estats_clear(NA);
+      float d[4] = {__builtin_inff(), -__builtin_inff(), __builtin_inff(), -__builtin_inff()};   // rs->r2, r2->rs
+      uint32_t fh = kNone, ft = kNone;
+      bool t0 = false, t1 = false;
+      for (int side = 0; side < 2; ++side) {
+        const uint32_t o = side ? e1s : e0s;
+        if (o == kNone) continue;
+        estats_add(A, st.e_A[o]);
+        estats_add(NA, st.e_NA[o]);
+        const float* od = &st.e_dir[(size_t)o * 4];
+        const bool rsIsU = st.e_u[o] == rs;          // od[0..1] = u->v
+        d[0] = fminf(d[0], od[rsIsU ? 0 : 2]); d[1] = fmaxf(d[1], od[rsIsU ? 1 : 3]);
+        d[2] = fminf(d[2], od[rsIsU ? 2 : 0]); d[3] = fmaxf(d[3], od[rsIsU ? 3 : 1]);
+        const uint32_t oh = st.e_fhead[o];
+        if (oh != kNone) {
+          if (fh == kNone) { fh = oh; ft = st.e_ftail[o]; }
+          else { st.le_next[ft] = oh; ft = st.e_ftail[o]; }
+        }
+        if (st.e_table[o]) { if (side) t1 = true; else t0 = true; }
+        st.e_alive[o] = 0;
+        if (st.e_table[o]) { st.pq.leaf_seq[o] = 0; pq_touch(st.pq, s.pq, 0, 0, o); }
+      }
+      const uint32_t old = (e0s != kNone) ? e0s : e1s;
+      const uint32_t posRs = (st.e_u[old] == rs) ? st.e_posu[old] : st.e_posv[old];
+      st.e_u[newE] = rs; st.e_v[newE] = r2; st.e_posu[newE] = posRs; st.e_posv[newE] = idx;
+      st.e_alive[newE] = 1; st.e_table[newE] = (t0 || t1) ? 1 : 0; st.e_orient[newE] = 1;
+      st.e_A[newE] = A; st.e_NA[newE] = NA;
+      float* nd = &st.e_dir[(size_t)newE * 4];
+      nd[0] = d[0]; nd[1] = d[1]; nd[2] = d[2]; nd[3] = d[3];
+      st.e_fhead[newE] = fh; st.e_ftail[newE] = ft;
+      // queue position (only meaningful for table edges): reference visit order, see greedy.hip
+      const uint32_t cat = rs < r0 ? 0u : (t0 ? 1u : 2u);
+      st.pq.leaf_seq[newE] = 0;
+      st.pq.leaf_sal[newE] = -__builtin_inf();
+      st.pool[st.adj_off[rs] + posRs] = newE;
+      st.pool[r2off + idx] = newE;
+      // stash the category in posv's upper bits? no: recompute it when scoring -- keep it in model[] later
+      st.e_posv[newE] = idx | (cat << 30);
+      // r2's mutual boundary extremes (entries r2 -> rs) for B(r2) and the "all but one" queries
+      atomicMin(&s.best_mn, ((unsigned long long)float_ord(d[2]) << 32) | newE);
+      atomicMax(&s.best_mx, ((unsigned long long)float_ord(d[3]) << 32) | newE);
+    }
+    __syncthreads();
+    const uint32_t newcount = s.newcount;
+    for (uint32_t j = tid; j < newcount; j += kBcThreads) {
+      const uint32_t rec = (uint32_t)ne + j;
+      const uint32_t rs = st.e_u[rec];
+      st.mark0[rs] = 0; st.mark1[rs] = 0;
+      const float* nd = &st.e_dir[(size_t)rec * 4];
+      if (rec != (uint32_t)(s.best_mn & 0xFFFFFFFFull)) atomicMin(&s.second_mn, ((unsigned long long)float_ord(nd[2]) << 32) | rec);
+      if (rec != (uint32_t)(s.best_mx & 0xFFFFFFFFull)) atomicMax(&s.second_mx, ((unsigned long long)float_ord(nd[3]) << 32) | rec);
+    }
+    __syncthreads();
+    const float bnmn = st.Bn[r2].mn, bnmx = st.Bn[r2].mx;
+    const float best_mn = newcount ? ord_float((uint32_t)(s.best_mn >> 32)) : __builtin_inff();
+    const float best_mx = newcount ? ord_float((uint32_t)(s.best_mx >> 32)) : -__builtin_inff();
+    const float second_mn = (s.second_mn != ~0ull) ? ord_float((uint32_t)(s.second_mn >> 32)) : __builtin_inff();
+    const float second_mx = (s.second_mx != 0ull) ? ord_float((uint32_t)(s.second_mx >> 32)) : -__builtin_inff();
+    const uint32_t arg_mn = (uint32_t)(s.best_mn & 0xFFFFFFFFull), arg_mx = (uint32_t)(s.best_mx & 0xFFFFFFFFull);
+    if (tid == 0) {
+      st.adj_off[r2] = r2off; st.adj_len[r2] = newcount;
+      st.Bmn[r2] = fminf(bnmn, best_mn); st.Bmx[r2] = fmaxf(bnmx, best_mx);
+    }
+    __syncthreads();
+
+    // ---- score the new table edges: features (one thread per edge) -> forest ((edge, tree) per thread) ----
+    for (uint32_t c0 = 0; c0 < newcount; c0 += kChunk) {
+      const uint32_t cn = min((uint32_t)kChunk, newcount - c0);
+      if ((uint32_t)tid < cn) {
+        const uint32_t rec = (uint32_t)ne + c0 + tid;
+        s.votes[tid] = 0; s.model[tid] = -1;
+        if (st.e_table[rec]) {
+          const uint32_t rs = st.e_u[rec];
+          float a, b;
+          excl_minmax(st, rs, rec, a, b);
+          const float c = fminf(bnmn, rec == arg_mn ? second_mn : best_mn);
+          const float d = fmaxf(bnmx, rec == arg_mx ? second_mx : best_mx);
+          double* x = &st.featbuf[(size_t)tid * fdim];
+          edge_features(st, rs, r2, rec, a, b, c, d, x);        // updateFb passes (rs, r2)
+          s.model[tid] = st.clf.kind == 1 ? 0 : pick_model(st.clf, x);
+        }
+      }
+      __syncthreads();
+      if (st.clf.kind == 0) {
+        const int ntree = st.clf.f[0].ntree;    // the three ensemble members are required to have equal size
+        for (uint32_t i = tid; i < cn * (uint32_t)ntree; i += kBcThreads) {
+          const uint32_t j = i / ntree, t = i % ntree;
+          const int m = s.model[j];
+          if (m < 0) continue;
+          if (forest_vote(st.clf.f[m], (int)t, &st.featbuf[(size_t)j * fdim])) atomicAdd(&s.votes[j], 1);
+        }
+      }
+      __syncthreads();
+      if ((uint32_t)tid < cn && s.model[tid] >= 0) {
+        const uint32_t rec = (uint32_t)ne + c0 + tid;
+        const double sal = st.clf.kind == 1 ? 1.0 - st.featbuf[(size_t)tid * fdim + st.clf.stub_index]
+                                            : (double)s.votes[tid] / (double)st.clf.f[s.model[tid]].ntree;
+        const uint32_t cat = st.e_posv[rec] >> 30;
+        st.pq.leaf_sal[rec] = sal;
+        st.pq.leaf_seq[rec] = ((k + 1ull) << 32) | ((unsigned long long)cat << 30) | st.e_u[rec];
+        pq_touch(st.pq, s.pq, 0, 0, rec);
+      }
+      __syncthreads();
+    }
+    for (uint32_t j = tid; j < newcount; j += kBcThreads) st.e_posv[(uint32_t)ne + j] &= 0x3FFFFFFFu;
+    pq_propagate<kBcThreads>(st.pq, s.pq, tid);
+    k += 1; ne += newcount; pool_used += total;
+  }
+  if (tid == 0) { st.ctrl[0] = k; st.ctrl[1] = ne; st.ctrl[2] = pool_used; st.ctrl[3] = status; }
+}
+
+}  // namespace
+
+// iteration order of the reference's region map, as ranks per leaf: replay of genPointMap (util/struct.hxx:77-92:
+// cmap in first-raster-occurrence order, pmap in cmap iteration order) and TRegionMap::init
+// (type/region_map.hxx:79-95: emplace in pmap iteration order) through the same libstdc++ container.
+static void rmap_ranks(const std::vector<uint32_t>& labels, const std::vector<long long>& first, std::vector<uint32_t>* rank) {
+  const size_t R = labels.size();
+  std::vector<uint32_t> byFirst(R);
+  for (size_t i = 0; i < R; ++i) byFirst[i] = (uint32_t)i;
+  std::sort(byFirst.begin(), byFirst.end(), [&](uint32_t a, uint32_t b) { return first[a] < first[b]; });
+  std::unordered_map<uint32_t, size_t> cmap;
+  for (uint32_t i : byFirst) cmap[labels[i]] = 1;
+  std::unordered_map<uint32_t, int> pmap;
+  for (auto const& cp : cmap) pmap[cp.first] = 0;
+  std::unordered_map<uint32_t, int> rmap;
+  for (auto const& pp : pmap) rmap.emplace(pp.first, 0);
+  std::unordered_map<uint32_t, uint32_t> pos;
+  uint32_t n = 0;
+  for (auto const& rp : rmap) pos[rp.first] = n++;
+  rank->resize(R);
+  for (size_t i = 0; i < R; ++i) (*rank)[i] = pos[labels[i]];
+}
+
+int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& clf, hipStream_t stream,
+              uint32_t* h_order, double* h_sal, double* h_feats, int64_t capacity, int64_t* n_merges,
+              double* ms_table, double* ms_init, double* ms_loop, int64_t* n_scored) {
+  const long long P = rag.P;
+  const uint32_t R = (uint32_t)rag.R;
+  *n_merges = 0;
+  if (R == 0 || P == 0) return GLIA_HMT_OK;
+  if (cfg.fdim > kMaxFeat) { set_error("merge_order_bc: feature vector too long"); return GLIA_HMT_ERR_ARG; }
+  hipEvent_t ev[4];
+  for (auto& e : ev) GLIA_HIP_TRY(hipEventCreate(&e));
+  GLIA_HIP_TRY(hipEventRecord(ev[0], stream));
+  DeviceBuffers buf;
+  int rc;
+  BcState st;
+  memset(&st, 0, sizeof(st));
+  st.R0 = R; st.P = P; st.cfg = cfg; st.clf = clf;
+
+  // host side: reference region-map iteration order
+  std::vector<uint32_t> lab(R), rrec((size_t)R * kRegionWords), rank;
+  GLIA_HIP_TRY(hipMemcpy(lab.data(), rag.d_rlabel, sizeof(uint32_t) * R, hipMemcpyDeviceToHost));
+  GLIA_HIP_TRY(hipMemcpy(rrec.data(), rag.d_rrec, sizeof(uint32_t) * kRegionWords * R, hipMemcpyDeviceToHost));
+  std::vector<long long> first(R);
+  for (uint32_t i = 0; i < R; ++i) { unsigned long long f; memcpy(&f, &rrec[(size_t)i * kRegionWords + R_FIRST], 8); first[i] = (long long)~f; }
+  rmap_ranks(lab, first, &rank);
+  uint32_t* d_rank;
+  if ((rc = buf.get(&d_rank, R, false, stream))) return rc;
+  GLIA_HIP_TRY(hipMemcpyAsync(d_rank, rank.data(), sizeof(uint32_t) * R, hipMemcpyHostToDevice, stream));
+
+  if ((rc = buf.get(&st.le_src, P, false, stream))) return rc;
+  if ((rc = buf.get(&st.le_dst, P, false, stream))) return rc;
+  if ((rc = buf.get(&st.le_stats, P, false, stream))) return rc;
+  if ((rc = buf.get(&st.le_next, P, false, stream))) return rc;
+  if ((rc = buf.get(&st.le_mutual, P, false, stream))) return rc;
+  if ((rc = buf.get(&st.le_start, (size_t)R + 1, false, stream))) return rc;
+  GLIA_HIP_TRY(hipMemsetAsync(st.le_start, 0xFF, sizeof(uint32_t) * ((size_t)R + 1), stream));
+  if ((rc = buf.get(&st.nm_out, R, true, stream))) return rc;
+  long long* partner; uint32_t* flag; uint32_t* eidx;
+  if ((rc = buf.get(&partner, P, false, stream))) return rc;
+  if ((rc = buf.get(&flag, P + 1, true, stream))) return rc;
+  if ((rc = buf.get(&eidx, P + 1, false, stream))) return rc;
+  const unsigned gP = (unsigned)((P + 255) / 256);
+  hipLaunchKernelGGL(bc_leaf_entries, dim3(gP), dim3(256), 0, stream, st, rag.d_pa, rag.d_pb, rag.d_prec, rag.d_rlabel, partner,
+                     cfg.bins, cfg.T);
+  hipLaunchKernelGGL(bc_fix_starts, dim3(1), dim3(1), 0, stream, st);
+  hipLaunchKernelGGL(bc_record_flags, dim3(gP), dim3(256), 0, stream, st, rag.d_pa, rag.d_pb, flag);
+  {
+    size_t tmp = 0;
+    GLIA_HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, flag, eidx, 0u, (size_t)(P + 1), rocprim::plus<uint32_t>(), stream));
+    char* d_tmp;
+    if ((rc = buf.get(&d_tmp, tmp ? tmp : 16, false, stream))) return rc;
+    GLIA_HIP_TRY(rocprim::exclusive_scan((void*)d_tmp, tmp, flag, eidx, 0u, (size_t)(P + 1), rocprim::plus<uint32_t>(), stream));
+  }
+  uint32_t E0 = 0;
+  GLIA_HIP_TRY(hipMemcpyAsync(&E0, eidx + P, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  GLIA_HIP_TRY(hipStreamSynchronize(stream));
+  if (E0 == 0) return GLIA_HMT_OK;
+
+  st.Ecap = (uint32_t)std::min<unsigned long long>(0xFFFFFF00ull, (unsigned long long)E0 * 6ull + (1u << 16));
+  st.pool_cap = (unsigned long long)E0 * 12ull + (1u << 16);
+  const size_t R2 = 2 * (size_t)R;
+  if ((rc = buf.get(&st.pts, R2, false, stream))) return rc;
+  if ((rc = buf.get(&st.Bn, R2, false, stream))) return rc;
+  if ((rc = buf.get(&st.Bt, R2, false, stream))) return rc;
+  if ((rc = buf.get(&st.Bmn, R2, false, stream))) return rc;
+  if ((rc = buf.get(&st.Bmx, R2, false, stream))) return rc;
+  if ((rc = buf.get(&st.parent, R2, false, stream))) return rc;
+  if ((rc = buf.get(&st.adj_off, R2, true, stream))) return rc;
+  if ((rc = buf.get(&st.adj_len, R2 + 1, true, stream))) return rc;
+  if ((rc = buf.get(&st.pool, st.pool_cap, false, stream))) return rc;
+  if ((rc = buf.get(&st.e_u, st.Ecap, false, stream))) return rc;
+  if ((rc = buf.get(&st.e_v, st.Ecap, false, stream))) return rc;
+  if ((rc = buf.get(&st.e_posu, st.Ecap, false, stream))) return rc;
+  if ((rc = buf.get(&st.e_posv, st.Ecap, false, stream))) return rc;
+  if ((rc = buf.get(&st.e_alive, st.Ecap, false, stream))) return rc;
+  if ((rc = buf.get(&st.e_table, st.Ecap, false, stream))) return rc;
+  if ((rc = buf.get(&st.e_orient, st.Ecap, false, stream))) return rc;
+  if ((rc = buf.get(&st.e_A, st.Ecap, false, stream))) return rc;
+  if ((rc = buf.get(&st.e_NA, st.Ecap, false, stream))) return rc;
+  if ((rc = buf.get(&st.e_dir, (size_t)st.Ecap * 4, false, stream))) return rc;
+  if ((rc = buf.get(&st.e_fhead, st.Ecap, false, stream))) return rc;
+  if ((rc = buf.get(&st.e_ftail, st.Ecap, false, stream))) return rc;
+  st.pq.nleaves = st.Ecap;
+  if ((rc = buf.get(&st.pq.leaf_sal, st.Ecap, false, stream))) return rc;
+  if ((rc = buf.get(&st.pq.leaf_seq, st.Ecap, false, stream))) return rc;
+  if ((rc = buf.get(&st.mark0, R2, true, stream))) return rc;
+  if ((rc = buf.get(&st.mark1, R2, true, stream))) return rc;
+  if ((rc = buf.get(&st.order, 3 * (size_t)R, false, stream))) return rc;
+  if ((rc = buf.get(&st.sal_out, (size_t)R, false, stream))) return rc;
+  if (h_feats) { if ((rc = buf.get(&st.feats_out, (size_t)R * cfg.fdim, false, stream))) return rc; }
+  if ((rc = buf.get(&st.featbuf, (size_t)kChunk * cfg.fdim, false, stream))) return rc;
+  if ((rc = buf.get(&st.ctrl, 8, true, stream))) return rc;
+  uint32_t* cursor;
+  if ((rc = buf.get(&cursor, R2, true, stream))) return rc;
+
+  hipLaunchKernelGGL(bc_init_dead, dim3((st.Ecap + 255) / 256), dim3(256), 0, stream, st, 0u);
+  hipLaunchKernelGGL(bc_leaf_regions, dim3((R + 255) / 256), dim3(256), 0, stream, st, rag.d_rrec, cfg.bins);
+  hipLaunchKernelGGL(bc_record_fill, dim3(gP), dim3(256), 0, stream, st, flag, eidx, partner, d_rank, st.adj_len);
+  {
+    size_t tmp = 0;
+    GLIA_HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, st.adj_len, st.adj_off, 0u, (size_t)R, rocprim::plus<uint32_t>(), stream));
+    char* d_tmp;
+    if ((rc = buf.get(&d_tmp, tmp ? tmp : 16, false, stream))) return rc;
+    GLIA_HIP_TRY(rocprim::exclusive_scan((void*)d_tmp, tmp, st.adj_len, st.adj_off, 0u, (size_t)R, rocprim::plus<uint32_t>(), stream));
+  }
+  hipLaunchKernelGGL(bc_adj_fill, dim3((E0 + 255) / 256), dim3(256), 0, stream, st, E0, cursor);
+  GLIA_HIP_TRY(hipGetLastError());
+  GLIA_HIP_TRY(hipEventRecord(ev[1], stream));
+  hipLaunchKernelGGL(bc_init_score, dim3((E0 + 127) / 128), dim3(128), 0, stream, st, E0);
+  GLIA_HIP_TRY(hipGetLastError());
+  if ((rc = pq_setup(buf, st.pq, stream))) return rc;
+  unsigned long long ctrl[4] = {0, E0, 2ull * E0, ST_RUN};
+  GLIA_HIP_TRY(hipMemcpyAsync(st.ctrl, ctrl, sizeof(ctrl), hipMemcpyHostToDevice, stream));
+  GLIA_HIP_TRY(hipEventRecord(ev[2], stream));
+
+  st.max_iters = 1ull << 14;
+  while (true) {
+    hipLaunchKernelGGL(greedy_bc_kernel, dim3(1), dim3(kBcThreads), 0, stream, st);
+    GLIA_HIP_TRY(hipGetLastError());
+    GLIA_HIP_TRY(hipMemcpyAsync(ctrl, st.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, stream));
+    GLIA_HIP_TRY(hipStreamSynchronize(stream));
+    if (ctrl[3] == ST_RUN) continue;
+    if (ctrl[3] == ST_DONE) break;
+    if (ctrl[3] == ST_NEED_POOL) {
+      const unsigned long long ncap = st.pool_cap * 2;
+      if ((rc = buf.grow(&st.pool, (size_t)st.pool_cap, (size_t)ncap, stream))) return rc;
+      st.pool_cap = ncap;
+    } else if (ctrl[3] == ST_NEED_EDGES) {
+      if (st.Ecap >= 0xFFFFFF00u) { set_error("greedy: more than 2^32 edge slots needed"); return GLIA_HMT_ERR_ARG; }
+      const uint32_t ocap = st.Ecap;
+      const uint32_t ncap = (uint32_t)std::min<unsigned long long>(0xFFFFFF00ull, (unsigned long long)ocap * 2ull);
+      if ((rc = buf.grow(&st.e_u, ocap, ncap, stream))) return rc;
+      if ((rc = buf.grow(&st.e_v, ocap, ncap, stream))) return rc;
+      if ((rc = buf.grow(&st.e_posu, ocap, ncap, stream))) return rc;
+      if ((rc = buf.grow(&st.e_posv, ocap, ncap, stream))) return rc;
+      if ((rc = buf.grow(&st.e_alive, ocap, ncap, stream))) return rc;
+      if ((rc = buf.grow(&st.e_table, ocap, ncap, stream))) return rc;
+      if ((rc = buf.grow(&st.e_orient, ocap, ncap, stream))) return rc;
+      if ((rc = buf.grow(&st.e_A, ocap, ncap, stream))) return rc;
+      if ((rc = buf.grow(&st.e_NA, ocap, ncap, stream))) return rc;
+      if ((rc = buf.grow(&st.e_dir, (size_t)ocap * 4, (size_t)ncap * 4, stream))) return rc;
+      if ((rc = buf.grow(&st.e_fhead, ocap, ncap, stream))) return rc;
+      if ((rc = buf.grow(&st.e_ftail, ocap, ncap, stream))) return rc;
+      if ((rc = buf.grow(&st.pq.leaf_sal, ocap, ncap, stream))) return rc;
+      if ((rc = buf.grow(&st.pq.leaf_seq, ocap, ncap, stream))) return rc;
+      st.Ecap = ncap; st.pq.nleaves = ncap;
+      hipLaunchKernelGGL(bc_init_dead, dim3((ncap - ocap + 255) / 256), dim3(256), 0, stream, st, ocap);
+      if ((rc = pq_setup(buf, st.pq, stream))) return rc;
+    }
+    unsigned long long zero = ST_RUN;
+    GLIA_HIP_TRY(hipMemcpyAsync(st.ctrl + 3, &zero, sizeof(zero), hipMemcpyHostToDevice, stream));
+  }
+  GLIA_HIP_TRY(hipEventRecord(ev[3], stream));
+  GLIA_HIP_TRY(hipEventSynchronize(ev[3]));
+  float t01 = 0, t12 = 0, t23 = 0;
+  (void)hipEventElapsedTime(&t01, ev[0], ev[1]);
+  (void)hipEventElapsedTime(&t12, ev[1], ev[2]);
+  (void)hipEventElapsedTime(&t23, ev[2], ev[3]);
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  *ms_table = t01; *ms_init = t12; *ms_loop = t23;
+  const int64_t n = (int64_t)ctrl[0];
+  *n_scored = (int64_t)ctrl[1];
+  if (n > capacity) { set_error("merge_order_bc: output capacity too small"); return GLIA_HMT_ERR_CAPACITY; }
+  if (n) {
+    GLIA_HIP_TRY(hipMemcpy(h_order, st.order, sizeof(uint32_t) * 3 * n, hipMemcpyDeviceToHost));
+    GLIA_HIP_TRY(hipMemcpy(h_sal, st.sal_out, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (h_feats) GLIA_HIP_TRY(hipMemcpy(h_feats, st.feats_out, sizeof(double) * (size_t)n * cfg.fdim, hipMemcpyDeviceToHost));
+  }
+  *n_merges = n;
+  return GLIA_HMT_OK;
+}
+
+}  // namespace glia

@@ -1,0 +1,153 @@
+// glia_amd/csrc/greedy_common.hpp -- pieces shared by the greedy merge kernels (pb-mean and classifier linkage):
+// the 64-ary tournament tree used as priority queue and small host helpers.
+#pragma once
+#include "hmt_internal.hpp"
+
+namespace glia {
+
+constexpr int kFan = 64;
+constexpr int kMaxLevels = 6;
+constexpr int kGreedyThreads = 512;
+constexpr int kWorkCap = 2048;
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+struct PqLevel {
+  double* sal;
+  unsigned long long* seq;
+  uint32_t* arg;
+  uint32_t* dirty;
+  uint32_t size;
+};
+
+
+enum { ST_RUN = 0, ST_DONE = 1, ST_NEED_EDGES = 2, ST_NEED_POOL = 3, ST_BAD_SALIENCY = 4 };
+
+struct Key { double sal; unsigned long long seq; uint32_t arg; };
+
+__device__ __forceinline__ bool better(const Key& a, const Key& b) {
+  return a.sal > b.sal || (a.sal == b.sal && a.seq > b.seq);
+}
+
+__device__ __forceinline__ Key wave_max(Key k) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    Key o;
+    o.sal = __shfl_xor(k.sal, off);
+    o.seq = __shfl_xor(k.seq, off);
+    o.arg = __shfl_xor(k.arg, off);
+    if (better(o, k)) k = o;
+  }
+  return k;
+}
+
+
+// The tree: level 0 nodes are the parents of the leaves (edge slots), the last level has one node.
+struct PqTree {
+  uint32_t nleaves;
+  double* leaf_sal;
+  unsigned long long* leaf_seq;   // 0 = dead
+  int nlevels;
+  PqLevel lv[kMaxLevels];
+};
+
+// recompute node j of level l with one wave (all 64 lanes must call)
+__device__ __forceinline__ void pq_recompute_node(const PqTree& t, int l, uint32_t j, int lane) {
+  Key k;
+  k.sal = -__builtin_inf(); k.seq = 0; k.arg = 0;
+  uint32_t ci = j * kFan + lane;
+  if (l == 0) {
+    if (ci < t.nleaves) { k.seq = t.leaf_seq[ci]; k.sal = k.seq ? t.leaf_sal[ci] : -__builtin_inf(); k.arg = ci; }
+  } else {
+    const PqLevel& c = t.lv[l - 1];
+    if (ci < c.size) { k.sal = c.sal[ci]; k.seq = c.seq[ci]; k.arg = c.arg[ci]; }
+  }
+  k = wave_max(k);
+  if (lane == 0) {
+    const PqLevel& d = t.lv[l];
+    d.sal[j] = k.sal; d.seq[j] = k.seq; d.arg[j] = k.arg;
+  }
+}
+
+struct PqWork {            // lives in LDS
+  uint32_t ovf;
+  uint32_t wln[2];
+  uint32_t wl[2][kWorkCap];
+};
+
+__device__ __forceinline__ void pq_touch(const PqTree& t, PqWork& w, int level, int which, uint32_t child) {
+  uint32_t p = child / kFan;
+  if (atomicExch(&t.lv[level].dirty[p], 1u) == 0u) {
+    uint32_t i = atomicAdd(&w.wln[which], 1u);
+    if (i < kWorkCap) w.wl[which][i] = p; else w.ovf = 1;
+  }
+}
+
+// apply all pending leaf changes level by level; every thread of the workgroup must call (contains barriers)
+template <int THREADS>
+__device__ __forceinline__ void pq_propagate(const PqTree& t, PqWork& w, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  constexpr int nwaves = THREADS / 64;
+  int cur = 0;
+  for (int l = 0; l < t.nlevels; ++l) {
+    __syncthreads();
+    const bool ovf = w.ovf != 0;
+    const uint32_t n = ovf ? t.lv[l].size : w.wln[cur];
+    for (uint32_t i = wave; i < n; i += nwaves) {
+      const uint32_t j = ovf ? i : w.wl[cur][i];
+      pq_recompute_node(t, l, j, lane);
+      if (lane == 0) {
+        t.lv[l].dirty[j] = 0;
+        if (!ovf && l + 1 < t.nlevels) pq_touch(t, w, l + 1, cur ^ 1, j);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) w.wln[cur] = 0;
+    cur ^= 1;
+  }
+  __syncthreads();
+  if (tid == 0) { w.ovf = 0; w.wln[0] = w.wln[1] = 0; }
+  __syncthreads();
+}
+
+__global__ void pq_build_level_kernel(PqTree t, int l);
+int pq_setup(struct DeviceBuffers& buf, PqTree& t, hipStream_t stream);
+
+inline __device__ double sdivide(double l, double r, double d) { return fabs(r) >= 2.22e-16 ? l / r : d; }   // glia_base.hxx:77-78
+
+// device allocations owned by one call
+struct DeviceBuffers {
+  std::vector<void*> all;
+  ~DeviceBuffers() { for (void* p : all) (void)hipFree(p); }
+  template <typename T> int get(T** p, size_t n, bool zero, hipStream_t s) {
+    GLIA_HIP_TRY(hipMalloc((void**)p, sizeof(T) * (n ? n : 1)));
+    all.push_back(*p);
+    if (zero) GLIA_HIP_TRY(hipMemsetAsync(*p, 0, sizeof(T) * (n ? n : 1), s));
+    return GLIA_HMT_OK;
+  }
+  template <typename T> int grow(T** p, size_t old_n, size_t new_n, hipStream_t s) {
+    T* q = nullptr;
+    GLIA_HIP_TRY(hipMalloc((void**)&q, sizeof(T) * (new_n ? new_n : 1)));
+    GLIA_HIP_TRY(hipMemcpyAsync(q, *p, sizeof(T) * old_n, hipMemcpyDeviceToDevice, s));
+    GLIA_HIP_TRY(hipStreamSynchronize(s));
+    for (auto& x : all) if (x == (void*)*p) { (void)hipFree(x); x = q; }
+    *p = q;
+    return GLIA_HMT_OK;
+  }
+};
+
+// binary searches over the sorted compact RAG
+__device__ __forceinline__ long long find_pair(const uint32_t* pa, const uint32_t* pb, long long P, uint32_t a, uint32_t b) {
+  long long lo = 0, hi = P;
+  while (lo < hi) {
+    long long mid = (lo + hi) >> 1;
+    if (pa[mid] < a || (pa[mid] == a && pb[mid] < b)) lo = mid + 1; else hi = mid;
+  }
+  return (lo < P && pa[lo] == a && pb[lo] == b) ? lo : -1;
+}
+__device__ __forceinline__ uint32_t find_label(const uint32_t* lab, uint32_t R, uint32_t key) {
+  uint32_t lo = 0, hi = R;
+  while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (lab[mid] < key) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+
+}  // namespace glia

@@ -84,6 +84,11 @@ int launch_synth(int dim, const int64_t dims[3], int S, int G, uint64_t seed, in
                  uint32_t* d_truth_tmp, float* d_pb, hipStream_t stream);
 int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, double* h_sal, int64_t capacity,
                 int64_t* n_merges, double* ms_table, double* ms_loop, int64_t* n_scored);
+struct BcCfg;
+struct DeviceClassifier;
+int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& clf, hipStream_t stream, uint32_t* h_order,
+              double* h_sal, double* h_feats, int64_t capacity, int64_t* n_merges, double* ms_table, double* ms_init,
+              double* ms_loop, int64_t* n_scored);
 int compact_tables(const AccParams& p, uint32_t rcap, uint32_t pcap, RagArrays* out, hipStream_t stream);
 
 __host__ __device__ inline uint32_t float_ord(float f) {

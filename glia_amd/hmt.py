@@ -140,6 +140,38 @@ def make_config(pb, rb=(), r=(), rl=(), b=(), thresholds=(0.2, 0.5, 0.8), normal
     return cfg
 
 
+class RandomForest:
+    """alg::RandomForest / alg::EnsembleRandomForest (alg/rf.hxx) loaded from GLIA model files onto the device."""
+
+    def __init__(self, ctx, model_files, predict_label=-1, distributor_args=None):
+        if isinstance(model_files, str):
+            model_files = [model_files]
+        arr = (C.c_char_p * len(model_files))(*[m.encode() for m in model_files])
+        dist = (C.c_double * 3)(*distributor_args) if distributor_args is not None else None
+        self.h = C.c_void_p()
+        _check(lib().glia_hmt_forest_load(ctx.h, C.c_int(len(model_files)), arr, C.c_int(predict_label), dist,
+                                          C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().glia_hmt_forest_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FeatureStubClassifier(RandomForest):
+    """Diagnostic scorer P(merge) = 1 - x[index] (tests; SURVEY.md Appendix D recipe P4)."""
+
+    def __init__(self, ctx, index):
+        self.h = C.c_void_p()
+        _check(lib().glia_hmt_forest_stub(ctx.h, C.c_int(index), C.byref(self.h)))
+
+
 class RegionMap:
     """Device-resident region adjacency structure with sufficient statistics.
     Mirrors TRegionMap(image, mask, onlyContour) (type/region_map.hxx:38-40)."""
@@ -212,6 +244,23 @@ class RegionMap:
         n = C.c_int64(0)
         _check(lib().glia_hmt_merge_order_pb(self.ctx.h, self.h, C.c_int(type), _np(order), _np(sal), C.c_int64(cap),
                                              C.byref(n)))
+        return order[:n.value].copy(), sal[:n.value].copy()
+
+    def feat_dim(self):
+        return lib().glia_hmt_feat_dim(self.h)
+
+    def merge_order_bc(self, classifier, want_feats=False):
+        """hmt/main_merge_order_bc.cxx (--bct 1).  Returns (order, saliency[, feats])."""
+        cap = max(self.num_regions, 1)
+        order = np.empty((cap, 3), np.uint32)
+        sal = np.empty(cap, np.float64)
+        d = self.feat_dim()
+        feats = np.empty((cap, d), np.float64) if want_feats else None
+        n = C.c_int64(0)
+        _check(lib().glia_hmt_merge_order_bc(self.ctx.h, self.h, classifier.h, _np(order), _np(sal), _np(feats),
+                                             C.c_int64(cap), C.byref(n)))
+        if want_feats:
+            return order[:n.value].copy(), sal[:n.value].copy(), feats[:n.value].copy()
         return order[:n.value].copy(), sal[:n.value].copy()
 
     def last_merge_timing(self):

@@ -111,6 +111,28 @@ int glia_hmt_rag_last_pass(const glia_hmt_rag* rag, double* ms, double* algorith
 int glia_hmt_merge_order_pb(glia_hmt_ctx* ctx, glia_hmt_rag* rag, int type, uint32_t* h_order,
                             double* h_saliency, int64_t capacity, int64_t* n_merges);
 
+/* ---- boundary classifier -------------------------------------------------------------------------
+ * glia_hmt_forest_load replaces alg::RandomForest(predictLabel, modelFile) (alg/rf.hxx:22-33) for n_models == 1
+ * and alg::EnsembleRandomForest + opt::ThresholdModelDistributor(dim0, dim1, threshold) (alg/rf.hxx:63-98,
+ * type/function.hxx:71-85; --bcmd) for n_models == 3.  Files are GLIA's binary RF models
+ * (ml/rf/ml_rf_model.cxx:378-455).  predict_label is BC_LABEL_MERGE = -1 in every reference caller.
+ * glia_hmt_forest_stub builds the diagnostic scorer P = 1 - x[feature_index] (tests only). */
+int glia_hmt_forest_load(glia_hmt_ctx* ctx, int n_models, const char* const* paths, int predict_label,
+                         const double* distributor_args /*[3] or NULL*/, glia_hmt_forest** out);
+int glia_hmt_forest_stub(glia_hmt_ctx* ctx, int feature_index, glia_hmt_forest** out);
+void glia_hmt_forest_free(glia_hmt_forest* forest);
+
+/* Length of one feature vector for the configuration the rag was built with (BoundaryClassificationFeats::dim,
+ * hmt/bc_feat.hxx:225-230; or selectFeatures' length with --simpf). */
+int glia_hmt_feat_dim(const glia_hmt_rag* rag);
+
+/* Replaces genMergeOrderGreedyUsingBoundaryClassifier (util/struct_merge_bc.hxx:45-58) with the fBcFeat / fBcPred
+ * pair of hmt/main_merge_order_bc.cxx:54-137 (bcType 1).  The rag must have been built with a feature
+ * configuration and only_contour = 0.  h_feats (optional, [capacity][feat_dim]) receives the feature vector each
+ * merged edge was scored with (the -b output, :148-157). */
+int glia_hmt_merge_order_bc(glia_hmt_ctx* ctx, glia_hmt_rag* rag, const glia_hmt_forest* forest, uint32_t* h_order,
+                            double* h_saliency, double* h_feats, int64_t capacity, int64_t* n_merges);
+
 /* Phase timings of the last merge_order_* call on this rag (ms): edge-table build, init, greedy loop. */
 int glia_hmt_last_merge_timing(const glia_hmt_rag* rag, double* ms_table, double* ms_init, double* ms_loop,
                                int64_t* n_edges_scored);

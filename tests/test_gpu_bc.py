@@ -1,0 +1,110 @@
+"""-m gpu: classifier-linkage merge tree (features K6 + forest K7 + greedy K5) vs the oracle."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    assert torch.cuda.is_available(), "GPU test run without a GPU"
+    from glia_amd import hmt
+    c = hmt.Context(0)
+    yield c
+    c.close()
+
+
+def _gpu_rm(ctx, labels, pb, bins=8, thr=(0.2, 0.5, 0.8), **kw):
+    import torch
+    from glia_amd import hmt
+    d_lab = torch.from_numpy(labels.view(np.int32)).cuda()
+    d_pb = torch.from_numpy(pb).cuda()
+    cfg = hmt.make_config(d_pb, rb=[(d_pb, bins, 0.0, 1.0)], thresholds=thr, **kw)
+    return hmt.RegionMap(ctx, d_lab, pb=d_pb, cfg=cfg)
+
+
+def _feat_close(a, b):
+    return np.allclose(a, b, rtol=1e-5, atol=1e-12)
+
+
+def test_p4_known_answer_stub_scorer(ctx):
+    """SURVEY.md Appendix D recipe P4: answers produced by the reference's own headers."""
+    from glia_amd import hmt
+    from _recipes import recipe_p1
+    lab, pb = recipe_p1(64, 8, 3, pb_shift=16)
+    rm = _gpu_rm(ctx, lab, pb)
+    assert rm.feat_dim() == 104
+    order, sal = rm.merge_order_bc(hmt.FeatureStubClassifier(ctx, 31))
+    assert len(order) == 511
+    for i, (x0, x1, x2, s) in enumerate([(433, 497, 513, 0.601676214), (347, 411, 514, 0.597735723),
+                                         (378, 442, 515, 0.597694034)]):
+        assert order[i].tolist() == [x0, x1, x2]
+        assert sal[i] == pytest.approx(s, rel=0, abs=5e-9)
+    assert rm.last_merge_timing()["n_edges_scored"] >= 9098 - 512
+
+
+CASES = [((24, 24, 24), 6, 12, 0, 8), ((32, 32, 32), 8, 16, 0, 8), ((40, 36, 28), 6, 12, 0, 8), ((64, 64), 4, 16, 0, 8),
+         ((33, 30, 40), 5, 20, 1, 16), ((48, 48, 48), 8, 16, 0, 8)]
+
+
+@pytest.mark.parametrize("shape,S,G,variant,bins", CASES)
+def test_stub_scorer_matches_oracle(ctx, shape, S, G, variant, bins):
+    from glia_amd import hmt
+    from oracle import pyoracle as O
+    labels, pb = O.synth(shape, S, G, variant=variant)
+    rm = _gpu_rm(ctx, labels, pb, bins=bins)
+    stub = 11 + 4 * 3 + 7 + 1          # mean of the boundary image over the shared boundary
+    order, sal, feats = rm.merge_order_bc(hmt.FeatureStubClassifier(ctx, stub), want_feats=True)
+    cfg = O.make_cfg(pb, rb=[(pb, bins, 0.0, 1.0)])
+    o_ref, s_ref, f_ref = O.Rag(labels).merge_order_bc(cfg, None, stub_index=stub, want_feats=True)
+    assert order.shape == o_ref.shape and (order == o_ref).all()
+    assert _feat_close(feats, f_ref)
+    if variant == 0:
+        assert (sal == s_ref).all()
+    else:
+        assert np.allclose(sal, s_ref, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("shape,S,G,ntree,depth", [((32, 32, 32), 8, 16, 31, 6), ((40, 36, 28), 6, 12, 255, 10),
+                                                   ((64, 64), 4, 16, 15, 4)])
+def test_random_forest_matches_oracle(ctx, shape, S, G, ntree, depth):
+    from glia_amd import hmt
+    from oracle import pyoracle as O
+    import _rf
+    labels, pb = O.synth(shape, S, G)
+    cfg = O.make_cfg(pb, rb=[(pb, 8, 0.0, 1.0)])
+    # feature rows to draw split thresholds from: the oracle's own vectors for a stub-scored run
+    _, _, f0 = O.Rag(labels).merge_order_bc(cfg, None, stub_index=31 if len(shape) == 3 else 30, want_feats=True)
+    rng = np.random.default_rng(7)
+    forest = _rf.random_forest(rng, ntree, depth, f0)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "model.bin")
+        _rf.write_model(path, forest)
+        clf = hmt.RandomForest(ctx, path, predict_label=-1)
+    rm = _gpu_rm(ctx, labels, pb)
+    order, sal, feats = rm.merge_order_bc(clf, want_feats=True)
+    o_ref, s_ref, f_ref = O.Rag(labels).merge_order_bc(cfg, O.make_forest(forest, -1), want_feats=True)
+    assert order.shape == o_ref.shape and (order == o_ref).all()
+    assert (sal == s_ref).all()              # votes / ntree: exact
+    assert _feat_close(feats, f_ref)
+
+
+def test_log_and_simple_features(ctx):
+    from glia_amd import hmt
+    from oracle import pyoracle as O
+    labels, pb = O.synth((32, 32, 32), 8, 16)
+    for kw, okw in [(dict(use_log_shape=True), dict(use_log=True)),
+                    (dict(use_simple_features=True), dict(use_simple=True)),
+                    (dict(normalizing_area=32.0 ** 3, normalizing_length=32.0 * 3 ** 0.5),
+                     dict(norm_area=32.0 ** 3, norm_len=32.0 * 3 ** 0.5))]:
+        rm = _gpu_rm(ctx, labels, pb, **kw)
+        cfg = O.make_cfg(pb, rb=[(pb, 8, 0.0, 1.0)], **okw)
+        stub = 5 if "use_simple_features" in kw else 34
+        order, sal, feats = rm.merge_order_bc(hmt.FeatureStubClassifier(ctx, stub), want_feats=True)
+        o_ref, s_ref, f_ref = O.Rag(labels).merge_order_bc(cfg, None, stub_index=stub, want_feats=True)
+        assert feats.shape == f_ref.shape
+        assert (order == o_ref).all() and _feat_close(feats, f_ref)
