@@ -85,6 +85,20 @@ __device__ inline double sdiv(double l, double r, double d) { return fabs(r) >= 
 __device__ inline double slog(double x, double d) { return x > 0.0 ? log(x) : d; }
 __device__ inline double ssqrt(double x, double d) { return x >= 0.0 ? sqrt(x) : d; }
 
+// std::pow(perim, D/(D-1)) of type/feat.hxx:78-79 for an integer-valued perim: exponent 2 (2D) is an exact
+// square; exponent 1.5 (3D) is perim*sqrt(perim) evaluated in double-double and rounded once, i.e. the correctly
+// rounded value, which is what glibc's pow returns except in vanishingly rare near-tie cases.
+__device__ inline double pow_perim(double x, int D) {
+  if (D == 2) return x * x;
+  if (!(x > 0.0)) return 0.0;
+  const double s = sqrt(x);                       // correctly rounded
+  const double r = __builtin_fma(-s, s, x);       // x - s*s, exact
+  const double sl = r / (2.0 * s);                // sqrt(x) = s + sl (+ O(ulp^2))
+  const double ph = x * s;
+  const double pl = __builtin_fma(x, s, -ph);     // x*s = ph + pl exactly
+  return ph + (pl + x * sl);
+}
+
 // histogram -> entropy (normalised by the set's voxel count), also returns the normalised histogram
 __device__ inline double hist_entropy(const uint32_t* hc, uint32_t n, int bins, double* h) {
   double ent = 0.0;
@@ -124,7 +138,7 @@ __device__ inline void region_feats(const BcCfg& c, const PStats& p, const EStat
   const int D = c.D, T = c.T;
   double area = (double)p.n;
   double perim = (double)((unsigned long long)b.n + (unsigned long long)p.border);
-  double compactness = sdiv(pow(perim, (double)D / (D - 1)), area, 0.0);
+  double compactness = sdiv(pow_perim(perim, D), area, 0.0);
   area = sdiv(area, c.norm_area, 0.0);
   perim = sdiv(perim, c.norm_len, 0.0);
   double bboxArea = 1.0;

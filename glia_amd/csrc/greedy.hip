@@ -285,6 +285,7 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
   if ((rc = buf.get(&st.e_posv, st.Ecap, false, stream))) return rc;
   if ((rc = buf.get(&st.e_mean, st.Ecap, false, stream))) return rc;
   if ((rc = buf.get(&st.e_n, st.Ecap, false, stream))) return rc;
+  st.pq.nleaves = st.Ecap;
   if ((rc = buf.get(&st.pq.leaf_sal, st.Ecap, false, stream))) return rc;
   if ((rc = buf.get(&st.pq.leaf_seq, st.Ecap, false, stream))) return rc;
   if ((rc = buf.get(&st.mark0, 2 * (size_t)R, true, stream))) return rc;

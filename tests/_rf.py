@@ -10,8 +10,8 @@ OFF = dict(n_ncat=104, n_catf=120, nrnodes=128, ntree=132, n_xbestsplit=144, n_c
 
 
 def random_forest(rng, ntree, max_depth, feat_values, nclass=2, p_leaf=0.15):
-    """feat_values: [n_samples, D] array; split thresholds are drawn from its entries so that splits are
-    informative (and x == threshold ties occur).  Returns arrays in the in-memory layout classForest walks."""
+    """feat_values: [n_samples, D] array; split thresholds are midpoints of neighbouring observed values, so
+    splits are informative.  Returns arrays in the in-memory layout classForest walks."""
     D = feat_values.shape[1]
     trees = []
     for _ in range(ntree):
@@ -23,7 +23,14 @@ def random_forest(rng, ntree, max_depth, feat_values, nclass=2, p_leaf=0.15):
                 nd.update(status=-1, var=0, split=0.0, left=0, right=0, cls=int(rng.integers(1, nclass + 1)))
             else:
                 var = int(rng.integers(0, D))
-                thr = float(feat_values[rng.integers(0, feat_values.shape[0]), var])
+                # like randomForest's split search, a split sits midway between two observed values, never on one:
+                # entropy (log2) and compactness (pow) agree with glibc only to the last ulp on the device
+                col = np.unique(feat_values[:, var])
+                if len(col) > 1:
+                    i = int(rng.integers(0, len(col) - 1))
+                    thr = float((col[i] + col[i + 1]) / 2.0)
+                else:
+                    thr = float(col[0]) + 0.5
                 nd.update(status=1, var=var + 1, split=thr, left=len(nodes) + 1, right=len(nodes) + 2, cls=0)
                 nodes.append(dict(depth=nd["depth"] + 1))
                 nodes.append(dict(depth=nd["depth"] + 1))
