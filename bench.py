@@ -19,20 +19,30 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def cpu_baseline(size, S):
-    """oracle (reference-faithful port, 1 thread): RAG build + pb-mean greedy on a size^3 sample."""
+def cpu_baseline(size, S, bc_size):
+    """oracle (reference-faithful port of GLIA's algorithm, 1 thread) on bounded sub-volumes of the same synthetic
+    workload: RAG + greedy pb-mean merge tree on size^3, and the classifier-path feature evaluations on bc_size^3."""
     import numpy as np  # noqa: F401
     from oracle import pyoracle as O
-    labels, pb = O.synth((size,) * 3, S, 4 * S)
+    labels, pb = O.synth((size,) * 3, S, 8 * S)
     t0 = time.time()
     rag = O.Rag(labels, only_contour=True)
     t1 = time.time()
     order, _ = rag.merge_order_pb(pb, type=2)
     t2 = time.time()
-    return {"value": len(order) / (t2 - t0), "unit": "region-merges/s", "cores": 1, "kind": "port",
-            "sample": "%d^3 synthetic volume, S=%d (%d regions): RAG %.2fs + greedy pb-mean %.2fs, oracle/hmt_oracle.cc"
-                      % (size, S, len(order) + 1, t1 - t0, t2 - t1),
-            "merge_loop_only": len(order) / max(t2 - t1, 1e-9)}
+    out = {"value": len(order) / (t2 - t0), "unit": "region-merges/s", "cores": 1, "kind": "port",
+           "sample": "%d^3 synthetic volume, S=%d (%d regions): RAG %.2fs + greedy pb-mean %.2fs, oracle/hmt_oracle.cc; "
+                     "edge features: classifier path on %d^3" % (size, S, len(order) + 1, t1 - t0, t2 - t1, bc_size),
+           "merge_loop_only": len(order) / max(t2 - t1, 1e-9)}
+    labels, pb = O.synth((bc_size,) * 3, S // 2, 4 * S)
+    cfg = O.make_cfg(pb, rb=[(pb, 8, 0.0, 1.0)])
+    rag = O.Rag(labels)
+    t0 = time.time()
+    order, _ = rag.merge_order_bc(cfg, None, stub_index=31)
+    t1 = time.time()
+    out["edge_features_per_sec"] = rag.n_feat_evals / (t1 - t0)
+    out["bc_merges_per_sec"] = len(order) / (t1 - t0)
+    return out
 
 
 def main():
@@ -42,13 +52,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--S", type=int, default=16)
-    ap.add_argument("--cpu-size", type=int, default=192)
+    ap.add_argument("--cpu-size", type=int, default=256)
+    ap.add_argument("--cpu-bc-size", type=int, default=40)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
+    import tempfile
     import torch
     import torch.distributed as dist
     from glia_amd import hmt
+    from glia_amd.synth_forest import synthetic_forest, write_model
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -61,6 +74,10 @@ def main():
     shape = (args.size,) * 3
     labels, pb = ctx.synth(shape, args.S, 8 * args.S, seed=0x9E3779B97F4A7C15 + rank)
     cfg = hmt.make_config(pb, rb=[(pb, 8, 0.0, 1.0)], thresholds=(0.2, 0.5, 0.8))
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "forest_rank%d.bin" % rank)
+        write_model(path, synthetic_forest(ntree=255, dim=3))
+        clf = hmt.RandomForest(ctx, path, predict_label=-1)
     N = labels.numel()
 
     def barrier():
@@ -70,11 +87,16 @@ def main():
         ctx.sync()
 
     def step():
-        rm = hmt.RegionMap(ctx, labels, pb=pb, only_contour=True, cfg=cfg)
-        order, sal = rm.merge_order_pb(type=2)
+        # K1-K3 accumulation (regions + directed pairs, all statistics) -> K4 compaction
+        rm = hmt.RegionMap(ctx, labels, pb=pb, only_contour=False, cfg=cfg)
         ms, by = rm.last_pass()
+        # K6 + K7: feature vector + forest score of every initial edge (TBoundaryTable::init, classifier linkage)
+        n_edges, ms_score = rm.score_initial_edges(clf)
+        # K4b + K5: edge table + greedy merge loop (pb-mean linkage), R-1 contractions
+        order, sal = rm.merge_order_pb(type=2)
         tm = rm.last_merge_timing()
-        info = dict(R=rm.num_regions, P=rm.num_pairs, merges=len(order), acc_ms=ms, acc_bytes=by, **tm)
+        info = dict(R=rm.num_regions, P=rm.num_pairs, merges=len(order), acc_ms=ms, acc_bytes=by, n_edges=n_edges,
+                    ms_score=ms_score, feat_dim=rm.feat_dim(), **tm)
         rm.close()
         return info
 
@@ -89,36 +111,42 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        m = torch.tensor([float(sum(i["merges"] for i in infos))], dtype=torch.float64, device="cuda")
+        m = torch.tensor([float(sum(i["merges"] for i in infos)), float(sum(i["n_edges"] for i in infos))],
+                         dtype=torch.float64, device="cuda")
         dist.all_reduce(m, op=dist.ReduceOp.SUM)
-        merges = float(m.item())
+        merges, edges = float(m[0].item()), float(m[1].item())
     else:
         merges = float(sum(i["merges"] for i in infos))
+        edges = float(sum(i["n_edges"] for i in infos))
 
     if rank == 0:
         acc_ms = sum(i["acc_ms"] for i in infos) / len(infos)
         achieved = infos[0]["acc_bytes"] / (acc_ms * 1e-3) / 1e9
         loop_ms = sum(i["ms_loop"] for i in infos) / len(infos)
+        score_ms = sum(i["ms_score"] for i in infos) / len(infos)
         out = {
             "metric": "region_merges_per_sec", "value": merges / dt, "unit": "region-merges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 labels / f32 image / f64 stats",
-            "data": "synthetic",
-            "config": {"workload": "%d^3 synthetic EM volume (jittered-Voronoi supervoxels S=%d, Q8 pb), RAG + boundary/"
-                                   "region statistics accumulation + edge table + greedy pb-mean merge tree"
-                                   % (args.size, args.S),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32 labels / f32 image / f64 statistics and features", "data": "synthetic",
+            "config": {"workload": "%d^3 synthetic EM volume (jittered-Voronoi supervoxels S=%d, Q8 pb): K1-K3 RAG + "
+                                   "boundary/region statistics accumulation, K4 edge table, K6+K7 feature vector (D_f=%d) + "
+                                   "255-tree forest score of every initial edge, K5 greedy pb-mean merge tree"
+                                   % (args.size, args.S, infos[0]["feat_dim"]),
                        "voxels": N, "regions": infos[0]["R"], "directed_pairs": infos[0]["P"],
-                       "merges_per_step": infos[0]["merges"], "parallelism": "replica x%d" % world},
-            "phases_ms": {"accumulate": acc_ms, "edge_table": sum(i["ms_table"] for i in infos) / len(infos),
-                          "merge_loop": loop_ms},
+                       "initial_edges": infos[0]["n_edges"], "merges_per_step": infos[0]["merges"],
+                       "parallelism": "replica x%d (the merge loop does not shard)" % world},
+            "edge_features_per_sec": edges / dt,
+            "phases_ms": {"accumulate": acc_ms, "edge_features_and_scores": score_ms,
+                          "edge_table": sum(i["ms_table"] for i in infos) / len(infos), "merge_loop": loop_ms},
             "merge_loop_merges_per_sec": infos[0]["merges"] / (loop_ms * 1e-3) if loop_ms else None,
-            "edge_stat_records_per_sec": (infos[0]["P"] + infos[0]["R"]) / (acc_ms * 1e-3),
+            "edge_feature_kernel_per_sec": infos[0]["n_edges"] / (score_ms * 1e-3) if score_ms else None,
             "roofline": {"bound": "hbm", "kernel": "rag_accumulate_kernel", "achieved": achieved, "peak": 8000.0,
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                          "algorithmic_bytes_per_launch": infos[0]["acc_bytes"], "avg_launch_ms": acc_ms},
         }
         if not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_size, args.S)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_size, args.S, args.cpu_bc_size)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

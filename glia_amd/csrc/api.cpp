@@ -514,7 +514,7 @@ int glia_hmt_merge_order_bc(glia_hmt_ctx* c, glia_hmt_rag* rag, const glia_hmt_f
   if (h_feats) feats.resize((size_t)R * cfg.fdim);
   int64_t n = 0;
   int rc = greedy_bc(rag->arr, cfg, forest->dc, c->stream, order.data(), sal.data(), h_feats ? feats.data() : nullptr, R, &n,
-                     &rag->ms_table, &rag->ms_init, &rag->ms_loop, &rag->n_scored);
+                     &rag->ms_table, &rag->ms_init, &rag->ms_loop, &rag->n_scored, false);
   if (rc) return rc;
   if (n > capacity) { set_error("merge_order_bc: output capacity too small"); return GLIA_HMT_ERR_CAPACITY; }
   std::vector<uint32_t> lab((size_t)R);
@@ -527,6 +527,25 @@ int glia_hmt_merge_order_bc(glia_hmt_ctx* c, glia_hmt_rag* rag, const glia_hmt_f
   for (int64_t i = 0; i < n; ++i) h_sal[i] = sal[i];
   if (h_feats) memcpy(h_feats, feats.data(), sizeof(double) * (size_t)n * cfg.fdim);
   *n_merges = n;
+  return GLIA_HMT_OK;
+}
+
+int glia_hmt_score_initial_edges(glia_hmt_ctx* c, glia_hmt_rag* rag, const glia_hmt_forest* forest, int64_t* n_edges,
+                                 double* ms) {
+  if (!c || !rag || !forest || rag->ctx != c) { set_error("score_initial_edges: invalid argument"); return GLIA_HMT_ERR_ARG; }
+  BcCfg cfg;
+  if (!make_bc_cfg(rag, &cfg) || rag->only_contour) {
+    set_error("score_initial_edges: the region map must be built with a feature configuration and with region points");
+    return GLIA_HMT_ERR_ARG;
+  }
+  if (forest->max_var >= cfg.fdim) { set_error("score_initial_edges: the classifier reads features beyond the vector"); return GLIA_HMT_ERR_ARG; }
+  GLIA_HIP_TRY(hipSetDevice(c->device));
+  int64_t n = 0;
+  int rc = greedy_bc(rag->arr, cfg, forest->dc, c->stream, nullptr, nullptr, nullptr, 0, &n, &rag->ms_table, &rag->ms_init,
+                     &rag->ms_loop, &rag->n_scored, true);
+  if (rc) return rc;
+  if (n_edges) *n_edges = rag->n_scored;
+  if (ms) *ms = rag->ms_init;
   return GLIA_HMT_OK;
 }
 

@@ -527,7 +527,7 @@ static void rmap_ranks(const std::vector<uint32_t>& labels, const std::vector<lo
 
 int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& clf, hipStream_t stream,
               uint32_t* h_order, double* h_sal, double* h_feats, int64_t capacity, int64_t* n_merges,
-              double* ms_table, double* ms_init, double* ms_loop, int64_t* n_scored) {
+              double* ms_table, double* ms_init, double* ms_loop, int64_t* n_scored, bool init_only) {
   const long long P = rag.P;
   const uint32_t R = (uint32_t)rag.R;
   *n_merges = 0;
@@ -639,6 +639,22 @@ int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& cl
   GLIA_HIP_TRY(hipMemcpyAsync(st.ctrl, ctrl, sizeof(ctrl), hipMemcpyHostToDevice, stream));
   GLIA_HIP_TRY(hipEventRecord(ev[2], stream));
 
+  if (init_only) {     // features + scores of the initial table edges only (TBoundaryTable::init)
+    uint32_t* d_cnt;
+    if ((rc = buf.get(&d_cnt, 1, true, stream))) return rc;
+    GLIA_HIP_TRY(hipEventSynchronize(ev[2]));
+    float t01 = 0, t12 = 0;
+    (void)hipEventElapsedTime(&t01, ev[0], ev[1]);
+    (void)hipEventElapsedTime(&t12, ev[1], ev[2]);
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    *ms_table = t01; *ms_init = t12; *ms_loop = 0;
+    std::vector<uint8_t> tab(E0);
+    GLIA_HIP_TRY(hipMemcpy(tab.data(), st.e_table, E0, hipMemcpyDeviceToHost));
+    int64_t nt = 0;
+    for (uint8_t t : tab) nt += t;
+    *n_scored = nt;
+    return GLIA_HMT_OK;
+  }
   st.max_iters = 1ull << 14;
   while (true) {
     hipLaunchKernelGGL(greedy_bc_kernel, dim3(1), dim3(kBcThreads), 0, stream, st);

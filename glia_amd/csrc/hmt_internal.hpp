@@ -88,7 +88,7 @@ struct BcCfg;
 struct DeviceClassifier;
 int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& clf, hipStream_t stream, uint32_t* h_order,
               double* h_sal, double* h_feats, int64_t capacity, int64_t* n_merges, double* ms_table, double* ms_init,
-              double* ms_loop, int64_t* n_scored);
+              double* ms_loop, int64_t* n_scored, bool init_only);
 int compact_tables(const AccParams& p, uint32_t rcap, uint32_t pcap, RagArrays* out, hipStream_t stream);
 
 __host__ __device__ inline uint32_t float_ord(float f) {

@@ -263,6 +263,11 @@ class RegionMap:
             return order[:n.value].copy(), sal[:n.value].copy(), feats[:n.value].copy()
         return order[:n.value].copy(), sal[:n.value].copy()
 
+    def score_initial_edges(self, classifier):
+        n, ms = C.c_int64(0), C.c_double(0)
+        _check(lib().glia_hmt_score_initial_edges(self.ctx.h, self.h, classifier.h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
     def last_merge_timing(self):
         a, b, c, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
         _check(lib().glia_hmt_last_merge_timing(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))

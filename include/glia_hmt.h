@@ -133,6 +133,12 @@ int glia_hmt_feat_dim(const glia_hmt_rag* rag);
 int glia_hmt_merge_order_bc(glia_hmt_ctx* ctx, glia_hmt_rag* rag, const glia_hmt_forest* forest, uint32_t* h_order,
                             double* h_saliency, double* h_feats, int64_t capacity, int64_t* n_merges);
 
+/* TBoundaryTable::init with the classifier linkage only (type/boundary_table.hxx:91-114 driven by
+ * util/struct_merge_bc.hxx:18-27): feature vector + score of every initial table edge, no merging.
+ * *ms = device time of the feature + forest kernel. */
+int glia_hmt_score_initial_edges(glia_hmt_ctx* ctx, glia_hmt_rag* rag, const glia_hmt_forest* forest,
+                                 int64_t* n_edges, double* ms);
+
 /* Phase timings of the last merge_order_* call on this rag (ms): edge-table build, init, greedy loop. */
 int glia_hmt_last_merge_timing(const glia_hmt_rag* rag, double* ms_table, double* ms_init, double* ms_loop,
                                int64_t* n_edges_scored);
