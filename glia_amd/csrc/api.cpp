@@ -458,6 +458,22 @@ int glia_hmt_forest_load(glia_hmt_ctx* c, int n_models, const char* const* paths
   return GLIA_HMT_OK;
 }
 
+int glia_hmt_forest_file_parse(const char* path, int predict_label, int* ntree, int* nrnodes, int* nclass,
+                               double* h_split, int* h_meta, int64_t capacity_nodes) {
+  if (!path || !ntree || !nrnodes || !nclass) { set_error("forest_file_parse: invalid argument"); return GLIA_HMT_ERR_ARG; }
+  HostForest hf;
+  int rc = load_forest_file(path, predict_label, &hf);
+  if (rc) return rc;
+  *ntree = hf.ntree; *nrnodes = hf.nrnodes; *nclass = hf.nclass;
+  const int64_t nodes = (int64_t)hf.ntree * hf.nrnodes;
+  if (h_split || h_meta) {
+    if (nodes > capacity_nodes) { set_error("forest_file_parse: capacity too small"); return GLIA_HMT_ERR_CAPACITY; }
+    if (h_split) memcpy(h_split, hf.split.data(), sizeof(double) * nodes);
+    if (h_meta) memcpy(h_meta, hf.meta.data(), sizeof(int) * 4 * nodes);
+  }
+  return GLIA_HMT_OK;
+}
+
 int glia_hmt_forest_stub(glia_hmt_ctx* c, int feature_index, glia_hmt_forest** out) {
   if (!c || !out || feature_index < 0) { set_error("forest_stub: invalid argument"); return GLIA_HMT_ERR_ARG; }
   glia_hmt_forest* f = new glia_hmt_forest;

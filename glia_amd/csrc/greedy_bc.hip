@@ -170,17 +170,17 @@ __global__ void bc_leaf_entries(BcState st, const uint32_t* pa, const uint32_t* 
   for (int k = 0; k < bins; ++k) s.hist[k] = w[P_HIST + k];
   st.le_stats[i] = s;
   if (j < 0) atomicAdd(&st.nm_out[src], 1u);
-  if (i == 0 || pa[i - 1] != a) st.le_start[src] = (uint32_t)i;
-  if (i == st.P - 1) st.le_start[st.R0] = (uint32_t)st.P;
 }
 
-// leaves without any out-entry: le_start must still be monotone (fill gaps from the right)
-__global__ void bc_fix_starts(BcState st) {
-  if (blockIdx.x || threadIdx.x) return;
-  uint32_t next = (uint32_t)st.P;
-  for (long long r = (long long)st.R0 - 1; r >= 0; --r) {
-    if (st.le_start[r] == kNone) st.le_start[r] = next; else next = st.le_start[r];
-  }
+// first out-entry of every leaf (pairs ascend by source label): lower bound of the leaf's label in pa
+__global__ void bc_leaf_starts(BcState st, const uint32_t* pa, const uint32_t* rlabel) {
+  uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > st.R0) return;
+  if (r == st.R0) { st.le_start[r] = (uint32_t)st.P; return; }
+  const uint32_t key = rlabel[r];
+  long long lo = 0, hi = st.P;
+  while (lo < hi) { long long mid = (lo + hi) >> 1; if (pa[mid] < key) lo = mid + 1; else hi = mid; }
+  st.le_start[r] = (uint32_t)lo;
 }
 
 __global__ void bc_leaf_regions(BcState st, const uint32_t* rrec, int bins) {
@@ -559,7 +559,6 @@ int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& cl
   if ((rc = buf.get(&st.le_next, P, false, stream))) return rc;
   if ((rc = buf.get(&st.le_mutual, P, false, stream))) return rc;
   if ((rc = buf.get(&st.le_start, (size_t)R + 1, false, stream))) return rc;
-  GLIA_HIP_TRY(hipMemsetAsync(st.le_start, 0xFF, sizeof(uint32_t) * ((size_t)R + 1), stream));
   if ((rc = buf.get(&st.nm_out, R, true, stream))) return rc;
   long long* partner; uint32_t* flag; uint32_t* eidx;
   if ((rc = buf.get(&partner, P, false, stream))) return rc;
@@ -568,7 +567,7 @@ int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& cl
   const unsigned gP = (unsigned)((P + 255) / 256);
   hipLaunchKernelGGL(bc_leaf_entries, dim3(gP), dim3(256), 0, stream, st, rag.d_pa, rag.d_pb, rag.d_prec, rag.d_rlabel, partner,
                      cfg.bins, cfg.T);
-  hipLaunchKernelGGL(bc_fix_starts, dim3(1), dim3(1), 0, stream, st);
+  hipLaunchKernelGGL(bc_leaf_starts, dim3((R + 256) / 256), dim3(256), 0, stream, st, rag.d_pa, rag.d_rlabel);
   hipLaunchKernelGGL(bc_record_flags, dim3(gP), dim3(256), 0, stream, st, rag.d_pa, rag.d_pb, flag);
   {
     size_t tmp = 0;

@@ -119,6 +119,11 @@ int glia_hmt_merge_order_pb(glia_hmt_ctx* ctx, glia_hmt_rag* rag, int type, uint
  * glia_hmt_forest_stub builds the diagnostic scorer P = 1 - x[feature_index] (tests only). */
 int glia_hmt_forest_load(glia_hmt_ctx* ctx, int n_models, const char* const* paths, int predict_label,
                          const double* distributor_args /*[3] or NULL*/, glia_hmt_forest** out);
+/* Host-only: parse a GLIA model file (rf_old::readModelFromBinaryFile, ml/rf/ml_rf_model.cxx:459-563) into the node
+ * arrays the device walks: h_split[tree][node], h_meta[tree][node][4] = {variable (0-based), left, right (0-based node),
+ * vote (-1 = internal node, else 1 iff the leaf's class is predict_label)}.  Needs no GPU. */
+int glia_hmt_forest_file_parse(const char* path, int predict_label, int* ntree, int* nrnodes, int* nclass,
+                               double* h_split, int* h_meta, int64_t capacity_nodes);
 int glia_hmt_forest_stub(glia_hmt_ctx* ctx, int feature_index, glia_hmt_forest** out);
 void glia_hmt_forest_free(glia_hmt_forest* forest);
 
