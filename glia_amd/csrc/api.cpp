@@ -182,9 +182,9 @@ int glia_hmt_synth(glia_hmt_ctx* c, int dim, const int64_t dims[3], int S, int G
   return rc;
 }
 
-int glia_hmt_rag_build(glia_hmt_ctx* c, int dim, const int64_t dims[3], const uint32_t* d_labels,
-                       const uint32_t* d_mask, int only_contour, const float* d_pb,
-                       const glia_hmt_feat_config* cfg, glia_hmt_rag** out) {
+static int rag_build_impl(glia_hmt_ctx* c, int dim, const int64_t dims[3], int64_t gz0, int64_t gnz, int64_t zb, int64_t ze,
+                          const uint32_t* d_labels, const uint32_t* d_mask, int only_contour, const float* d_pb,
+                          const glia_hmt_feat_config* cfg, glia_hmt_rag** out) {
   if (!c || !dims || !d_labels || !out || (dim != 2 && dim != 3)) {
     set_error("rag_build: invalid argument");
     return GLIA_HMT_ERR_ARG;
@@ -241,7 +241,7 @@ int glia_hmt_rag_build(glia_hmt_ctx* c, int dim, const int64_t dims[3], const ui
   uint32_t pcap = c->hint_pcap ? c->hint_pcap : next_pow2(std::max<int64_t>(1 << 14, N / 32));
 
   glia_hmt_rag* rag = new glia_hmt_rag;
-  rag->ctx = c; rag->dim = dim; rag->dims[0] = nx; rag->dims[1] = ny; rag->dims[2] = nz;
+  rag->ctx = c; rag->dim = dim; rag->dims[0] = nx; rag->dims[1] = ny; rag->dims[2] = gnz;
   rag->only_contour = only_contour != 0;
   rag->bins = bins; rag->nthr = nthr;
   if (cfg) { rag->cfg = *cfg; rag->has_cfg = true; }
@@ -252,9 +252,10 @@ int glia_hmt_rag_build(glia_hmt_ctx* c, int dim, const int64_t dims[3], const ui
     AccParams p;
     p.lab = d_labels; p.img = img;
     p.nx = nx; p.ny = ny; p.nz = nz; p.dim = dim;
+    p.gz0 = gz0; p.gnz = gnz; p.zb = zb; p.ze = ze;
     p.nbx = (int)((nx + kTileX - 1) / kTileX);
     p.nby = (int)((ny + kTileY - 1) / kTileY);
-    p.nbz = (int)((nz + kTZ - 1) / kTZ);
+    p.nbz = (int)((ze - zb + kTZ - 1) / kTZ);
     p.hist = make_hist_spec(bins, lo, hi);
     p.nthr = nthr;
     for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) p.thr_f[i] = i < nthr ? ceil_f32(thr[i]) : std::numeric_limits<float>::infinity();
@@ -278,7 +279,7 @@ int glia_hmt_rag_build(glia_hmt_ctx* c, int dim, const int64_t dims[3], const ui
       fprintf(stderr, "[glia_hmt debug] region runs %u (lds-miss %u), pair runs %u (lds-miss %u), drains %u\n", flags[2], flags[4], flags[3], flags[5], flags[6]);
       (void)hipMemsetAsync(c->flags, 0, 64, c->stream);
     }
-    rag->alg_bytes = (double)N * 8.0;
+    rag->alg_bytes = (double)(nx * ny * (ze - zb)) * 8.0;
     if (flags[0] || flags[1]) {
       // a table filled up: drop the partial result, grow and redo the pass
       if (attempt >= 6) { delete rag; set_error("rag_build: hash tables keep overflowing"); return GLIA_HMT_ERR_HIP; }
@@ -293,6 +294,102 @@ int glia_hmt_rag_build(glia_hmt_ctx* c, int dim, const int64_t dims[3], const ui
     if (rc) { delete rag; return rc; }
     break;
   }
+  *out = rag;
+  return GLIA_HMT_OK;
+}
+
+int glia_hmt_rag_build(glia_hmt_ctx* c, int dim, const int64_t dims[3], const uint32_t* d_labels,
+                       const uint32_t* d_mask, int only_contour, const float* d_pb,
+                       const glia_hmt_feat_config* cfg, glia_hmt_rag** out) {
+  if (!dims) { set_error("rag_build: invalid argument"); return GLIA_HMT_ERR_ARG; }
+  const int64_t nz = dim == 3 ? dims[2] : 1;
+  return rag_build_impl(c, dim, dims, 0, nz, 0, nz, d_labels, d_mask, only_contour, d_pb, cfg, out);
+}
+
+int glia_hmt_rag_build_slab(glia_hmt_ctx* c, const int64_t dims_local[3], int64_t z_global_of_plane0, int64_t nz_global,
+                            int64_t z_begin, int64_t z_end, const uint32_t* d_labels, int only_contour, const float* d_pb,
+                            const glia_hmt_feat_config* cfg, glia_hmt_rag** out) {
+  if (!dims_local || z_begin < 0 || z_end > dims_local[2] || z_begin >= z_end || z_global_of_plane0 < 0 ||
+      z_global_of_plane0 + dims_local[2] > nz_global ||
+      (z_begin > 0 ? false : z_global_of_plane0 != 0) || (z_end < dims_local[2] ? false : z_global_of_plane0 + z_end != nz_global)) {
+    // the plane below z_begin / above z_end-1 must be present unless the slab touches the volume face
+    set_error("rag_build_slab: slab range or halo planes inconsistent");
+    return GLIA_HMT_ERR_ARG;
+  }
+  return rag_build_impl(c, 3, dims_local, z_global_of_plane0, nz_global, z_begin, z_end, d_labels, nullptr, only_contour, d_pb,
+                        cfg, out);
+}
+
+int glia_hmt_rag_merge(glia_hmt_ctx* c, glia_hmt_rag* const* parts, int n_parts, glia_hmt_rag** out) {
+  if (!c || !parts || n_parts < 1 || n_parts > 255 || !out) { set_error("rag_merge: invalid argument"); return GLIA_HMT_ERR_ARG; }
+  GLIA_HIP_TRY(hipSetDevice(c->device));
+  std::vector<RagArrays> arrs;
+  for (int i = 0; i < n_parts; ++i) {
+    if (!parts[i] || parts[i]->ctx != c || parts[i]->bins != parts[0]->bins || parts[i]->nthr != parts[0]->nthr ||
+        parts[i]->dims[0] != parts[0]->dims[0] || parts[i]->dims[1] != parts[0]->dims[1] || parts[i]->dims[2] != parts[0]->dims[2]) {
+      set_error("rag_merge: parts do not belong together");
+      return GLIA_HMT_ERR_ARG;
+    }
+    arrs.push_back(parts[i]->arr);
+  }
+  glia_hmt_rag* rag = new glia_hmt_rag(*parts[0]);
+  rag->arr = RagArrays();
+  rag->pass_ms = 0; rag->alg_bytes = 0;
+  for (int i = 0; i < n_parts; ++i) { rag->pass_ms += parts[i]->pass_ms; rag->alg_bytes += parts[i]->alg_bytes; }
+  int rc = merge_rag_arrays(arrs.data(), n_parts, &rag->arr, c->stream);
+  if (rc) { delete rag; return rc; }
+  *out = rag;
+  return GLIA_HMT_OK;
+}
+
+int glia_hmt_rag_device_arrays(const glia_hmt_rag* r, const uint32_t** d_region_label, const uint32_t** d_region_rec,
+                               const uint32_t** d_pair_a, const uint32_t** d_pair_b, const uint32_t** d_pair_rec,
+                               int* region_words, int* pair_words) {
+  if (!r) return GLIA_HMT_ERR_ARG;
+  if (d_region_label) *d_region_label = r->arr.d_rlabel;
+  if (d_region_rec) *d_region_rec = r->arr.d_rrec;
+  if (d_pair_a) *d_pair_a = r->arr.d_pa;
+  if (d_pair_b) *d_pair_b = r->arr.d_pb;
+  if (d_pair_rec) *d_pair_rec = r->arr.d_prec;
+  if (region_words) *region_words = kRegionWords;
+  if (pair_words) *pair_words = kPairWords;
+  return GLIA_HMT_OK;
+}
+
+int glia_hmt_rag_copy_arrays(const glia_hmt_rag* r, uint32_t* d_region_label, uint32_t* d_region_rec, uint32_t* d_pair_a,
+                             uint32_t* d_pair_b, uint32_t* d_pair_rec) {
+  if (!r) return GLIA_HMT_ERR_ARG;
+  GLIA_HIP_TRY(hipSetDevice(r->ctx->device));
+  hipStream_t st = r->ctx->stream;
+  const size_t R = (size_t)r->arr.R, P = (size_t)r->arr.P;
+  if (d_region_label && R) GLIA_HIP_TRY(hipMemcpyAsync(d_region_label, r->arr.d_rlabel, 4 * R, hipMemcpyDeviceToDevice, st));
+  if (d_region_rec && R) GLIA_HIP_TRY(hipMemcpyAsync(d_region_rec, r->arr.d_rrec, 4 * R * kRegionWords, hipMemcpyDeviceToDevice, st));
+  if (d_pair_a && P) GLIA_HIP_TRY(hipMemcpyAsync(d_pair_a, r->arr.d_pa, 4 * P, hipMemcpyDeviceToDevice, st));
+  if (d_pair_b && P) GLIA_HIP_TRY(hipMemcpyAsync(d_pair_b, r->arr.d_pb, 4 * P, hipMemcpyDeviceToDevice, st));
+  if (d_pair_rec && P) GLIA_HIP_TRY(hipMemcpyAsync(d_pair_rec, r->arr.d_prec, 4 * P * kPairWords, hipMemcpyDeviceToDevice, st));
+  GLIA_HIP_TRY(hipStreamSynchronize(st));
+  return GLIA_HMT_OK;
+}
+
+int glia_hmt_rag_from_arrays(glia_hmt_ctx* c, const glia_hmt_rag* like, int64_t n_regions, const uint32_t* d_region_label,
+                             const uint32_t* d_region_rec, int64_t n_pairs, const uint32_t* d_pair_a, const uint32_t* d_pair_b,
+                             const uint32_t* d_pair_rec, glia_hmt_rag** out) {
+  if (!c || !like || !out || n_regions < 0 || n_pairs < 0) { set_error("rag_from_arrays: invalid argument"); return GLIA_HMT_ERR_ARG; }
+  GLIA_HIP_TRY(hipSetDevice(c->device));
+  glia_hmt_rag* rag = new glia_hmt_rag(*like);
+  rag->ctx = c;
+  rag->arr = RagArrays();
+  rag->arr.R = n_regions; rag->arr.P = n_pairs;
+  auto dup = [&](uint32_t** dst, const uint32_t* src, size_t n) -> int {
+    GLIA_HIP_TRY(hipMalloc(dst, sizeof(uint32_t) * (n ? n : 1)));
+    if (n) GLIA_HIP_TRY(hipMemcpyAsync(*dst, src, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, c->stream));
+    return GLIA_HMT_OK;
+  };
+  int rc;
+  if ((rc = dup(&rag->arr.d_rlabel, d_region_label, (size_t)n_regions)) || (rc = dup(&rag->arr.d_rrec, d_region_rec, (size_t)n_regions * kRegionWords)) ||
+      (rc = dup(&rag->arr.d_pa, d_pair_a, (size_t)n_pairs)) || (rc = dup(&rag->arr.d_pb, d_pair_b, (size_t)n_pairs)) ||
+      (rc = dup(&rag->arr.d_prec, d_pair_rec, (size_t)n_pairs * kPairWords))) { glia_hmt_rag_free(rag); return rc; }
+  GLIA_HIP_TRY(hipStreamSynchronize(c->stream));
   *out = rag;
   return GLIA_HMT_OK;
 }

@@ -53,7 +53,9 @@ struct HistSpec {
 struct AccParams {
   const uint32_t* lab;
   const float* img;
-  int64_t nx, ny, nz;
+  int64_t nx, ny, nz;                // extent of the arrays handed in (nz includes halo planes of a slab)
+  int64_t gz0, gnz;                  // slab mode: global z of local plane 0 and global depth (gz0 = 0, gnz = nz otherwise)
+  int64_t zb, ze;                    // local planes [zb, ze) are accumulated (the halo planes only feed the neighbour rule)
   int dim;
   int nbx, nby, nbz;
   HistSpec hist;
@@ -90,6 +92,7 @@ int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& cl
               double* h_sal, double* h_feats, int64_t capacity, int64_t* n_merges, double* ms_table, double* ms_init,
               double* ms_loop, int64_t* n_scored, bool init_only);
 int compact_tables(const AccParams& p, uint32_t rcap, uint32_t pcap, RagArrays* out, hipStream_t stream);
+int merge_rag_arrays(const RagArrays* parts, int n_parts, RagArrays* out, hipStream_t stream);
 
 __host__ __device__ inline uint32_t float_ord(float f) {
   uint32_t u = __builtin_bit_cast(uint32_t, f);

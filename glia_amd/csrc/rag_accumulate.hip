@@ -277,12 +277,13 @@ __global__ __launch_bounds__(kThreads, 2) void rag_accumulate_kernel(const AccPa
   const int lane = tid & 63, wave = tid >> 6;
   const int64_t nx = p.nx, ny = p.ny, nz = p.nz;
   Tile tile;
-  tile.x0 = (int64_t)bx * kTileX; tile.y0 = (int64_t)by * kTileY; tile.z0 = (int64_t)bz * kTZ;
+  tile.x0 = (int64_t)bx * kTileX; tile.y0 = (int64_t)by * kTileY; tile.z0 = p.zb + (int64_t)bz * kTZ;
   const int xrel0 = (lane % kLanesPerRow) * kVX;
   const int yrel = wave * kRowsPerWave + (lane / kLanesPerRow);
   const int64_t x0 = tile.x0 + xrel0;
   const int64_t y = tile.y0 + yrel;
-  const int64_t z1 = (tile.z0 + kTZ < nz) ? tile.z0 + kTZ : nz;
+  const int64_t z1 = (tile.z0 + kTZ < p.ze) ? tile.z0 + kTZ : p.ze;
+  const int64_t gz0 = p.gz0, gnz = p.gnz;
   const bool rowOk = (y < ny) && (x0 < nx);
   const int64_t sy = nx, sz = nx * ny;
   const bool is3d = p.dim == 3;
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(kThreads, 2) void rag_accumulate_kernel(const AccPa
     TableParams tp;
     tp.rkeys = p.rkeys; tp.rrec = p.rrec; tp.pkeys = p.pkeys; tp.prec = p.prec; tp.flags = p.flags;
     tp.rmask = p.rmask; tp.pmask = p.pmask; tp.nx = p.nx; tp.ny = p.ny;
-    tp.x0 = tile.x0; tp.y0 = tile.y0; tp.z0 = tile.z0;
+    tp.x0 = tile.x0; tp.y0 = tile.y0; tp.z0 = tile.z0 + p.gz0;     // global coordinates for bbox / first-voxel index
     s.tp = tp;
   }
   __syncthreads();
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(kThreads, 2) void rag_accumulate_kernel(const AccPa
     uint32_t right = __shfl_down(Lc.v[0], 1, kLanesPerRow);
     if ((lane % kLanesPerRow) == 0) left = (rowOk && x0 > 0) ? p.lab[z * sz + y * sy + x0 - 1] : 0u;
     if ((lane % kLanesPerRow) == kLanesPerRow - 1) right = (rowOk && x0 + kVX < nx) ? p.lab[z * sz + y * sy + x0 + kVX] : 0u;
-    const bool zmv = is3d && z > 0, zpv = is3d && z + 1 < nz;
+    const bool zmv = is3d && (z + gz0) > 0, zpv = is3d && (z + gz0) + 1 < gnz;
     const bool ymv = y > 0, ypv = y + 1 < ny;
     // a run lasts at most kTZ planes x 4 voxels = 128 voxels, so the 8-bit packed counters cannot overflow.
     // Serpentine x order: a lane that straddles a wall changes key once per plane instead of twice.
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(kThreads, 2) void rag_accumulate_kernel(const AccPa
   }
   __syncthreads();
   constexpr int RW = Lds<BINS>::kRegWords, PW = Lds<BINS>::kPairWordsL;
-  const uint32_t tx = (uint32_t)tile.x0, ty = (uint32_t)tile.y0, tz = (uint32_t)tile.z0;
+  const uint32_t tx = (uint32_t)tile.x0, ty = (uint32_t)tile.y0, tz = (uint32_t)(tile.z0 + gz0);
   for (int it = tid; it < kRegSlots * RW; it += kThreads) {
     const int slot = it / RW, w = it % RW;
     const int g = gslot[slot];
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(kThreads, 2) void rag_accumulate_kernel(const AccPa
     else if (w == LR_MAX) { atomicMax(&dst[R_MAX], val); }
     else if (w == LR_FIRST) {
       const uint32_t first = 0xFFFFFu - val;
-      const unsigned long long fidx = (unsigned long long)((tile.z0 + (first >> 11)) * sz + (tile.y0 + ((first >> kXB) & kYM)) * sy +
+      const unsigned long long fidx = (unsigned long long)((tile.z0 + gz0 + (first >> 11)) * sz + (tile.y0 + ((first >> kXB) & kYM)) * sy +
                                                            (tile.x0 + (first & kXM)));
       atomicMax(reinterpret_cast<unsigned long long*>(&dst[R_FIRST]), ~fidx);
     } else if (w >= LR_HIST) { if (val) atomicAdd(&dst[R_HIST + (w - LR_HIST)], val); }

@@ -1,0 +1,144 @@
+// glia_amd/csrc/rag_merge.hip -- C1: combine the partial region adjacency structures of several z-slabs.
+// Every leaf / directed-pair statistic is a commutative monoid (adds, unsigned max, f64 adds), so partial
+// records with the same key are reduced; parts are combined in part order, which makes the f64 sums
+// reproducible (and exact for Q8 images).  There is no reference counterpart: GLIA is single-node
+// (SURVEY.md 8e); the algebra is that of rag_accumulate.hip's table fold.
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "greedy_common.hpp"
+
+namespace glia {
+namespace {
+
+__global__ void make_region_keys(const uint32_t* lab, unsigned long long* keys, uint32_t* idx, uint32_t n, uint32_t base, uint32_t part) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // sort key: label, then part (radix sort is stable, so equal labels keep part order anyway)
+  keys[base + i] = ((unsigned long long)lab[i] << 8) | part;
+  idx[base + i] = base + i;
+}
+__global__ void make_pair_keys(const uint32_t* a, const uint32_t* b, unsigned long long* keys, uint32_t* idx, uint32_t n, uint32_t base) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  keys[base + i] = ((unsigned long long)a[i] << 32) | b[i];
+  idx[base + i] = base + i;
+}
+__global__ void head_flags(const unsigned long long* keys, uint32_t* flag, uint32_t n, int shift) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  flag[i] = (i == 0 || (keys[i] >> shift) != (keys[i - 1] >> shift)) ? 1u : 0u;
+}
+
+// one thread per output word of every segment head
+template <bool REGION>
+__global__ void combine_records(const unsigned long long* keys, const uint32_t* idx, const uint32_t* flag, const uint32_t* oidx,
+                                const uint32_t* src /*concatenated records*/, uint32_t n, int shift, uint32_t* dst,
+                                uint32_t* out_a, uint32_t* out_b) {
+  constexpr int W = REGION ? kRegionWords : kPairWords;
+  unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t i = (uint32_t)(t / W);
+  const int w = (int)(t % W);
+  if (i >= n || !flag[i]) return;
+  const uint32_t o = oidx[i];
+  const unsigned long long k = keys[i] >> shift;
+  if (w == 0) {
+    if (REGION) out_a[o] = (uint32_t)k;
+    else { out_a[o] = (uint32_t)(k >> 32); out_b[o] = (uint32_t)k; }
+  }
+  bool isF64 = false, isF64hi = false, isMax = false, isU64max = false, isU64hi = false;
+  if (REGION) {
+    isF64 = (w == R_SUM || w == R_SQ); isF64hi = (w == R_SUM + 1 || w == R_SQ + 1);
+    isMax = (w >= R_LO && w < R_SUM) || w == R_MIN || w == R_MAX;
+    isU64max = (w == R_FIRST); isU64hi = (w == R_FIRST + 1);
+  } else {
+    isF64 = (w == P_SUM || w == P_SQ); isF64hi = (w == P_SUM + 1 || w == P_SQ + 1);
+    isMax = (w == P_MIN || w == P_MAX);
+  }
+  if (isF64hi || isU64hi) return;
+  uint32_t acc = 0;
+  double dacc = 0.0;
+  unsigned long long uacc = 0;
+  for (uint32_t j = i; j < n && (keys[j] >> shift) == k; ++j) {
+    const uint32_t* r = &src[(size_t)idx[j] * W];
+    if (isF64) { double d; memcpy(&d, &r[w], 8); dacc += d; }
+    else if (isU64max) { unsigned long long u; memcpy(&u, &r[w], 8); uacc = u > uacc ? u : uacc; }
+    else if (isMax) acc = r[w] > acc ? r[w] : acc;
+    else acc += r[w];
+  }
+  uint32_t* d = &dst[(size_t)o * W];
+  if (isF64) memcpy(&d[w], &dacc, 8);
+  else if (isU64max) memcpy(&d[w], &uacc, 8);
+  else d[w] = acc;
+}
+
+template <bool REGION>
+int merge_kind(const RagArrays* parts, int n_parts, RagArrays* out, hipStream_t stream) {
+  constexpr int W = REGION ? kRegionWords : kPairWords;
+  uint64_t total = 0;
+  for (int p = 0; p < n_parts; ++p) total += (uint64_t)(REGION ? parts[p].R : parts[p].P);
+  if (total >= (1ull << 32)) { set_error("rag_merge: too many records"); return GLIA_HMT_ERR_ARG; }
+  const uint32_t n = (uint32_t)total;
+  DeviceBuffers buf;
+  int rc;
+  unsigned long long *k0, *k1; uint32_t *i0, *i1, *flag, *oidx, *src;
+  if ((rc = buf.get(&k0, n, false, stream))) return rc;
+  if ((rc = buf.get(&k1, n, false, stream))) return rc;
+  if ((rc = buf.get(&i0, n, false, stream))) return rc;
+  if ((rc = buf.get(&i1, n, false, stream))) return rc;
+  if ((rc = buf.get(&flag, (size_t)n + 1, true, stream))) return rc;
+  if ((rc = buf.get(&oidx, (size_t)n + 1, false, stream))) return rc;
+  if ((rc = buf.get(&src, (size_t)n * W, false, stream))) return rc;
+  uint32_t base = 0;
+  for (int p = 0; p < n_parts; ++p) {
+    const uint32_t m = (uint32_t)(REGION ? parts[p].R : parts[p].P);
+    if (!m) continue;
+    if (REGION) hipLaunchKernelGGL(make_region_keys, dim3((m + 255) / 256), dim3(256), 0, stream, parts[p].d_rlabel, k0, i0, m, base, (uint32_t)p);
+    else hipLaunchKernelGGL(make_pair_keys, dim3((m + 255) / 256), dim3(256), 0, stream, parts[p].d_pa, parts[p].d_pb, k0, i0, m, base);
+    GLIA_HIP_TRY(hipMemcpyAsync(src + (size_t)base * W, REGION ? parts[p].d_rrec : parts[p].d_prec, sizeof(uint32_t) * (size_t)m * W,
+                                hipMemcpyDeviceToDevice, stream));
+    base += m;
+  }
+  const int shift = REGION ? 8 : 0;
+  uint32_t nout = 0;
+  if (n) {
+    size_t tmp = 0;
+    GLIA_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, k0, k1, i0, i1, (size_t)n, 0, 64, stream));
+    char* d_tmp;
+    if ((rc = buf.get(&d_tmp, tmp ? tmp : 16, false, stream))) return rc;
+    GLIA_HIP_TRY(rocprim::radix_sort_pairs((void*)d_tmp, tmp, k0, k1, i0, i1, (size_t)n, 0, 64, stream));
+    hipLaunchKernelGGL(head_flags, dim3((n + 255) / 256), dim3(256), 0, stream, k1, flag, n, shift);
+    size_t tmp2 = 0;
+    GLIA_HIP_TRY(rocprim::exclusive_scan(nullptr, tmp2, flag, oidx, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), stream));
+    char* d_tmp2;
+    if ((rc = buf.get(&d_tmp2, tmp2 ? tmp2 : 16, false, stream))) return rc;
+    GLIA_HIP_TRY(rocprim::exclusive_scan((void*)d_tmp2, tmp2, flag, oidx, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), stream));
+    GLIA_HIP_TRY(hipMemcpyAsync(&nout, oidx + n, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    GLIA_HIP_TRY(hipStreamSynchronize(stream));
+  }
+  uint32_t *dst, *oa, *ob = nullptr;
+  GLIA_HIP_TRY(hipMalloc(&dst, sizeof(uint32_t) * W * (size_t)(nout ? nout : 1)));
+  GLIA_HIP_TRY(hipMalloc(&oa, sizeof(uint32_t) * (size_t)(nout ? nout : 1)));
+  if (!REGION) GLIA_HIP_TRY(hipMalloc(&ob, sizeof(uint32_t) * (size_t)(nout ? nout : 1)));
+  if (n) {
+    const unsigned long long threads = (unsigned long long)n * W;
+    hipLaunchKernelGGL(combine_records<REGION>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, k1, i1, flag, oidx, src, n,
+                       shift, dst, oa, ob);
+    GLIA_HIP_TRY(hipGetLastError());
+    GLIA_HIP_TRY(hipStreamSynchronize(stream));
+  }
+  if (REGION) { out->R = nout; out->d_rlabel = oa; out->d_rrec = dst; }
+  else { out->P = nout; out->d_pa = oa; out->d_pb = ob; out->d_prec = dst; }
+  return GLIA_HMT_OK;
+}
+
+}  // namespace
+
+int merge_rag_arrays(const RagArrays* parts, int n_parts, RagArrays* out, hipStream_t stream) {
+  int rc = merge_kind<true>(parts, n_parts, out, stream);
+  if (rc) return rc;
+  return merge_kind<false>(parts, n_parts, out, stream);
+}
+
+}  // namespace glia

@@ -176,19 +176,31 @@ class RegionMap:
     """Device-resident region adjacency structure with sufficient statistics.
     Mirrors TRegionMap(image, mask, onlyContour) (type/region_map.hxx:38-40)."""
 
-    def __init__(self, ctx, labels, pb=None, mask=None, only_contour=False, cfg=None):
-        assert labels.is_cuda and labels.is_contiguous() and labels.element_size() == 4
+    def __init__(self, ctx, labels, pb=None, mask=None, only_contour=False, cfg=None, slab=None, _handle=None):
+        """slab = (z_global_of_plane0, nz_global, z_begin, z_end): build the PARTIAL map of a z-slab whose planes
+        (plus halo planes) are `labels` / `pb` (see include/glia_hmt.h, glia_hmt_rag_build_slab)."""
         self.ctx = ctx
-        self.shape = tuple(labels.shape)
-        self.dim, d = _dims(self.shape)
-        self._keep = (labels, pb, mask, cfg)
         self.cfg = cfg
+        self._keep = (labels, pb, mask, cfg)
         self.h = C.c_void_p()
-        _check(lib().glia_hmt_rag_build(
-            ctx.h, C.c_int(self.dim), d, C.c_void_p(labels.data_ptr()),
-            C.c_void_p(mask.data_ptr()) if mask is not None else None, C.c_int(int(only_contour)),
-            C.c_void_p(pb.data_ptr()) if pb is not None else None,
-            C.byref(cfg) if cfg is not None else None, C.byref(self.h)))
+        if _handle is not None:
+            self.h = _handle
+        else:
+            assert labels.is_cuda and labels.is_contiguous() and labels.element_size() == 4
+            self.shape = tuple(labels.shape)
+            self.dim, d = _dims(self.shape)
+            if slab is None:
+                _check(lib().glia_hmt_rag_build(
+                    ctx.h, C.c_int(self.dim), d, C.c_void_p(labels.data_ptr()),
+                    C.c_void_p(mask.data_ptr()) if mask is not None else None, C.c_int(int(only_contour)),
+                    C.c_void_p(pb.data_ptr()) if pb is not None else None,
+                    C.byref(cfg) if cfg is not None else None, C.byref(self.h)))
+            else:
+                gz0, gnz, zb, ze = slab
+                _check(lib().glia_hmt_rag_build_slab(
+                    ctx.h, d, C.c_int64(gz0), C.c_int64(gnz), C.c_int64(zb), C.c_int64(ze), C.c_void_p(labels.data_ptr()),
+                    C.c_int(int(only_contour)), C.c_void_p(pb.data_ptr()) if pb is not None else None,
+                    C.byref(cfg) if cfg is not None else None, C.byref(self.h)))
         self.bins = cfg.region[0].bins if cfg is not None and cfg.n_region else \
             (cfg.boundary[0].bins if cfg is not None and cfg.n_boundary else 8)
         self.nthr = cfg.n_thresholds if cfg is not None else 0
@@ -211,6 +223,38 @@ class RegionMap:
     @property
     def num_pairs(self):
         return lib().glia_hmt_rag_num_pairs(self.h)
+
+    @staticmethod
+    def merge(ctx, parts):
+        """glia_hmt_rag_merge: combine the partial maps of several slabs (same configuration)."""
+        arr = (C.c_void_p * len(parts))(*[p.h for p in parts])
+        h = C.c_void_p()
+        _check(lib().glia_hmt_rag_merge(ctx.h, arr, C.c_int(len(parts)), C.byref(h)))
+        return RegionMap(ctx, None, cfg=parts[0].cfg, _handle=h)
+
+    def to_tensors(self):
+        """The compact record arrays as torch tensors on the context's device (for torch.distributed)."""
+        import torch
+        dev = torch.device("cuda", self.ctx.device)
+        R, P = self.num_regions, self.num_pairs
+        rw, pw = C.c_int(), C.c_int()
+        _check(lib().glia_hmt_rag_device_arrays(self.h, None, None, None, None, None, C.byref(rw), C.byref(pw)))
+        t = dict(rlabel=torch.empty(R, dtype=torch.int32, device=dev), rrec=torch.empty((R, rw.value), dtype=torch.int32, device=dev),
+                 pa=torch.empty(P, dtype=torch.int32, device=dev), pb=torch.empty(P, dtype=torch.int32, device=dev),
+                 prec=torch.empty((P, pw.value), dtype=torch.int32, device=dev))
+        _check(lib().glia_hmt_rag_copy_arrays(self.h, *[C.c_void_p(t[k].data_ptr()) for k in ("rlabel", "rrec", "pa", "pb", "prec")]))
+        return t
+
+    @staticmethod
+    def from_tensors(ctx, like, t):
+        h = C.c_void_p()
+        for k in t:
+            assert t[k].is_cuda and t[k].is_contiguous()
+        _check(lib().glia_hmt_rag_from_arrays(ctx.h, like.h, C.c_int64(t["rlabel"].numel()), C.c_void_p(t["rlabel"].data_ptr()),
+                                              C.c_void_p(t["rrec"].data_ptr()), C.c_int64(t["pa"].numel()),
+                                              C.c_void_p(t["pa"].data_ptr()), C.c_void_p(t["pb"].data_ptr()),
+                                              C.c_void_p(t["prec"].data_ptr()), C.byref(h)))
+        return RegionMap(ctx, None, cfg=like.cfg, _handle=h)
 
     def last_pass(self):
         ms, by = C.c_double(), C.c_double()

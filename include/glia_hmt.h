@@ -86,6 +86,27 @@ typedef struct {
 int glia_hmt_rag_build(glia_hmt_ctx* ctx, int dim, const int64_t dims[3], const uint32_t* d_labels,
                        const uint32_t* d_mask, int only_contour, const float* d_pb,
                        const glia_hmt_feat_config* cfg, glia_hmt_rag** out);
+/* ---- z-slab partition for volumes split across GPUs (no reference counterpart: GLIA is single-node) ----------
+ * A rank owns global planes [z_global_of_plane0 + z_begin, z_global_of_plane0 + z_end) and hands in its planes plus
+ * one halo plane on each side that is not a face of the volume (dims_local[2] = planes handed in).  The result is a
+ * PARTIAL region map: every statistic is a commutative monoid, so partial maps of all slabs are combined with
+ * glia_hmt_rag_merge into exactly the map glia_hmt_rag_build gives for the whole volume.  Between ranks the partial
+ * records travel as the plain device arrays glia_hmt_rag_device_arrays exposes (all-gather over RCCL: glia_amd/slab.py)
+ * and are wrapped again with glia_hmt_rag_from_arrays (`like` supplies configuration and dimensions). */
+int glia_hmt_rag_build_slab(glia_hmt_ctx* ctx, const int64_t dims_local[3], int64_t z_global_of_plane0,
+                            int64_t nz_global, int64_t z_begin, int64_t z_end, const uint32_t* d_labels,
+                            int only_contour, const float* d_pb, const glia_hmt_feat_config* cfg, glia_hmt_rag** out);
+int glia_hmt_rag_merge(glia_hmt_ctx* ctx, glia_hmt_rag* const* parts, int n_parts, glia_hmt_rag** out);
+int glia_hmt_rag_device_arrays(const glia_hmt_rag* rag, const uint32_t** d_region_label, const uint32_t** d_region_rec,
+                               const uint32_t** d_pair_a, const uint32_t** d_pair_b, const uint32_t** d_pair_rec,
+                               int* region_words, int* pair_words);
+/* copies the compact arrays into caller-owned device buffers ([R], [R][region_words], [P], [P], [P][pair_words]) */
+int glia_hmt_rag_copy_arrays(const glia_hmt_rag* rag, uint32_t* d_region_label, uint32_t* d_region_rec,
+                             uint32_t* d_pair_a, uint32_t* d_pair_b, uint32_t* d_pair_rec);
+int glia_hmt_rag_from_arrays(glia_hmt_ctx* ctx, const glia_hmt_rag* like, int64_t n_regions,
+                             const uint32_t* d_region_label, const uint32_t* d_region_rec, int64_t n_pairs,
+                             const uint32_t* d_pair_a, const uint32_t* d_pair_b, const uint32_t* d_pair_rec,
+                             glia_hmt_rag** out);
 void glia_hmt_rag_free(glia_hmt_rag* rag);
 int64_t glia_hmt_rag_num_regions(const glia_hmt_rag* rag);
 int64_t glia_hmt_rag_num_pairs(const glia_hmt_rag* rag);     /* directed label pairs */

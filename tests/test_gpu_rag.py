@@ -100,3 +100,42 @@ def test_rag_matches_oracle(ctx, shape, S, G, variant, bins):
     # threshold counts are monotone and bounded by the pair's voxel count
     assert (par["thr"][:, 0] <= par["count"]).all() and (np.diff(par["thr"], axis=1) <= 0).all()
     rm.close()
+
+
+@pytest.mark.parametrize("shape,S,G,variant,nslab", [((64, 40, 64), 8, 16, 0, 2), ((70, 36, 28), 6, 12, 1, 3),
+                                                    ((33, 64, 128), 8, 32, 0, 4)])
+def test_slab_partials_merge_to_the_whole(ctx, shape, S, G, variant, nslab):
+    """z-slab partition: partial maps of the slabs (one halo plane per cut), merged, are bit-identical
+    to the single-pass map -- regions, bounding boxes, first voxels, directed pairs and every statistic."""
+    torch = _torch()
+    from glia_amd import hmt, slab
+    from oracle import pyoracle as O
+    labels, pb = O.synth(shape, S, G, variant=variant)
+    d_lab = torch.from_numpy(labels.view(np.int32)).cuda()
+    d_pb = torch.from_numpy(pb).cuda()
+    mk = lambda img: hmt.make_config(img, rb=[(img, 8, 0.0, 1.0)])
+    whole = hmt.RegionMap(ctx, d_lab, pb=d_pb, cfg=mk(d_pb))
+    parts = []
+    nz = shape[0]
+    for r in range(nslab):
+        lo, hi, zb, ze = slab.slab_with_halo(nz, nslab, r)
+        sl, sp = d_lab[lo:hi].contiguous(), d_pb[lo:hi].contiguous()
+        parts.append(hmt.RegionMap(ctx, sl, pb=sp, cfg=mk(sp), slab=(lo, nz, zb, ze)))
+    # through the same tensors the RCCL exchange ships
+    rebuilt = [hmt.RegionMap.from_tensors(ctx, p, p.to_tensors()) for p in parts]
+    merged = hmt.RegionMap.merge(ctx, rebuilt)
+    a, b = whole.regions(), merged.regions()
+    for k in a:
+        if variant == 0 or k not in ("sum", "sumsq"):
+            assert (a[k] == b[k]).all(), k
+        else:
+            assert np.allclose(a[k], b[k], rtol=1e-13), k
+    a, b = whole.pairs(), merged.pairs()
+    for k in a:
+        if variant == 0 or k not in ("sum", "sumsq"):
+            assert (a[k] == b[k]).all(), k
+        else:
+            assert np.allclose(a[k], b[k], rtol=1e-13), k
+    o1, s1 = whole.merge_order_pb(type=2)
+    o2, s2 = merged.merge_order_pb(type=2)
+    assert (o1 == o2).all() and (variant == 1 or (s1 == s2).all())
