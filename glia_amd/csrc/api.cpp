@@ -7,6 +7,7 @@
 #include <cstring>
 #include <limits>
 #include <mutex>
+#include <unordered_map>
 
 #include "bc_features.hpp"
 #include "forest.hpp"
@@ -641,6 +642,75 @@ int glia_hmt_merge_order_bc(glia_hmt_ctx* c, glia_hmt_rag* rag, const glia_hmt_f
   if (h_feats) memcpy(h_feats, feats.data(), sizeof(double) * (size_t)n * cfg.fdim);
   *n_merges = n;
   return GLIA_HMT_OK;
+}
+
+int glia_hmt_bc_feat(glia_hmt_ctx* c, glia_hmt_rag* rag, const uint32_t* h_order, int64_t n_merges, double* h_feats) {
+  if (!c || !rag || !h_order || !h_feats || n_merges < 0 || rag->ctx != c) { set_error("bc_feat: invalid argument"); return GLIA_HMT_ERR_ARG; }
+  BcCfg cfg;
+  if (!make_bc_cfg(rag, &cfg) || rag->only_contour) {
+    set_error("bc_feat: the region map must be built with a feature configuration and with region points");
+    return GLIA_HMT_ERR_ARG;
+  }
+  GLIA_HIP_TRY(hipSetDevice(c->device));
+  const int64_t R = rag->arr.R;
+  if (n_merges == 0) return GLIA_HMT_OK;
+  if (n_merges >= R) { set_error("bc_feat: more merges than regions"); return GLIA_HMT_ERR_ARG; }
+  // keys -> dense ids: leaves by label, the region created by merge i is R + i (RegionMap(seg, mask, order, false),
+  // type/region_map.hxx:42-48,67-68)
+  std::vector<uint32_t> lab((size_t)R);
+  GLIA_HIP_TRY(hipMemcpy(lab.data(), rag->arr.d_rlabel, sizeof(uint32_t) * R, hipMemcpyDeviceToHost));
+  std::unordered_map<uint32_t, uint32_t> id;
+  id.reserve((size_t)R * 2);
+  for (int64_t i = 0; i < R; ++i) id[lab[i]] = (uint32_t)i;
+  std::vector<uint32_t> forced((size_t)2 * n_merges);
+  std::vector<uint8_t> used((size_t)R + n_merges, 0);
+  for (int64_t i = 0; i < n_merges; ++i) {
+    for (int s2 = 0; s2 < 2; ++s2) {
+      auto it = id.find(h_order[3 * i + s2]);
+      if (it == id.end() || used[it->second]) { set_error("bc_feat: merge order refers to an unknown or already merged region"); return GLIA_HMT_ERR_ARG; }
+      used[it->second] = 1;
+      forced[2 * i + s2] = it->second;
+    }
+    if (id.count(h_order[3 * i + 2])) { set_error("bc_feat: merge order reuses a region key"); return GLIA_HMT_ERR_ARG; }
+    id[h_order[3 * i + 2]] = (uint32_t)(R + i);
+  }
+  std::vector<uint32_t> order((size_t)3 * R);
+  std::vector<double> sal((size_t)R), feats((size_t)R * cfg.fdim);
+  DeviceClassifier none;
+  memset(&none, 0, sizeof(none));
+  none.kind = 1;
+  int64_t n = 0;
+  int rc = greedy_bc(rag->arr, cfg, none, c->stream, order.data(), sal.data(), feats.data(), R, &n, &rag->ms_table, &rag->ms_init,
+                     &rag->ms_loop, &rag->n_scored, false, forced.data(), n_merges);
+  if (rc) return rc;
+  if (n != n_merges) { set_error("bc_feat: internal error, merges not completed"); return GLIA_HMT_ERR_HIP; }
+  memcpy(h_feats, feats.data(), sizeof(double) * (size_t)n * cfg.fdim);
+  return GLIA_HMT_OK;
+}
+
+// hmt::genTree (hmt/tree_build.hxx:12-38): order -> array tree, children before parents
+int64_t glia_hmt_gen_tree(const uint32_t* h_order, int64_t n_merges, uint32_t* node_label, int32_t* parent, int32_t* child0,
+                          int32_t* child1, int64_t capacity) {
+  if (!h_order || !node_label || !parent || !child0 || !child1 || n_merges < 0) { set_error("gen_tree: invalid argument"); return GLIA_HMT_ERR_ARG; }
+  std::unordered_map<uint32_t, int> nmap;
+  int64_t ni = 0;
+  auto add = [&](uint32_t label, int c0, int c1) -> int64_t {
+    if (ni >= capacity) return -1;
+    node_label[ni] = label; parent[ni] = -1; child0[ni] = c0; child1[ni] = c1;
+    nmap.emplace(label, (int)ni);
+    return ni++;
+  };
+  for (int64_t i = 0; i < n_merges; ++i) {
+    const uint32_t x0 = h_order[3 * i], x1 = h_order[3 * i + 1], x2 = h_order[3 * i + 2];
+    auto n0 = nmap.find(x0);
+    int64_t i0 = n0 == nmap.end() ? add(x0, -1, -1) : n0->second;
+    auto n1 = nmap.find(x1);
+    int64_t i1 = n1 == nmap.end() ? add(x1, -1, -1) : n1->second;
+    if (i0 < 0 || i1 < 0 || ni >= capacity) { set_error("gen_tree: output capacity too small"); return GLIA_HMT_ERR_CAPACITY; }
+    parent[i0] = (int32_t)ni; parent[i1] = (int32_t)ni;
+    add(x2, (int)i0, (int)i1);
+  }
+  return ni;
 }
 
 int glia_hmt_score_initial_edges(glia_hmt_ctx* c, glia_hmt_rag* rag, const glia_hmt_forest* forest, int64_t* n_edges,

@@ -69,6 +69,8 @@ struct BcState {
   double* featbuf;               // [kChunk][fdim]
   unsigned long long* ctrl;
   unsigned long long max_iters;
+  const uint32_t* forced;        // bc_feat mode: [forced_n][2] region pairs to merge, in this order (no queue, no scoring)
+  unsigned long long forced_n;
   BcCfg cfg;
   DeviceClassifier clf;
 };
@@ -116,12 +118,16 @@ __device__ void edge_features(const BcState& st, uint32_t first, uint32_t second
   pstats_add(p2, st.pts[second]);
   EStats b2 = st.Bt[first];
   estats_add(b2, st.Bt[second]);
-  estats_sub_additive(b2, st.e_A[rec]);
   b2.mn = fminf(ex0mn, ex1mn); b2.mx = fmaxf(ex0mx, ex1mx);
-  EStats sh = st.e_A[rec];
-  estats_add(sh, st.e_NA[rec]);
-  for (uint32_t f = st.e_fhead[rec]; f != kNone; f = st.le_next[f])
-    if (leaf_alive(st, st.le_dst[f])) estats_add(sh, st.le_stats[f]);
+  EStats sh;
+  estats_clear(sh);
+  if (rec != kNone) {      // kNone: the two regions share no record (bc_feat on an order that merges non-neighbours)
+    estats_sub_additive(b2, st.e_A[rec]);
+    sh = st.e_A[rec];
+    estats_add(sh, st.e_NA[rec]);
+    for (uint32_t f = st.e_fhead[rec]; f != kNone; f = st.le_next[f])
+      if (leaf_alive(st, st.le_dst[f])) estats_add(sh, st.le_stats[f]);
+  }
   feat::bc_features(st.cfg, st.pts[first], b0, st.pts[second], b1, p2, b2, sh, out);
 }
 
@@ -296,10 +302,13 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
       s.stop = ST_RUN; s.newcount = 0;
       s.best_mn = s.second_mn = ~0ull; s.best_mx = s.second_mx = 0ull;
       s.ex[0] = s.ex[2] = 0xFFFFFFFFu; s.ex[1] = s.ex[3] = 0u;
-      if (root.seq[0] == 0) s.stop = ST_DONE;
+      const bool forced = st.forced != nullptr;
+      if (forced ? (k >= st.forced_n) : (root.seq[0] == 0)) s.stop = ST_DONE;
       else {
-        const uint32_t e = root.arg[0];
-        s.e = e; s.r0 = st.e_u[e]; s.r1 = st.e_v[e];
+        const uint32_t e = forced ? kNone : root.arg[0];
+        s.e = e;
+        if (forced) { s.r0 = st.forced[2 * k]; s.r1 = st.forced[2 * k + 1]; }
+        else { s.r0 = st.e_u[e]; s.r1 = st.e_v[e]; }
         s.len0 = st.adj_len[s.r0]; s.len1 = st.adj_len[s.r1];
         s.off0 = st.adj_off[s.r0]; s.off1 = st.adj_off[s.r1];
         const unsigned long long tot = (unsigned long long)s.len0 + s.len1;
@@ -307,12 +316,22 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
         else if (pool_used + tot > st.pool_cap) s.stop = ST_NEED_POOL;
         else {
           st.order[3 * k + 0] = s.r0; st.order[3 * k + 1] = s.r1; st.order[3 * k + 2] = st.R0 + (uint32_t)k;
-          st.sal_out[k] = root.sal[0];
+          st.sal_out[k] = forced ? 0.0 : root.sal[0];
         }
       }
     }
     __syncthreads();
     if (s.stop != ST_RUN) { status = s.stop; break; }
+    const bool forced = st.forced != nullptr;
+    if (forced) {      // the record between the two regions, if any
+      for (uint32_t i = tid; i < s.len0; i += kBcThreads) {
+        const uint32_t eid = st.pool[s.off0 + i];
+        if (!st.e_alive[eid]) continue;
+        const uint32_t u = st.e_u[eid], v = st.e_v[eid];
+        if ((u == s.r0 && v == s.r1) || (u == s.r1 && v == s.r0)) s.e = eid;
+      }
+      __syncthreads();
+    }
     const uint32_t r0 = s.r0, r1 = s.r1, e = s.e, len0 = s.len0, len1 = s.len1, off0 = s.off0, off1 = s.off1;
     const uint32_t r2 = st.R0 + (uint32_t)k;
     const uint32_t total = len0 + len1;
@@ -334,7 +353,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
         float m0 = fminf(st.Bn[r0].mn, ord_float(s.ex[0])), x0 = fmaxf(st.Bn[r0].mx, ord_float(s.ex[1]));
         float m1 = fminf(st.Bn[r1].mn, ord_float(s.ex[2])), x1 = fmaxf(st.Bn[r1].mx, ord_float(s.ex[3]));
         double x[kMaxFeat];
-        if (st.e_orient[e]) edge_features(st, r0, r1, e, m0, x0, m1, x1, x);
+        if (forced || st.e_orient[e]) edge_features(st, r0, r1, e, m0, x0, m1, x1, x);   // bc_feat: (x0, x1) as given
         else edge_features(st, r1, r0, e, m1, x1, m0, x0, x);
         for (int i = 0; i < fdim; ++i) st.feats_out[(size_t)k * fdim + i] = x[i];
       }
@@ -351,10 +370,10 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
       st.Bn[r2] = bn;
       EStats bt = st.Bt[r0];
       estats_add(bt, st.Bt[r1]);
-      estats_sub_additive(bt, st.e_A[e]);
+      if (e != kNone) estats_sub_additive(bt, st.e_A[e]);
       st.Bt[r2] = bt;
       st.parent[r0] = r2; st.parent[r1] = r2; st.parent[r2] = r2;
-      st.e_alive[e] = 0; st.pq.leaf_seq[e] = 0; pq_touch(st.pq, s.pq, 0, 0, e);
+      if (e != kNone) { st.e_alive[e] = 0; if (!forced) { st.pq.leaf_seq[e] = 0; pq_touch(st.pq, s.pq, 0, 0, e); } }
     }
     // ---- phase A: mark the neighbours of r0 / r1 with the record that reaches them ----
     for (uint32_t i = tid; i < total; i += kBcThreads) {
@@ -411,7 +430,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
         }
         if (st.e_table[o]) { if (side) t1 = true; else t0 = true; }
         st.e_alive[o] = 0;
-        if (st.e_table[o]) { st.pq.leaf_seq[o] = 0; pq_touch(st.pq, s.pq, 0, 0, o); }
+        if (st.e_table[o] && !forced) { st.pq.leaf_seq[o] = 0; pq_touch(st.pq, s.pq, 0, 0, o); }
       }
       const uint32_t old = (e0s != kNone) ? e0s : e1s;
       const uint32_t posRs = (st.e_u[old] == rs) ? st.e_posu[old] : st.e_posv[old];
@@ -457,7 +476,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
     __syncthreads();
 
     // ---- score the new table edges: features (one thread per edge) -> forest ((edge, tree) per thread) ----
-    for (uint32_t c0 = 0; c0 < newcount; c0 += kChunk) {
+    for (uint32_t c0 = 0; c0 < (forced ? 0u : newcount); c0 += kChunk) {
       const uint32_t cn = min((uint32_t)kChunk, newcount - c0);
       if ((uint32_t)tid < cn) {
         const uint32_t rec = (uint32_t)ne + c0 + tid;
@@ -496,7 +515,8 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
       __syncthreads();
     }
     for (uint32_t j = tid; j < newcount; j += kBcThreads) st.e_posv[(uint32_t)ne + j] &= 0x3FFFFFFFu;
-    pq_propagate<kBcThreads>(st.pq, s.pq, tid);
+    if (!forced) pq_propagate<kBcThreads>(st.pq, s.pq, tid);
+    else __syncthreads();
     k += 1; ne += newcount; pool_used += total;
   }
   if (tid == 0) { st.ctrl[0] = k; st.ctrl[1] = ne; st.ctrl[2] = pool_used; st.ctrl[3] = status; }
@@ -527,7 +547,8 @@ static void rmap_ranks(const std::vector<uint32_t>& labels, const std::vector<lo
 
 int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& clf, hipStream_t stream,
               uint32_t* h_order, double* h_sal, double* h_feats, int64_t capacity, int64_t* n_merges,
-              double* ms_table, double* ms_init, double* ms_loop, int64_t* n_scored, bool init_only) {
+              double* ms_table, double* ms_init, double* ms_loop, int64_t* n_scored, bool init_only,
+              const uint32_t* h_forced, int64_t n_forced) {
   const long long P = rag.P;
   const uint32_t R = (uint32_t)rag.R;
   *n_merges = 0;
@@ -631,7 +652,13 @@ int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& cl
   hipLaunchKernelGGL(bc_adj_fill, dim3((E0 + 255) / 256), dim3(256), 0, stream, st, E0, cursor);
   GLIA_HIP_TRY(hipGetLastError());
   GLIA_HIP_TRY(hipEventRecord(ev[1], stream));
-  hipLaunchKernelGGL(bc_init_score, dim3((E0 + 127) / 128), dim3(128), 0, stream, st, E0);
+  if (!h_forced) hipLaunchKernelGGL(bc_init_score, dim3((E0 + 127) / 128), dim3(128), 0, stream, st, E0);
+  if (h_forced) {
+    uint32_t* d_forced;
+    if ((rc = buf.get(&d_forced, (size_t)2 * n_forced + 2, false, stream))) return rc;
+    GLIA_HIP_TRY(hipMemcpyAsync(d_forced, h_forced, sizeof(uint32_t) * 2 * (size_t)n_forced, hipMemcpyHostToDevice, stream));
+    st.forced = d_forced; st.forced_n = (unsigned long long)n_forced;
+  }
   GLIA_HIP_TRY(hipGetLastError());
   if ((rc = pq_setup(buf, st.pq, stream))) return rc;
   unsigned long long ctrl[4] = {0, E0, 2ull * E0, ST_RUN};

@@ -90,7 +90,8 @@ struct BcCfg;
 struct DeviceClassifier;
 int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& clf, hipStream_t stream, uint32_t* h_order,
               double* h_sal, double* h_feats, int64_t capacity, int64_t* n_merges, double* ms_table, double* ms_init,
-              double* ms_loop, int64_t* n_scored, bool init_only);
+              double* ms_loop, int64_t* n_scored, bool init_only, const uint32_t* h_forced = nullptr,
+              int64_t n_forced = 0);
 int compact_tables(const AccParams& p, uint32_t rcap, uint32_t pcap, RagArrays* out, hipStream_t stream);
 int merge_rag_arrays(const RagArrays* parts, int n_parts, RagArrays* out, hipStream_t stream);
 

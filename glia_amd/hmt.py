@@ -140,6 +140,19 @@ def make_config(pb, rb=(), r=(), rl=(), b=(), thresholds=(0.2, 0.5, 0.8), normal
     return cfg
 
 
+def gen_tree(order):
+    """hmt::genTree (hmt/tree_build.hxx:12-38) -> (label, parent, child0, child1) arrays."""
+    order = np.ascontiguousarray(order, dtype=np.uint32)
+    cap = 3 * len(order) + 1      # a forest of several components has more than 2n+1 nodes
+    lab = np.empty(cap, np.uint32)
+    par = np.empty(cap, np.int32); c0 = np.empty(cap, np.int32); c1 = np.empty(cap, np.int32)
+    lib().glia_hmt_gen_tree.restype = C.c_int64
+    n = lib().glia_hmt_gen_tree(_np(order), C.c_int64(len(order)), _np(lab), _np(par), _np(c0), _np(c1), C.c_int64(cap))
+    if n < 0:
+        raise HmtError(int(n), lib().glia_hmt_last_error().decode())
+    return lab[:n], par[:n], c0[:n], c1[:n]
+
+
 class RandomForest:
     """alg::RandomForest / alg::EnsembleRandomForest (alg/rf.hxx) loaded from GLIA model files onto the device."""
 
@@ -306,6 +319,13 @@ class RegionMap:
         if want_feats:
             return order[:n.value].copy(), sal[:n.value].copy(), feats[:n.value].copy()
         return order[:n.value].copy(), sal[:n.value].copy()
+
+    def bc_feat(self, order):
+        """hmt/main_bc_feat.cxx: feature rows for a given merge order."""
+        order = np.ascontiguousarray(order, dtype=np.uint32)
+        feats = np.empty((len(order), self.feat_dim()), np.float64)
+        _check(lib().glia_hmt_bc_feat(self.ctx.h, self.h, _np(order), C.c_int64(len(order)), _np(feats)))
+        return feats
 
     def score_initial_edges(self, classifier):
         n, ms = C.c_int64(0), C.c_double(0)

@@ -159,6 +159,17 @@ int glia_hmt_feat_dim(const glia_hmt_rag* rag);
 int glia_hmt_merge_order_bc(glia_hmt_ctx* ctx, glia_hmt_rag* rag, const glia_hmt_forest* forest, uint32_t* h_order,
                             double* h_saliency, double* h_feats, int64_t capacity, int64_t* n_merges);
 
+/* Replaces the bc_feat pipeline (hmt/main_bc_feat.cxx:27-112) for a GIVEN merge order: RegionMap(seg, mask, order,
+ * false) + RegionFeats of every tree node + BoundaryFeats of every merge (the OpenMP parfor loops of :59-101),
+ * without the optional saliency features (-y).  h_order: n_merges triples (x0, x1, x2); h_feats: [n_merges][feat_dim],
+ * row i = features of merge i with regions in the file's orientation and the area-ordered swap of :88-91. */
+int glia_hmt_bc_feat(glia_hmt_ctx* ctx, glia_hmt_rag* rag, const uint32_t* h_order, int64_t n_merges, double* h_feats);
+
+/* Replaces hmt::genTree (hmt/tree_build.hxx:12-38): merge order -> array tree (children before parents, root last).
+ * Host-only.  Returns the number of nodes (2 * n_merges + 1 for one connected tree) or a negative status. */
+int64_t glia_hmt_gen_tree(const uint32_t* h_order, int64_t n_merges, uint32_t* node_label, int32_t* parent,
+                          int32_t* child0, int32_t* child1, int64_t capacity);
+
 /* TBoundaryTable::init with the classifier linkage only (type/boundary_table.hxx:91-114 driven by
  * util/struct_merge_bc.hxx:18-27): feature vector + score of every initial table edge, no merging.
  * *ms = device time of the feature + forest kernel. */

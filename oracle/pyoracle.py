@@ -246,7 +246,7 @@ def forest_predict(forest, x):
 
 def gen_tree(order):
     order = np.ascontiguousarray(order, dtype=np.uint32)
-    cap = 2 * len(order) + 1
+    cap = 3 * len(order) + 1      # a forest of several components has more than 2n+1 nodes
     lab = np.empty(cap, np.uint32)
     par = np.empty(cap, np.int32); c0 = np.empty(cap, np.int32); c1 = np.empty(cap, np.int32)
     n = lib().orc_gen_tree(_p(order), C.c_int64(len(order)), _p(lab), _p(par), _p(c0), _p(c1), C.c_int64(cap))

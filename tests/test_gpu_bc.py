@@ -108,3 +108,21 @@ def test_log_and_simple_features(ctx):
         o_ref, s_ref, f_ref = O.Rag(labels).merge_order_bc(cfg, None, stub_index=stub, want_feats=True)
         assert feats.shape == f_ref.shape
         assert (order == o_ref).all() and _feat_close(feats, f_ref)
+
+
+@pytest.mark.parametrize("shape,S,G", [((32, 32, 32), 8, 16), ((40, 36, 28), 6, 12), ((64, 64), 4, 16)])
+def test_bc_feat_for_a_given_order(ctx, shape, S, G):
+    """hmt/main_bc_feat.cxx path: features of every merge of a GIVEN order (here: the pb-mean order)."""
+    from oracle import pyoracle as O
+    labels, pb = O.synth(shape, S, G)
+    order, _ = O.Rag(labels, only_contour=True).merge_order_pb(pb, type=2)
+    rm = _gpu_rm(ctx, labels, pb)
+    feats = rm.bc_feat(order)
+    ref = O.Rag(labels).bc_feat(O.make_cfg(pb, rb=[(pb, 8, 0.0, 1.0)]), order)
+    assert feats.shape == ref.shape and _feat_close(feats, ref)
+    # a merge order that joins non-neighbouring regions first (no shared record)
+    labs = np.unique(labels)
+    far = np.array([[labs[0], labs[-1], labs.max() + 1]], dtype=np.uint32)
+    f2 = rm.bc_feat(far)
+    r2 = O.Rag(labels).bc_feat(O.make_cfg(pb, rb=[(pb, 8, 0.0, 1.0)]), far)
+    assert _feat_close(f2, r2)
