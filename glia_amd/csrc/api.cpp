@@ -644,6 +644,37 @@ int glia_hmt_merge_order_bc(glia_hmt_ctx* c, glia_hmt_rag* rag, const glia_hmt_f
   return GLIA_HMT_OK;
 }
 
+int glia_hmt_pre_merge(glia_hmt_ctx* c, glia_hmt_rag* rag, const int* size_thresholds, int n_thresholds,
+                       double rpb_threshold, uint32_t* h_order, double* h_sal, int64_t capacity, int64_t* n_merges) {
+  if (!c || !rag || !size_thresholds || n_thresholds < 1 || n_thresholds > 2 || !h_order || !h_sal || !n_merges || rag->ctx != c) {
+    set_error("pre_merge: invalid argument");
+    return GLIA_HMT_ERR_ARG;
+  }
+  if (rag->only_contour) { set_error("pre_merge: the region map must hold region points (only_contour = 0)"); return GLIA_HMT_ERR_ARG; }
+  GLIA_HIP_TRY(hipSetDevice(c->device));
+  const int64_t R = rag->arr.R, P = rag->arr.P;
+  *n_merges = 0;
+  if (R == 0 || P == 0) return GLIA_HMT_OK;
+  std::vector<uint32_t> order((size_t)3 * R);
+  std::vector<double> sal((size_t)R);
+  long long sizes[2] = {size_thresholds[0], n_thresholds > 1 ? size_thresholds[1] : 0};
+  int64_t n = 0;
+  int rc = greedy_mean(rag->arr, c->stream, order.data(), sal.data(), R, &n, &rag->ms_table, &rag->ms_loop, &rag->n_scored,
+                       n_thresholds, sizes, rpb_threshold);
+  if (rc) return rc;
+  if (n > capacity) { set_error("pre_merge: output capacity too small"); return GLIA_HMT_ERR_CAPACITY; }
+  std::vector<uint32_t> lab((size_t)R);
+  GLIA_HIP_TRY(hipMemcpy(lab.data(), rag->arr.d_rlabel, sizeof(uint32_t) * R, hipMemcpyDeviceToHost));
+  const uint32_t maxKey = lab[R - 1];
+  for (int64_t i = 0; i < 3 * n; ++i) {
+    const uint32_t id = order[i];
+    h_order[i] = id < (uint32_t)R ? lab[id] : maxKey + 1u + (id - (uint32_t)R);
+  }
+  for (int64_t i = 0; i < n; ++i) h_sal[i] = sal[i];
+  *n_merges = n;
+  return GLIA_HMT_OK;
+}
+
 int glia_hmt_bc_feat(glia_hmt_ctx* c, glia_hmt_rag* rag, const uint32_t* h_order, int64_t n_merges, double* h_feats) {
   if (!c || !rag || !h_order || !h_feats || n_merges < 0 || rag->ctx != c) { set_error("bc_feat: invalid argument"); return GLIA_HMT_ERR_ARG; }
   BcCfg cfg;

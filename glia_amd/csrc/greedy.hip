@@ -68,6 +68,11 @@ struct GreedyState {
   double* e_mean;
   int* e_n;
   PqTree pq;
+  uint8_t* e_alive;               // record exists in the table (it may have left the queue: pre_merge rejections)
+  // pre_merge condition (gadget/main_pre_merge.cxx:27-76); cond_n == 0: f_true
+  int cond_n; unsigned long long cond_t0, cond_t1; double cond_rpb;
+  unsigned long long* rsz;        // [2*R0] region sizes (updateRegion = true)
+  double* rsum;                   // [2*R0] sum of pb over the region's voxels
   uint32_t *mark0, *mark1;        // [2*R0], zero between contractions
   uint32_t* order;                // [R0][3] dense ids
   double* sal_out;
@@ -79,7 +84,7 @@ struct GreedyState {
 namespace {
 
 struct Shared {
-  uint32_t r0, r1, e, stop, len0, len1, off0, off1, newcount;
+  uint32_t r0, r1, e, stop, len0, len1, off0, off1, newcount, reject;
   PqWork pq;
 };
 
@@ -98,23 +103,42 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_mean_kernel(GreedyState
       const PqLevel& root = st.pq.lv[st.pq.nlevels - 1];
       s.stop = ST_RUN;
       s.newcount = 0;
+      s.reject = 0;
       if (root.seq[0] == 0) s.stop = ST_DONE;
       else {
         uint32_t e = root.arg[0];
         s.e = e; s.r0 = st.e_u[e]; s.r1 = st.e_v[e];
+        if (st.cond_n > 0) {
+          // TBoundaryTable::top(fcond) walks the queue from the best item down and returns the first one fcond accepts.
+          // fcond depends only on the two regions, which cannot change while the item lives, so an item it rejects
+          // is rejected for good: take it out of the queue (it stays in the table and is folded into later updates).
+          unsigned long long sz0 = st.rsz[s.r0], sz1 = st.rsz[s.r1];
+          double su0 = st.rsum[s.r0], su1 = st.rsum[s.r1];
+          if (sz0 > sz1) { unsigned long long t = sz0; sz0 = sz1; sz1 = t; double d = su0; su0 = su1; su1 = d; }
+          bool ok = sz0 < st.cond_t0;
+          if (!ok && st.cond_n > 1) {
+            if (sz0 < st.cond_t1 && sdivide(su0, (double)sz0, 0.0) > st.cond_rpb) ok = true;
+            if (!ok && sz1 < st.cond_t1 && sdivide(su1, (double)sz1, 0.0) > st.cond_rpb) ok = true;
+          }
+          if (!ok) { s.reject = 1; st.pq.leaf_seq[e] = 0; pq_touch(st.pq, s.pq, 0, 0, e); }
+        }
         s.len0 = st.adj_len[s.r0]; s.len1 = st.adj_len[s.r1];
         s.off0 = st.adj_off[s.r0]; s.off1 = st.adj_off[s.r1];
         unsigned long long tot = (unsigned long long)s.len0 + s.len1;
-        if (ne + tot > st.Ecap) s.stop = ST_NEED_EDGES;
+        if (s.reject) {}      // nothing is contracted: no capacity needed
+        else if (ne + tot > st.Ecap) s.stop = ST_NEED_EDGES;
         else if (pool_used + tot > st.pool_cap) s.stop = ST_NEED_POOL;
         else {
           st.order[3 * k + 0] = s.r0; st.order[3 * k + 1] = s.r1; st.order[3 * k + 2] = st.R0 + (uint32_t)k;
           st.sal_out[k] = root.sal[0];
+          st.rsz[st.R0 + (uint32_t)k] = st.rsz[s.r0] + st.rsz[s.r1];       // TRegionMap::merge (updateRegion)
+          st.rsum[st.R0 + (uint32_t)k] = st.rsum[s.r0] + st.rsum[s.r1];
         }
       }
     }
     __syncthreads();
     if (s.stop != ST_RUN) { status = s.stop; break; }
+    if (s.reject) { pq_propagate<kGreedyThreads>(st.pq, s.pq, tid); continue; }
     const uint32_t r0 = s.r0, r1 = s.r1, e = s.e, len0 = s.len0, len1 = s.len1, off0 = s.off0, off1 = s.off1;
     const uint32_t r2 = st.R0 + (uint32_t)k;
     const uint32_t total = len0 + len1;
@@ -124,7 +148,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_mean_kernel(GreedyState
     for (uint32_t i = tid; i < total; i += kGreedyThreads) {
       const bool side1 = i >= len0;
       const uint32_t eid = st.pool[side1 ? off1 + (i - len0) : off0 + i];
-      if (eid == e || st.pq.leaf_seq[eid] == 0) continue;
+      if (eid == e || !st.e_alive[eid]) continue;
       const uint32_t r = side1 ? r1 : r0;
       const uint32_t u = st.e_u[eid], v = st.e_v[eid];
       const uint32_t rs = (u == r) ? v : u;
@@ -168,14 +192,14 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_mean_kernel(GreedyState
       const uint32_t posRs = (st.e_u[old] == rs) ? st.e_posu[old] : st.e_posv[old];
       st.e_u[newE] = rs; st.e_v[newE] = r2; st.e_posu[newE] = posRs; st.e_posv[newE] = idx;
       st.e_mean[newE] = first; st.e_n[newE] = second;
-      st.pq.leaf_sal[newE] = -first; st.pq.leaf_seq[newE] = seq;
+      st.pq.leaf_sal[newE] = -first; st.pq.leaf_seq[newE] = seq; st.e_alive[newE] = 1;
       st.pool[st.adj_off[rs] + posRs] = newE;
       st.pool[r2off + idx] = newE;
       pq_touch(st.pq, s.pq, 0, 0, newE);
-      if (e0s != kNone) { st.pq.leaf_seq[e0s] = 0; pq_touch(st.pq, s.pq, 0, 0, e0s); }
-      if (e1s != kNone) { st.pq.leaf_seq[e1s] = 0; pq_touch(st.pq, s.pq, 0, 0, e1s); }
+      if (e0s != kNone) { st.e_alive[e0s] = 0; if (st.pq.leaf_seq[e0s]) { st.pq.leaf_seq[e0s] = 0; pq_touch(st.pq, s.pq, 0, 0, e0s); } }
+      if (e1s != kNone) { st.e_alive[e1s] = 0; if (st.pq.leaf_seq[e1s]) { st.pq.leaf_seq[e1s] = 0; pq_touch(st.pq, s.pq, 0, 0, e1s); } }
     }
-    if (tid == 0) { st.pq.leaf_seq[e] = 0; pq_touch(st.pq, s.pq, 0, 0, e); }
+    if (tid == 0) { st.e_alive[e] = 0; st.pq.leaf_seq[e] = 0; pq_touch(st.pq, s.pq, 0, 0, e); }
     if (__syncthreads_or(bad ? 1 : 0)) { status = ST_BAD_SALIENCY; break; }
 
     // ---- phase C: reset marks, publish r2's list ----
@@ -220,7 +244,7 @@ __global__ void edge_fill(const uint32_t* pa, const uint32_t* pb, const uint32_t
   const int n = (int)(wi[P_CNT] + wj[P_CNT]);
   const double mean = sdivide(si + sj, (double)n, 0.0);
   st.e_u[e] = u; st.e_v[e] = v; st.e_mean[e] = mean; st.e_n[e] = n;
-  st.pq.leaf_sal[e] = -mean; st.pq.leaf_seq[e] = (unsigned long long)e + 1ull;
+  st.pq.leaf_sal[e] = -mean; st.pq.leaf_seq[e] = (unsigned long long)e + 1ull; st.e_alive[e] = 1;
   atomicAdd(&deg[u], 1u);
   atomicAdd(&deg[v], 1u);
 }
@@ -234,6 +258,14 @@ __global__ void adj_fill(GreedyState st, uint32_t E0, uint32_t* cursor) {
   st.pool[st.adj_off[v] + pv] = e; st.e_posv[e] = pv;
 }
 
+__global__ void region_sizes(const uint32_t* rrec, uint32_t R, unsigned long long* rsz, double* rsum) {
+  uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const uint32_t* w = &rrec[(size_t)r * kRegionWords];
+  rsz[r] = w[R_CNT];
+  double d; memcpy(&d, &w[R_SUM], 8); rsum[r] = d;
+}
+
 __global__ void fill_leaves_dead(PqTree t, uint32_t from) {
   uint32_t i = from + blockIdx.x * blockDim.x + threadIdx.x;
   if (i < t.nleaves) { t.leaf_seq[i] = 0; t.leaf_sal[i] = -__builtin_inf(); }
@@ -244,7 +276,8 @@ __global__ void fill_leaves_dead(PqTree t, uint32_t from) {
 // Runs the pb-mean greedy merge on a compact RAG.  h_order receives dense ids (leaf i = i-th label ascending,
 // merged region R+k); the caller maps them to keys.
 int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, double* h_sal, int64_t capacity,
-                int64_t* n_merges, double* ms_table, double* ms_loop, int64_t* n_scored) {
+                int64_t* n_merges, double* ms_table, double* ms_loop, int64_t* n_scored, int cond_n,
+                const long long* cond_sizes, double cond_rpb) {
   const long long P = rag.P;
   const uint32_t R = (uint32_t)rag.R;
   *n_merges = 0;
@@ -288,6 +321,12 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
   st.pq.nleaves = st.Ecap;
   if ((rc = buf.get(&st.pq.leaf_sal, st.Ecap, false, stream))) return rc;
   if ((rc = buf.get(&st.pq.leaf_seq, st.Ecap, false, stream))) return rc;
+  if ((rc = buf.get(&st.e_alive, st.Ecap, true, stream))) return rc;
+  if ((rc = buf.get(&st.rsz, 2 * (size_t)R, true, stream))) return rc;
+  if ((rc = buf.get(&st.rsum, 2 * (size_t)R, true, stream))) return rc;
+  st.cond_n = cond_n; st.cond_rpb = cond_rpb;
+  st.cond_t0 = cond_n > 0 ? (unsigned long long)cond_sizes[0] : 0; st.cond_t1 = cond_n > 1 ? (unsigned long long)cond_sizes[1] : 0;
+  hipLaunchKernelGGL(region_sizes, dim3((R + 255) / 256), dim3(256), 0, stream, rag.d_rrec, R, st.rsz, st.rsum);
   if ((rc = buf.get(&st.mark0, 2 * (size_t)R, true, stream))) return rc;
   if ((rc = buf.get(&st.mark1, 2 * (size_t)R, true, stream))) return rc;
   if ((rc = buf.get(&st.order, 3 * (size_t)R, false, stream))) return rc;
@@ -338,6 +377,7 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
       if ((rc = buf.grow(&st.e_posv, ocap, ncap, stream))) return rc;
       if ((rc = buf.grow(&st.e_mean, ocap, ncap, stream))) return rc;
       if ((rc = buf.grow(&st.e_n, ocap, ncap, stream))) return rc;
+      if ((rc = buf.grow(&st.e_alive, ocap, ncap, stream))) return rc;
       if ((rc = buf.grow(&st.pq.leaf_sal, ocap, ncap, stream))) return rc;
       if ((rc = buf.grow(&st.pq.leaf_seq, ocap, ncap, stream))) return rc;
       st.Ecap = ncap; st.pq.nleaves = ncap;

@@ -85,7 +85,8 @@ int launch_accumulate(const AccParams& p, hipStream_t stream);
 int launch_synth(int dim, const int64_t dims[3], int S, int G, uint64_t seed, int variant, uint32_t* d_labels,
                  uint32_t* d_truth_tmp, float* d_pb, hipStream_t stream);
 int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, double* h_sal, int64_t capacity,
-                int64_t* n_merges, double* ms_table, double* ms_loop, int64_t* n_scored);
+                int64_t* n_merges, double* ms_table, double* ms_loop, int64_t* n_scored, int cond_n = 0,
+                const long long* cond_sizes = nullptr, double cond_rpb = 0.0);
 struct BcCfg;
 struct DeviceClassifier;
 int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& clf, hipStream_t stream, uint32_t* h_order,

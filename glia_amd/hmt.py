@@ -320,6 +320,17 @@ class RegionMap:
             return order[:n.value].copy(), sal[:n.value].copy(), feats[:n.value].copy()
         return order[:n.value].copy(), sal[:n.value].copy()
 
+    def pre_merge(self, size_thresholds, rpb_threshold):
+        """gadget/main_pre_merge.cxx: pb-mean merges restricted by the region-size condition."""
+        cap = max(self.num_regions, 1)
+        order = np.empty((cap, 3), np.uint32)
+        sal = np.empty(cap, np.float64)
+        st = (C.c_int * len(size_thresholds))(*size_thresholds)
+        n = C.c_int64(0)
+        _check(lib().glia_hmt_pre_merge(self.ctx.h, self.h, st, C.c_int(len(size_thresholds)), C.c_double(rpb_threshold),
+                                        _np(order), _np(sal), C.c_int64(cap), C.byref(n)))
+        return order[:n.value].copy(), sal[:n.value].copy()
+
     def bc_feat(self, order):
         """hmt/main_bc_feat.cxx: feature rows for a given merge order."""
         order = np.ascontiguousarray(order, dtype=np.uint32)

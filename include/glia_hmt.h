@@ -159,6 +159,14 @@ int glia_hmt_feat_dim(const glia_hmt_rag* rag);
 int glia_hmt_merge_order_bc(glia_hmt_ctx* ctx, glia_hmt_rag* rag, const glia_hmt_forest* forest, uint32_t* h_order,
                             double* h_saliency, double* h_feats, int64_t capacity, int64_t* n_merges);
 
+/* Replaces the merge engine of pre_merge (gadget/main_pre_merge.cxx:20-76): pb-mean linkage with updateRegion = true
+ * and the size condition -- an edge may merge only if its smaller region has fewer than size_thresholds[0] voxels, or
+ * (n_thresholds == 2) a region smaller than size_thresholds[1] has mean pb above rpb_threshold.  The region map must
+ * have been built with only_contour = 0 and the pb image.  Relabelling the volume (transformKeys/transformImage,
+ * :77-79) stays with the caller. */
+int glia_hmt_pre_merge(glia_hmt_ctx* ctx, glia_hmt_rag* rag, const int* size_thresholds, int n_thresholds,
+                       double rpb_threshold, uint32_t* h_order, double* h_saliency, int64_t capacity, int64_t* n_merges);
+
 /* Replaces the bc_feat pipeline (hmt/main_bc_feat.cxx:27-112) for a GIVEN merge order: RegionMap(seg, mask, order,
  * false) + RegionFeats of every tree node + BoundaryFeats of every merge (the OpenMP parfor loops of :59-101),
  * without the optional saliency features (-y).  h_order: n_merges triples (x0, x1, x2); h_feats: [n_merges][feat_dim],

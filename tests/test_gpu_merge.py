@@ -113,3 +113,21 @@ def test_full_size_properties(ctx):
     assert len(np.unique(used)) == 2 * n                  # every region is merged exactly once
     assert (np.diff(sal) <= 1e-12).all()                  # mean linkage is reducible: saliency never increases
     rm.close()
+
+
+@pytest.mark.parametrize("shape,S,G,variant,sizes,rpb", [((32, 32, 32), 8, 16, 0, (300,), 0.0), ((40, 36, 28), 6, 12, 0, (150, 400), 0.30),
+                                                        ((96, 96), 8, 32, 0, (40, 120), 0.25), ((48, 48, 48), 6, 12, 1, (100, 500), 0.28)])
+def test_pre_merge_condition(ctx, shape, S, G, variant, sizes, rpb):
+    """gadget/main_pre_merge.cxx:27-76: mean linkage, updateRegion, size / mean-pb condition."""
+    import torch
+    from glia_amd import hmt
+    from oracle import pyoracle as O
+    labels, pb = O.synth(shape, S, G, variant=variant)
+    d_lab = torch.from_numpy(labels.view(np.int32)).cuda()
+    d_pb = torch.from_numpy(pb).cuda()
+    rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, only_contour=False)
+    order, sal = rm.pre_merge(list(sizes), rpb)
+    o_ref, s_ref = O.Rag(labels).pre_merge(pb, list(sizes), rpb)
+    assert 0 < len(o_ref) < rm.num_regions - 1            # the condition really stops the loop early
+    assert order.shape == o_ref.shape and (order == o_ref).all()
+    assert (sal == s_ref).all() if variant == 0 else np.allclose(sal, s_ref, rtol=0, atol=1e-12)
