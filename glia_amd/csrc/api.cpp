@@ -514,17 +514,21 @@ int glia_hmt_merge_order_pb(glia_hmt_ctx* c, glia_hmt_rag* rag, int type, uint32
 }
 
 static int upload_forest(const HostForest& hf, glia_hmt_forest* f, int slot, hipStream_t stream) {
-  double* d_split = nullptr;
-  int4* d_meta = nullptr;
-  GLIA_HIP_TRY(hipMalloc(&d_split, sizeof(double) * hf.split.size()));
-  f->allocs.push_back(d_split);
-  GLIA_HIP_TRY(hipMalloc(&d_meta, sizeof(int) * hf.meta.size()));
-  f->allocs.push_back(d_meta);
-  GLIA_HIP_TRY(hipMemcpyAsync(d_split, hf.split.data(), sizeof(double) * hf.split.size(), hipMemcpyHostToDevice, stream));
-  GLIA_HIP_TRY(hipMemcpyAsync(d_meta, hf.meta.data(), sizeof(int) * hf.meta.size(), hipMemcpyHostToDevice, stream));
+  std::vector<PackedNode> nodes;
+  std::vector<int> roots;
+  int rc = pack_forest(hf, &nodes, &roots);
+  if (rc) return rc;
+  PackedNode* d_nodes = nullptr;
+  int* d_roots = nullptr;
+  GLIA_HIP_TRY(hipMalloc(&d_nodes, sizeof(PackedNode) * nodes.size()));
+  f->allocs.push_back(d_nodes);
+  GLIA_HIP_TRY(hipMalloc(&d_roots, sizeof(int) * roots.size()));
+  f->allocs.push_back(d_roots);
+  GLIA_HIP_TRY(hipMemcpyAsync(d_nodes, nodes.data(), sizeof(PackedNode) * nodes.size(), hipMemcpyHostToDevice, stream));
+  GLIA_HIP_TRY(hipMemcpyAsync(d_roots, roots.data(), sizeof(int) * roots.size(), hipMemcpyHostToDevice, stream));
   GLIA_HIP_TRY(hipStreamSynchronize(stream));
   f->dc.f[slot].ntree = hf.ntree; f->dc.f[slot].nrnodes = hf.nrnodes;
-  f->dc.f[slot].split = d_split; f->dc.f[slot].meta = d_meta;
+  f->dc.f[slot].nodes = d_nodes; f->dc.f[slot].root = d_roots;
   if (hf.max_var > f->max_var) f->max_var = hf.max_var;
   return GLIA_HMT_OK;
 }

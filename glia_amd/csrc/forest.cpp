@@ -150,4 +150,34 @@ int load_forest_file(const char* path, int predict_label, HostForest* out) {
   return GLIA_HMT_OK;
 }
 
+
+int pack_forest(const HostForest& hf, std::vector<PackedNode>* nodes, std::vector<int>* roots) {
+  nodes->clear();
+  roots->assign(hf.ntree, 0);
+  std::vector<int> queue;
+  for (int j = 0; j < hf.ntree; ++j) {
+    const size_t base = (size_t)j * hf.nrnodes;
+    const int first = (int)nodes->size();
+    (*roots)[j] = first;
+    queue.assign(1, 0);
+    nodes->push_back(PackedNode());
+    for (size_t q = 0; q < queue.size(); ++q) {
+      if ((int)queue.size() > hf.nrnodes) { set_error("forest: tree has a cycle"); return GLIA_HMT_ERR_IO; }
+      const int k = queue[q];
+      const int* m = &hf.meta[(base + k) * 4];
+      PackedNode n;
+      n.split = hf.split[base + k];
+      if (m[3] >= 0) { n.var = -1 - m[3]; n.left = 0; }
+      else {
+        n.var = m[0];
+        n.left = (int)nodes->size();
+        queue.push_back(m[1]); queue.push_back(m[2]);
+        nodes->push_back(PackedNode()); nodes->push_back(PackedNode());
+      }
+      (*nodes)[first + q] = n;
+    }
+  }
+  return GLIA_HMT_OK;
+}
+
 }  // namespace glia

@@ -10,11 +10,20 @@ struct HostForest {
   std::vector<int> meta;       // [ntree][nrnodes][4] = {var (0-based), left, right (0-based), vote (-1 = internal node)}
 };
 
-struct DeviceForest {
-  int ntree, nrnodes;
-  const double* split;
-  const int4* meta;
+// Device layout: only the nodes a walk can reach, renumbered breadth-first per tree so that the two daughters of a
+// node are adjacent (right = left + 1).  16 bytes per node = one load per level, and a forest of the reference's
+// default size (255 trees) fits the 4 MiB L2 of an XCD.
+struct PackedNode {
+  double split;
+  int var;       // >= 0: internal node, feature index;  < 0: terminal, vote = -1 - var
+  int left;      // index of the left daughter in the packed array (absolute)
 };
+struct DeviceForest {
+  int ntree, nrnodes;          // nrnodes: depth bound for the walk
+  const PackedNode* nodes;
+  const int* root;             // [ntree] index of each tree's root
+};
+int pack_forest(const HostForest& hf, std::vector<PackedNode>* nodes, std::vector<int>* roots);
 
 // What fBcPred evaluates (hmt/main_merge_order_bc.cxx:127-137): one forest, or three forests behind a
 // ThresholdModelDistributor (type/function.hxx:71-85), or -- diagnostics only -- 1 - x[index].

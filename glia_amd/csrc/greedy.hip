@@ -30,7 +30,7 @@ namespace glia {
 __global__ void pq_build_level_kernel(PqTree t, int l) {
   const int lane = threadIdx.x & 63;
   uint32_t j = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (j < t.lv[l].size) pq_recompute_node(t, l, j, lane);
+  if (j < t.lv[l].size) (void)pq_recompute_node(t, l, j, lane, true);   // fresh memory: always write
 }
 
 // (re)allocates the tree levels above t.nleaves leaves and builds them from the current leaf keys
@@ -95,10 +95,18 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_mean_kernel(GreedyState
   unsigned long long k = st.ctrl[0], ne = st.ctrl[1], pool_used = st.ctrl[2];
   uint32_t status = ST_RUN;
   if (tid == 0) { s.pq.wln[0] = s.pq.wln[1] = 0; s.pq.ovf = 0; }
+  for (int i = tid; i < kSetSlots; i += blockDim.x) { s.pq.set[0][i] = 0; s.pq.set[1][i] = 0; }
   __syncthreads();
 
+#ifdef GLIA_HMT_PROFILE
+  unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#define PH(i) do { if (tid == 0) { unsigned long long tn = __builtin_readcyclecounter(); tph[i] += tn - tlast; tlast = tn; } } while (0)
+#else
+#define PH(i) do {} while (0)
+#endif
   for (unsigned long long it = 0; it < st.max_iters; ++it) {
     // ---- pop (TBoundaryTable::top) ----
+    PH(5);
     if (tid == 0) {
       const PqLevel& root = st.pq.lv[st.pq.nlevels - 1];
       s.stop = ST_RUN;
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_mean_kernel(GreedyState
             if (sz0 < st.cond_t1 && sdivide(su0, (double)sz0, 0.0) > st.cond_rpb) ok = true;
             if (!ok && sz1 < st.cond_t1 && sdivide(su1, (double)sz1, 0.0) > st.cond_rpb) ok = true;
           }
-          if (!ok) { s.reject = 1; st.pq.leaf_seq[e] = 0; pq_touch(st.pq, s.pq, 0, 0, e); }
+          if (!ok) { s.reject = 1; st.pq.leaf_seq[e] = 0; pq_leaf_removed(st.pq, s.pq, e); }
         }
         s.len0 = st.adj_len[s.r0]; s.len1 = st.adj_len[s.r1];
         s.off0 = st.adj_off[s.r0]; s.off1 = st.adj_off[s.r1];
@@ -137,6 +145,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_mean_kernel(GreedyState
       }
     }
     __syncthreads();
+    PH(0);
     if (s.stop != ST_RUN) { status = s.stop; break; }
     if (s.reject) { pq_propagate<kGreedyThreads>(st.pq, s.pq, tid); continue; }
     const uint32_t r0 = s.r0, r1 = s.r1, e = s.e, len0 = s.len0, len1 = s.len1, off0 = s.off0, off1 = s.off1;
@@ -155,6 +164,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_mean_kernel(GreedyState
       (side1 ? st.mark1 : st.mark0)[rs] = eid + 1u;
     }
     __syncthreads();
+    PH(1);
 
     // ---- phase B: one new edge (rs, r2) per distinct neighbour (TBoundaryTable::update) ----
     bool bad = false;
@@ -195,12 +205,13 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_mean_kernel(GreedyState
       st.pq.leaf_sal[newE] = -first; st.pq.leaf_seq[newE] = seq; st.e_alive[newE] = 1;
       st.pool[st.adj_off[rs] + posRs] = newE;
       st.pool[r2off + idx] = newE;
-      pq_touch(st.pq, s.pq, 0, 0, newE);
-      if (e0s != kNone) { st.e_alive[e0s] = 0; if (st.pq.leaf_seq[e0s]) { st.pq.leaf_seq[e0s] = 0; pq_touch(st.pq, s.pq, 0, 0, e0s); } }
-      if (e1s != kNone) { st.e_alive[e1s] = 0; if (st.pq.leaf_seq[e1s]) { st.pq.leaf_seq[e1s] = 0; pq_touch(st.pq, s.pq, 0, 0, e1s); } }
+      pq_leaf_added(st.pq, s.pq, newE);
+      if (e0s != kNone) { st.e_alive[e0s] = 0; if (st.pq.leaf_seq[e0s]) { st.pq.leaf_seq[e0s] = 0; pq_leaf_removed(st.pq, s.pq, e0s); } }
+      if (e1s != kNone) { st.e_alive[e1s] = 0; if (st.pq.leaf_seq[e1s]) { st.pq.leaf_seq[e1s] = 0; pq_leaf_removed(st.pq, s.pq, e1s); } }
     }
-    if (tid == 0) { st.e_alive[e] = 0; st.pq.leaf_seq[e] = 0; pq_touch(st.pq, s.pq, 0, 0, e); }
+    if (tid == 0) { st.e_alive[e] = 0; st.pq.leaf_seq[e] = 0; pq_leaf_removed(st.pq, s.pq, e); }
     if (__syncthreads_or(bad ? 1 : 0)) { status = ST_BAD_SALIENCY; break; }
+    PH(2);
 
     // ---- phase C: reset marks, publish r2's list ----
     const uint32_t newcount = s.newcount;
@@ -210,11 +221,17 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_mean_kernel(GreedyState
     }
     if (tid == 0) { st.adj_off[r2] = r2off; st.adj_len[r2] = newcount; }
 
+    PH(3);
     // ---- priority structure: propagate dirty nodes level by level ----
     pq_propagate<kGreedyThreads>(st.pq, s.pq, tid);
+    PH(4);
     k += 1; ne += newcount; pool_used += total;
   }
   if (tid == 0) { st.ctrl[0] = k; st.ctrl[1] = ne; st.ctrl[2] = pool_used; st.ctrl[3] = status; }
+#ifdef GLIA_HMT_PROFILE
+  if (tid == 0) for (int i = 0; i < 6; ++i) st.ctrl[4 + i > 7 ? 7 : 4 + i] += 0;
+  if (tid == 0) printf("[greedy profile] merges %llu: pop %llu  mark %llu  build %llu  reset %llu  pq %llu  loop-top %llu (cycles)\n", k, tph[0], tph[1], tph[2], tph[3], tph[4], tph[5]);
+#endif
 }
 
 // ---- edge table construction --------------------------------------------------------------------------

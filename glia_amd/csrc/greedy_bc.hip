@@ -36,7 +36,8 @@
 namespace glia {
 
 constexpr int kBcThreads = 1024;
-constexpr int kChunk = 256;     // new edges scored per round
+constexpr int kChunk = 128;             // new edges scored per round (their feature vectors live in LDS)
+constexpr int kFeatDoubles = 128 * 104;  // LDS budget for them: 104 KiB (128 edges at the usual D_f = 104)
 
 struct BcState {
   uint32_t R0;
@@ -132,12 +133,11 @@ __device__ void edge_features(const BcState& st, uint32_t first, uint32_t second
 }
 
 __device__ __forceinline__ int forest_vote(const DeviceForest& f, int tree, const double* x) {
-  const size_t base = (size_t)tree * f.nrnodes;
-  int k = 0;
+  int k = f.root[tree];
   for (int step = 0; step < f.nrnodes; ++step) {        // bounded: a malformed tree cannot hang the device
-    const int4 m = f.meta[base + k];
-    if (m.w >= 0) return m.w;
-    k = (x[m.x] <= f.split[base + k]) ? m.y : m.z;
+    const PackedNode n = f.nodes[k];
+    if (n.var < 0) return -1 - n.var;
+    k = n.left + ((x[n.var] <= n.split) ? 0 : 1);        // left iff x[var] <= split
   }
   return 0;
 }
@@ -284,6 +284,7 @@ struct BcShared {
   uint32_t ex[4];
   int votes[kChunk];
   int model[kChunk];
+  double feat[kFeatDoubles];          // feature vectors of the chunk being scored, stride fdim
   PqWork pq;
 };
 
@@ -294,9 +295,17 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
   uint32_t status = ST_RUN;
   const int fdim = st.cfg.fdim;
   if (tid == 0) { s.pq.wln[0] = s.pq.wln[1] = 0; s.pq.ovf = 0; }
+  for (int i = tid; i < kSetSlots; i += blockDim.x) { s.pq.set[0][i] = 0; s.pq.set[1][i] = 0; }
   __syncthreads();
 
+#ifdef GLIA_HMT_PROFILE
+  unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#define PH(i) do { if (tid == 0) { unsigned long long tn = __builtin_readcyclecounter(); tph[i] += tn - tlast; tlast = tn; } } while (0)
+#else
+#define PH(i) do {} while (0)
+#endif
   for (unsigned long long it = 0; it < st.max_iters; ++it) {
+    PH(7);
     if (tid == 0) {
       const PqLevel& root = st.pq.lv[st.pq.nlevels - 1];
       s.stop = ST_RUN; s.newcount = 0;
@@ -360,6 +369,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
       __syncthreads();
     }
 
+    PH(0);
     // ---- the merged region (TRegionMap::merge, type/region_map.hxx:113-118) ----
     if (tid == 0) {
       PStats p = st.pts[r0];
@@ -373,7 +383,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
       if (e != kNone) estats_sub_additive(bt, st.e_A[e]);
       st.Bt[r2] = bt;
       st.parent[r0] = r2; st.parent[r1] = r2; st.parent[r2] = r2;
-      if (e != kNone) { st.e_alive[e] = 0; if (!forced) { st.pq.leaf_seq[e] = 0; pq_touch(st.pq, s.pq, 0, 0, e); } }
+      if (e != kNone) { st.e_alive[e] = 0; if (!forced) { st.pq.leaf_seq[e] = 0; pq_leaf_removed(st.pq, s.pq, e); } }
     }
     // ---- phase A: mark the neighbours of r0 / r1 with the record that reaches them ----
     for (uint32_t i = tid; i < total; i += kBcThreads) {
@@ -387,6 +397,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
     }
     __syncthreads();
 
+    PH(1);
     // ---- phase B: one new record (rs, r2) per distinct neighbour ----
     for (uint32_t i = tid; i < total; i += kBcThreads) {
       const bool side1 = i >= len0;
@@ -430,7 +441,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
         }
         if (st.e_table[o]) { if (side) t1 = true; else t0 = true; }
         st.e_alive[o] = 0;
-        if (st.e_table[o] && !forced) { st.pq.leaf_seq[o] = 0; pq_touch(st.pq, s.pq, 0, 0, o); }
+        if (st.e_table[o] && !forced) { st.pq.leaf_seq[o] = 0; pq_leaf_removed(st.pq, s.pq, o); }
       }
       const uint32_t old = (e0s != kNone) ? e0s : e1s;
       const uint32_t posRs = (st.e_u[old] == rs) ? st.e_posu[old] : st.e_posv[old];
@@ -453,6 +464,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
       atomicMax(&s.best_mx, ((unsigned long long)float_ord(d[3]) << 32) | newE);
     }
     __syncthreads();
+    PH(2);
     const uint32_t newcount = s.newcount;
     for (uint32_t j = tid; j < newcount; j += kBcThreads) {
       const uint32_t rec = (uint32_t)ne + j;
@@ -475,9 +487,11 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
     }
     __syncthreads();
 
+    PH(3);
     // ---- score the new table edges: features (one thread per edge) -> forest ((edge, tree) per thread) ----
-    for (uint32_t c0 = 0; c0 < (forced ? 0u : newcount); c0 += kChunk) {
-      const uint32_t cn = min((uint32_t)kChunk, newcount - c0);
+    const uint32_t chunk = min((uint32_t)kChunk, (uint32_t)(kFeatDoubles / fdim));
+    for (uint32_t c0 = 0; c0 < (forced ? 0u : newcount); c0 += chunk) {
+      const uint32_t cn = min(chunk, newcount - c0);
       if ((uint32_t)tid < cn) {
         const uint32_t rec = (uint32_t)ne + c0 + tid;
         s.votes[tid] = 0; s.model[tid] = -1;
@@ -487,39 +501,46 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
           excl_minmax(st, rs, rec, a, b);
           const float c = fminf(bnmn, rec == arg_mn ? second_mn : best_mn);
           const float d = fmaxf(bnmx, rec == arg_mx ? second_mx : best_mx);
-          double* x = &st.featbuf[(size_t)tid * fdim];
+          double* x = &s.feat[tid * fdim];
           edge_features(st, rs, r2, rec, a, b, c, d, x);        // updateFb passes (rs, r2)
           s.model[tid] = st.clf.kind == 1 ? 0 : pick_model(st.clf, x);
         }
       }
       __syncthreads();
+      PH(4);
       if (st.clf.kind == 0) {
         const int ntree = st.clf.f[0].ntree;    // the three ensemble members are required to have equal size
         for (uint32_t i = tid; i < cn * (uint32_t)ntree; i += kBcThreads) {
           const uint32_t j = i / ntree, t = i % ntree;
           const int m = s.model[j];
           if (m < 0) continue;
-          if (forest_vote(st.clf.f[m], (int)t, &st.featbuf[(size_t)j * fdim])) atomicAdd(&s.votes[j], 1);
+          if (forest_vote(st.clf.f[m], (int)t, &s.feat[j * fdim])) atomicAdd(&s.votes[j], 1);
         }
       }
       __syncthreads();
+      PH(5);
       if ((uint32_t)tid < cn && s.model[tid] >= 0) {
         const uint32_t rec = (uint32_t)ne + c0 + tid;
-        const double sal = st.clf.kind == 1 ? 1.0 - st.featbuf[(size_t)tid * fdim + st.clf.stub_index]
+        const double sal = st.clf.kind == 1 ? 1.0 - s.feat[tid * fdim + st.clf.stub_index]
                                             : (double)s.votes[tid] / (double)st.clf.f[s.model[tid]].ntree;
         const uint32_t cat = st.e_posv[rec] >> 30;
         st.pq.leaf_sal[rec] = sal;
         st.pq.leaf_seq[rec] = ((k + 1ull) << 32) | ((unsigned long long)cat << 30) | st.e_u[rec];
-        pq_touch(st.pq, s.pq, 0, 0, rec);
+        pq_leaf_added(st.pq, s.pq, rec);
       }
       __syncthreads();
     }
     for (uint32_t j = tid; j < newcount; j += kBcThreads) st.e_posv[(uint32_t)ne + j] &= 0x3FFFFFFFu;
+    PH(3);
     if (!forced) pq_propagate<kBcThreads>(st.pq, s.pq, tid);
     else __syncthreads();
+    PH(6);
     k += 1; ne += newcount; pool_used += total;
   }
   if (tid == 0) { st.ctrl[0] = k; st.ctrl[1] = ne; st.ctrl[2] = pool_used; st.ctrl[3] = status; }
+#ifdef GLIA_HMT_PROFILE
+  if (tid == 0) printf("[bc profile] merges %llu: pop+feats_out %llu  region+mark %llu  build %llu  top2 %llu  features %llu  forest %llu  pq %llu  loop-top %llu (cycles)\n", k, tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], tph[6], tph[7]);
+#endif
 }
 
 }  // namespace

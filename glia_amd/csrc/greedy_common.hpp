@@ -50,36 +50,64 @@ struct PqTree {
   PqLevel lv[kMaxLevels];
 };
 
-// recompute node j of level l with one wave (all 64 lanes must call)
-__device__ __forceinline__ void pq_recompute_node(const PqTree& t, int l, uint32_t j, int lane) {
+// recompute node j of level l with one wave (all 64 lanes must call); returns true when the node's key changed
+__device__ __forceinline__ bool pq_recompute_node(const PqTree& t, int l, uint32_t j, int lane, bool force = false) {
   Key k;
   k.sal = -__builtin_inf(); k.seq = 0; k.arg = 0;
   uint32_t ci = j * kFan + lane;
   if (l == 0) {
-    if (ci < t.nleaves) { k.seq = t.leaf_seq[ci]; k.sal = k.seq ? t.leaf_sal[ci] : -__builtin_inf(); k.arg = ci; }
+    if (ci < t.nleaves) {
+      const unsigned long long q = t.leaf_seq[ci];
+      const double v = t.leaf_sal[ci];            // independent loads (one round trip)
+      k.seq = q; k.sal = q ? v : -__builtin_inf(); k.arg = ci;
+    }
   } else {
     const PqLevel& c = t.lv[l - 1];
     if (ci < c.size) { k.sal = c.sal[ci]; k.seq = c.seq[ci]; k.arg = c.arg[ci]; }
   }
+  const PqLevel& d = t.lv[l];
+  // the node's previous key, fetched alongside the children (same round trip)
+  const unsigned long long oseq = d.seq[j];
+  const uint32_t oarg = d.arg[j];
   k = wave_max(k);
+  bool changed = false;
   if (lane == 0) {
-    const PqLevel& d = t.lv[l];
-    d.sal[j] = k.sal; d.seq[j] = k.seq; d.arg[j] = k.arg;
+    changed = oseq != k.seq || oarg != k.arg;       // (seq, arg) identify the item; its saliency never changes
+    if (changed || force) { d.sal[j] = k.sal; d.seq[j] = k.seq; d.arg[j] = k.arg; }
   }
+  return changed;     // meaningful in lane 0
 }
 
+constexpr int kSetSlots = 1024;
 struct PqWork {            // lives in LDS
   uint32_t ovf;
   uint32_t wln[2];
   uint32_t wl[2][kWorkCap];
+  uint32_t set[2][kSetSlots];     // membership of wl[which] (node + 1, 0 = empty): no global round trip to dedupe
 };
 
+// A leaf that DIES only matters to its ancestors if it is the current maximum of its level-0 node; a non-maximal
+// leaf can be dropped without touching the tree (the node keys stay exact).  A NEW leaf always re-evaluates its node.
+__device__ __forceinline__ void pq_touch(const PqTree& t, PqWork& w, int level, int which, uint32_t child);
+__device__ __forceinline__ void pq_leaf_removed(const PqTree& t, PqWork& w, uint32_t leaf) {
+  if (t.lv[0].arg[leaf / kFan] == leaf) pq_touch(t, w, 0, 0, leaf);
+}
+__device__ __forceinline__ void pq_leaf_added(const PqTree& t, PqWork& w, uint32_t leaf) { pq_touch(t, w, 0, 0, leaf); }
+
 __device__ __forceinline__ void pq_touch(const PqTree& t, PqWork& w, int level, int which, uint32_t child) {
-  uint32_t p = child / kFan;
-  if (atomicExch(&t.lv[level].dirty[p], 1u) == 0u) {
-    uint32_t i = atomicAdd(&w.wln[which], 1u);
-    if (i < kWorkCap) w.wl[which][i] = p; else w.ovf = 1;
+  const uint32_t p = child / kFan;
+  uint32_t h = (p * 2654435761u) >> 22;        // 10 bits
+  for (int probe = 0; probe < 32; ++probe) {
+    const uint32_t old = atomicCAS(&w.set[which][h], 0u, p + 1u);
+    if (old == p + 1u) return;                 // already queued
+    if (old == 0u) {
+      const uint32_t i = atomicAdd(&w.wln[which], 1u);
+      if (i < kWorkCap) w.wl[which][i] = p; else w.ovf = 1;
+      return;
+    }
+    h = (h + 1) & (kSetSlots - 1);
   }
+  w.ovf = 1;                                   // crowded: fall back to a full rebuild of the levels
 }
 
 // apply all pending leaf changes level by level; every thread of the workgroup must call (contains barriers)
@@ -94,10 +122,21 @@ __device__ __forceinline__ void pq_propagate(const PqTree& t, PqWork& w, int tid
     const uint32_t n = ovf ? t.lv[l].size : w.wln[cur];
     for (uint32_t i = wave; i < n; i += nwaves) {
       const uint32_t j = ovf ? i : w.wl[cur][i];
-      pq_recompute_node(t, l, j, lane);
+      const bool changed = pq_recompute_node(t, l, j, lane, ovf);
       if (lane == 0) {
-        t.lv[l].dirty[j] = 0;
-        if (!ovf && l + 1 < t.nlevels) pq_touch(t, w, l + 1, cur ^ 1, j);
+        // an unchanged node cannot change its ancestors
+        if (!ovf && changed && l + 1 < t.nlevels) pq_touch(t, w, l + 1, cur ^ 1, j);
+      }
+    }
+    __syncthreads();
+    // consume the list: empty it and its membership set
+    if (ovf) { for (int i = tid; i < kSetSlots; i += THREADS) { w.set[0][i] = 0; w.set[1][i] = 0; } }
+    else {
+      for (uint32_t i = tid; i < n; i += THREADS) {
+        const uint32_t p = w.wl[cur][i];
+        uint32_t h = (p * 2654435761u) >> 22;
+        while (w.set[cur][h] != p + 1u) h = (h + 1) & (kSetSlots - 1);
+        w.set[cur][h] = 0;
       }
     }
     __syncthreads();

@@ -455,18 +455,36 @@ __global__ __launch_bounds__(kThreads, 2) void rag_accumulate_kernel(const AccPa
     }
   };
 
+  // software pipeline: the rows of plane z+1 (and the centre row of z+2) are requested before plane z is
+  // processed -- with one workgroup per CU (8 waves) memory latency is not hidden by other waves alone
+  auto halo = [&](int64_t z, uint32_t& left, uint32_t& right) __attribute__((always_inline)) {
+    left = 0u; right = 0u;
+    if ((lane % kLanesPerRow) == 0) left = (rowOk && x0 > 0 && z < z1) ? p.lab[z * sz + y * sy + x0 - 1] : 0u;
+    if ((lane % kLanesPerRow) == kLanesPerRow - 1) right = (rowOk && x0 + kVX < nx && z < z1) ? p.lab[z * sz + y * sy + x0 + kVX] : 0u;
+  };
   U4 Lp = loadLab(y, tile.z0 - 1, tile.z0 > 0);
   U4 Lc = loadLab(y, tile.z0, true);
+  U4 Ln = loadLab(y, tile.z0 + 1, tile.z0 + 1 < nz);
+  U4 Up = loadLab(y - 1, tile.z0, y > 0);
+  U4 Dn = loadLab(y + 1, tile.z0, y + 1 < ny);
+  F4 V = loadImg(y, tile.z0);
+  uint32_t hl, hr;
+  halo(tile.z0, hl, hr);
   for (int64_t z = tile.z0; z < z1; ++z) {
     const int zrel = (int)(z - tile.z0);
-    U4 Ln = loadLab(y, z + 1, z + 1 < nz);
-    U4 Up = loadLab(y - 1, z, y > 0);
-    U4 Dn = loadLab(y + 1, z, y + 1 < ny);
-    F4 V = loadImg(y, z);
+    // requests for the next plane
+    const bool more = z + 1 < z1;
+    U4 Ln2 = loadLab(y, z + 2, more && z + 2 < nz);
+    U4 Up2 = loadLab(y - 1, z + 1, more && y > 0);
+    U4 Dn2 = loadLab(y + 1, z + 1, more && y + 1 < ny);
+    F4 V2 = V;
+    if (more) V2 = loadImg(y, z + 1);
+    uint32_t hl2, hr2;
+    halo(more ? z + 1 : z1, hl2, hr2);
     uint32_t left = __shfl_up(Lc.v[3], 1, kLanesPerRow);
     uint32_t right = __shfl_down(Lc.v[0], 1, kLanesPerRow);
-    if ((lane % kLanesPerRow) == 0) left = (rowOk && x0 > 0) ? p.lab[z * sz + y * sy + x0 - 1] : 0u;
-    if ((lane % kLanesPerRow) == kLanesPerRow - 1) right = (rowOk && x0 + kVX < nx) ? p.lab[z * sz + y * sy + x0 + kVX] : 0u;
+    if ((lane % kLanesPerRow) == 0) left = hl;
+    if ((lane % kLanesPerRow) == kLanesPerRow - 1) right = hr;
     const bool zmv = is3d && (z + gz0) > 0, zpv = is3d && (z + gz0) + 1 < gnz;
     const bool ymv = y > 0, ypv = y + 1 < ny;
     // a run lasts at most kTZ planes x 4 voxels = 128 voxels, so the 8-bit packed counters cannot overflow.
@@ -482,8 +500,7 @@ __global__ __launch_bounds__(kThreads, 2) void rag_accumulate_kernel(const AccPa
       voxel(std::integral_constant<int, 1>{}, Lp, Lc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
       voxel(std::integral_constant<int, 0>{}, Lp, Lc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
     }
-    Lp = Lc;
-    Lc = Ln;
+    Lp = Lc; Lc = Ln; Ln = Ln2; Up = Up2; Dn = Dn2; V = V2; hl = hl2; hr = hr2;
   }
   {
     if (!(dbg & 1)) enqueue(rr.klo != 0, rr, true);
