@@ -1,0 +1,151 @@
+// cli/common.hpp -- shared pieces of the drop-in command line tools (hmt/main_merge_order_pb.cxx,
+// hmt/main_merge_order_bc.cxx).  GLIA reads images through ITK, which this image does not have; the tools here
+// read MetaImage files (.mha / .mhd + raw, uncompressed; ITK writes them natively) and keep GLIA's flags,
+// output formats (util/text_io.hxx:103-133) and error behaviour (message on stderr, exit status 1).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../include/glia_hmt.h"
+
+namespace cli {
+
+[[noreturn]] inline void perr(const std::string& msg) {   // glia_base.hxx:66-69
+  std::cerr << msg << std::endl;
+  exit(EXIT_FAILURE);
+}
+inline void check(int rc) { if (rc) perr(glia_hmt_last_error()); }
+inline void hipCheck(hipError_t e) { if (e != hipSuccess) perr(std::string("Error: HIP: ") + hipGetErrorString(e)); }
+
+struct Volume {
+  int dim = 0;
+  int64_t dims[3] = {1, 1, 1};
+  std::vector<uint32_t> u32;
+  std::vector<float> f32;
+  size_t size() const { return (size_t)dims[0] * dims[1] * dims[2]; }
+};
+
+// MetaImage reader: ObjectType = Image, NDims 2|3, ElementType MET_{UCHAR,USHORT,UINT,ULONG,SHORT,INT,FLOAT,DOUBLE},
+// CompressedData = False, ElementDataFile = LOCAL | <file>
+inline Volume readMetaImage(const std::string& file, bool wantFloat) {
+  std::ifstream is(file, std::ios::binary);
+  if (!is) perr("Error: cannot open file " + file);
+  std::map<std::string, std::string> kv;
+  std::string line;
+  std::streampos dataPos = 0;
+  while (std::getline(is, line)) {
+    size_t eq = line.find('=');
+    if (eq == std::string::npos) continue;
+    auto trim = [](std::string s) { size_t a = s.find_first_not_of(" \t\r"), b = s.find_last_not_of(" \t\r"); return a == std::string::npos ? std::string() : s.substr(a, b - a + 1); };
+    std::string k = trim(line.substr(0, eq)), v = trim(line.substr(eq + 1));
+    kv[k] = v;
+    if (k == "ElementDataFile") { dataPos = is.tellg(); break; }
+  }
+  if (kv.count("CompressedData") && (kv["CompressedData"] == "True" || kv["CompressedData"] == "true"))
+    perr("Error: compressed MetaImage files are not supported: " + file);
+  Volume vol;
+  vol.dim = atoi(kv["NDims"].c_str());
+  if (vol.dim != 2 && vol.dim != 3) perr("Error: unsupported image dimension in " + file);
+  std::istringstream ds(kv["DimSize"]);
+  for (int i = 0; i < vol.dim; ++i) ds >> vol.dims[i];
+  const std::string et = kv["ElementType"];
+  size_t es = et == "MET_UCHAR" ? 1 : (et == "MET_USHORT" || et == "MET_SHORT") ? 2 : (et == "MET_UINT" || et == "MET_INT" || et == "MET_FLOAT") ? 4
+              : (et == "MET_ULONG" || et == "MET_DOUBLE" || et == "MET_ULONG_LONG") ? 8 : 0;
+  if (!es) perr("Error: unsupported MetaImage element type " + et);
+  const size_t n = vol.size();
+  std::vector<char> raw(n * es);
+  if (kv["ElementDataFile"] == "LOCAL") { is.seekg(dataPos); is.read(raw.data(), raw.size()); }
+  else {
+    std::string dir = file.substr(0, file.find_last_of('/') == std::string::npos ? 0 : file.find_last_of('/') + 1);
+    std::ifstream rs(dir + kv["ElementDataFile"], std::ios::binary);
+    if (!rs) perr("Error: cannot open file " + dir + kv["ElementDataFile"]);
+    rs.read(raw.data(), raw.size());
+    if (!rs) perr("Error: truncated image data in " + file);
+  }
+  auto get = [&](size_t i) -> double {
+    const char* p = raw.data() + i * es;
+    if (et == "MET_UCHAR") return *(const uint8_t*)p;
+    if (et == "MET_USHORT") return *(const uint16_t*)p;
+    if (et == "MET_SHORT") return *(const int16_t*)p;
+    if (et == "MET_UINT") return *(const uint32_t*)p;
+    if (et == "MET_INT") return *(const int32_t*)p;
+    if (et == "MET_FLOAT") return *(const float*)p;
+    if (et == "MET_DOUBLE") return *(const double*)p;
+    return (double)*(const uint64_t*)p;
+  };
+  if (wantFloat) { vol.f32.resize(n); for (size_t i = 0; i < n; ++i) vol.f32[i] = (float)get(i); }
+  else { vol.u32.resize(n); for (size_t i = 0; i < n; ++i) vol.u32[i] = (uint32_t)get(i); }
+  return vol;
+}
+
+template <typename T> T* upload(const std::vector<T>& v) {
+  T* d = nullptr;
+  hipCheck(hipMalloc(&d, sizeof(T) * (v.empty() ? 1 : v.size())));
+  hipCheck(hipMemcpy(d, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+  return d;
+}
+
+// writeData(file, data, delim[, precision]) of util/text_io.hxx:103-133: every element is followed by the delimiter
+inline void writeOrder(const std::string& file, const std::vector<uint32_t>& o, int64_t n) {
+  std::ofstream os(file);
+  if (!os) perr("Error: cannot create file " + file);
+  for (int64_t i = 0; i < n; ++i) os << o[3 * i] << " " << o[3 * i + 1] << " " << o[3 * i + 2] << "\n";
+}
+inline void writeDoubles(const std::string& file, const double* d, int64_t n, int precision = -1) {
+  std::ofstream os(file);
+  if (!os) perr("Error: cannot create file " + file);
+  if (precision > 0) os.precision(precision);
+  for (int64_t i = 0; i < n; ++i) os << d[i] << "\n";
+}
+inline void writeRows(const std::string& file, const double* d, int64_t rows, int cols, int precision) {
+  std::ofstream os(file);
+  if (!os) perr("Error: cannot create file " + file);
+  if (precision > 0) os.precision(precision);
+  for (int64_t i = 0; i < rows; ++i) { for (int k = 0; k < cols; ++k) os << d[i * cols + k] << " "; os << "\n"; }
+}
+
+// boost::program_options-like parsing: --long value | -s value | multitoken | repeated options accumulate
+struct Args {
+  std::map<std::string, std::vector<std::string>> v;
+  bool has(const std::string& k) const { return v.count(k) > 0; }
+  std::string str(const std::string& k, const std::string& def = "") const { auto it = v.find(k); return it == v.end() || it->second.empty() ? def : it->second.back(); }
+  std::vector<std::string> all(const std::string& k) const { auto it = v.find(k); return it == v.end() ? std::vector<std::string>() : it->second; }
+};
+inline Args parse(int argc, char** argv, const std::map<std::string, std::string>& shortToLong, const std::vector<std::string>& known,
+                  const std::string& usage) {
+  Args a;
+  std::string cur;
+  for (int i = 1; i < argc; ++i) {
+    std::string t = argv[i];
+    bool isOpt = t.size() > 1 && t[0] == '-' && !(isdigit((unsigned char)t[1]) || t[1] == '.');
+    if (isOpt) {
+      std::string name = t[1] == '-' ? t.substr(2) : (shortToLong.count(t.substr(1)) ? shortToLong.at(t.substr(1)) : "?");
+      size_t eq = name.find('=');
+      std::string val;
+      if (eq != std::string::npos) { val = name.substr(eq + 1); name = name.substr(0, eq); }
+      bool ok = false;
+      for (auto& k : known) if (k == name) ok = true;
+      if (name == "help") { std::cerr << usage << std::endl; exit(EXIT_FAILURE); }
+      if (!ok) { std::cerr << "Error: unrecognised option '" << t << "'" << std::endl << usage << std::endl; exit(EXIT_FAILURE); }
+      cur = name;
+      a.v[cur];
+      if (eq != std::string::npos) a.v[cur].push_back(val);
+    } else {
+      if (cur.empty()) { std::cerr << "Error: too many positional options" << std::endl << usage << std::endl; exit(EXIT_FAILURE); }
+      a.v[cur].push_back(t);
+    }
+  }
+  return a;
+}
+
+}  // namespace cli
