@@ -80,6 +80,7 @@ struct glia_hmt_rag {
   int64_t n_scored = 0;
   glia_hmt_feat_config cfg;
   bool has_cfg = false;
+  VolumeRef vol;                 // whole-volume builds only: the caller keeps the volumes alive while the handle lives
 };
 
 static int free_tables(glia_hmt_ctx* c) {
@@ -246,6 +247,10 @@ static int rag_build_impl(glia_hmt_ctx* c, int dim, const int64_t dims[3], int64
   rag->only_contour = only_contour != 0;
   rag->bins = bins; rag->nthr = nthr;
   if (cfg) { rag->cfg = *cfg; rag->has_cfg = true; }
+  if (zb == 0 && ze == nz && gz0 == 0 && gnz == nz) {
+    rag->vol.lab = d_labels; rag->vol.pb = d_pb ? d_pb : img; rag->vol.dim = dim;
+    rag->vol.nx = nx; rag->vol.ny = ny; rag->vol.nz = nz;
+  }
 
   for (int attempt = 0;; ++attempt) {
     int rc = ensure_tables(c, rcap, pcap);
@@ -477,11 +482,11 @@ int glia_hmt_merge_order_pb(glia_hmt_ctx* c, glia_hmt_rag* rag, int type, uint32
     set_error("merge_order_pb: invalid argument");
     return GLIA_HMT_ERR_ARG;
   }
-  if (type == 1) {
-    set_error("merge_order_pb: median linkage (type 1) is not implemented on the device yet");
+  if (type == 1 && !rag->vol.lab) {
+    set_error("merge_order_pb: median linkage needs the volumes the RAG was built from (whole-volume build)");
     return GLIA_HMT_ERR_UNSUPPORTED;
   }
-  if (type != 2) {   // hmt/main_merge_order_pb.cxx:36
+  if (type != 1 && type != 2) {   // hmt/main_merge_order_pb.cxx:36
     set_error("Error: unsupported boundary stats type...");
     return GLIA_HMT_ERR_ARG;
   }
@@ -493,7 +498,7 @@ int glia_hmt_merge_order_pb(glia_hmt_ctx* c, glia_hmt_rag* rag, int type, uint32
   std::vector<double> sal((size_t)R);
   int64_t n = 0;
   int rc = greedy_mean(rag->arr, c->stream, order.data(), sal.data(), R, &n, &rag->ms_table, &rag->ms_loop,
-                       &rag->n_scored);
+                       &rag->n_scored, 0, nullptr, 0.0, type == 1 ? &rag->vol : nullptr);
   if (rc) return rc;
   if (n > capacity) { set_error("merge_order_pb: output capacity too small"); return GLIA_HMT_ERR_CAPACITY; }
   // dense id -> key.  Leaves: i-th label ascending.  Merged regions: maxKey + 1 + k (util/struct_merge.hxx:19,27-31),

@@ -22,6 +22,7 @@
 // so every key comparison of the reference is an id comparison here.
 #include <cstring>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
 
 #include "greedy_common.hpp"
 
@@ -65,8 +66,13 @@ struct GreedyState {
   unsigned long long pool_cap;
   uint32_t Ecap;
   uint32_t *e_u, *e_v, *e_posu, *e_posv;
-  double* e_mean;
+  double* e_mean;                 // mean linkage: boundary mean; median linkage: the current median
   int* e_n;
+  // median linkage (util/struct_merge.hxx:90-136): every edge owns a SORTED run of its boundary values in `vals`
+  float* vals;
+  unsigned long long vals_cap;
+  unsigned long long* e_off;      // [Ecap] start of the edge's run
+  unsigned long long* rbv;        // [2*R0] values held by the region's incident edges (capacity pre-check)
   PqTree pq;
   uint8_t* e_alive;               // record exists in the table (it may have left the queue: pre_merge rejections)
   // pre_merge condition (gadget/main_pre_merge.cxx:27-76); cond_n == 0: f_true
@@ -76,7 +82,7 @@ struct GreedyState {
   uint32_t *mark0, *mark1;        // [2*R0], zero between contractions
   uint32_t* order;                // [R0][3] dense ids
   double* sal_out;
-  unsigned long long* ctrl;       // [0] merges done, [1] edges used, [2] pool used, [3] status
+  unsigned long long* ctrl;       // [0] merges done, [1] edges used, [2] pool used, [3] status, [4] values used
   unsigned long long max_iters;
 };
 
@@ -87,12 +93,30 @@ struct Shared {
   uint32_t r0, r1, e, stop, len0, len1, off0, off1, newcount, reject;
   PqWork pq;
 };
+struct MedianJobs {               // median linkage: the value runs to merge in one batch of phase B
+  uint32_t n;
+  uint32_t newE[kGreedyThreads], e0[kGreedyThreads], e1[kGreedyThreads];
+  unsigned long long off[kGreedyThreads + 1];
+};
+struct NoJobs { uint32_t n, newE[1], e0[1], e1[1]; unsigned long long off[2]; };   // mean linkage: never touched
 
-__global__ __launch_bounds__(kGreedyThreads) void greedy_mean_kernel(GreedyState st) {
+// number of elements of the sorted run a[0..n) that are < v (strict = true) or <= v
+__device__ __forceinline__ uint32_t run_rank(const float* a, uint32_t n, float v, bool strict) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    const float x = a[mid];
+    if (strict ? (x < v) : (x <= v)) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+template <bool MEDIAN>
+__global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState st) {
   __shared__ Shared s;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int nwaves = kGreedyThreads / 64;
-  unsigned long long k = st.ctrl[0], ne = st.ctrl[1], pool_used = st.ctrl[2];
+  __shared__ typename std::conditional<MEDIAN, MedianJobs, NoJobs>::type jobs;
+  const int tid = threadIdx.x;
+  unsigned long long k = st.ctrl[0], ne = st.ctrl[1], pool_used = st.ctrl[2], vals_used = st.ctrl[4];
   uint32_t status = ST_RUN;
   if (tid == 0) { s.pq.wln[0] = s.pq.wln[1] = 0; s.pq.ovf = 0; }
   for (int i = tid; i < kSetSlots; i += blockDim.x) { s.pq.set[0][i] = 0; s.pq.set[1][i] = 0; }
@@ -136,7 +160,9 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_mean_kernel(GreedyState
         if (s.reject) {}      // nothing is contracted: no capacity needed
         else if (ne + tot > st.Ecap) s.stop = ST_NEED_EDGES;
         else if (pool_used + tot > st.pool_cap) s.stop = ST_NEED_POOL;
+        else if (MEDIAN && vals_used + st.rbv[s.r0] + st.rbv[s.r1] > st.vals_cap) s.stop = ST_NEED_VALUES;
         else {
+          if (MEDIAN) st.rbv[st.R0 + (uint32_t)k] = st.rbv[s.r0] + st.rbv[s.r1] - 2ull * (unsigned long long)st.e_n[e];
           st.order[3 * k + 0] = s.r0; st.order[3 * k + 1] = s.r1; st.order[3 * k + 2] = st.R0 + (uint32_t)k;
           st.sal_out[k] = root.sal[0];
           st.rsz[st.R0 + (uint32_t)k] = st.rsz[s.r0] + st.rsz[s.r1];       // TRegionMap::merge (updateRegion)
@@ -168,46 +194,97 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_mean_kernel(GreedyState
 
     // ---- phase B: one new edge (rs, r2) per distinct neighbour (TBoundaryTable::update) ----
     bool bad = false;
-    for (uint32_t i = tid; i < total; i += kGreedyThreads) {
-      const bool side1 = i >= len0;
-      const uint32_t eid = st.pool[side1 ? off1 + (i - len0) : off0 + i];
-      if (eid == e) continue;
-      const uint32_t u = st.e_u[eid], v = st.e_v[eid];
-      const uint32_t r = side1 ? r1 : r0;
-      if (u != r && v != r) continue;                // stale tombstone of an older contraction
-      const uint32_t rs = (u == r) ? v : u;
-      uint32_t e0s, e1s;
-      if (!side1) {
-        if (st.mark0[rs] != eid + 1u) continue;      // dead edge (not marked in phase A)
-        e0s = eid;
-        const uint32_t m = st.mark1[rs];
-        e1s = m ? m - 1u : kNone;
-      } else {
-        if (st.mark1[rs] != eid + 1u) continue;
-        if (st.mark0[rs] != 0u) continue;            // common neighbour: handled from the r0 side
-        e0s = kNone; e1s = eid;
+    for (uint32_t base = 0; base < total; base += kGreedyThreads) {
+      if (MEDIAN) { if (tid == 0) jobs.n = 0; __syncthreads(); }
+      const uint32_t i = base + tid;
+      do {
+        if (i >= total) break;
+        const bool side1 = i >= len0;
+        const uint32_t eid = st.pool[side1 ? off1 + (i - len0) : off0 + i];
+        if (eid == e) break;
+        const uint32_t u = st.e_u[eid], v = st.e_v[eid];
+        const uint32_t r = side1 ? r1 : r0;
+        if (u != r && v != r) break;                   // stale tombstone of an older contraction
+        const uint32_t rs = (u == r) ? v : u;
+        uint32_t e0s, e1s;
+        if (!side1) {
+          if (st.mark0[rs] != eid + 1u) break;         // dead edge (not marked in phase A)
+          e0s = eid;
+          const uint32_t m = st.mark1[rs];
+          e1s = m ? m - 1u : kNone;
+        } else {
+          if (st.mark1[rs] != eid + 1u) break;
+          if (st.mark0[rs] != 0u) break;               // common neighbour: handled from the r0 side
+          e0s = kNone; e1s = eid;
+        }
+        const uint32_t idx = atomicAdd(&s.newcount, 1u);
+        const uint32_t newE = (uint32_t)ne + idx;
+        const uint32_t old = (e0s != kNone) ? e0s : e1s;
+        double first = 0.0;
+        int second = 0;
+        if (!MEDIAN) {
+          // util/struct_merge.hxx:62-76
+          if (e0s != kNone) { const int n0 = st.e_n[e0s]; first += st.e_mean[e0s] * n0; second += n0; }
+          if (e1s != kNone) { const int n1 = st.e_n[e1s]; first += st.e_mean[e1s] * n1; second += n1; }
+          first = sdivide(first, (double)second, 0.0);
+          if (first == -1.0) bad = true;               // DUMMY -> "invalid boundary saliency" (:78-79)
+        } else {
+          // util/struct_merge.hxx:118-127: the value lists are spliced; one list alone is moved (its run is reused)
+          if (e0s != kNone) second += st.e_n[e0s];
+          if (e1s != kNone) second += st.e_n[e1s];
+          if (e0s != kNone && e1s != kNone) {
+            const uint32_t j = atomicAdd(&jobs.n, 1u);
+            jobs.newE[j] = newE; jobs.e0[j] = e0s; jobs.e1[j] = e1s;
+          } else { first = st.e_mean[old]; st.e_off[newE] = st.e_off[old]; }
+        }
+        const uint32_t cat = rs < r0 ? 0u : (e0s != kNone ? 1u : 2u);
+        const unsigned long long seq = ((k + 1ull) << 32) | ((unsigned long long)cat << 30) | rs;
+        const uint32_t posRs = (st.e_u[old] == rs) ? st.e_posu[old] : st.e_posv[old];
+        st.e_u[newE] = rs; st.e_v[newE] = r2; st.e_posu[newE] = posRs; st.e_posv[newE] = idx;
+        st.e_mean[newE] = first; st.e_n[newE] = second;
+        st.pq.leaf_sal[newE] = -first; st.pq.leaf_seq[newE] = seq; st.e_alive[newE] = 1;
+        st.pool[st.adj_off[rs] + posRs] = newE;
+        st.pool[r2off + idx] = newE;
+        pq_leaf_added(st.pq, s.pq, newE);
+        if (e0s != kNone) { st.e_alive[e0s] = 0; if (st.pq.leaf_seq[e0s]) { st.pq.leaf_seq[e0s] = 0; pq_leaf_removed(st.pq, s.pq, e0s); } }
+        if (e1s != kNone) { st.e_alive[e1s] = 0; if (st.pq.leaf_seq[e1s]) { st.pq.leaf_seq[e1s] = 0; pq_leaf_removed(st.pq, s.pq, e1s); } }
+      } while (false);
+      if (MEDIAN) {
+        __syncthreads();
+        const uint32_t J = jobs.n;
+        if (J) {
+          if (tid == 0) {
+            unsigned long long o = 0;
+            for (uint32_t j = 0; j < J; ++j) { jobs.off[j] = o; o += (unsigned long long)st.e_n[jobs.newE[j]]; }
+            jobs.off[J] = o;
+          }
+          __syncthreads();
+          const unsigned long long tot = jobs.off[J];
+          // stable merge of the two sorted runs, one output element per step: its position is its own index plus
+          // its rank in the other run (ties: the (r0,rs) run first)
+          for (unsigned long long x = tid; x < tot; x += kGreedyThreads) {
+            uint32_t lo = 0, hi = J;
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (jobs.off[mid] <= x) lo = mid; else hi = mid; }
+            const uint32_t t = (uint32_t)(x - jobs.off[lo]);
+            const uint32_t ea = jobs.e0[lo], eb = jobs.e1[lo];
+            const uint32_t na = (uint32_t)st.e_n[ea], nb = (uint32_t)st.e_n[eb];
+            const float* A = st.vals + st.e_off[ea];
+            const float* B = st.vals + st.e_off[eb];
+            float* out = st.vals + vals_used + jobs.off[lo];
+            if (t < na) { const float a = A[t]; out[t + run_rank(B, nb, a, true)] = a; }
+            else { const float b = B[t - na]; out[(t - na) + run_rank(A, na, b, false)] = b; }
+          }
+          __syncthreads();
+          if ((uint32_t)tid < J) {
+            const uint32_t newE = jobs.newE[tid];
+            const unsigned long long off = vals_used + jobs.off[tid];
+            const double med = (double)st.vals[off + (uint32_t)st.e_n[newE] / 2u];   // util/stats.hxx:83-91
+            st.e_off[newE] = off; st.e_mean[newE] = med; st.pq.leaf_sal[newE] = -med;
+          }
+          vals_used += tot;
+          __syncthreads();
+        }
       }
-      const uint32_t idx = atomicAdd(&s.newcount, 1u);
-      const uint32_t newE = (uint32_t)ne + idx;
-      // util/struct_merge.hxx:62-76
-      double first = 0.0;
-      int second = 0;
-      if (e0s != kNone) { const int n0 = st.e_n[e0s]; first += st.e_mean[e0s] * n0; second += n0; }
-      if (e1s != kNone) { const int n1 = st.e_n[e1s]; first += st.e_mean[e1s] * n1; second += n1; }
-      first = sdivide(first, (double)second, 0.0);
-      if (first == -1.0) bad = true;               // DUMMY -> "invalid boundary saliency" (:78-79)
-      const uint32_t cat = rs < r0 ? 0u : (e0s != kNone ? 1u : 2u);
-      const unsigned long long seq = ((k + 1ull) << 32) | ((unsigned long long)cat << 30) | rs;
-      const uint32_t old = (e0s != kNone) ? e0s : e1s;
-      const uint32_t posRs = (st.e_u[old] == rs) ? st.e_posu[old] : st.e_posv[old];
-      st.e_u[newE] = rs; st.e_v[newE] = r2; st.e_posu[newE] = posRs; st.e_posv[newE] = idx;
-      st.e_mean[newE] = first; st.e_n[newE] = second;
-      st.pq.leaf_sal[newE] = -first; st.pq.leaf_seq[newE] = seq; st.e_alive[newE] = 1;
-      st.pool[st.adj_off[rs] + posRs] = newE;
-      st.pool[r2off + idx] = newE;
-      pq_leaf_added(st.pq, s.pq, newE);
-      if (e0s != kNone) { st.e_alive[e0s] = 0; if (st.pq.leaf_seq[e0s]) { st.pq.leaf_seq[e0s] = 0; pq_leaf_removed(st.pq, s.pq, e0s); } }
-      if (e1s != kNone) { st.e_alive[e1s] = 0; if (st.pq.leaf_seq[e1s]) { st.pq.leaf_seq[e1s] = 0; pq_leaf_removed(st.pq, s.pq, e1s); } }
     }
     if (tid == 0) { st.e_alive[e] = 0; st.pq.leaf_seq[e] = 0; pq_leaf_removed(st.pq, s.pq, e); }
     if (__syncthreads_or(bad ? 1 : 0)) { status = ST_BAD_SALIENCY; break; }
@@ -227,7 +304,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_mean_kernel(GreedyState
     PH(4);
     k += 1; ne += newcount; pool_used += total;
   }
-  if (tid == 0) { st.ctrl[0] = k; st.ctrl[1] = ne; st.ctrl[2] = pool_used; st.ctrl[3] = status; }
+  if (tid == 0) { st.ctrl[0] = k; st.ctrl[1] = ne; st.ctrl[2] = pool_used; st.ctrl[3] = status; st.ctrl[4] = vals_used; }
 #ifdef GLIA_HMT_PROFILE
   if (tid == 0) for (int i = 0; i < 6; ++i) st.ctrl[4 + i > 7 ? 7 : 4 + i] += 0;
   if (tid == 0) printf("[greedy profile] merges %llu: pop %llu  mark %llu  build %llu  reset %llu  pq %llu  loop-top %llu (cycles)\n", k, tph[0], tph[1], tph[2], tph[3], tph[4], tph[5]);
@@ -283,6 +360,45 @@ __global__ void region_sizes(const uint32_t* rrec, uint32_t R, unsigned long lon
   double d; memcpy(&d, &w[R_SUM], 8); rsum[r] = d;
 }
 
+// median linkage, initFb (util/struct_merge.hxx:97-103): the pb value of every voxel on either directed boundary of a
+// table edge.  The voxel's pair is re-derived with the neighbour rule of getContourTraits (type/neighbor.hxx:109-126).
+__global__ void median_collect(VolumeRef vol, const uint32_t* pa, const uint32_t* pb, long long P, const uint32_t* flag,
+                               const uint32_t* eidx, const unsigned long long* e_off, uint32_t* cursor, float* out) {
+  const long long N = vol.nx * vol.ny * vol.nz;
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= N) return;
+  const long long x = p % vol.nx, y = (p / vol.nx) % vol.ny, z = p / (vol.nx * vol.ny);
+  const uint32_t t = vol.lab[p];
+  uint32_t nb = t;
+  const long long sy = vol.nx, sz = vol.nx * vol.ny;
+  do {
+    uint32_t q;
+    if (x > 0 && (q = vol.lab[p - 1]) != t) { nb = q; break; }
+    if (x + 1 < vol.nx && (q = vol.lab[p + 1]) != t) { nb = q; break; }
+    if (y > 0 && (q = vol.lab[p - sy]) != t) { nb = q; break; }
+    if (y + 1 < vol.ny && (q = vol.lab[p + sy]) != t) { nb = q; break; }
+    if (vol.dim == 3) {
+      if (z > 0 && (q = vol.lab[p - sz]) != t) { nb = q; break; }
+      if (z + 1 < vol.nz && (q = vol.lab[p + sz]) != t) { nb = q; break; }
+    }
+  } while (false);
+  if (nb == t) return;
+  const long long i = find_pair(pa, pb, P, t < nb ? t : nb, t < nb ? nb : t);
+  if (i < 0 || !flag[i]) return;                         // not a mutual boundary: no table edge
+  const uint32_t e = eidx[i];
+  out[e_off[e] + atomicAdd(&cursor[e], 1u)] = vol.pb[p];
+}
+
+__global__ void median_init(GreedyState st, uint32_t E0) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E0) return;
+  const uint32_t n = (uint32_t)st.e_n[e];
+  const double med = (double)st.vals[st.e_off[e] + n / 2u];      // amedian, util/stats.hxx:83-91
+  st.e_mean[e] = med; st.pq.leaf_sal[e] = -med;
+  atomicAdd(&st.rbv[st.e_u[e]], (unsigned long long)n);
+  atomicAdd(&st.rbv[st.e_v[e]], (unsigned long long)n);
+}
+
 __global__ void fill_leaves_dead(PqTree t, uint32_t from) {
   uint32_t i = from + blockIdx.x * blockDim.x + threadIdx.x;
   if (i < t.nleaves) { t.leaf_seq[i] = 0; t.leaf_sal[i] = -__builtin_inf(); }
@@ -294,7 +410,7 @@ __global__ void fill_leaves_dead(PqTree t, uint32_t from) {
 // merged region R+k); the caller maps them to keys.
 int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, double* h_sal, int64_t capacity,
                 int64_t* n_merges, double* ms_table, double* ms_loop, int64_t* n_scored, int cond_n,
-                const long long* cond_sizes, double cond_rpb) {
+                const long long* cond_sizes, double cond_rpb, const VolumeRef* median_of) {
   const long long P = rag.P;
   const uint32_t R = (uint32_t)rag.R;
   *n_merges = 0;
@@ -334,7 +450,7 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
   if ((rc = buf.get(&st.e_posu, st.Ecap, false, stream))) return rc;
   if ((rc = buf.get(&st.e_posv, st.Ecap, false, stream))) return rc;
   if ((rc = buf.get(&st.e_mean, st.Ecap, false, stream))) return rc;
-  if ((rc = buf.get(&st.e_n, st.Ecap, false, stream))) return rc;
+  if ((rc = buf.get(&st.e_n, st.Ecap, true, stream))) return rc;
   st.pq.nleaves = st.Ecap;
   if ((rc = buf.get(&st.pq.leaf_sal, st.Ecap, false, stream))) return rc;
   if ((rc = buf.get(&st.pq.leaf_seq, st.Ecap, false, stream))) return rc;
@@ -365,15 +481,53 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
   }
   hipLaunchKernelGGL(adj_fill, dim3((E0 + 255) / 256), dim3(256), 0, stream, st, E0, cursor);
   GLIA_HIP_TRY(hipGetLastError());
+  unsigned long long n_values = 0;
+  if (median_of) {
+    // sorted value runs: offsets = scan of the edges' voxel counts, one scatter pass over the volume, segmented sort
+    if ((rc = buf.get(&st.e_off, st.Ecap, false, stream))) return rc;
+    if ((rc = buf.get(&st.rbv, 2 * (size_t)R, true, stream))) return rc;
+    {
+      size_t tmp = 0;
+      GLIA_HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, st.e_n, st.e_off, 0ull, (size_t)E0 + 1, rocprim::plus<unsigned long long>(), stream));
+      void* d_tmp;
+      if ((rc = buf.get((char**)&d_tmp, tmp ? tmp : 16, false, stream))) return rc;
+      GLIA_HIP_TRY(rocprim::exclusive_scan(d_tmp, tmp, st.e_n, st.e_off, 0ull, (size_t)E0 + 1, rocprim::plus<unsigned long long>(), stream));
+    }
+    GLIA_HIP_TRY(hipMemcpyAsync(&n_values, st.e_off + E0, sizeof(n_values), hipMemcpyDeviceToHost, stream));
+    GLIA_HIP_TRY(hipStreamSynchronize(stream));
+    if (n_values >= 0xFFFFFFFFull) { set_error("merge_order_pb: more than 2^32 boundary voxels (median linkage)"); return GLIA_HMT_ERR_ARG; }
+    st.vals_cap = n_values * 4ull + (1ull << 20);
+    float* unsorted;
+    if ((rc = buf.get(&st.vals, (size_t)st.vals_cap, false, stream))) return rc;
+    if ((rc = buf.get(&unsorted, (size_t)n_values, false, stream))) return rc;
+    uint32_t* vcursor;
+    if ((rc = buf.get(&vcursor, (size_t)E0, true, stream))) return rc;
+    const long long N = median_of->nx * median_of->ny * median_of->nz;
+    hipLaunchKernelGGL(median_collect, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, *median_of, rag.d_pa, rag.d_pb, P,
+                       flag, eidx, st.e_off, vcursor, unsorted);
+    GLIA_HIP_TRY(hipGetLastError());
+    {
+      size_t tmp = 0;
+      GLIA_HIP_TRY(rocprim::segmented_radix_sort_keys(nullptr, tmp, unsorted, st.vals, (unsigned)n_values, (unsigned)E0, st.e_off,
+                                                      st.e_off + 1, 0, 32, stream));
+      void* d_tmp;
+      if ((rc = buf.get((char**)&d_tmp, tmp ? tmp : 16, false, stream))) return rc;
+      GLIA_HIP_TRY(rocprim::segmented_radix_sort_keys(d_tmp, tmp, unsorted, st.vals, (unsigned)n_values, (unsigned)E0, st.e_off,
+                                                      st.e_off + 1, 0, 32, stream));
+    }
+    hipLaunchKernelGGL(median_init, dim3((E0 + 255) / 256), dim3(256), 0, stream, st, E0);
+    GLIA_HIP_TRY(hipGetLastError());
+  }
   if ((rc = pq_setup(buf, st.pq, stream))) return rc;
-  unsigned long long ctrl[4] = {0, E0, 2ull * E0, ST_RUN};
+  unsigned long long ctrl[5] = {0, E0, 2ull * E0, ST_RUN, n_values};
   GLIA_HIP_TRY(hipMemcpyAsync(st.ctrl, ctrl, sizeof(ctrl), hipMemcpyHostToDevice, stream));
   GLIA_HIP_TRY(hipEventRecord(ev[1], stream));
 
   // ---- the loop, in bounded launches so a contraction budget can be re-negotiated between them ----
   st.max_iters = 1ull << 16;
   while (true) {
-    hipLaunchKernelGGL(greedy_mean_kernel, dim3(1), dim3(kGreedyThreads), 0, stream, st);
+    if (median_of) hipLaunchKernelGGL(greedy_pb_kernel<true>, dim3(1), dim3(kGreedyThreads), 0, stream, st);
+    else hipLaunchKernelGGL(greedy_pb_kernel<false>, dim3(1), dim3(kGreedyThreads), 0, stream, st);
     GLIA_HIP_TRY(hipGetLastError());
     GLIA_HIP_TRY(hipMemcpyAsync(ctrl, st.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, stream));
     GLIA_HIP_TRY(hipStreamSynchronize(stream));
@@ -384,6 +538,10 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
       unsigned long long ncap = st.pool_cap * 2;
       if ((rc = buf.grow(&st.pool, (size_t)st.pool_cap, (size_t)ncap, stream))) return rc;
       st.pool_cap = ncap;
+    } else if (ctrl[3] == ST_NEED_VALUES) {
+      unsigned long long ncap = st.vals_cap * 2;
+      if ((rc = buf.grow(&st.vals, (size_t)ctrl[4], (size_t)ncap, stream))) return rc;
+      st.vals_cap = ncap;
     } else if (ctrl[3] == ST_NEED_EDGES) {
       if (st.Ecap >= 0xFFFFFF00u) { set_error("greedy: more than 2^32 edge slots needed"); return GLIA_HMT_ERR_ARG; }
       uint32_t ocap = st.Ecap;
@@ -394,6 +552,7 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
       if ((rc = buf.grow(&st.e_posv, ocap, ncap, stream))) return rc;
       if ((rc = buf.grow(&st.e_mean, ocap, ncap, stream))) return rc;
       if ((rc = buf.grow(&st.e_n, ocap, ncap, stream))) return rc;
+      if (median_of && (rc = buf.grow(&st.e_off, ocap, ncap, stream))) return rc;
       if ((rc = buf.grow(&st.e_alive, ocap, ncap, stream))) return rc;
       if ((rc = buf.grow(&st.pq.leaf_sal, ocap, ncap, stream))) return rc;
       if ((rc = buf.grow(&st.pq.leaf_seq, ocap, ncap, stream))) return rc;

@@ -20,7 +20,7 @@ struct PqLevel {
 };
 
 
-enum { ST_RUN = 0, ST_DONE = 1, ST_NEED_EDGES = 2, ST_NEED_POOL = 3, ST_BAD_SALIENCY = 4 };
+enum { ST_RUN = 0, ST_DONE = 1, ST_NEED_EDGES = 2, ST_NEED_POOL = 3, ST_BAD_SALIENCY = 4, ST_NEED_VALUES = 5 };
 
 struct Key { double sal; unsigned long long seq; uint32_t arg; };
 

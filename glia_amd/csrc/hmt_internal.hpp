@@ -84,9 +84,16 @@ struct RagArrays {
 int launch_accumulate(const AccParams& p, hipStream_t stream);
 int launch_synth(int dim, const int64_t dims[3], int S, int G, uint64_t seed, int variant, uint32_t* d_labels,
                  uint32_t* d_truth_tmp, float* d_pb, hipStream_t stream);
+// the volume a RAG was built from: median linkage re-reads the boundary voxels' values (util/struct_merge.hxx:97-103)
+struct VolumeRef {
+  const uint32_t* lab = nullptr;
+  const float* pb = nullptr;
+  int dim = 3;
+  long long nx = 1, ny = 1, nz = 1;
+};
 int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, double* h_sal, int64_t capacity,
                 int64_t* n_merges, double* ms_table, double* ms_loop, int64_t* n_scored, int cond_n = 0,
-                const long long* cond_sizes = nullptr, double cond_rpb = 0.0);
+                const long long* cond_sizes = nullptr, double cond_rpb = 0.0, const VolumeRef* median_of = nullptr);
 struct BcCfg;
 struct DeviceClassifier;
 int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& clf, hipStream_t stream, uint32_t* h_order,

@@ -1,0 +1,86 @@
+"""-m gpu: the drop-in command line tools (cli/) write the reference's text formats (util/text_io.hxx:103-133)
+with the oracle's values.  Images travel as MetaImage files, the format ITK writes natively."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "cli")
+
+
+def write_mha(path, arr, local=True):
+    et = {np.dtype(np.uint32): "MET_UINT", np.dtype(np.float32): "MET_FLOAT", np.dtype(np.uint16): "MET_USHORT",
+          np.dtype(np.uint8): "MET_UCHAR"}[arr.dtype]
+    dims = " ".join(str(d) for d in arr.shape[::-1])
+    hdr = ("ObjectType = Image\nNDims = %d\nBinaryData = True\nBinaryDataByteOrderMSB = False\nCompressedData = False\n"
+           "DimSize = %s\nElementType = %s\nElementDataFile = %s\n") % (arr.ndim, dims, et, "LOCAL" if local else os.path.basename(path) + ".raw")
+    with open(path, "wb") as f:
+        f.write(hdr.encode())
+        if local:
+            f.write(np.ascontiguousarray(arr).tobytes())
+    if not local:
+        np.ascontiguousarray(arr).tofile(path + ".raw")
+
+
+@pytest.fixture(scope="module")
+def tools():
+    import torch
+    assert torch.cuda.is_available(), "GPU test run without a GPU"
+    subprocess.check_call(["make", "-C", CLI])
+    return CLI
+
+
+def _g(v, prec=6):
+    return "%.*g" % (prec, v)
+
+
+@pytest.mark.parametrize("shape,local", [((32, 32, 32), True), ((48, 40), False)])
+def test_merge_order_pb_cli(tools, tmp_path, shape, local):
+    from oracle import pyoracle as O
+    labels, pb = O.synth(shape, 8 if len(shape) == 3 else 4, 16)
+    seg, pbf = str(tmp_path / "seg.mha"), str(tmp_path / "pb.mhd")
+    write_mha(seg, labels, True)
+    write_mha(pbf, pb, local)
+    order_f, sal_f = str(tmp_path / "order.txt"), str(tmp_path / "sal.txt")
+    subprocess.check_call([os.path.join(tools, "merge_order_pb"), "-s", seg, "-p", pbf, "-t", "2", "-o", order_f, "-y", sal_f])
+    o_ref, s_ref = O.Rag(labels, only_contour=True).merge_order_pb(pb, type=2)
+    got = np.loadtxt(order_f, dtype=np.int64).reshape(-1, 3)
+    assert (got == o_ref).all()
+    lines = open(sal_f).read().split("\n")
+    assert lines[-1] == "" and lines[:-1] == [_g(s) for s in s_ref]       # default ostream precision
+
+
+def test_merge_order_pb_cli_errors(tools, tmp_path):
+    r = subprocess.run([os.path.join(tools, "merge_order_pb"), "-s", str(tmp_path / "missing.mha"), "-p", "x.mha"], capture_output=True)
+    assert r.returncode == 1 and b"Error" in r.stderr
+    r = subprocess.run([os.path.join(tools, "merge_order_pb"), "-p", "x.mha"], capture_output=True)
+    assert r.returncode == 1 and b"required" in r.stderr
+
+
+def test_merge_order_bc_cli(tools, tmp_path):
+    from oracle import pyoracle as O
+    import _rf
+    shape = (32, 32, 32)
+    labels, pb = O.synth(shape, 8, 16)
+    cfg = O.make_cfg(pb, rb=[(pb, 8, 0.0, 1.0)])
+    _, _, f0 = O.Rag(labels).merge_order_bc(cfg, None, stub_index=31, want_feats=True)
+    forest = _rf.random_forest(np.random.default_rng(3), 31, 6, f0)
+    model = str(tmp_path / "model.bin")
+    _rf.write_model(model, forest)
+    seg, pbf = str(tmp_path / "seg.mha"), str(tmp_path / "pb.mha")
+    write_mha(seg, labels)
+    write_mha(pbf, pb)
+    order_f, sal_f, feat_f = (str(tmp_path / n) for n in ("order.txt", "sal.txt", "bfeat.txt"))
+    subprocess.check_call([os.path.join(tools, "merge_order_bc"), "--bct", "1", "--bcm", model, "-s", seg, "--pb", pbf,
+                           "--rbi", pbf, "--rbb", "8", "--rbl", "0.0", "--rbu", "1.0", "--bt", "0.2", "0.5", "0.8",
+                           "-n", "0", "-l", "0", "-o", order_f, "--sal", sal_f, "-b", feat_f])
+    o_ref, s_ref, f_ref = O.Rag(labels).merge_order_bc(cfg, O.make_forest(forest, -1), want_feats=True)
+    assert (np.loadtxt(order_f, dtype=np.int64).reshape(-1, 3) == o_ref).all()
+    assert open(sal_f).read().split("\n")[:-1] == [_g(s) for s in s_ref]
+    rows = [ln.split(" ") for ln in open(feat_f).read().split("\n")[:-1]]
+    assert len(rows) == len(f_ref) and all(r[-1] == "" and len(r) == f_ref.shape[1] + 1 for r in rows)   # trailing delimiter
+    got = np.array([[float(x) for x in r[:-1]] for r in rows])
+    assert np.allclose(got, f_ref, rtol=6e-8, atol=1e-12)            # FLT_PREC = 8 significant digits: half a unit of the 8th

@@ -15,13 +15,13 @@ def ctx():
     c.close()
 
 
-def _gpu_order(ctx, labels, pb, only_contour=True):
+def _gpu_order(ctx, labels, pb, only_contour=True, type=2):
     import torch
     from glia_amd import hmt
     d_lab = torch.from_numpy(labels.view(np.int32)).cuda()
     d_pb = torch.from_numpy(pb).cuda()
     rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, only_contour=only_contour)
-    out = rm.merge_order_pb(type=2)
+    out = rm.merge_order_pb(type=type)
     rm.close()
     return out
 
@@ -131,3 +131,49 @@ def test_pre_merge_condition(ctx, shape, S, G, variant, sizes, rpb):
     assert 0 < len(o_ref) < rm.num_regions - 1            # the condition really stops the loop early
     assert order.shape == o_ref.shape and (order == o_ref).all()
     assert (sal == s_ref).all() if variant == 0 else np.allclose(sal, s_ref, rtol=0, atol=1e-12)
+
+
+# ---- median linkage (hmt/main_merge_order_pb.cxx -t 1, the tool's default; util/struct_merge.hxx:90-136) ----
+@pytest.mark.parametrize("N,B,dim,n,expect", [
+    (128, 8, 2, 255, [(77, 78, 257, -0.128828347), (207, 208, 258, -0.194080412), (25, 41, 259, -0.195844293)]),
+    (64, 8, 3, 511, [(303, 367, 513, -0.320634127), (28, 36, 514, -0.321784198), (378, 442, 515, -0.321870983)]),
+])
+def test_median_reference_known_answers(ctx, N, B, dim, n, expect):
+    """SURVEY.md Appendix D recipe P1 (median), answers produced by the reference's own headers."""
+    from _recipes import recipe_p1
+    lab, pb = recipe_p1(N, B, dim)
+    order, sal = _gpu_order(ctx, lab, pb, type=1)
+    assert len(order) == n
+    for i, (x0, x1, x2, s) in enumerate(expect):
+        assert order[i].tolist() == [x0, x1, x2]
+        assert sal[i] == pytest.approx(s, rel=0, abs=5e-9)
+
+
+@pytest.mark.parametrize("shape,S,G,variant", CASES + [((33, 30, 40), 5, 20, 1)])
+def test_median_order_matches_oracle(ctx, shape, S, G, variant):
+    """Saliency = an order statistic of the f32 values: bit-identical for Q8 and for continuous pb alike."""
+    from oracle import pyoracle as O
+    labels, pb = O.synth(shape, S, G, variant=variant)
+    order, sal = _gpu_order(ctx, labels, pb, type=1)
+    o_ref, s_ref = O.Rag(labels, only_contour=True).merge_order_pb(pb, type=1)
+    assert order.shape == o_ref.shape
+    assert (order == o_ref).all()
+    assert (sal == s_ref).all()
+
+
+def test_median_ties(ctx):
+    from oracle import pyoracle as O
+    labels, pb = O.synth((48, 48, 48), 6, 12)
+    for q in (np.full(labels.shape, 0.25, np.float32), (np.floor(pb * 4) / 4).astype(np.float32)):
+        order, sal = _gpu_order(ctx, labels, q, type=1)
+        o_ref, s_ref = O.Rag(labels, only_contour=True).merge_order_pb(q, type=1)
+        assert (order == o_ref).all() and (sal == s_ref).all()
+
+
+def test_median_point_mode_non_mutual(ctx):
+    lab = np.array([[1, 1, 4, 4], [2, 3, 4, 4], [2, 3, 5, 5]], dtype=np.uint32)
+    pb = np.array([[(1 + x + 4 * y) / 16 for x in range(4)] for y in range(3)], dtype=np.float32)
+    from oracle import pyoracle as O
+    order, sal = _gpu_order(ctx, lab, pb, only_contour=False, type=1)
+    o_ref, s_ref = O.Rag(lab, only_contour=False).merge_order_pb(pb, type=1)
+    assert (order == o_ref).all() and (sal == s_ref).all()
