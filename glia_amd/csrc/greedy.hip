@@ -93,12 +93,20 @@ struct Shared {
   uint32_t r0, r1, e, stop, len0, len1, off0, off1, newcount, reject;
   PqWork pq;
 };
+constexpr uint32_t kMergeTile = 1024;      // outputs merged through LDS by one wave at a time
 struct MedianJobs {               // median linkage: the value runs to merge in one batch of phase B
   uint32_t n;
   uint32_t newE[kGreedyThreads], e0[kGreedyThreads], e1[kGreedyThreads];
-  unsigned long long off[kGreedyThreads + 1];
+  unsigned long long off[kGreedyThreads + 1];    // output offset of job j (elements)
+  uint32_t toff[kGreedyThreads + 1];             // first tile of job j
+  uint32_t tjob[kGreedyThreads], ta0[kGreedyThreads], ta1[kGreedyThreads];   // tiles of the current round
+  float buf[kGreedyThreads / 64][2 * kMergeTile];
 };
-struct NoJobs { uint32_t n, newE[1], e0[1], e1[1]; unsigned long long off[2]; };   // mean linkage: never touched
+struct NoJobs {                   // mean linkage: never touched
+  uint32_t n, newE[1], e0[1], e1[1], toff[2], tjob[1], ta0[1], ta1[1];
+  unsigned long long off[2];
+  float buf[kGreedyThreads / 64][2];
+};
 
 // number of elements of the sorted run a[0..n) that are < v (strict = true) or <= v
 __device__ __forceinline__ uint32_t run_rank(const float* a, uint32_t n, float v, bool strict) {
@@ -109,6 +117,21 @@ __device__ __forceinline__ uint32_t run_rank(const float* a, uint32_t n, float v
     if (strict ? (x < v) : (x <= v)) lo = mid + 1; else hi = mid;
   }
   return lo;
+}
+
+// merge path: how many elements of A are among the first d outputs of the stable merge (ties: A first)
+__device__ __forceinline__ uint32_t merge_split(const float* A, uint32_t na, const float* B, uint32_t nb, uint32_t d) {
+  uint32_t lo = d > nb ? d - nb : 0u, hi = d < na ? d : na;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (A[mid] <= B[d - 1u - mid]) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 template <bool MEDIAN>
@@ -255,24 +278,61 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
         if (J) {
           if (tid == 0) {
             unsigned long long o = 0;
-            for (uint32_t j = 0; j < J; ++j) { jobs.off[j] = o; o += (unsigned long long)st.e_n[jobs.newE[j]]; }
-            jobs.off[J] = o;
+            uint32_t to = 0;
+            for (uint32_t j = 0; j < J; ++j) {
+              const uint32_t n = (uint32_t)st.e_n[jobs.newE[j]];
+              jobs.off[j] = o; jobs.toff[j] = to;
+              o += n; to += (n + kMergeTile - 1) / kMergeTile;
+            }
+            jobs.off[J] = o; jobs.toff[J] = to;
           }
           __syncthreads();
           const unsigned long long tot = jobs.off[J];
-          // stable merge of the two sorted runs, one output element per step: its position is its own index plus
-          // its rank in the other run (ties: the (r0,rs) run first)
-          for (unsigned long long x = tid; x < tot; x += kGreedyThreads) {
-            uint32_t lo = 0, hi = J;
-            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (jobs.off[mid] <= x) lo = mid; else hi = mid; }
-            const uint32_t t = (uint32_t)(x - jobs.off[lo]);
-            const uint32_t ea = jobs.e0[lo], eb = jobs.e1[lo];
-            const uint32_t na = (uint32_t)st.e_n[ea], nb = (uint32_t)st.e_n[eb];
-            const float* A = st.vals + st.e_off[ea];
-            const float* B = st.vals + st.e_off[eb];
-            float* out = st.vals + vals_used + jobs.off[lo];
-            if (t < na) { const float a = A[t]; out[t + run_rank(B, nb, a, true)] = a; }
-            else { const float b = B[t - na]; out[(t - na) + run_rank(A, na, b, false)] = b; }
+          const uint32_t ntiles = jobs.toff[J];
+          // stable merge of the two sorted runs (ties: the (r0,rs) run first).  Merge-path splits cut every job into
+          // tiles of kMergeTile outputs; a wave stages a tile's two input pieces in LDS, places every element at
+          // (own index + rank in the other piece) and streams the tile out.
+          const int lane = tid & 63, wave = tid >> 6;
+          for (uint32_t round0 = 0; round0 < ntiles; round0 += kGreedyThreads) {
+            const uint32_t q = round0 + (uint32_t)tid;
+            if (q < ntiles) {
+              uint32_t lo = 0, hi = J;
+              while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (jobs.toff[mid] <= q) lo = mid; else hi = mid; }
+              const uint32_t ea = jobs.e0[lo], eb = jobs.e1[lo];
+              const uint32_t na = (uint32_t)st.e_n[ea], nb = (uint32_t)st.e_n[eb], n = na + nb;
+              const float* A = st.vals + st.e_off[ea];
+              const float* B = st.vals + st.e_off[eb];
+              const uint32_t d0 = (q - jobs.toff[lo]) * kMergeTile, d1 = d0 + kMergeTile < n ? d0 + kMergeTile : n;
+              jobs.tjob[tid] = lo;
+              jobs.ta0[tid] = d0 == 0 ? 0u : merge_split(A, na, B, nb, d0);
+              jobs.ta1[tid] = d1 == n ? na : merge_split(A, na, B, nb, d1);
+            }
+            __syncthreads();
+            const uint32_t cnt = ntiles - round0 < (uint32_t)kGreedyThreads ? ntiles - round0 : (uint32_t)kGreedyThreads;
+            float* in = jobs.buf[wave];
+            float* ob = in + kMergeTile;
+            for (uint32_t t = wave; t < cnt; t += kGreedyThreads / 64) {
+              const uint32_t j = jobs.tjob[t], a0 = jobs.ta0[t], a1 = jobs.ta1[t];
+              const uint32_t ea = jobs.e0[j], eb = jobs.e1[j];
+              const uint32_t n = (uint32_t)st.e_n[ea] + (uint32_t)st.e_n[eb];
+              const uint32_t d0 = (round0 + t - jobs.toff[j]) * kMergeTile, d1 = d0 + kMergeTile < n ? d0 + kMergeTile : n;
+              const uint32_t b0 = d0 - a0, la = a1 - a0, lb = (d1 - a1) - b0;
+              const float* A = st.vals + st.e_off[ea] + a0;
+              const float* B = st.vals + st.e_off[eb] + b0;
+              float* out = st.vals + vals_used + jobs.off[j] + d0;
+              for (uint32_t i = lane; i < la; i += 64) in[i] = A[i];
+              for (uint32_t i = lane; i < lb; i += 64) in[la + i] = B[i];
+              wave_lds_sync();
+              for (uint32_t i = lane; i < la + lb; i += 64) {
+                const float v = in[i];
+                const uint32_t pos = i < la ? i + run_rank(in + la, lb, v, true) : (i - la) + run_rank(in, la, v, false);
+                ob[pos] = v;
+              }
+              wave_lds_sync();
+              for (uint32_t i = lane; i < la + lb; i += 64) out[i] = ob[i];
+              wave_lds_sync();
+            }
+            __syncthreads();
           }
           __syncthreads();
           if ((uint32_t)tid < J) {
