@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -12,6 +13,7 @@
 #include <fstream>
 #include <iostream>
 #include <map>
+#include <set>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -146,6 +148,78 @@ inline Args parse(int argc, char** argv, const std::map<std::string, std::string
     }
   }
   return a;
+}
+
+// MetaImage writer (single .mha file, uncompressed); 16-bit output for --write16 (castWriteImage<UInt16Image>)
+inline void writeMetaImage(const std::string& file, int dim, const int64_t dims[3], const std::vector<uint32_t>& v, bool as16) {
+  std::ofstream os(file, std::ios::binary);
+  if (!os) perr("Error: cannot create file " + file);
+  os << "ObjectType = Image\nNDims = " << dim << "\nBinaryData = True\nBinaryDataByteOrderMSB = False\nCompressedData = False\nDimSize =";
+  for (int i = 0; i < dim; ++i) os << " " << dims[i];
+  os << "\nElementType = " << (as16 ? "MET_USHORT" : "MET_UINT") << "\nElementDataFile = LOCAL\n";
+  if (as16) {
+    std::vector<uint16_t> w(v.size());
+    for (size_t i = 0; i < v.size(); ++i) w[i] = (uint16_t)v[i];
+    os.write((const char*)w.data(), w.size() * 2);
+  } else os.write((const char*)v.data(), v.size() * 4);
+}
+
+// readData(order, file, true) of util/text_io.hxx:193-213 for TTriple<Label> (type/tuple.hxx:26-28)
+inline std::vector<uint32_t> readOrder(const std::string& file) {
+  std::ifstream is(file);
+  if (!is) perr("Error: invalid data file dimension in " + file);
+  std::vector<uint32_t> o;
+  unsigned long long x;
+  while (is >> x) o.push_back((uint32_t)x);
+  if (o.size() % 3) perr("Error: invalid data file dimension in " + file);
+  return o;
+}
+
+inline bool flagOf(const Args& a, const char* k) { std::string v = a.str(k, "0"); return v == "1" || v == "true"; }
+
+// prepareImages (hmt/hmt_util.hxx:17-56) + the shape normalisers of hmt/main_merge_order_bc.cxx:36-39 / main_bc_feat.cxx:43-46
+struct FeatInputs {
+  Volume seg, pb;
+  uint32_t* dLab = nullptr;
+  float* dPb = nullptr;
+  glia_hmt_feat_config cfg;
+};
+inline void loadFeatInputs(const Args& a, FeatInputs& f) {
+  const std::string pbFile = a.str("pb");
+  std::set<std::string> files = {pbFile};
+  for (const char* k : {"rbi", "rli", "ri", "bi"}) for (auto& x : a.all(k)) files.insert(x);
+  if (files.size() != 1) perr("Error: the MI355X path supports a single image volume shared by --pb/--rbi in this version...");
+  f.seg = readMetaImage(a.str("segImage"), false);
+  f.pb = readMetaImage(pbFile, true);
+  if (f.seg.dim != f.pb.dim || f.seg.size() != f.pb.size()) perr("Error: image sizes do not match...");
+  f.dLab = upload(f.seg.u32);
+  f.dPb = upload(f.pb.f32);
+  memset(&f.cfg, 0, sizeof(f.cfg));
+  auto addAll = [&](const char* ki, const char* kb, const char* kl, const char* ku, glia_hmt_image* list, int& n) {
+    auto im = a.all(ki), b = a.all(kb), l = a.all(kl), u = a.all(ku);
+    for (size_t i = 0; i < im.size(); ++i) {
+      if (i >= b.size() || i >= l.size() || i >= u.size()) perr("Error: histogram parameters missing for an input image...");
+      if (n >= GLIA_HMT_MAX_IMAGES) perr("Error: too many input images...");
+      list[n].d_image = f.dPb; list[n].bins = atoi(b[i].c_str()); list[n].lo = atof(l[i].c_str()); list[n].hi = atof(u[i].c_str()); ++n;
+    }
+  };
+  // --rbi images are appended to BOTH the region and the boundary list, before the exclusive ones
+  addAll("rbi", "rbb", "rbl", "rbu", f.cfg.region, f.cfg.n_region);
+  addAll("rbi", "rbb", "rbl", "rbu", f.cfg.boundary, f.cfg.n_boundary);
+  addAll("ri", "rb", "rl", "ru", f.cfg.region, f.cfg.n_region);
+  addAll("bi", "bb", "bl", "bu", f.cfg.boundary, f.cfg.n_boundary);
+  addAll("rli", "rlb", "rll", "rlu", f.cfg.rlabel, f.cfg.n_rlabel);
+  f.cfg.d_pb = f.dPb;
+  auto bt = a.all("bt");
+  if (bt.size() > GLIA_HMT_MAX_THRESH) perr("Error: too many boundary thresholds for this version...");
+  f.cfg.n_thresholds = (int)bt.size();
+  for (size_t i = 0; i < bt.size(); ++i) f.cfg.thresholds[i] = atof(bt[i].c_str());
+  double vol = 1.0, diag = 0.0;
+  for (int i = 0; i < f.seg.dim; ++i) { vol *= (double)f.seg.dims[i]; diag += (double)f.seg.dims[i] * (double)f.seg.dims[i]; }
+  f.cfg.normalizing_area = flagOf(a, "ns") ? vol : 1.0;
+  f.cfg.normalizing_length = flagOf(a, "ns") ? std::sqrt(diag) : 1.0;
+  f.cfg.use_log_shape = flagOf(a, "logs");
+  f.cfg.use_simple_features = flagOf(a, "simpf");
 }
 
 }  // namespace cli

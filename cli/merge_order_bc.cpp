@@ -3,8 +3,6 @@
 //                  [--rbi img --rbb bins --rbl lo --rbu hi] [--bt t0 t1 ..] [-n 0|1] [-l 0|1] [--simpf 0|1]
 //                  -o order.txt [--sal saliency.txt] [-b feats.txt]
 // Limits of this round: all image lists must name ONE volume (the --rbi pb --pb pb configuration).
-#include <set>
-
 #include "common.hpp"
 
 using namespace cli;
@@ -20,44 +18,11 @@ int main(int argc, char* argv[]) {
     if (!a.has(req)) { std::cerr << "Error: the option '--" << req << "' is required but missing\n" << usage; perr("Error: unable to parse input arguments"); }
   if (atoi(a.str("bct").c_str()) != 1) perr("Error: unsupported classifier type...");     // MLP2 (--bct 2) is out of scope
   if (a.has("maskImage")) perr("Error: mask images are not supported by the MI355X path yet...");
-  auto flag = [&](const char* k) { std::string v = a.str(k, "0"); return v == "1" || v == "true"; };
-  const std::string pbFile = a.str("pb");
-  std::set<std::string> files = {pbFile};
-  for (const char* k : {"rbi", "rli", "ri", "bi"}) for (auto& f : a.all(k)) files.insert(f);
-  if (files.size() != 1) perr("Error: the MI355X path supports a single image volume shared by --pb/--rbi in this version...");
-  Volume seg = readMetaImage(a.str("segImage"), false), pb = readMetaImage(pbFile, true);
-  if (seg.dim != pb.dim || seg.size() != pb.size()) perr("Error: image sizes do not match...");
-  uint32_t* dLab = upload(seg.u32);
-  float* dPb = upload(pb.f32);
-  glia_hmt_feat_config cfg;
-  memset(&cfg, 0, sizeof(cfg));
-  auto addAll = [&](const char* ki, const char* kb, const char* kl, const char* ku, glia_hmt_image* list, int& n) {
-    auto im = a.all(ki), b = a.all(kb), l = a.all(kl), u = a.all(ku);
-    for (size_t i = 0; i < im.size(); ++i) {
-      if (i >= b.size() || i >= l.size() || i >= u.size()) perr("Error: histogram parameters missing for an input image...");
-      list[n].d_image = dPb; list[n].bins = atoi(b[i].c_str()); list[n].lo = atof(l[i].c_str()); list[n].hi = atof(u[i].c_str()); ++n;
-    }
-  };
-  // prepareImages (hmt/hmt_util.hxx:17-56): --rbi images are appended to BOTH the region and the boundary list
-  addAll("rbi", "rbb", "rbl", "rbu", cfg.region, cfg.n_region);
-  cfg.n_boundary = 0; addAll("rbi", "rbb", "rbl", "rbu", cfg.boundary, cfg.n_boundary);
-  addAll("ri", "rb", "rl", "ru", cfg.region, cfg.n_region);
-  addAll("bi", "bb", "bl", "bu", cfg.boundary, cfg.n_boundary);
-  addAll("rli", "rlb", "rll", "rlu", cfg.rlabel, cfg.n_rlabel);
-  cfg.d_pb = dPb;
-  auto bt = a.all("bt");
-  if (bt.size() > GLIA_HMT_MAX_THRESH) perr("Error: too many boundary thresholds for this version...");
-  cfg.n_thresholds = (int)bt.size();
-  for (size_t i = 0; i < bt.size(); ++i) cfg.thresholds[i] = atof(bt[i].c_str());
-  double vol = 1.0, diag = 0.0;
-  for (int i = 0; i < seg.dim; ++i) { vol *= (double)seg.dims[i]; diag += (double)seg.dims[i] * (double)seg.dims[i]; }
-  cfg.normalizing_area = flag("ns") ? vol : 1.0;                 // getImageVolume / getImageDiagonal (:36-39)
-  cfg.normalizing_length = flag("ns") ? sqrt(diag) : 1.0;
-  cfg.use_log_shape = flag("logs"); cfg.use_simple_features = flag("simpf");
-
+  FeatInputs f;
+  loadFeatInputs(a, f);
   glia_hmt_ctx* ctx; glia_hmt_rag* rag; glia_hmt_forest* bc;
   check(glia_hmt_ctx_create(0, nullptr, &ctx));
-  check(glia_hmt_rag_build(ctx, seg.dim, seg.dims, dLab, nullptr, /*only_contour=*/0, dPb, &cfg, &rag));
+  check(glia_hmt_rag_build(ctx, f.seg.dim, f.seg.dims, f.dLab, nullptr, /*only_contour=*/0, f.dPb, &f.cfg, &rag));
   auto models = a.all("bcm");
   std::vector<const char*> paths;
   for (auto& m : models) paths.push_back(m.c_str());
@@ -77,6 +42,6 @@ int main(int argc, char* argv[]) {
   if (a.has("sal")) writeDoubles(a.str("sal"), sal.data(), n);
   if (a.has("bfeat")) writeRows(a.str("bfeat"), feats.data(), n, d, /*FLT_PREC*/ 8);
   glia_hmt_forest_free(bc); glia_hmt_rag_free(rag); glia_hmt_ctx_destroy(ctx);
-  (void)hipFree(dLab); (void)hipFree(dPb);
+  (void)hipFree(f.dLab); (void)hipFree(f.dPb);
   return EXIT_SUCCESS;
 }

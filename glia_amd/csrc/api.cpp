@@ -66,6 +66,7 @@ struct glia_hmt_ctx {
   uint32_t* flags = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   uint32_t hint_rcap = 0, hint_pcap = 0;
+  double transform_ms = 0;
 };
 
 struct glia_hmt_rag {
@@ -729,6 +730,32 @@ int glia_hmt_bc_feat(glia_hmt_ctx* c, glia_hmt_rag* rag, const uint32_t* h_order
 }
 
 // hmt::genTree (hmt/tree_build.hxx:12-38): order -> array tree, children before parents
+int64_t glia_hmt_transform_keys(const uint32_t* h_order, int64_t n_merges, uint32_t* h_src, uint32_t* h_dst, int64_t capacity) {
+  if (!h_order || !h_src || !h_dst || n_merges < 0) { set_error("transform_keys: invalid argument"); return GLIA_HMT_ERR_ARG; }
+  std::vector<uint32_t> s, d;
+  int rc = transform_keys(h_order, n_merges, &s, &d);
+  if (rc) return rc;
+  if ((int64_t)s.size() > capacity) { set_error("transform_keys: output capacity too small"); return GLIA_HMT_ERR_CAPACITY; }
+  std::copy(s.begin(), s.end(), h_src);
+  std::copy(d.begin(), d.end(), h_dst);
+  return (int64_t)s.size();
+}
+
+int glia_hmt_transform_image(glia_hmt_ctx* c, uint32_t* d_labels, int64_t n_voxels, const uint32_t* h_src, const uint32_t* h_dst,
+                             int64_t n_map, const uint32_t* d_mask, int fill_missing) {
+  if (!c || !d_labels || n_voxels < 0 || n_map < 0 || (n_map && (!h_src || !h_dst))) { set_error("transform_image: invalid argument"); return GLIA_HMT_ERR_ARG; }
+  GLIA_HIP_TRY(hipSetDevice(c->device));
+  return transform_image(d_labels, n_voxels, h_src, h_dst, n_map, d_mask, fill_missing, c->stream, &c->transform_ms);
+}
+
+int glia_hmt_relabel_image(glia_hmt_ctx* c, uint32_t* d_labels, int64_t n_voxels, int64_t min_size, uint32_t* n_labels) {
+  if (!c || !d_labels || n_voxels < 0 || !n_labels) { set_error("relabel_image: invalid argument"); return GLIA_HMT_ERR_ARG; }
+  GLIA_HIP_TRY(hipSetDevice(c->device));
+  return relabel_image(d_labels, n_voxels, min_size, n_labels, c->stream);
+}
+
+double glia_hmt_last_transform_ms(const glia_hmt_ctx* c) { return c ? c->transform_ms : 0.0; }
+
 int64_t glia_hmt_gen_tree(const uint32_t* h_order, int64_t n_merges, uint32_t* node_label, int32_t* parent, int32_t* child0,
                           int32_t* child1, int64_t capacity) {
   if (!h_order || !node_label || !parent || !child0 || !child1 || n_merges < 0) { set_error("gen_tree: invalid argument"); return GLIA_HMT_ERR_ARG; }

@@ -101,6 +101,10 @@ int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& cl
               double* ms_loop, int64_t* n_scored, bool init_only, const uint32_t* h_forced = nullptr,
               int64_t n_forced = 0);
 int compact_tables(const AccParams& p, uint32_t rcap, uint32_t pcap, RagArrays* out, hipStream_t stream);
+int transform_keys(const uint32_t* order, int64_t n, std::vector<uint32_t>* src, std::vector<uint32_t>* dst);
+int transform_image(uint32_t* d_lab, int64_t n, const uint32_t* h_src, const uint32_t* h_dst, int64_t m, const uint32_t* d_mask,
+                    int fill_missing, hipStream_t stream, double* ms);
+int relabel_image(uint32_t* d_lab, int64_t n, int64_t min_size, uint32_t* n_labels, hipStream_t stream);
 int merge_rag_arrays(const RagArrays* parts, int n_parts, RagArrays* out, hipStream_t stream);
 
 __host__ __device__ inline uint32_t float_ord(float f) {

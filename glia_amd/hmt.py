@@ -78,6 +78,13 @@ def _np(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def _fence(t):
+    """The library works on its own HIP stream: finish whatever torch has queued on the tensor's device first
+    (a clone() or copy_ producing the input), so the kernels below see the data."""
+    import torch
+    torch.cuda.current_stream(t.device).synchronize()
+
+
 class Context:
     def __init__(self, device=0, stream=None):
         self.h = C.c_void_p()
@@ -153,6 +160,40 @@ def gen_tree(order):
     return lab[:n], par[:n], c0[:n], c1[:n]
 
 
+def transform_keys(order):
+    """transformKeys (util/struct_merge.hxx:188-210): merge order -> (src, dst) label map, sorted by src."""
+    order = np.ascontiguousarray(order, dtype=np.uint32)
+    cap = 2 * len(order) + 1
+    src = np.empty(cap, np.uint32); dst = np.empty(cap, np.uint32)
+    lib().glia_hmt_transform_keys.restype = C.c_int64
+    n = lib().glia_hmt_transform_keys(_np(order), C.c_int64(len(order)), _np(src), _np(dst), C.c_int64(cap))
+    if n < 0:
+        raise HmtError(int(n), lib().glia_hmt_last_error().decode())
+    return src[:n].copy(), dst[:n].copy()
+
+
+def transform_image(ctx, labels, src, dst, mask=None, fill_missing=False):
+    """transformImage (util/image.hxx:227-242): rewrites the CUDA label tensor in place."""
+    src = np.ascontiguousarray(src, dtype=np.uint32); dst = np.ascontiguousarray(dst, dtype=np.uint32)
+    assert labels.is_cuda and labels.is_contiguous() and labels.element_size() == 4
+    _fence(labels)
+    _check(lib().glia_hmt_transform_image(ctx.h, C.c_void_p(labels.data_ptr()), C.c_int64(labels.numel()), _np(src), _np(dst),
+                                          C.c_int64(len(src)), C.c_void_p(mask.data_ptr()) if mask is not None else None,
+                                          C.c_int(1 if fill_missing else 0)))
+    lib().glia_hmt_last_transform_ms.restype = C.c_double
+    return lib().glia_hmt_last_transform_ms(ctx.h)
+
+
+def relabel_image(ctx, labels, min_size=0):
+    """relabelImage (util/image.hxx:992-1001): consecutive labels by decreasing size, in place; returns #labels."""
+    assert labels.is_cuda and labels.is_contiguous() and labels.element_size() == 4
+    _fence(labels)
+    n = C.c_uint32(0)
+    _check(lib().glia_hmt_relabel_image(ctx.h, C.c_void_p(labels.data_ptr()), C.c_int64(labels.numel()), C.c_int64(min_size),
+                                        C.byref(n)))
+    return n.value
+
+
 class RandomForest:
     """alg::RandomForest / alg::EnsembleRandomForest (alg/rf.hxx) loaded from GLIA model files onto the device."""
 
@@ -200,6 +241,7 @@ class RegionMap:
             self.h = _handle
         else:
             assert labels.is_cuda and labels.is_contiguous() and labels.element_size() == 4
+            _fence(labels)
             self.shape = tuple(labels.shape)
             self.dim, d = _dims(self.shape)
             if slab is None:
@@ -263,6 +305,7 @@ class RegionMap:
         h = C.c_void_p()
         for k in t:
             assert t[k].is_cuda and t[k].is_contiguous()
+        _fence(t["rlabel"])
         _check(lib().glia_hmt_rag_from_arrays(ctx.h, like.h, C.c_int64(t["rlabel"].numel()), C.c_void_p(t["rlabel"].data_ptr()),
                                               C.c_void_p(t["rrec"].data_ptr()), C.c_int64(t["pa"].numel()),
                                               C.c_void_p(t["pa"].data_ptr()), C.c_void_p(t["pb"].data_ptr()),

@@ -173,6 +173,26 @@ int glia_hmt_pre_merge(glia_hmt_ctx* ctx, glia_hmt_rag* rag, const int* size_thr
  * row i = features of merge i with regions in the file's orientation and the area-ordered swap of :88-91. */
 int glia_hmt_bc_feat(glia_hmt_ctx* ctx, glia_hmt_rag* rag, const uint32_t* h_order, int64_t n_merges, double* h_feats);
 
+/* ---- label-volume rewrites either side of the path (gadget/main_pre_merge.cxx:77-79, gadget/main_apply_merges.cxx:28-34) ----
+ * transformKeys (util/struct_merge.hxx:188-210): every key that is merged and is not itself created by a merge maps
+ * to the key it finally ends up in.  Host-only; pairs come out sorted by source key.  Returns the number of pairs
+ * (capacity: 2 * n_merges is always enough) or a negative status. */
+int64_t glia_hmt_transform_keys(const uint32_t* h_order, int64_t n_merges, uint32_t* h_src, uint32_t* h_dst, int64_t capacity);
+
+/* transformImage (util/image.hxx:227-242 and :246-257): rewrites d_labels IN PLACE -- every voxel whose mask value is
+ * not MASK_OUT_VAL (0; d_mask may be NULL) and whose label has an entry in (h_src -> h_dst) receives the mapped label;
+ * labels without an entry are kept, or set to BG_VAL (0) when fill_missing != 0.  Volumes must be 16-byte aligned. */
+int glia_hmt_transform_image(glia_hmt_ctx* ctx, uint32_t* d_labels, int64_t n_voxels, const uint32_t* h_src,
+                             const uint32_t* h_dst, int64_t n_map, const uint32_t* d_mask, int fill_missing);
+
+/* relabelImage (util/image.hxx:992-1001) = itk::RelabelComponentImageFilter, in place: objects (labels != 0) get the
+ * consecutive labels 1..n by decreasing voxel count (ties: smaller original label first), objects smaller than
+ * min_size (> 0) become 0.  ITK is not available to pin this against; labels must be < 2^28. */
+int glia_hmt_relabel_image(glia_hmt_ctx* ctx, uint32_t* d_labels, int64_t n_voxels, int64_t min_size, uint32_t* n_labels);
+
+/* milliseconds of the last glia_hmt_transform_image kernel on this context (HIP events) */
+double glia_hmt_last_transform_ms(const glia_hmt_ctx* ctx);
+
 /* Replaces hmt::genTree (hmt/tree_build.hxx:12-38): merge order -> array tree (children before parents, root last).
  * Host-only.  Returns the number of nodes (2 * n_merges + 1 for one connected tree) or a negative status. */
 int64_t glia_hmt_gen_tree(const uint32_t* h_order, int64_t n_merges, uint32_t* node_label, int32_t* parent,

@@ -1128,4 +1128,58 @@ int64_t orc_gen_tree(const orc_label* order, int64_t n_merges, orc_label* node_l
   return ni;
 }
 
+
+// util/struct_merge.hxx:188-210 -- same containers, same chain walk; pairs are emitted sorted by source key
+int64_t orc_transform_keys(const orc_label* order, int64_t n_merges, orc_label* src, orc_label* dst, int64_t cap) {
+  std::unordered_set<Label> newKeys;
+  std::unordered_map<Label, Label> omap, lmap;
+  for (int64_t i = 0; i < n_merges; ++i) {
+    omap[order[3 * i]] = order[3 * i + 2];
+    omap[order[3 * i + 1]] = order[3 * i + 2];
+    newKeys.insert(order[3 * i + 2]);
+  }
+  for (auto const& op : omap) {
+    if (newKeys.count(op.first) == 0) {
+      Label d = op.second;
+      auto oit = omap.find(d);
+      while (oit != omap.end()) { d = oit->second; oit = omap.find(d); }
+      lmap[op.first] = d;
+    }
+  }
+  std::map<Label, Label> sorted(lmap.begin(), lmap.end());
+  if ((int64_t)sorted.size() > cap) return -1;
+  int64_t k = 0;
+  for (auto const& lp : sorted) { src[k] = lp.first; dst[k] = lp.second; ++k; }
+  return k;
+}
+
+// util/image.hxx:227-242 (mask + optional fill) -- in place
+void orc_transform_image(orc_label* lab, int64_t n, const orc_label* src, const orc_label* dst, int64_t m,
+                         const orc_label* mask, int fill_missing) {
+  std::unordered_map<Label, Label> lmap;
+  for (int64_t i = 0; i < m; ++i) lmap[src[i]] = dst[i];
+  for (int64_t i = 0; i < n; ++i) {
+    if (!mask || mask[i] != MASK_OUT_VAL) {
+      auto lit = lmap.find(lab[i]);
+      if (lit != lmap.end()) lab[i] = lit->second;
+      else if (fill_missing) lab[i] = BG_VAL;
+    }
+  }
+}
+
+// util/image.hxx:992-1001 -> itk::RelabelComponentImageFilter (ITK absent: PARITY UNPINNED).  Restated from its
+// documented behaviour: objects sorted by size (largest first, ties by smaller label), background 0 kept.
+int64_t orc_relabel_image(orc_label* lab, int64_t n, int64_t min_size) {
+  std::map<Label, int64_t> cnt;
+  for (int64_t i = 0; i < n; ++i) if (lab[i] != BG_VAL) ++cnt[lab[i]];
+  std::vector<std::pair<Label, int64_t>> objs(cnt.begin(), cnt.end());
+  std::sort(objs.begin(), objs.end(), [](std::pair<Label, int64_t> const& a, std::pair<Label, int64_t> const& b) {
+    return a.second != b.second ? a.second > b.second : a.first < b.first; });
+  std::unordered_map<Label, Label> lmap;
+  Label next = 1;
+  for (auto const& o : objs) lmap[o.first] = (min_size > 0 && o.second < min_size) ? BG_VAL : next++;
+  for (int64_t i = 0; i < n; ++i) if (lab[i] != BG_VAL) lab[i] = lmap[lab[i]];
+  return (int64_t)next - 1;
+}
+
 }  // extern "C"

@@ -135,6 +135,12 @@ double orc_forest_predict(const orc_forest*, const double* x, int d);
 int64_t orc_gen_tree(const orc_label* order, int64_t n_merges, orc_label* node_label,
                      int32_t* parent, int32_t* child0, int32_t* child1, int64_t cap);
 
+// label-volume rewrites (util/struct_merge.hxx:188-210, util/image.hxx:227-242, :992-1001)
+int64_t orc_transform_keys(const orc_label* order, int64_t n_merges, orc_label* src, orc_label* dst, int64_t cap);
+void orc_transform_image(orc_label* lab, int64_t n, const orc_label* src, const orc_label* dst, int64_t m,
+                         const orc_label* mask, int fill_missing);
+int64_t orc_relabel_image(orc_label* lab, int64_t n, int64_t min_size);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,9 @@ def lib():
         L.orc_bc_feat.restype = C.c_int64
         L.orc_pre_merge.restype = C.c_int64
         L.orc_gen_tree.restype = C.c_int64
+        L.orc_transform_keys.restype = C.c_int64
+        L.orc_relabel_image.restype = C.c_int64
+        L.orc_transform_image.restype = None
         L.orc_forest_predict.restype = C.c_double
         _LIB = L
     return _LIB
@@ -252,3 +255,27 @@ def gen_tree(order):
     n = lib().orc_gen_tree(_p(order), C.c_int64(len(order)), _p(lab), _p(par), _p(c0), _p(c1), C.c_int64(cap))
     assert n >= 0
     return lab[:n], par[:n], c0[:n], c1[:n]
+
+
+def transform_keys(order):
+    order = np.ascontiguousarray(order, dtype=np.uint32)
+    cap = 2 * len(order) + 1
+    src = np.empty(cap, np.uint32); dst = np.empty(cap, np.uint32)
+    n = lib().orc_transform_keys(_p(order), C.c_int64(len(order)), _p(src), _p(dst), C.c_int64(cap))
+    assert n >= 0
+    return src[:n].copy(), dst[:n].copy()
+
+
+def transform_image(labels, src, dst, mask=None, fill_missing=False):
+    out = np.ascontiguousarray(labels, dtype=np.uint32).copy()
+    src = np.ascontiguousarray(src, dtype=np.uint32); dst = np.ascontiguousarray(dst, dtype=np.uint32)
+    m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint32)
+    lib().orc_transform_image(_p(out), C.c_int64(out.size), _p(src), _p(dst), C.c_int64(len(src)),
+                              _p(m) if m is not None else None, C.c_int(1 if fill_missing else 0))
+    return out
+
+
+def relabel_image(labels, min_size=0):
+    out = np.ascontiguousarray(labels, dtype=np.uint32).copy()
+    n = lib().orc_relabel_image(_p(out), C.c_int64(out.size), C.c_int64(min_size))
+    return out, int(n)

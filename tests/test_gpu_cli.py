@@ -84,3 +84,61 @@ def test_merge_order_bc_cli(tools, tmp_path):
     assert len(rows) == len(f_ref) and all(r[-1] == "" and len(r) == f_ref.shape[1] + 1 for r in rows)   # trailing delimiter
     got = np.array([[float(x) for x in r[:-1]] for r in rows])
     assert np.allclose(got, f_ref, rtol=6e-8, atol=1e-12)            # FLT_PREC = 8 significant digits: half a unit of the 8th
+
+
+def read_mha(path):
+    raw = open(path, "rb").read()
+    i = raw.index(b"ElementDataFile = LOCAL\n") + len(b"ElementDataFile = LOCAL\n")
+    hdr = dict(ln.split(" = ") for ln in raw[:i].decode().strip().split("\n"))
+    dims = [int(x) for x in hdr["DimSize"].split()][::-1]
+    dt = {"MET_UINT": np.uint32, "MET_USHORT": np.uint16}[hdr["ElementType"]]
+    return np.frombuffer(raw[i:], dtype=dt).reshape(dims)
+
+
+def test_bc_feat_cli(tools, tmp_path):
+    from oracle import pyoracle as O
+    labels, pb = O.synth((32, 32, 32), 8, 16)
+    cfg = O.make_cfg(pb, rb=[(pb, 8, 0.0, 1.0)], use_log=True)
+    order, _ = O.Rag(labels, only_contour=True).merge_order_pb(pb, type=2)
+    seg, pbf, order_f, feat_f = (str(tmp_path / n) for n in ("seg.mha", "pb.mha", "order.txt", "bfeat.txt"))
+    write_mha(seg, labels)
+    write_mha(pbf, pb)
+    with open(order_f, "w") as f:
+        for r in order:
+            f.write("%d %d %d\n" % tuple(r))
+    subprocess.check_call([os.path.join(tools, "bc_feat"), "-s", seg, "-o", order_f, "--pb", pbf, "--rbi", pbf, "--rbb", "8",
+                           "--rbl", "0", "--rbu", "1", "--bt", "0.2", "0.5", "0.8", "-l", "1", "-b", feat_f])
+    f_ref = O.Rag(labels).bc_feat(cfg, order)
+    got = np.array([[float(x) for x in ln.split(" ")[:-1]] for ln in open(feat_f).read().split("\n")[:-1]])
+    assert got.shape == f_ref.shape and np.allclose(got, f_ref, rtol=6e-8, atol=1e-12)
+
+
+@pytest.mark.parametrize("relabel,w16", [(0, 0), (1, 1)])
+def test_pre_merge_and_apply_merges_cli(tools, tmp_path, relabel, w16):
+    from oracle import pyoracle as O
+    labels, pb = O.synth((48, 48, 48), 6, 12)
+    seg, pbf, out, out2, order_f = (str(tmp_path / n) for n in ("seg.mha", "pb.mha", "out.mha", "out2.mha", "order.txt"))
+    write_mha(seg, labels)
+    write_mha(pbf, pb)
+    subprocess.check_call([os.path.join(tools, "pre_merge"), "-s", seg, "-p", pbf, "-t", "100", "500", "-b", "0.28", "-r", str(relabel),
+                           "-u", str(w16), "-o", out])
+    o_ref, _ = O.Rag(labels).pre_merge(pb, [100, 500], 0.28)
+    ref = O.transform_image(labels, *O.transform_keys(o_ref))
+    if relabel:
+        ref, _ = O.relabel_image(ref)
+    got = read_mha(out)
+    assert got.dtype == (np.uint16 if w16 else np.uint32) and (got == ref).all()
+    # apply_merges with the order split over two files (they are concatenated and sorted by x2) and a mask
+    with open(order_f, "w") as f:
+        for r in o_ref[::2]:
+            f.write("%d %d %d\n" % tuple(r))
+    with open(order_f + "2", "w") as f:
+        for r in o_ref[1::2]:
+            f.write("%d %d %d\n" % tuple(r))
+    mask = np.ones(labels.shape, np.uint32)
+    mask[:, :, :10] = 0
+    maskf = str(tmp_path / "mask.mha")
+    write_mha(maskf, mask)
+    subprocess.check_call([os.path.join(tools, "apply_merges"), "-i", seg, "-m", maskf, "-g", order_f, "-g", order_f + "2", "-o", out2])
+    ref2 = O.transform_image(labels, *O.transform_keys(o_ref), mask=mask)
+    assert (read_mha(out2) == ref2).all()
