@@ -14,7 +14,6 @@ int main(int argc, char* argv[]) {
                  known, usage);
   for (const char* req : {"segImage", "mergeOrder", "pb"})
     if (!a.has(req)) { std::cerr << "Error: the option '--" << req << "' is required but missing\n" << usage; perr("Error: unable to parse input arguments"); }
-  if (a.has("maskImage")) perr("Error: mask images are not supported by the MI355X path yet...");
   if (a.has("saliency")) perr("Error: saliency features (-y) are not supported by the MI355X path yet...");
   FeatInputs f;
   loadFeatInputs(a, f);
@@ -23,7 +22,8 @@ int main(int argc, char* argv[]) {
   if (!a.has("bfeat")) return EXIT_SUCCESS;                                       // :75 nothing else is written
   glia_hmt_ctx* ctx; glia_hmt_rag* rag;
   check(glia_hmt_ctx_create(0, nullptr, &ctx));
-  check(glia_hmt_rag_build(ctx, f.seg.dim, f.seg.dims, f.dLab, nullptr, /*only_contour=*/0, f.dPb, &f.cfg, &rag));
+  uint32_t* dMask = loadMask(a, "maskImage", f.seg.size());
+  check(glia_hmt_rag_build(ctx, f.seg.dim, f.seg.dims, f.dLab, dMask, /*only_contour=*/0, f.dPb, &f.cfg, &rag));
   const int d = glia_hmt_feat_dim(rag);
   std::vector<double> feats((size_t)(n ? n : 1) * d);
   check(glia_hmt_bc_feat(ctx, rag, order.data(), n, feats.data()));

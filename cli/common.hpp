@@ -175,6 +175,14 @@ inline std::vector<uint32_t> readOrder(const std::string& file) {
   return o;
 }
 
+// optional mask image (-m): uploaded as a u32 volume, NULL when the option is absent
+inline uint32_t* loadMask(const Args& a, const char* key, size_t expect) {
+  if (!a.has(key)) return nullptr;
+  Volume m = readMetaImage(a.str(key), false);
+  if (m.size() != expect) perr("Error: image sizes do not match...");
+  return upload(m.u32);
+}
+
 inline bool flagOf(const Args& a, const char* k) { std::string v = a.str(k, "0"); return v == "1" || v == "true"; }
 
 // prepareImages (hmt/hmt_util.hxx:17-56) + the shape normalisers of hmt/main_merge_order_bc.cxx:36-39 / main_bc_feat.cxx:43-46

@@ -17,12 +17,12 @@ int main(int argc, char* argv[]) {
   for (const char* req : {"bct", "bcm", "segImage", "pb", "mergeOrder"})
     if (!a.has(req)) { std::cerr << "Error: the option '--" << req << "' is required but missing\n" << usage; perr("Error: unable to parse input arguments"); }
   if (atoi(a.str("bct").c_str()) != 1) perr("Error: unsupported classifier type...");     // MLP2 (--bct 2) is out of scope
-  if (a.has("maskImage")) perr("Error: mask images are not supported by the MI355X path yet...");
   FeatInputs f;
   loadFeatInputs(a, f);
   glia_hmt_ctx* ctx; glia_hmt_rag* rag; glia_hmt_forest* bc;
   check(glia_hmt_ctx_create(0, nullptr, &ctx));
-  check(glia_hmt_rag_build(ctx, f.seg.dim, f.seg.dims, f.dLab, nullptr, /*only_contour=*/0, f.dPb, &f.cfg, &rag));
+  uint32_t* dMask = loadMask(a, "maskImage", f.seg.size());
+  check(glia_hmt_rag_build(ctx, f.seg.dim, f.seg.dims, f.dLab, dMask, /*only_contour=*/0, f.dPb, &f.cfg, &rag));
   auto models = a.all("bcm");
   std::vector<const char*> paths;
   for (auto& m : models) paths.push_back(m.c_str());

@@ -16,14 +16,14 @@ int main(int argc, char* argv[]) {
   if (!a.has("segImage") || !a.has("pbImage")) { std::cerr << "Error: the option '--segImage'/'--pbImage' is required but missing\n" << usage; return EXIT_FAILURE; }
   const int type = atoi(a.str("type", "1").c_str());
   if (type != 1 && type != 2) perr("Error: unsupported boundary stats type...");          // :36
-  if (a.has("maskImage")) perr("Error: mask images are not supported by the MI355X path yet...");
   Volume seg = readMetaImage(a.str("segImage"), false), pb = readMetaImage(a.str("pbImage"), true);
   if (seg.dim != pb.dim || seg.size() != pb.size()) perr("Error: image sizes do not match...");
   uint32_t* dLab = upload(seg.u32);
   float* dPb = upload(pb.f32);
   glia_hmt_ctx* ctx; glia_hmt_rag* rag;
   check(glia_hmt_ctx_create(0, nullptr, &ctx));
-  check(glia_hmt_rag_build(ctx, seg.dim, seg.dims, dLab, nullptr, /*only_contour=*/1, dPb, nullptr, &rag));   // :27
+  uint32_t* dMask = loadMask(a, "maskImage", seg.size());
+  check(glia_hmt_rag_build(ctx, seg.dim, seg.dims, dLab, dMask, /*only_contour=*/1, dPb, nullptr, &rag));   // :27
   int64_t cap = glia_hmt_rag_num_regions(rag), n = 0;
   std::vector<uint32_t> order(3 * (cap ? cap : 1));
   std::vector<double> sal(cap ? cap : 1);

@@ -13,7 +13,6 @@ int main(int argc, char* argv[]) {
                  {"segImage", "pbImage", "maskImage", "sizeThreshold", "rpbThreshold", "relabel", "write16", "compress", "outputImage"}, usage);
   for (const char* req : {"segImage", "pbImage", "sizeThreshold", "outputImage"})
     if (!a.has(req)) { std::cerr << "Error: the option '--" << req << "' is required but missing\n" << usage; return EXIT_FAILURE; }
-  if (a.has("maskImage")) perr("Error: mask images are not supported by the MI355X path yet...");
   if (flagOf(a, "compress")) perr("Error: compressed output is not supported...");
   auto ts = a.all("sizeThreshold");
   if (ts.empty() || ts.size() > 2) perr("Error: one or two size thresholds expected...");
@@ -25,14 +24,15 @@ int main(int argc, char* argv[]) {
   float* dPb = upload(pb.f32);
   glia_hmt_ctx* ctx; glia_hmt_rag* rag;
   check(glia_hmt_ctx_create(0, nullptr, &ctx));
-  check(glia_hmt_rag_build(ctx, seg.dim, seg.dims, dLab, nullptr, /*only_contour=*/0, dPb, nullptr, &rag));   // :20
+  uint32_t* dMask = loadMask(a, "maskImage", seg.size());
+  check(glia_hmt_rag_build(ctx, seg.dim, seg.dims, dLab, dMask, /*only_contour=*/0, dPb, nullptr, &rag));   // :20
   int64_t cap = glia_hmt_rag_num_regions(rag), n = 0;
   std::vector<uint32_t> order(3 * (cap ? cap : 1)), src(2 * (cap ? cap : 1)), dst(2 * (cap ? cap : 1));
   std::vector<double> sal(cap ? cap : 1);
   check(glia_hmt_pre_merge(ctx, rag, sizes, (int)ts.size(), rpb, order.data(), sal.data(), cap, &n));
   int64_t m = glia_hmt_transform_keys(order.data(), n, src.data(), dst.data(), (int64_t)src.size());         // :77-78
   if (m < 0) perr(glia_hmt_last_error());
-  check(glia_hmt_transform_image(ctx, dLab, (int64_t)seg.size(), src.data(), dst.data(), m, nullptr, 0));    // :79
+  check(glia_hmt_transform_image(ctx, dLab, (int64_t)seg.size(), src.data(), dst.data(), m, dMask, 0));      // :79 (region points only: unmasked voxels)
   uint32_t nl = 0;
   if (flagOf(a, "relabel")) check(glia_hmt_relabel_image(ctx, dLab, (int64_t)seg.size(), 0, &nl));           // :80
   hipCheck(hipMemcpy(seg.u32.data(), dLab, seg.size() * 4, hipMemcpyDeviceToHost));

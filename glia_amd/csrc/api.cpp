@@ -82,6 +82,7 @@ struct glia_hmt_rag {
   glia_hmt_feat_config cfg;
   bool has_cfg = false;
   VolumeRef vol;                 // whole-volume builds only: the caller keeps the volumes alive while the handle lives
+  uint32_t* d_folded = nullptr;  // labels with the mask folded in (owned)
 };
 
 static int free_tables(glia_hmt_ctx* c) {
@@ -192,7 +193,6 @@ static int rag_build_impl(glia_hmt_ctx* c, int dim, const int64_t dims[3], int64
     set_error("rag_build: invalid argument");
     return GLIA_HMT_ERR_ARG;
   }
-  if (d_mask) { set_error("rag_build: mask images are not supported yet"); return GLIA_HMT_ERR_UNSUPPORTED; }
   const int64_t nx = dims[0], ny = dims[1], nz = dim == 3 ? dims[2] : 1;
   if (nx <= 0 || ny <= 0 || nz <= 0 || nx >= (1ll << 31) || ny >= (1ll << 31) || nz >= (1ll << 31)) {
     set_error("rag_build: bad dimensions");
@@ -248,16 +248,25 @@ static int rag_build_impl(glia_hmt_ctx* c, int dim, const int64_t dims[3], int64
   rag->only_contour = only_contour != 0;
   rag->bins = bins; rag->nthr = nthr;
   if (cfg) { rag->cfg = *cfg; rag->has_cfg = true; }
+  const uint32_t* lab_nb = d_labels;
+  const uint32_t* lab_c = d_labels;
+  if (d_mask) {
+    GLIA_HIP_TRY(hipMalloc(&rag->d_folded, sizeof(uint32_t) * (size_t)N));
+    int rcm = launch_mask_fold(d_labels, d_mask, rag->d_folded, N, c->stream);
+    if (rcm) { glia_hmt_rag_free(rag); return rcm; }
+    lab_nb = rag->d_folded;
+    lab_c = only_contour ? d_labels : rag->d_folded;      // util/struct.hxx:133-143 has no mask test on the centre voxel
+  }
   if (zb == 0 && ze == nz && gz0 == 0 && gnz == nz) {
-    rag->vol.lab = d_labels; rag->vol.pb = d_pb ? d_pb : img; rag->vol.dim = dim;
+    rag->vol.lab = lab_c; rag->vol.lab_nb = lab_nb; rag->vol.pb = d_pb ? d_pb : img; rag->vol.dim = dim;
     rag->vol.nx = nx; rag->vol.ny = ny; rag->vol.nz = nz;
   }
 
   for (int attempt = 0;; ++attempt) {
     int rc = ensure_tables(c, rcap, pcap);
-    if (rc) { delete rag; return rc; }
+    if (rc) { glia_hmt_rag_free(rag); return rc; }
     AccParams p;
-    p.lab = d_labels; p.img = img;
+    p.lab = lab_nb; p.lab_c = lab_c; p.masked = d_mask ? 1 : 0; p.img = img;
     p.nx = nx; p.ny = ny; p.nz = nz; p.dim = dim;
     p.gz0 = gz0; p.gnz = gnz; p.zb = zb; p.ze = ze;
     p.nbx = (int)((nx + kTileX - 1) / kTileX);
@@ -270,15 +279,15 @@ static int rag_build_impl(glia_hmt_ctx* c, int dim, const int64_t dims[3], int64
     p.pkeys = c->pkeys; p.prec = c->prec; p.pmask = c->pcap - 1;
     p.flags = c->flags;
     { const char* dbg = getenv("GLIA_HMT_DEBUG"); p.debug = dbg ? (uint32_t)strtoul(dbg, nullptr, 0) : 0u; }
-    if ((int64_t)p.nbx * p.nby * p.nbz >= (1ll << 31)) { delete rag; set_error("rag_build: volume too large"); return GLIA_HMT_ERR_ARG; }
+    if ((int64_t)p.nbx * p.nby * p.nbz >= (1ll << 31)) { glia_hmt_rag_free(rag); set_error("rag_build: volume too large"); return GLIA_HMT_ERR_ARG; }
     hipError_t e = hipEventRecord(c->ev0, c->stream);
     if (e == hipSuccess) { rc = launch_accumulate(p, c->stream); e = hipEventRecord(c->ev1, c->stream); }
-    if (e != hipSuccess) { delete rag; set_error(hipGetErrorString(e)); return GLIA_HMT_ERR_HIP; }
-    if (rc) { delete rag; return rc; }
+    if (e != hipSuccess) { glia_hmt_rag_free(rag); set_error(hipGetErrorString(e)); return GLIA_HMT_ERR_HIP; }
+    if (rc) { glia_hmt_rag_free(rag); return rc; }
     uint32_t flags[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     e = hipMemcpyAsync(flags, c->flags, sizeof(flags), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) { delete rag; set_error(std::string("rag_build: ") + hipGetErrorString(e)); return GLIA_HMT_ERR_HIP; }
+    if (e != hipSuccess) { glia_hmt_rag_free(rag); set_error(std::string("rag_build: ") + hipGetErrorString(e)); return GLIA_HMT_ERR_HIP; }
     float ms = 0;
     (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
     rag->pass_ms = ms;
@@ -289,16 +298,16 @@ static int rag_build_impl(glia_hmt_ctx* c, int dim, const int64_t dims[3], int64
     rag->alg_bytes = (double)(nx * ny * (ze - zb)) * 8.0;
     if (flags[0] || flags[1]) {
       // a table filled up: drop the partial result, grow and redo the pass
-      if (attempt >= 6) { delete rag; set_error("rag_build: hash tables keep overflowing"); return GLIA_HMT_ERR_HIP; }
+      if (attempt >= 6) { glia_hmt_rag_free(rag); set_error("rag_build: hash tables keep overflowing"); return GLIA_HMT_ERR_HIP; }
       (void)hipMemsetAsync(c->flags, 0, 64, c->stream);
       rc = clear_tables(c);
-      if (rc) { delete rag; return rc; }
+      if (rc) { glia_hmt_rag_free(rag); return rc; }
       if (flags[0]) rcap = c->rcap * 4;
       if (flags[1]) pcap = c->pcap * 4;
       continue;
     }
     rc = compact_tables(p, c->rcap, c->pcap, &rag->arr, c->stream);
-    if (rc) { delete rag; return rc; }
+    if (rc) { glia_hmt_rag_free(rag); return rc; }
     break;
   }
   *out = rag;
@@ -406,6 +415,7 @@ void glia_hmt_rag_free(glia_hmt_rag* r) {
   (void)hipSetDevice(r->ctx->device);
   (void)hipFree(r->arr.d_rlabel); (void)hipFree(r->arr.d_rrec);
   (void)hipFree(r->arr.d_pa); (void)hipFree(r->arr.d_pb); (void)hipFree(r->arr.d_prec);
+  if (r->d_folded) (void)hipFree(r->d_folded);
   delete r;
 }
 

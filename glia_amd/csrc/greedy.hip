@@ -429,17 +429,19 @@ __global__ void median_collect(VolumeRef vol, const uint32_t* pa, const uint32_t
   if (p >= N) return;
   const long long x = p % vol.nx, y = (p / vol.nx) % vol.ny, z = p / (vol.nx * vol.ny);
   const uint32_t t = vol.lab[p];
+  if (t == kMaskedLabel) return;                          // masked-out centre (point-map mode)
   uint32_t nb = t;
   const long long sy = vol.nx, sz = vol.nx * vol.ny;
+  const uint32_t* L = vol.lab_nb;                         // masked-out neighbours hold kMaskedLabel: invalid
   do {
     uint32_t q;
-    if (x > 0 && (q = vol.lab[p - 1]) != t) { nb = q; break; }
-    if (x + 1 < vol.nx && (q = vol.lab[p + 1]) != t) { nb = q; break; }
-    if (y > 0 && (q = vol.lab[p - sy]) != t) { nb = q; break; }
-    if (y + 1 < vol.ny && (q = vol.lab[p + sy]) != t) { nb = q; break; }
+    if (x > 0 && (q = L[p - 1]) != t && q != kMaskedLabel) { nb = q; break; }
+    if (x + 1 < vol.nx && (q = L[p + 1]) != t && q != kMaskedLabel) { nb = q; break; }
+    if (y > 0 && (q = L[p - sy]) != t && q != kMaskedLabel) { nb = q; break; }
+    if (y + 1 < vol.ny && (q = L[p + sy]) != t && q != kMaskedLabel) { nb = q; break; }
     if (vol.dim == 3) {
-      if (z > 0 && (q = vol.lab[p - sz]) != t) { nb = q; break; }
-      if (z + 1 < vol.nz && (q = vol.lab[p + sz]) != t) { nb = q; break; }
+      if (z > 0 && (q = L[p - sz]) != t && q != kMaskedLabel) { nb = q; break; }
+      if (z + 1 < vol.nz && (q = L[p + sz]) != t && q != kMaskedLabel) { nb = q; break; }
     }
   } while (false);
   if (nb == t) return;

@@ -51,7 +51,9 @@ struct HistSpec {
 };
 
 struct AccParams {
-  const uint32_t* lab;
+  const uint32_t* lab;               // labels; with a mask: the folded copy (masked-out voxels hold kMaskedLabel)
+  const uint32_t* lab_c;             // labels of the centre voxels (differs from lab only for contour-only mode + mask)
+  int masked;                        // a mask was given
   const float* img;
   int64_t nx, ny, nz;                // extent of the arrays handed in (nz includes halo planes of a slab)
   int64_t gz0, gnz;                  // slab mode: global z of local plane 0 and global depth (gz0 = 0, gnz = nz otherwise)
@@ -84,9 +86,16 @@ struct RagArrays {
 int launch_accumulate(const AccParams& p, hipStream_t stream);
 int launch_synth(int dim, const int64_t dims[3], int S, int G, uint64_t seed, int variant, uint32_t* d_labels,
                  uint32_t* d_truth_tmp, float* d_pb, hipStream_t stream);
+// Masks (type/neighbor.hxx:80-86, util/struct.hxx:86-91,133-143): a masked-out NEIGHBOUR is invalid like an out-of-bounds one;
+// a masked-out CENTRE voxel is skipped in point-map mode and processed in contour-only mode.  The mask is folded into a
+// copy of the label volume once (sentinel label), so the streaming pass keeps its label loads.
+constexpr uint32_t kMaskedLabel = 0xFFFFFFFFu;
+int launch_mask_fold(const uint32_t* lab, const uint32_t* mask, uint32_t* out, int64_t n, hipStream_t stream);
+
 // the volume a RAG was built from: median linkage re-reads the boundary voxels' values (util/struct_merge.hxx:97-103)
 struct VolumeRef {
-  const uint32_t* lab = nullptr;
+  const uint32_t* lab = nullptr;      // centre labels
+  const uint32_t* lab_nb = nullptr;   // neighbour labels (the folded copy when a mask was given, else = lab)
   const float* pb = nullptr;
   int dim = 3;
   long long nx = 1, ny = 1, nz = 1;

@@ -251,7 +251,7 @@ struct U4 { uint32_t v[4]; };
 struct F4 { float v[4]; };
 typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
 
-template <int BINS, bool VEC>
+template <int BINS, bool VEC, bool MASK>
 __global__ __launch_bounds__(kThreads, 2) void rag_accumulate_kernel(const AccParams p) {
   __shared__ __attribute__((aligned(16))) Lds<BINS> s;
   constexpr int EW = Lds<BINS>::kEntryWords;
@@ -304,11 +304,11 @@ __global__ __launch_bounds__(kThreads, 2) void rag_accumulate_kernel(const AccPa
   }
   __syncthreads();
 
-  auto loadLab = [&](int64_t yy, int64_t zz, bool ok) __attribute__((always_inline)) -> U4 {
+  auto loadLabFrom = [&](const uint32_t* base, int64_t yy, int64_t zz, bool ok) __attribute__((always_inline)) -> U4 {
     U4 r;
     r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0;
     if (ok && rowOk) {
-      const uint32_t* q = p.lab + zz * sz + yy * sy + x0;
+      const uint32_t* q = base + zz * sz + yy * sy + x0;
       if (VEC) {
         uint4 t = *reinterpret_cast<const uint4*>(q);
         r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
@@ -319,6 +319,8 @@ __global__ __launch_bounds__(kThreads, 2) void rag_accumulate_kernel(const AccPa
     }
     return r;
   };
+  auto loadLab = [&](int64_t yy, int64_t zz, bool ok) __attribute__((always_inline)) -> U4 { return loadLabFrom(p.lab, yy, zz, ok); };
+  const bool sepCentre = MASK && p.lab_c != p.lab;     // contour-only mode: the centre keeps its label under the mask
   auto loadImg = [&](int64_t yy, int64_t zz) __attribute__((always_inline)) -> F4 {
     F4 r;
     r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0.f;
@@ -376,16 +378,21 @@ __global__ __launch_bounds__(kThreads, 2) void rag_accumulate_kernel(const AccPa
   const float t0 = p.thr_f[0], t1 = p.thr_f[1], t2 = p.thr_f[2], t3 = p.thr_f[3];   // +inf beyond nthr
 
   // one voxel: neighbour rule, run bookkeeping, accumulation
-  auto voxel = [&](auto I, const U4& Lp, const U4& Lc, const U4& Ln, const U4& Up, const U4& Dn, const F4& V,
+  auto voxel = [&](auto I, const U4& Lp, const U4& Lc, const U4& Cc, const U4& Ln, const U4& Up, const U4& Dn, const F4& V,
                    uint32_t left, uint32_t right, int zrel, bool zmv, bool zpv, bool ymv, bool ypv)
                    __attribute__((always_inline)) {
     constexpr int i = decltype(I)::value;
     const int64_t x = x0 + i;
-    const bool ok = rowOk && (VEC || x < nx) && !(dbg & 4);
-    const uint32_t L = Lc.v[i];
+    const uint32_t L = MASK ? Cc.v[i] : Lc.v[i];
+    const bool ok = rowOk && (VEC || x < nx) && !(dbg & 4) && (!MASK || L != kMaskedLabel);
     const uint32_t xm = (i == 0) ? left : Lc.v[i > 0 ? i - 1 : 0];
     const uint32_t xp = (i == kVX - 1) ? right : Lc.v[i < kVX - 1 ? i + 1 : kVX - 1];
-    const bool xmv = x > 0, xpv = x + 1 < nx;
+    bool xmv = x > 0, xpv = x + 1 < nx;
+    if (MASK) {
+      xmv = xmv && xm != kMaskedLabel; xpv = xpv && xp != kMaskedLabel;
+      ymv = ymv && Up.v[i] != kMaskedLabel; ypv = ypv && Dn.v[i] != kMaskedLabel;
+      zmv = zmv && Lp.v[i] != kMaskedLabel; zpv = zpv && Ln.v[i] != kMaskedLabel;
+    }
     uint32_t b = L;
     b = (zpv && Ln.v[i] != L) ? Ln.v[i] : b;
     b = (zmv && Lp.v[i] != L) ? Lp.v[i] : b;
@@ -487,18 +494,20 @@ __global__ __launch_bounds__(kThreads, 2) void rag_accumulate_kernel(const AccPa
     if ((lane % kLanesPerRow) == kLanesPerRow - 1) right = hr;
     const bool zmv = is3d && (z + gz0) > 0, zpv = is3d && (z + gz0) + 1 < gnz;
     const bool ymv = y > 0, ypv = y + 1 < ny;
+    U4 Cc = Lc;
+    if (MASK && sepCentre) Cc = loadLabFrom(p.lab_c, y, z, true);
     // a run lasts at most kTZ planes x 4 voxels = 128 voxels, so the 8-bit packed counters cannot overflow.
     // Serpentine x order: a lane that straddles a wall changes key once per plane instead of twice.
     if ((zrel & 1) == 0) {
-      voxel(std::integral_constant<int, 0>{}, Lp, Lc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
-      voxel(std::integral_constant<int, 1>{}, Lp, Lc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
-      voxel(std::integral_constant<int, 2>{}, Lp, Lc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
-      voxel(std::integral_constant<int, 3>{}, Lp, Lc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
+      voxel(std::integral_constant<int, 0>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
+      voxel(std::integral_constant<int, 1>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
+      voxel(std::integral_constant<int, 2>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
+      voxel(std::integral_constant<int, 3>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
     } else {
-      voxel(std::integral_constant<int, 3>{}, Lp, Lc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
-      voxel(std::integral_constant<int, 2>{}, Lp, Lc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
-      voxel(std::integral_constant<int, 1>{}, Lp, Lc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
-      voxel(std::integral_constant<int, 0>{}, Lp, Lc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
+      voxel(std::integral_constant<int, 3>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
+      voxel(std::integral_constant<int, 2>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
+      voxel(std::integral_constant<int, 1>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
+      voxel(std::integral_constant<int, 0>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
     }
     Lp = Lc; Lc = Ln; Ln = Ln2; Up = Up2; Dn = Dn2; V = V2; hl = hl2; hr = hr2;
   }
@@ -572,16 +581,30 @@ __global__ __launch_bounds__(kThreads, 2) void rag_accumulate_kernel(const AccPa
 
 }  // namespace
 
+template <int BINS, bool VEC>
+static void launch_bv(const AccParams& p, uint32_t nb, hipStream_t stream) {
+  if (p.masked) hipLaunchKernelGGL((rag_accumulate_kernel<BINS, VEC, true>), dim3(nb), dim3(kThreads), 0, stream, p);
+  else hipLaunchKernelGGL((rag_accumulate_kernel<BINS, VEC, false>), dim3(nb), dim3(kThreads), 0, stream, p);
+}
+
 int launch_accumulate(const AccParams& p, hipStream_t stream) {
   const uint32_t nb = (uint32_t)p.nbx * p.nby * p.nbz;
   const bool vec = (p.nx % kTileX) == 0;
-  if (p.hist.bins <= 8) {
-    if (vec) hipLaunchKernelGGL((rag_accumulate_kernel<8, true>), dim3(nb), dim3(kThreads), 0, stream, p);
-    else hipLaunchKernelGGL((rag_accumulate_kernel<8, false>), dim3(nb), dim3(kThreads), 0, stream, p);
-  } else {
-    if (vec) hipLaunchKernelGGL((rag_accumulate_kernel<16, true>), dim3(nb), dim3(kThreads), 0, stream, p);
-    else hipLaunchKernelGGL((rag_accumulate_kernel<16, false>), dim3(nb), dim3(kThreads), 0, stream, p);
-  }
+  if (p.hist.bins <= 8) { if (vec) launch_bv<8, true>(p, nb, stream); else launch_bv<8, false>(p, nb, stream); }
+  else { if (vec) launch_bv<16, true>(p, nb, stream); else launch_bv<16, false>(p, nb, stream); }
+  GLIA_HIP_TRY(hipGetLastError());
+  return GLIA_HMT_OK;
+}
+
+namespace {
+__global__ void mask_fold_kernel(const uint32_t* lab, const uint32_t* mask, uint32_t* out, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = mask[i] != 0u /* MASK_OUT_VAL, glia_image.hxx:28 */ ? lab[i] : kMaskedLabel;
+}
+}  // namespace
+
+int launch_mask_fold(const uint32_t* lab, const uint32_t* mask, uint32_t* out, int64_t n, hipStream_t stream) {
+  hipLaunchKernelGGL(mask_fold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, lab, mask, out, (long long)n);
   GLIA_HIP_TRY(hipGetLastError());
   return GLIA_HMT_OK;
 }

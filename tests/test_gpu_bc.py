@@ -126,3 +126,25 @@ def test_bc_feat_for_a_given_order(ctx, shape, S, G):
     f2 = rm.bc_feat(far)
     r2 = O.Rag(labels).bc_feat(O.make_cfg(pb, rb=[(pb, 8, 0.0, 1.0)]), far)
     assert _feat_close(f2, r2)
+
+
+def test_classifier_linkage_with_mask(ctx):
+    """merge_order_bc -m: RegionMap(seg, mask, false): masked voxels belong to no region, masked neighbours are invalid"""
+    import torch
+    from glia_amd import hmt
+    from oracle import pyoracle as O
+    labels, pb = O.synth((32, 32, 32), 8, 16)
+    rng = np.random.default_rng(12)
+    mask = (rng.random(labels.shape) > 0.1).astype(np.uint32)
+    mask[:, :, :4] = 0
+    d_lab = torch.from_numpy(labels.view(np.int32)).cuda()
+    d_pb = torch.from_numpy(pb).cuda()
+    d_mask = torch.from_numpy(mask.view(np.int32)).cuda()
+    cfg = hmt.make_config(d_pb, rb=[(d_pb, 8, 0.0, 1.0)])
+    rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, mask=d_mask, cfg=cfg)
+    stub = 11 + 4 * 3 + 7 + 1
+    order, sal, feats = rm.merge_order_bc(hmt.FeatureStubClassifier(ctx, stub), want_feats=True)
+    ocfg = O.make_cfg(pb, rb=[(pb, 8, 0.0, 1.0)])
+    o_ref, s_ref, f_ref = O.Rag(labels, mask=mask).merge_order_bc(ocfg, None, stub_index=stub, want_feats=True)
+    assert order.shape == o_ref.shape and (order == o_ref).all()
+    assert (sal == s_ref).all() and _feat_close(feats, f_ref)

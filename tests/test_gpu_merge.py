@@ -177,3 +177,24 @@ def test_median_point_mode_non_mutual(ctx):
     order, sal = _gpu_order(ctx, lab, pb, only_contour=False, type=1)
     o_ref, s_ref = O.Rag(lab, only_contour=False).merge_order_pb(pb, type=1)
     assert (order == o_ref).all() and (sal == s_ref).all()
+
+
+@pytest.mark.parametrize("shape,S,G", [((32, 32, 32), 8, 16), ((40, 36, 28), 6, 12), ((64, 64), 4, 16)])
+@pytest.mark.parametrize("type", [1, 2])
+def test_merge_order_with_mask(ctx, shape, S, G, type):
+    """merge_order_pb -m: RegionMap(seg, mask, true) (hmt/main_merge_order_pb.cxx:24-27)"""
+    import torch
+    from glia_amd import hmt
+    from oracle import pyoracle as O
+    labels, pb = O.synth(shape, S, G)
+    rng = np.random.default_rng(11)
+    mask = (rng.random(shape) > 0.2).astype(np.uint32)
+    mask[..., :3] = 0
+    d_lab = torch.from_numpy(labels.view(np.int32)).cuda()
+    d_pb = torch.from_numpy(pb).cuda()
+    d_mask = torch.from_numpy(mask.view(np.int32)).cuda()
+    rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, mask=d_mask, only_contour=True)
+    order, sal = rm.merge_order_pb(type=type)
+    o_ref, s_ref = O.Rag(labels, mask=mask, only_contour=True).merge_order_pb(pb, type=type)
+    assert order.shape == o_ref.shape and (order == o_ref).all() and (sal == s_ref).all()
+    rm.close()

@@ -139,3 +139,50 @@ def test_slab_partials_merge_to_the_whole(ctx, shape, S, G, variant, nslab):
     o1, s1 = whole.merge_order_pb(type=2)
     o2, s2 = merged.merge_order_pb(type=2)
     assert (o1 == o2).all() and (variant == 1 or (s1 == s2).all())
+
+
+def _mask_for(shape, seed=3):
+    """a mask with holes, a masked face and a few fully masked supervoxels-worth of space"""
+    rng = np.random.default_rng(seed)
+    m = (rng.random(shape) > 0.15).astype(np.uint32) * 5
+    m[..., :2] = 0
+    sl = tuple(slice(s // 3, s // 3 + max(2, s // 5)) for s in shape)
+    m[sl] = 0
+    return m
+
+
+@pytest.mark.parametrize("shape,S,G", [((32, 32, 32), 8, 16), ((40, 36, 28), 6, 12), ((64, 64), 4, 16), ((16, 32, 128), 8, 16)])
+@pytest.mark.parametrize("only_contour", [False, True])
+def test_rag_with_mask_matches_oracle(ctx, shape, S, G, only_contour):
+    """type/neighbor.hxx:80-86 (masked neighbours are invalid), util/struct.hxx:86-91 (point-map mode skips masked
+    voxels) and :133-143 (contour-only mode does not test the centre voxel)."""
+    torch = _torch()
+    from glia_amd import hmt
+    from oracle import pyoracle as O
+    labels, pb = O.synth(shape, S, G)
+    mask = _mask_for(shape)
+    d_lab = torch.from_numpy(labels.view(np.int32)).cuda()
+    d_pb = torch.from_numpy(pb).cuda()
+    d_mask = torch.from_numpy(mask.view(np.int32)).cuda()
+    rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, mask=d_mask, only_contour=only_contour)
+    rag = O.Rag(labels, mask=mask, only_contour=only_contour)
+    a, b, n = rag.pairs()
+    ps = rag.pair_stats(pb)
+    par = rm.pairs()
+    assert (par["a"] == a).all() and (par["b"] == b).all() and (par["count"] == n).all()
+    assert (par["sum"] == ps[0]).all() and (par["sumsq"] == ps[1]).all()
+    assert (par["min"] == ps[2]).all() and (par["max"] == ps[3]).all()
+    if not only_contour:
+        lab, npts, nborder = rag.regions()
+        rs = rag.region_stats(pb)
+        reg = rm.regions()
+        assert (reg["label"] == lab).all() and (reg["count"] == npts).all() and (reg["border"] == nborder).all()
+        assert (reg["sum"] == rs[0]).all() and (reg["sumsq"] == rs[1]).all()
+        assert (reg["lo"] == rs[4]).all() and (reg["hi"] == rs[5]).all()
+        flat, mflat = labels.reshape(-1), mask.reshape(-1)
+        first = {}
+        for i in range(flat.size - 1, -1, -1):
+            if mflat[i]:
+                first[int(flat[i])] = i
+        assert [first[int(l)] for l in reg["label"]] == reg["first"].tolist()
+    rm.close()
