@@ -50,6 +50,12 @@ int pq_setup(DeviceBuffers& buf, PqTree& t, hipStream_t stream) {
     if ((rc = buf.get(&L.dirty, n, true, stream))) return rc;
     if (n == 1) break;
   }
+  {
+    int rc;
+    if ((rc = buf.get(&t.glist[0], t.lv[0].size, false, stream))) return rc;
+    if ((rc = buf.get(&t.glist[1], t.lv[0].size, false, stream))) return rc;
+    if ((rc = buf.get(&t.gcount, 2, true, stream))) return rc;
+  }
   for (int l = 0; l < t.nlevels; ++l) {
     unsigned long long threads = (unsigned long long)t.lv[l].size * 64ull;
     hipLaunchKernelGGL(pq_build_level_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, t, l);
@@ -62,7 +68,7 @@ struct GreedyState {
   uint32_t R0;
   uint32_t* adj_off;   // [2*R0] start of a region's incident-edge list in pool
   uint32_t* adj_len;   // [2*R0] slots in that list (live edges + tombstones)
-  uint32_t* pool;
+  uint2* pool;         // incident-edge lists: (edge slot | kNone tombstone, the neighbour it leads to)
   unsigned long long pool_cap;
   uint32_t Ecap;
   uint32_t *e_u, *e_v, *e_posu, *e_posv;
@@ -74,7 +80,6 @@ struct GreedyState {
   unsigned long long* e_off;      // [Ecap] start of the edge's run
   unsigned long long* rbv;        // [2*R0] values held by the region's incident edges (capacity pre-check)
   PqTree pq;
-  uint8_t* e_alive;               // record exists in the table (it may have left the queue: pre_merge rejections)
   // pre_merge condition (gadget/main_pre_merge.cxx:27-76); cond_n == 0: f_true
   int cond_n; unsigned long long cond_t0, cond_t1; double cond_rpb;
   unsigned long long* rsz;        // [2*R0] region sizes (updateRegion = true)
@@ -89,9 +94,14 @@ struct GreedyState {
 
 namespace {
 
+constexpr uint32_t kMarkSlots = 2048;      // LDS neighbour table of one contraction
+constexpr uint32_t kMarkMax = 1408;        // contractions with more incident entries use the global mark arrays
 struct Shared {
   uint32_t r0, r1, e, stop, len0, len1, off0, off1, newcount, reject;
   PqWork pq;
+  // neighbours of the contracted pair: key = neighbour + 1, values = (edge to r0) + 1, (edge to r1) + 1
+  uint32_t mk[kMarkSlots], mv0[kMarkSlots], mv1[kMarkSlots];
+  uint32_t items[kMarkMax], nitems;
 };
 constexpr uint32_t kMergeTile = 1024;      // outputs merged through LDS by one wave at a time
 struct MedianJobs {               // median linkage: the value runs to merge in one batch of phase B
@@ -141,12 +151,16 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
   const int tid = threadIdx.x;
   unsigned long long k = st.ctrl[0], ne = st.ctrl[1], pool_used = st.ctrl[2], vals_used = st.ctrl[4];
   uint32_t status = ST_RUN;
-  if (tid == 0) { s.pq.wln[0] = s.pq.wln[1] = 0; s.pq.ovf = 0; }
+  if (tid == 0) { s.pq.wln[0] = s.pq.wln[1] = 0; s.pq.ovf = 0; s.pq.spill = 0; s.nitems = 0; }
   for (int i = tid; i < kSetSlots; i += blockDim.x) { s.pq.set[0][i] = 0; s.pq.set[1][i] = 0; }
+  for (uint32_t i = tid; i < kMarkSlots; i += blockDim.x) { s.mk[i] = 0; s.mv0[i] = 0; s.mv1[i] = 0; }
+  // levels >= 2 of the priority tree move to LDS for the lifetime of this launch (written back at the end)
+  const PqTree& pq = st.pq;
   __syncthreads();
 
 #ifdef GLIA_HMT_PROFILE
   unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+  unsigned long long tb[4] = {0, 0, 0, 0}, nb[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0}, titer = tlast;
 #define PH(i) do { if (tid == 0) { unsigned long long tn = __builtin_readcyclecounter(); tph[i] += tn - tlast; tlast = tn; } } while (0)
 #else
 #define PH(i) do {} while (0)
@@ -155,7 +169,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
     // ---- pop (TBoundaryTable::top) ----
     PH(5);
     if (tid == 0) {
-      const PqLevel& root = st.pq.lv[st.pq.nlevels - 1];
+      const PqLevel& root = pq.lv[pq.nlevels - 1];
       s.stop = ST_RUN;
       s.newcount = 0;
       s.reject = 0;
@@ -175,7 +189,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
             if (sz0 < st.cond_t1 && sdivide(su0, (double)sz0, 0.0) > st.cond_rpb) ok = true;
             if (!ok && sz1 < st.cond_t1 && sdivide(su1, (double)sz1, 0.0) > st.cond_rpb) ok = true;
           }
-          if (!ok) { s.reject = 1; st.pq.leaf_seq[e] = 0; pq_leaf_removed(st.pq, s.pq, e); }
+          if (!ok) { s.reject = 1; pq.leaf_seq[e] = 0; pq_leaf_removed(pq, s.pq, e); }
         }
         s.len0 = st.adj_len[s.r0]; s.len1 = st.adj_len[s.r1];
         s.off0 = st.adj_off[s.r0]; s.off1 = st.adj_off[s.r1];
@@ -196,53 +210,68 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
     __syncthreads();
     PH(0);
     if (s.stop != ST_RUN) { status = s.stop; break; }
-    if (s.reject) { pq_propagate<kGreedyThreads>(st.pq, s.pq, tid); continue; }
+    if (s.reject) { pq_propagate<kGreedyThreads>(pq, s.pq, tid); continue; }
     const uint32_t r0 = s.r0, r1 = s.r1, e = s.e, len0 = s.len0, len1 = s.len1, off0 = s.off0, off1 = s.off1;
     const uint32_t r2 = st.R0 + (uint32_t)k;
     const uint32_t total = len0 + len1;
     const uint32_t r2off = (uint32_t)pool_used;
+    const bool small = total <= kMarkMax;          // the usual case: neighbour matching entirely in LDS
 
-    // ---- phase A: mark the neighbours of r0 / r1 with the edge that reaches them ----
+    // ---- phase A: one table entry per distinct neighbour, holding the edge(s) that reach it ----
     for (uint32_t i = tid; i < total; i += kGreedyThreads) {
       const bool side1 = i >= len0;
-      const uint32_t eid = st.pool[side1 ? off1 + (i - len0) : off0 + i];
-      if (eid == e || !st.e_alive[eid]) continue;
-      const uint32_t r = side1 ? r1 : r0;
-      const uint32_t u = st.e_u[eid], v = st.e_v[eid];
-      const uint32_t rs = (u == r) ? v : u;
-      (side1 ? st.mark1 : st.mark0)[rs] = eid + 1u;
+      const uint2 pe = st.pool[side1 ? off1 + (i - len0) : off0 + i];
+      const uint32_t eid = pe.x, rs = pe.y;
+      if (eid == e || eid == kNone) continue;        // the contracted edge / the dead twin of an earlier contraction
+      if (small) {
+        uint32_t h = (rs * 2654435761u) >> 21;
+        while (true) {
+          const uint32_t old = atomicCAS(&s.mk[h], 0u, rs + 1u);
+          if (old == 0u) { s.items[atomicAdd(&s.nitems, 1u)] = h; break; }
+          if (old == rs + 1u) break;
+          h = (h + 1u) & (kMarkSlots - 1u);
+        }
+        (side1 ? s.mv1 : s.mv0)[h] = eid + 1u;
+      } else (side1 ? st.mark1 : st.mark0)[rs] = eid + 1u;
     }
     __syncthreads();
     PH(1);
 
     // ---- phase B: one new edge (rs, r2) per distinct neighbour (TBoundaryTable::update) ----
     bool bad = false;
-    for (uint32_t base = 0; base < total; base += kGreedyThreads) {
+    const uint32_t nwork = small ? s.nitems : total;
+    for (uint32_t base = 0; base < nwork; base += kGreedyThreads) {
       if (MEDIAN) { if (tid == 0) jobs.n = 0; __syncthreads(); }
       const uint32_t i = base + tid;
       do {
-        if (i >= total) break;
-        const bool side1 = i >= len0;
-        const uint32_t eid = st.pool[side1 ? off1 + (i - len0) : off0 + i];
-        if (eid == e) break;
-        const uint32_t u = st.e_u[eid], v = st.e_v[eid];
-        const uint32_t r = side1 ? r1 : r0;
-        if (u != r && v != r) break;                   // stale tombstone of an older contraction
-        const uint32_t rs = (u == r) ? v : u;
-        uint32_t e0s, e1s;
-        if (!side1) {
-          if (st.mark0[rs] != eid + 1u) break;         // dead edge (not marked in phase A)
-          e0s = eid;
-          const uint32_t m = st.mark1[rs];
-          e1s = m ? m - 1u : kNone;
+        if (i >= nwork) break;
+        uint32_t rs, e0s, e1s;
+        if (small) {
+          const uint32_t h = s.items[i];
+          rs = s.mk[h] - 1u;
+          const uint32_t m0 = s.mv0[h], m1 = s.mv1[h];
+          e0s = m0 ? m0 - 1u : kNone; e1s = m1 ? m1 - 1u : kNone;
+          s.mk[h] = 0u; s.mv0[h] = 0u; s.mv1[h] = 0u;          // the table is clean again when the phase ends
         } else {
-          if (st.mark1[rs] != eid + 1u) break;
-          if (st.mark0[rs] != 0u) break;               // common neighbour: handled from the r0 side
-          e0s = kNone; e1s = eid;
+          const bool side1 = i >= len0;
+          const uint2 pe = st.pool[side1 ? off1 + (i - len0) : off0 + i];
+          const uint32_t eid = pe.x;
+          rs = pe.y;
+          if (eid == e || eid == kNone) break;
+          if (!side1) {
+            e0s = eid;
+            const uint32_t m = st.mark1[rs];
+            e1s = m ? m - 1u : kNone;
+          } else {
+            if (st.mark0[rs] != 0u) break;             // common neighbour: handled from the r0 side
+            e0s = kNone; e1s = eid;
+          }
         }
         const uint32_t idx = atomicAdd(&s.newcount, 1u);
         const uint32_t newE = (uint32_t)ne + idx;
         const uint32_t old = (e0s != kNone) ? e0s : e1s;
+        const uint32_t posRs = (st.e_u[old] == rs) ? st.e_posu[old] : st.e_posv[old];
+        const uint32_t offRs = st.adj_off[rs];
         double first = 0.0;
         int second = 0;
         if (!MEDIAN) {
@@ -260,17 +289,21 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
             jobs.newE[j] = newE; jobs.e0[j] = e0s; jobs.e1[j] = e1s;
           } else { first = st.e_mean[old]; st.e_off[newE] = st.e_off[old]; }
         }
+        if (e0s != kNone && e1s != kNone) {
+          // rs held two entries (to r0 and to r1): one is reused for the new edge, the other becomes a tombstone
+          const uint32_t pos1 = (st.e_u[e1s] == rs) ? st.e_posu[e1s] : st.e_posv[e1s];
+          st.pool[offRs + pos1] = make_uint2(kNone, 0u);
+        }
         const uint32_t cat = rs < r0 ? 0u : (e0s != kNone ? 1u : 2u);
         const unsigned long long seq = ((k + 1ull) << 32) | ((unsigned long long)cat << 30) | rs;
-        const uint32_t posRs = (st.e_u[old] == rs) ? st.e_posu[old] : st.e_posv[old];
         st.e_u[newE] = rs; st.e_v[newE] = r2; st.e_posu[newE] = posRs; st.e_posv[newE] = idx;
         st.e_mean[newE] = first; st.e_n[newE] = second;
-        st.pq.leaf_sal[newE] = -first; st.pq.leaf_seq[newE] = seq; st.e_alive[newE] = 1;
-        st.pool[st.adj_off[rs] + posRs] = newE;
-        st.pool[r2off + idx] = newE;
-        pq_leaf_added(st.pq, s.pq, newE);
-        if (e0s != kNone) { st.e_alive[e0s] = 0; if (st.pq.leaf_seq[e0s]) { st.pq.leaf_seq[e0s] = 0; pq_leaf_removed(st.pq, s.pq, e0s); } }
-        if (e1s != kNone) { st.e_alive[e1s] = 0; if (st.pq.leaf_seq[e1s]) { st.pq.leaf_seq[e1s] = 0; pq_leaf_removed(st.pq, s.pq, e1s); } }
+        pq.leaf_sal[newE] = -first; pq.leaf_seq[newE] = seq;
+        st.pool[offRs + posRs] = make_uint2(newE, r2);
+        st.pool[r2off + idx] = make_uint2(newE, rs);
+        pq_leaf_added(pq, s.pq, newE);
+        if (e0s != kNone && pq.leaf_seq[e0s]) { pq.leaf_seq[e0s] = 0; pq_leaf_removed(pq, s.pq, e0s); }
+        if (e1s != kNone && pq.leaf_seq[e1s]) { pq.leaf_seq[e1s] = 0; pq_leaf_removed(pq, s.pq, e1s); }
       } while (false);
       if (MEDIAN) {
         __syncthreads();
@@ -339,34 +372,47 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
             const uint32_t newE = jobs.newE[tid];
             const unsigned long long off = vals_used + jobs.off[tid];
             const double med = (double)st.vals[off + (uint32_t)st.e_n[newE] / 2u];   // util/stats.hxx:83-91
-            st.e_off[newE] = off; st.e_mean[newE] = med; st.pq.leaf_sal[newE] = -med;
+            st.e_off[newE] = off; st.e_mean[newE] = med; pq.leaf_sal[newE] = -med;
           }
           vals_used += tot;
           __syncthreads();
         }
       }
-    }
-    if (tid == 0) { st.e_alive[e] = 0; st.pq.leaf_seq[e] = 0; pq_leaf_removed(st.pq, s.pq, e); }
+        }
+    if (tid == 0) { pq.leaf_seq[e] = 0; pq_leaf_removed(pq, s.pq, e); s.nitems = 0; }
     if (__syncthreads_or(bad ? 1 : 0)) { status = ST_BAD_SALIENCY; break; }
     PH(2);
 
-    // ---- phase C: reset marks, publish r2's list ----
+    // ---- phase C: publish r2's list; the rare big contraction resets the global marks it used ----
     const uint32_t newcount = s.newcount;
-    for (uint32_t j = tid; j < newcount; j += kGreedyThreads) {
-      const uint32_t rs = st.e_u[(uint32_t)ne + j];
-      st.mark0[rs] = 0; st.mark1[rs] = 0;
+    if (!small) {
+      for (uint32_t j = tid; j < newcount; j += kGreedyThreads) {
+        const uint32_t rs = st.e_u[(uint32_t)ne + j];
+        st.mark0[rs] = 0; st.mark1[rs] = 0;
+      }
     }
     if (tid == 0) { st.adj_off[r2] = r2off; st.adj_len[r2] = newcount; }
 
     PH(3);
     // ---- priority structure: propagate dirty nodes level by level ----
-    pq_propagate<kGreedyThreads>(st.pq, s.pq, tid);
+    pq_propagate<kGreedyThreads>(pq, s.pq, tid);
     PH(4);
+#ifdef GLIA_HMT_PROFILE
+    if (tid == 0) {
+      const unsigned long long tn = __builtin_readcyclecounter();
+      const int b = total <= 64 ? 0 : total <= 512 ? 1 : total <= kMarkMax ? 2 : 3;
+      tb[b] += tn - titer; nb[b] += 1; db[b] += total; titer = tn;
+    }
+#endif
     k += 1; ne += newcount; pool_used += total;
   }
+  __syncthreads();
   if (tid == 0) { st.ctrl[0] = k; st.ctrl[1] = ne; st.ctrl[2] = pool_used; st.ctrl[3] = status; st.ctrl[4] = vals_used; }
 #ifdef GLIA_HMT_PROFILE
-  if (tid == 0) for (int i = 0; i < 6; ++i) st.ctrl[4 + i > 7 ? 7 : 4 + i] += 0;
+  if (tid == 0) printf("[greedy profile] pq levels: cycles %llu %llu %llu %llu  nodes %llu %llu %llu %llu  spilled %llu %llu %llu %llu\n", g_pqprof[0], g_pqprof[1], g_pqprof[2],
+                       g_pqprof[3], g_pqprof[8], g_pqprof[9], g_pqprof[10], g_pqprof[11], g_pqprof[16], g_pqprof[17], g_pqprof[18], g_pqprof[19]);
+  if (tid == 0) printf("[greedy profile] by degree (<=64, <=512, <=1408, more): merges %llu %llu %llu %llu  cycles %llu %llu %llu %llu  entries %llu %llu %llu %llu\n",
+                       nb[0], nb[1], nb[2], nb[3], tb[0], tb[1], tb[2], tb[3], db[0], db[1], db[2], db[3]);
   if (tid == 0) printf("[greedy profile] merges %llu: pop %llu  mark %llu  build %llu  reset %llu  pq %llu  loop-top %llu (cycles)\n", k, tph[0], tph[1], tph[2], tph[3], tph[4], tph[5]);
 #endif
 }
@@ -398,7 +444,7 @@ __global__ void edge_fill(const uint32_t* pa, const uint32_t* pb, const uint32_t
   const int n = (int)(wi[P_CNT] + wj[P_CNT]);
   const double mean = sdivide(si + sj, (double)n, 0.0);
   st.e_u[e] = u; st.e_v[e] = v; st.e_mean[e] = mean; st.e_n[e] = n;
-  st.pq.leaf_sal[e] = -mean; st.pq.leaf_seq[e] = (unsigned long long)e + 1ull; st.e_alive[e] = 1;
+  st.pq.leaf_sal[e] = -mean; st.pq.leaf_seq[e] = (unsigned long long)e + 1ull;
   atomicAdd(&deg[u], 1u);
   atomicAdd(&deg[v], 1u);
 }
@@ -408,8 +454,8 @@ __global__ void adj_fill(GreedyState st, uint32_t E0, uint32_t* cursor) {
   if (e >= E0) return;
   const uint32_t u = st.e_u[e], v = st.e_v[e];
   const uint32_t pu = atomicAdd(&cursor[u], 1u), pv = atomicAdd(&cursor[v], 1u);
-  st.pool[st.adj_off[u] + pu] = e; st.e_posu[e] = pu;
-  st.pool[st.adj_off[v] + pv] = e; st.e_posv[e] = pv;
+  st.pool[st.adj_off[u] + pu] = make_uint2(e, v); st.e_posu[e] = pu;
+  st.pool[st.adj_off[v] + pv] = make_uint2(e, u); st.e_posv[e] = pv;
 }
 
 __global__ void region_sizes(const uint32_t* rrec, uint32_t R, unsigned long long* rsz, double* rsum) {
@@ -516,7 +562,6 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
   st.pq.nleaves = st.Ecap;
   if ((rc = buf.get(&st.pq.leaf_sal, st.Ecap, false, stream))) return rc;
   if ((rc = buf.get(&st.pq.leaf_seq, st.Ecap, false, stream))) return rc;
-  if ((rc = buf.get(&st.e_alive, st.Ecap, true, stream))) return rc;
   if ((rc = buf.get(&st.rsz, 2 * (size_t)R, true, stream))) return rc;
   if ((rc = buf.get(&st.rsum, 2 * (size_t)R, true, stream))) return rc;
   st.cond_n = cond_n; st.cond_rpb = cond_rpb;
@@ -615,7 +660,6 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
       if ((rc = buf.grow(&st.e_mean, ocap, ncap, stream))) return rc;
       if ((rc = buf.grow(&st.e_n, ocap, ncap, stream))) return rc;
       if (median_of && (rc = buf.grow(&st.e_off, ocap, ncap, stream))) return rc;
-      if ((rc = buf.grow(&st.e_alive, ocap, ncap, stream))) return rc;
       if ((rc = buf.grow(&st.pq.leaf_sal, ocap, ncap, stream))) return rc;
       if ((rc = buf.grow(&st.pq.leaf_seq, ocap, ncap, stream))) return rc;
       st.Ecap = ncap; st.pq.nleaves = ncap;

@@ -1,6 +1,8 @@
 // glia_amd/csrc/greedy_common.hpp -- pieces shared by the greedy merge kernels (pb-mean and classifier linkage):
 // the 64-ary tournament tree used as priority queue and small host helpers.
 #pragma once
+#include <rocprim/warp/warp_reduce.hpp>
+
 #include "hmt_internal.hpp"
 
 namespace glia {
@@ -8,7 +10,7 @@ namespace glia {
 constexpr int kFan = 64;
 constexpr int kMaxLevels = 6;
 constexpr int kGreedyThreads = 512;
-constexpr int kWorkCap = 2048;
+constexpr int kWorkCap = 2048;       // >= kSetSlots: every list entry owns a set entry, so the set fills up first
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
 struct PqLevel {
@@ -28,16 +30,14 @@ __device__ __forceinline__ bool better(const Key& a, const Key& b) {
   return a.sal > b.sal || (a.sal == b.sal && a.seq > b.seq);
 }
 
+struct KeyMax { __device__ __forceinline__ Key operator()(const Key& a, const Key& b) const { return better(b, a) ? b : a; } };
+// 64-lane maximum by (saliency, seq); the result is valid in lane 0 (rocPRIM's DPP reduction: no LDS round trips)
 __device__ __forceinline__ Key wave_max(Key k) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    Key o;
-    o.sal = __shfl_xor(k.sal, off);
-    o.seq = __shfl_xor(k.seq, off);
-    o.arg = __shfl_xor(k.arg, off);
-    if (better(o, k)) k = o;
-  }
-  return k;
+  using WR = rocprim::warp_reduce<Key, 64>;
+  __shared__ typename WR::storage_type storage;       // empty for the DPP implementation
+  Key out;
+  WR().reduce(k, out, storage, KeyMax());
+  return out;
 }
 
 
@@ -48,6 +48,10 @@ struct PqTree {
   unsigned long long* leaf_seq;   // 0 = dead
   int nlevels;
   PqLevel lv[kMaxLevels];
+  // big contractions dirty more nodes than the LDS worklist holds: the rest goes to these lists (deduplicated by the
+  // levels' dirty flags), [2] = current / next level
+  uint32_t* glist[2];
+  uint32_t* gcount;
 };
 
 // recompute node j of level l with one wave (all 64 lanes must call); returns true when the node's key changed
@@ -81,6 +85,8 @@ __device__ __forceinline__ bool pq_recompute_node(const PqTree& t, int l, uint32
 constexpr int kSetSlots = 1024;
 struct PqWork {            // lives in LDS
   uint32_t ovf;
+  uint32_t spill;                 // some node went to the global lists
+  uint32_t fast[2][16];           // small propagations: the node each wave handles on the next level
   uint32_t wln[2];
   uint32_t wl[2][kWorkCap];
   uint32_t set[2][kSetSlots];     // membership of wl[which] (node + 1, 0 = empty): no global round trip to dedupe
@@ -107,19 +113,56 @@ __device__ __forceinline__ void pq_touch(const PqTree& t, PqWork& w, int level, 
     }
     h = (h + 1) & (kSetSlots - 1);
   }
-  w.ovf = 1;                                   // crowded: fall back to a full rebuild of the levels
+  // LDS set crowded (kWorkCap >= kSetSlots, so the list itself cannot fill up first): spill to the global list
+  w.spill = 1u;
+  if (atomicExch(&t.lv[level].dirty[p], 1u) == 0u) t.glist[which][atomicAdd(&t.gcount[which], 1u)] = p;
 }
 
+#ifdef GLIA_HMT_PROFILE
+__device__ unsigned long long g_pqprof[32];     // [l] cycles of level l, [8+l] nodes recomputed at level l, [16+l] spilled nodes
+#endif
 // apply all pending leaf changes level by level; every thread of the workgroup must call (contains barriers)
 template <int THREADS>
 __device__ __forceinline__ void pq_propagate(const PqTree& t, PqWork& w, int tid) {
   const int lane = tid & 63, wave = tid >> 6;
   constexpr int nwaves = THREADS / 64;
+  static_assert(nwaves <= 16, "PqWork::fast");
+  __syncthreads();
+  if (w.wln[0] <= (uint32_t)nwaves && !w.spill && !w.ovf) {
+    // The usual case -- at most one dirty node per wave: every wave walks its node up the tree, one barrier per
+    // level; waves whose node did not change, or whose parent is taken by a lower wave, drop out.
+    const uint32_t n0 = w.wln[0];
+    uint32_t node = (uint32_t)wave < n0 ? w.wl[0][wave] : kNone;
+    if (node != kNone && lane == 0) {
+      uint32_t h = (node * 2654435761u) >> 22;
+      while (w.set[0][h] != node + 1u) h = (h + 1) & (kSetSlots - 1);
+      w.set[0][h] = 0;
+    }
+    for (int l = 0; l < t.nlevels; ++l) {
+      uint32_t parent = kNone;
+      if (node != kNone) {
+        const bool changed = pq_recompute_node(t, l, node, lane, false);
+        const bool ch = __shfl((int)changed, 0) != 0;
+        if (ch && l + 1 < t.nlevels) parent = node / kFan;
+      }
+      if (lane == 0) w.fast[l & 1][wave] = parent;
+      __syncthreads();
+      if (parent != kNone) for (int j = 0; j < wave; ++j) if (w.fast[l & 1][j] == parent) { parent = kNone; break; }
+      node = parent;
+    }
+    if (tid == 0) w.wln[0] = 0;
+    __syncthreads();
+    return;
+  }
   int cur = 0;
   for (int l = 0; l < t.nlevels; ++l) {
+#ifdef GLIA_HMT_PROFILE
+    const unsigned long long tl0 = __builtin_readcyclecounter();
+#endif
     __syncthreads();
     const bool ovf = w.ovf != 0;
     const uint32_t n = ovf ? t.lv[l].size : w.wln[cur];
+    const uint32_t ng = (ovf || !w.spill) ? 0u : t.gcount[cur];
     for (uint32_t i = wave; i < n; i += nwaves) {
       const uint32_t j = ovf ? i : w.wl[cur][i];
       const bool changed = pq_recompute_node(t, l, j, lane, ovf);
@@ -128,7 +171,16 @@ __device__ __forceinline__ void pq_propagate(const PqTree& t, PqWork& w, int tid
         if (!ovf && changed && l + 1 < t.nlevels) pq_touch(t, w, l + 1, cur ^ 1, j);
       }
     }
+    for (uint32_t i = wave; i < ng; i += nwaves) {
+      const uint32_t j = t.glist[cur][i];
+      const bool changed = pq_recompute_node(t, l, j, lane, false);
+      if (lane == 0) {
+        t.lv[l].dirty[j] = 0u;
+        if (changed && l + 1 < t.nlevels) pq_touch(t, w, l + 1, cur ^ 1, j);
+      }
+    }
     __syncthreads();
+    if (tid == 0 && ng) t.gcount[cur] = 0u;
     // consume the list: empty it and its membership set
     if (ovf) { for (int i = tid; i < kSetSlots; i += THREADS) { w.set[0][i] = 0; w.set[1][i] = 0; } }
     else {
@@ -141,10 +193,13 @@ __device__ __forceinline__ void pq_propagate(const PqTree& t, PqWork& w, int tid
     }
     __syncthreads();
     if (tid == 0) w.wln[cur] = 0;
+#ifdef GLIA_HMT_PROFILE
+    if (tid == 0) { g_pqprof[l] += __builtin_readcyclecounter() - tl0; g_pqprof[8 + l] += n; g_pqprof[16 + l] += ng; }
+#endif
     cur ^= 1;
   }
   __syncthreads();
-  if (tid == 0) { w.ovf = 0; w.wln[0] = w.wln[1] = 0; }
+  if (tid == 0) { w.ovf = 0; w.spill = 0; w.wln[0] = w.wln[1] = 0; }
   __syncthreads();
 }
 
