@@ -82,7 +82,10 @@ typedef struct {
  * operator needs: per label (count, border count, bbox, image moments, histogram) and per
  * DIRECTED label pair (a->b) (boundary voxel count, image moments, histogram, threshold counts).
  * cfg may be NULL when only merge_order_pb will be called (then d_pb must be given).
- * d_mask must be NULL for now (GLIA_HMT_ERR_UNSUPPORTED otherwise). */
+ * d_mask (optional, u32 volume, MASK_OUT_VAL = 0 masks a voxel out): masked-out neighbours are invalid like
+ * out-of-bounds ones (type/neighbor.hxx:80-86); a masked-out centre voxel belongs to no region when only_contour = 0
+ * (util/struct.hxx:86-91) and is still processed when only_contour = 1 (:133-143 has no mask test).
+ * The label / mask / image volumes must stay alive while the handle lives: median linkage re-reads them. */
 int glia_hmt_rag_build(glia_hmt_ctx* ctx, int dim, const int64_t dims[3], const uint32_t* d_labels,
                        const uint32_t* d_mask, int only_contour, const float* d_pb,
                        const glia_hmt_feat_config* cfg, glia_hmt_rag** out);
@@ -128,7 +131,9 @@ int glia_hmt_rag_last_pass(const glia_hmt_rag* rag, double* ms, double* algorith
  * util/struct_merge.hxx:90-136) and genMergeOrderGreedyUsingPbMean (type 2, :38-85) as called by
  * merge_order_pb (hmt/main_merge_order_pb.cxx:27-36) with fcond = f_true.
  * Output: h_order[3*i..] = (x0, x1, x2) of merge i (TTriple, type/tuple.hxx:8-29),
- * h_saliency[i] = popped queue key.  *n_merges <= capacity. */
+ * h_saliency[i] = popped queue key.  *n_merges <= capacity.  Type 1 (the tool's default) keeps, per table edge, the
+ * SORTED run of its boundary voxels' values; a contraction merges runs (merge path) and reads the order statistic
+ * n/2 (stats::amedian, util/stats.hxx:83-91).  It needs a handle built by glia_hmt_rag_build (whole volume). */
 int glia_hmt_merge_order_pb(glia_hmt_ctx* ctx, glia_hmt_rag* rag, int type, uint32_t* h_order,
                             double* h_saliency, int64_t capacity, int64_t* n_merges);
 
