@@ -8,6 +8,8 @@ A "step" is one pass of the hot path over one synthetic volume that is already r
 the merge loop does not shard -- SURVEY.md 8e).  `roofline` describes the dominant streaming kernel
 (rag_accumulate: 8 algorithmic bytes per voxel), timed live with HIP events on the library's stream.
 `cpu_baseline` times the oracle (the CPU restatement of GLIA's algorithm) on a bounded sub-volume on this host.
+With N > 1 an extra, separately timed phase (`slab_rag`) splits ONE volume into z-slabs across the ranks and exchanges
+the partial region/pair records over RCCL (glia_amd/slab.py).
 """
 import argparse
 import json
@@ -45,6 +47,42 @@ def cpu_baseline(size, S, bc_size):
     return out
 
 
+def slab_phase(ctx, hmt, dist, torch, size, S, world, rank):
+    """SURVEY.md 8e / BASELINE config 4: ONE volume z-split across the ranks -- every rank accumulates its slab (one halo
+    plane per cut), the compact partial records cross RCCL once (all_gather), every rank merges them by key.  Timed
+    apart from `value` (the merge loop does not shard); rank 0 checks the result against its single-pass build."""
+    from glia_amd import slab
+    labels, pb = ctx.synth((size,) * 3, S, 8 * S)            # the same volume on every rank (same seed)
+    lo, hi, zb, ze = slab.slab_with_halo(size, world, rank)
+    sl, sp = labels[lo:hi], pb[lo:hi]
+    cfg = hmt.make_config(sp, rb=[(sp, 8, 0.0, 1.0)], thresholds=(0.2, 0.5, 0.8))
+
+    def once():
+        part = hmt.RegionMap(ctx, sl, pb=sp, cfg=cfg, slab=(lo, size, zb, ze))
+        merged = slab.exchange_and_merge(ctx, part)
+        part.close()
+        return merged
+
+    once().close()                                           # warm-up (RCCL channels, allocations)
+    dist.barrier(); torch.cuda.synchronize(); ctx.sync()
+    t0 = time.time()
+    merged = once()
+    dist.barrier(); torch.cuda.synchronize(); ctx.sync()
+    t = torch.tensor([time.time() - t0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    out = {"ms": float(t.item()) * 1e3, "slab_planes_per_rank": ze - zb, "regions": merged.num_regions, "pairs": merged.num_pairs}
+    if rank == 0:
+        wcfg = hmt.make_config(pb, rb=[(pb, 8, 0.0, 1.0)], thresholds=(0.2, 0.5, 0.8))
+        whole = hmt.RegionMap(ctx, labels, pb=pb, cfg=wcfg)
+        a, b = whole.pairs(), merged.pairs()
+        ra, rb = whole.regions(), merged.regions()
+        out["identical_to_single_pass"] = bool(all((a[k] == b[k]).all() for k in a) and all((ra[k] == rb[k]).all() for k in ra))
+        out["ms_single_gpu_accumulate"] = whole.last_pass()[0]
+        whole.close()
+    merged.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -55,6 +93,9 @@ def main():
     ap.add_argument("--cpu-size", type=int, default=256)
     ap.add_argument("--cpu-bc-size", type=int, default=40)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-slab", action="store_true", help="N > 1: skip the z-slab split + RCCL exchange phase")
+    ap.add_argument("--slab-timeout", type=int, default=240)
+    ap.add_argument("--force-slab", action="store_true", help="rehearse the slab phase with a 1-rank RCCL group (N = 1)")
     args = ap.parse_args()
 
     import tempfile
@@ -69,6 +110,9 @@ def main():
     torch.cuda.set_device(local)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    elif args.force_slab:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29517", rank=0, world_size=1,
+                                device_id=torch.device("cuda", local))
 
     ctx = hmt.Context(local)
     shape = (args.size,) * 3
@@ -119,6 +163,7 @@ def main():
         merges = float(sum(i["merges"] for i in infos))
         edges = float(sum(i["n_edges"] for i in infos))
 
+    out = None
     if rank == 0:
         acc_ms = sum(i["acc_ms"] for i in infos) / len(infos)
         achieved = infos[0]["acc_bytes"] / (acc_ms * 1e-3) / 1e9
@@ -157,8 +202,36 @@ def main():
         }
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.cpu_size, args.S, args.cpu_bc_size)
-        print(json.dumps(out))
-    if world > 1:
+
+    def emit(slab_info):
+        if rank == 0:
+            if slab_info is not None:
+                out["slab_rag"] = slab_info     # z-slab split of ONE volume + RCCL record exchange
+            print(json.dumps(out), flush=True)
+
+    if (world > 1 or args.force_slab) and not args.no_slab:
+        # Outside the timed region and never allowed to take the bench line down: an exception is reported inside the
+        # line, a hang (a collective that never completes) is cut by a watchdog that emits the line without it.
+        import threading
+
+        def give_up():
+            emit({"error": "slab phase did not finish within %d s" % args.slab_timeout})
+            os._exit(0)
+
+        dog = threading.Timer(args.slab_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            del labels, pb, cfg
+            torch.cuda.empty_cache()
+            slab_info = slab_phase(ctx, hmt, dist, torch, args.size, args.S, world, rank)
+        except Exception as e:          # noqa: BLE001
+            slab_info = {"error": "%s: %s" % (type(e).__name__, e)}
+        dog.cancel()
+        emit(slab_info)
+    else:
+        emit(None)
+    if world > 1 or args.force_slab:
         dist.destroy_process_group()
 
 
