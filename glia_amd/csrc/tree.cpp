@@ -1,0 +1,103 @@
+// glia_amd/csrc/tree.cpp -- the step after the merge path: merge tree with node potentials, greedy
+// tree resolution, label transform of the picked nodes.  Host-only (the trees have 2R-1 nodes; the voxel work is
+// glia_hmt_transform_image).  Reference: hmt/tree_build.hxx:41-63 (genTreeWithNodePotentials), hmt/tree_greedy.hxx:36-70,
+// 76-152 (pickTreeNode / resolveTreeGreedy with comp = potential <), hmt/tree_segment.hxx:10-21 (genLabelTransform),
+// hmt/main_segment_greedy.cxx:33-86.  The reference re-scans every node for each pick (O(n^2)); here the same pick
+// sequence comes out of a heap ordered by (potential descending, node index ascending) with lazy invalidation.
+#include <algorithm>
+#include <queue>
+#include <unordered_map>
+#include <vector>
+
+#include "hmt_internal.hpp"
+
+using namespace glia;
+
+extern "C" {
+
+int64_t glia_hmt_tree_potentials(const uint32_t* h_order, int64_t n_merges, const double* h_merge_probs,
+                                 const double* h_region_probs, uint32_t* node_label, int32_t* parent, int32_t* child0,
+                                 int32_t* child1, double* potential, int64_t capacity) {
+  if (!h_order || !node_label || !parent || !child0 || !child1 || !potential || n_merges < 0) {
+    set_error("tree_potentials: invalid argument");
+    return GLIA_HMT_ERR_ARG;
+  }
+  const int64_t n = glia_hmt_gen_tree(h_order, n_merges, node_label, parent, child0, child1, capacity);
+  if (n < 0) return n;
+  // genTree visits the nodes in index order; an inner node's callback sees its (already created) children
+  int64_t mi = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    if (child0[i] < 0) { potential[i] = 1.0; continue; }           // leaf: set by its parent below (or 1.0 without probabilities)
+    if (!h_merge_probs) { potential[i] = 1.0; continue; }          // main_segment_greedy.cxx:46-50
+    const double p = h_merge_probs[mi++];
+    potential[i] = p;
+    const double pSplit = 1.0 - p;
+    for (int32_t c : {child0[i], child1[i]}) {
+      if (child0[c] < 0) potential[c] = pSplit * pSplit;
+      else potential[c] *= pSplit;
+    }
+  }
+  if (h_merge_probs && n > 0) potential[n - 1] *= potential[n - 1];   // root() = last node (type/tree.hxx:100)
+  if (h_region_probs) for (int64_t i = 0; i < n; ++i) potential[i] *= std::max(h_region_probs[i], 2.22e-16 /* FEPS */);
+  return n;
+}
+
+int64_t glia_hmt_resolve_tree_greedy(const int32_t* parent, const int32_t* child0, const int32_t* child1,
+                                     const double* potential, int64_t n_nodes, int32_t* h_picks, int64_t capacity) {
+  if (!parent || !child0 || !child1 || !potential || !h_picks || n_nodes < 0) {
+    set_error("resolve_tree_greedy: invalid argument");
+    return GLIA_HMT_ERR_ARG;
+  }
+  // pickTreeNode keeps the FIRST node (index order) among those of maximal potential: `comp(tree[ret], node)` is a strict <
+  struct Item { double p; int32_t i; };
+  auto worse = [](const Item& a, const Item& b) { return a.p < b.p || (a.p == b.p && a.i > b.i); };
+  std::priority_queue<Item, std::vector<Item>, decltype(worse)> heap(worse);
+  for (int64_t i = 0; i < n_nodes; ++i) heap.push(Item{potential[i], (int32_t)i});
+  std::vector<char> valid((size_t)n_nodes, 1);
+  std::vector<int32_t> stack;
+  int64_t np = 0;
+  while (!heap.empty()) {
+    const Item it = heap.top();
+    heap.pop();
+    if (!valid[it.i]) continue;
+    if (np >= capacity) { set_error("resolve_tree_greedy: output capacity too small"); return GLIA_HMT_ERR_CAPACITY; }
+    h_picks[np++] = it.i;
+    valid[it.i] = 0;
+    for (int32_t a = parent[it.i]; a >= 0; a = parent[a]) valid[a] = 0;          // traverseAncestors
+    stack.assign(1, it.i);                                                        // traverseDescendants
+    while (!stack.empty()) {
+      const int32_t x = stack.back();
+      stack.pop_back();
+      for (int32_t c : {child0[x], child1[x]}) if (c >= 0 && valid[c]) { valid[c] = 0; stack.push_back(c); }
+    }
+  }
+  return np;
+}
+
+int64_t glia_hmt_label_transform(const uint32_t* node_label, const int32_t* child0, const int32_t* child1, int64_t n_nodes,
+                                 const int32_t* h_picks, int64_t n_picks, uint32_t key_to_assign, uint32_t* h_src,
+                                 uint32_t* h_dst, int64_t capacity) {
+  if (!node_label || !child0 || !child1 || !h_picks || !h_src || !h_dst || n_nodes < 0 || n_picks < 0) {
+    set_error("label_transform: invalid argument");
+    return GLIA_HMT_ERR_ARG;
+  }
+  int64_t m = 0;
+  std::vector<int32_t> stack;
+  for (int64_t k = 0; k < n_picks; ++k) {
+    const int32_t pk = h_picks[k];
+    if (pk < 0 || pk >= n_nodes) { set_error("label_transform: pick out of range"); return GLIA_HMT_ERR_ARG; }
+    stack.assign(1, pk);
+    while (!stack.empty()) {
+      const int32_t x = stack.back();
+      stack.pop_back();
+      if (child0[x] < 0) {
+        if (m >= capacity) { set_error("label_transform: output capacity too small"); return GLIA_HMT_ERR_CAPACITY; }
+        h_src[m] = node_label[x]; h_dst[m] = key_to_assign; ++m;
+      } else { stack.push_back(child0[x]); stack.push_back(child1[x]); }
+    }
+    ++key_to_assign;
+  }
+  return m;
+}
+
+}  // extern "C"

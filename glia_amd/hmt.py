@@ -194,6 +194,57 @@ def relabel_image(ctx, labels, min_size=0):
     return n.value
 
 
+def _tree_potentials(L, prefix, order, merge_probs, region_probs, ptr):
+    order = np.ascontiguousarray(order, dtype=np.uint32)
+    cap = 3 * len(order) + 1
+    lab = np.empty(cap, np.uint32); par = np.empty(cap, np.int32); c0 = np.empty(cap, np.int32); c1 = np.empty(cap, np.int32)
+    pot = np.empty(cap, np.float64)
+    mp = None if merge_probs is None else np.ascontiguousarray(merge_probs, dtype=np.float64)
+    rp = None if region_probs is None else np.ascontiguousarray(region_probs, dtype=np.float64)
+    f = getattr(L, prefix + "tree_potentials"); f.restype = C.c_int64
+    n = f(ptr(order), C.c_int64(len(order)), ptr(mp) if mp is not None else None, ptr(rp) if rp is not None else None,
+          ptr(lab), ptr(par), ptr(c0), ptr(c1), ptr(pot), C.c_int64(cap))
+    assert n >= 0
+    return lab[:n].copy(), par[:n].copy(), c0[:n].copy(), c1[:n].copy(), pot[:n].copy()
+
+
+def _resolve(L, prefix, par, c0, c1, pot, ptr):
+    par = np.ascontiguousarray(par, np.int32); c0 = np.ascontiguousarray(c0, np.int32); c1 = np.ascontiguousarray(c1, np.int32)
+    pot = np.ascontiguousarray(pot, np.float64)
+    picks = np.empty(max(len(par), 1), np.int32)
+    f = getattr(L, prefix + "resolve_tree_greedy"); f.restype = C.c_int64
+    n = f(ptr(par), ptr(c0), ptr(c1), ptr(pot), C.c_int64(len(par)), ptr(picks), C.c_int64(len(picks)))
+    assert n >= 0
+    return picks[:n].copy()
+
+
+def _label_transform(L, prefix, lab, c0, c1, picks, key, ptr):
+    lab = np.ascontiguousarray(lab, np.uint32); c0 = np.ascontiguousarray(c0, np.int32); c1 = np.ascontiguousarray(c1, np.int32)
+    picks = np.ascontiguousarray(picks, np.int32)
+    src = np.empty(max(len(lab), 1), np.uint32); dst = np.empty(max(len(lab), 1), np.uint32)
+    f = getattr(L, prefix + "label_transform"); f.restype = C.c_int64
+    n = f(ptr(lab), ptr(c0), ptr(c1), C.c_int64(len(lab)), ptr(picks), C.c_int64(len(picks)), C.c_uint32(key), ptr(src), ptr(dst),
+          C.c_int64(len(src)))
+    assert n >= 0
+    o = np.argsort(src[:n], kind="stable")
+    return src[:n][o].copy(), dst[:n][o].copy()
+
+
+def tree_potentials(order, merge_probs=None, region_probs=None):
+    """genTree / genTreeWithNodePotentials (hmt/tree_build.hxx:12-63) -> (label, parent, child0, child1, potential)."""
+    return _tree_potentials(lib(), "glia_hmt_", order, merge_probs, region_probs, _np)
+
+
+def resolve_tree_greedy(parent, child0, child1, potential):
+    """resolveTreeGreedy (hmt/tree_greedy.hxx:104-152, one tree): node indices in pick order."""
+    return _resolve(lib(), "glia_hmt_", parent, child0, child1, potential, _np)
+
+
+def label_transform(node_label, child0, child1, picks, key_to_assign=1):
+    """genLabelTransform (hmt/tree_segment.hxx:10-21) -> (src, dst) sorted by src."""
+    return _label_transform(lib(), "glia_hmt_", node_label, child0, child1, picks, key_to_assign, _np)
+
+
 class RandomForest:
     """alg::RandomForest / alg::EnsembleRandomForest (alg/rf.hxx) loaded from GLIA model files onto the device."""
 

@@ -178,6 +178,25 @@ int glia_hmt_pre_merge(glia_hmt_ctx* ctx, glia_hmt_rag* rag, const int* size_thr
  * row i = features of merge i with regions in the file's orientation and the area-ordered swap of :88-91. */
 int glia_hmt_bc_feat(glia_hmt_ctx* ctx, glia_hmt_rag* rag, const uint32_t* h_order, int64_t n_merges, double* h_feats);
 
+/* ---- the step after the merge path: tree resolution (hmt/main_segment_greedy.cxx:33-86), host-only ----
+ * glia_hmt_tree_potentials = genTree / genTreeWithNodePotentials (hmt/tree_build.hxx:12-63): array tree of the merge
+ * order plus a potential per node -- merge probability of the node, times (1 - p) of its parent; leaves: (1 - p_parent)^2;
+ * the root (= last node) squared; optionally times max(region_prob[node], FEPS).  h_merge_probs == NULL: all 1.0.
+ * Returns the number of nodes. */
+int64_t glia_hmt_tree_potentials(const uint32_t* h_order, int64_t n_merges, const double* h_merge_probs,
+                                 const double* h_region_probs, uint32_t* node_label, int32_t* parent, int32_t* child0,
+                                 int32_t* child1, double* potential, int64_t capacity);
+/* resolveTreeGreedy (hmt/tree_greedy.hxx:36-70,104-152 for one tree, comp = potential <): repeatedly picks the valid
+ * node of highest potential (first in node order among equals) and invalidates its ancestors and descendants.
+ * h_picks receives node indices in pick order; returns their number. */
+int64_t glia_hmt_resolve_tree_greedy(const int32_t* parent, const int32_t* child0, const int32_t* child1,
+                                     const double* potential, int64_t n_nodes, int32_t* h_picks, int64_t capacity);
+/* genLabelTransform (hmt/tree_segment.hxx:10-21): every leaf label under pick k maps to key_to_assign + k.  The pairs
+ * feed glia_hmt_transform_image (fill_missing = 1 reproduces segment_greedy's default --ignore true). */
+int64_t glia_hmt_label_transform(const uint32_t* node_label, const int32_t* child0, const int32_t* child1, int64_t n_nodes,
+                                 const int32_t* h_picks, int64_t n_picks, uint32_t key_to_assign, uint32_t* h_src,
+                                 uint32_t* h_dst, int64_t capacity);
+
 /* ---- label-volume rewrites either side of the path (gadget/main_pre_merge.cxx:77-79, gadget/main_apply_merges.cxx:28-34) ----
  * transformKeys (util/struct_merge.hxx:188-210): every key that is merged and is not itself created by a merge maps
  * to the key it finally ends up in.  Host-only; pairs come out sorted by source key.  Returns the number of pairs

@@ -13,6 +13,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <queue>
 #include <unordered_map>
 #include <unordered_set>
 #include <utility>
@@ -1180,6 +1181,98 @@ int64_t orc_relabel_image(orc_label* lab, int64_t n, int64_t min_size) {
   for (auto const& o : objs) lmap[o.first] = (min_size > 0 && o.second < min_size) ? BG_VAL : next++;
   for (int64_t i = 0; i < n; ++i) if (lab[i] != BG_VAL) lab[i] = lmap[lab[i]];
   return (int64_t)next - 1;
+}
+
+
+// hmt/tree_build.hxx:41-63 (+ main_segment_greedy.cxx:46-59): potentials are attached while genTree builds the nodes
+int64_t orc_tree_potentials(const orc_label* order, int64_t n_merges, const double* merge_probs, const double* region_probs,
+                            orc_label* node_label, int32_t* parent, int32_t* child0, int32_t* child1, double* potential,
+                            int64_t cap) {
+  std::unordered_map<Label, int> nmap;
+  int ni = 0;
+  const double* mpit = merge_probs;
+  auto visit = [&](int node, Label r) {           // the callback genTree applies to every new node
+    node_label[node] = r;
+    if (!merge_probs) { potential[node] = 1.0; return; }
+    if (child0[node] >= 0) {
+      potential[node] = *mpit;
+      double pSplit = 1.0 - *mpit;
+      for (int c : {child0[node], child1[node]}) {
+        if (child0[c] < 0) potential[c] = pSplit * pSplit;
+        else potential[c] *= pSplit;
+      }
+      ++mpit;
+    }
+  };
+  auto add = [&](Label l, int c0, int c1) -> int {
+    if (ni >= cap) return -1;
+    parent[ni] = -1; child0[ni] = c0; child1[ni] = c1; potential[ni] = 0.0;
+    visit(ni, l);
+    nmap.emplace(l, ni);
+    return ni++;
+  };
+  for (int64_t i = 0; i < n_merges; ++i) {
+    Label x0 = order[3 * i], x1 = order[3 * i + 1], x2 = order[3 * i + 2];
+    auto n0 = nmap.find(x0);
+    int i0 = n0 == nmap.end() ? add(x0, -1, -1) : n0->second;
+    auto n1 = nmap.find(x1);
+    int i1 = n1 == nmap.end() ? add(x1, -1, -1) : n1->second;
+    if (i0 < 0 || i1 < 0 || ni >= cap) return -1;
+    parent[i0] = ni; parent[i1] = ni;
+    add(x2, i0, i1);
+  }
+  if (merge_probs && ni > 0) potential[ni - 1] *= potential[ni - 1];
+  if (region_probs) for (int i = 0; i < ni; ++i) potential[i] *= std::max(region_probs[i], FEPS);
+  return ni;
+}
+
+// hmt/tree_greedy.hxx:76-92 + 104-152 for one tree: full scan per pick, validity flags, ancestors then BFS descendants
+int64_t orc_resolve_tree_greedy(const int32_t* parent, const int32_t* child0, const int32_t* child1, const double* potential,
+                                int64_t n, int32_t* picks, int64_t cap) {
+  std::vector<bool> validity((size_t)n, true);
+  int64_t np = 0;
+  auto pickNode = [&]() {
+    int ret = -1;
+    for (int i = 0; i < n; ++i)
+      if (validity[i] && (ret < 0 || potential[ret] < potential[i])) ret = i;
+    return ret;
+  };
+  int pi = pickNode();
+  while (pi >= 0) {
+    if (np >= cap) return -1;
+    picks[np++] = pi;
+    validity[pi] = false;
+    for (int a = parent[pi]; a >= 0; a = parent[a]) validity[a] = false;
+    std::queue<int> q;
+    for (int c : {child0[pi], child1[pi]}) if (c >= 0) q.push(c);
+    while (!q.empty()) {
+      int x = q.front(); q.pop();
+      validity[x] = false;
+      for (int c : {child0[x], child1[x]}) if (c >= 0) q.push(c);
+    }
+    pi = pickNode();
+  }
+  return np;
+}
+
+// hmt/tree_segment.hxx:10-21: pairs sorted by source label (the reference fills an unordered_map)
+int64_t orc_label_transform(const orc_label* node_label, const int32_t* child0, const int32_t* child1, int64_t n,
+                            const int32_t* picks, int64_t n_picks, orc_label key, orc_label* src, orc_label* dst, int64_t cap) {
+  std::map<Label, Label> lmap;
+  for (int64_t k = 0; k < n_picks; ++k) {
+    std::queue<int> q;
+    q.push(picks[k]);
+    while (!q.empty()) {
+      int x = q.front(); q.pop();
+      if (child0[x] < 0) lmap[node_label[x]] = key;
+      else { q.push(child0[x]); q.push(child1[x]); }
+    }
+    ++key;
+  }
+  if ((int64_t)lmap.size() > cap) return -1;
+  int64_t m = 0;
+  for (auto const& lp : lmap) { src[m] = lp.first; dst[m] = lp.second; ++m; }
+  return m;
 }
 
 }  // extern "C"

@@ -135,6 +135,15 @@ double orc_forest_predict(const orc_forest*, const double* x, int d);
 int64_t orc_gen_tree(const orc_label* order, int64_t n_merges, orc_label* node_label,
                      int32_t* parent, int32_t* child0, int32_t* child1, int64_t cap);
 
+// tree resolution (hmt/tree_build.hxx:41-63, hmt/tree_greedy.hxx:76-152, hmt/tree_segment.hxx:10-21)
+int64_t orc_tree_potentials(const orc_label* order, int64_t n_merges, const double* merge_probs, const double* region_probs,
+                            orc_label* node_label, int32_t* parent, int32_t* child0, int32_t* child1, double* potential,
+                            int64_t cap);
+int64_t orc_resolve_tree_greedy(const int32_t* parent, const int32_t* child0, const int32_t* child1, const double* potential,
+                                int64_t n, int32_t* picks, int64_t cap);
+int64_t orc_label_transform(const orc_label* node_label, const int32_t* child0, const int32_t* child1, int64_t n,
+                            const int32_t* picks, int64_t n_picks, orc_label key, orc_label* src, orc_label* dst, int64_t cap);
+
 // label-volume rewrites (util/struct_merge.hxx:188-210, util/image.hxx:227-242, :992-1001)
 int64_t orc_transform_keys(const orc_label* order, int64_t n_merges, orc_label* src, orc_label* dst, int64_t cap);
 void orc_transform_image(orc_label* lab, int64_t n, const orc_label* src, const orc_label* dst, int64_t m,

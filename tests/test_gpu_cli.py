@@ -142,3 +142,28 @@ def test_pre_merge_and_apply_merges_cli(tools, tmp_path, relabel, w16):
     subprocess.check_call([os.path.join(tools, "apply_merges"), "-i", seg, "-m", maskf, "-g", order_f, "-g", order_f + "2", "-o", out2])
     ref2 = O.transform_image(labels, *O.transform_keys(o_ref), mask=mask)
     assert (read_mha(out2) == ref2).all()
+
+
+def test_end_to_end_classifier_tree_to_final_segmentation(tools, tmp_path):
+    """seg + pb -> merge_order_bc (order + P(merge) per merge) -> segment_greedy -> final label image, against the same
+    chain run through the oracle (merge order, potentials, full-scan greedy picks, label transform, fill-missing)."""
+    from oracle import pyoracle as O
+    import _rf
+    labels, pb = O.synth((32, 32, 32), 8, 16)
+    cfg = O.make_cfg(pb, rb=[(pb, 8, 0.0, 1.0)])
+    _, _, f0 = O.Rag(labels).merge_order_bc(cfg, None, stub_index=31, want_feats=True)
+    forest = _rf.random_forest(np.random.default_rng(3), 31, 6, f0)
+    model, seg, pbf, order_f, sal_f, out = (str(tmp_path / n) for n in ("model.bin", "seg.mha", "pb.mha", "order.txt", "sal.txt", "final.mha"))
+    _rf.write_model(model, forest)
+    write_mha(seg, labels)
+    write_mha(pbf, pb)
+    subprocess.check_call([os.path.join(tools, "merge_order_bc"), "--bct", "1", "--bcm", model, "-s", seg, "--pb", pbf, "--rbi", pbf, "--rbb", "8",
+                           "--rbl", "0.0", "--rbu", "1.0", "--bt", "0.2", "0.5", "0.8", "-o", order_f, "--sal", sal_f])
+    subprocess.check_call([os.path.join(tools, "segment_greedy"), "-s", seg, "-o", order_f, "-p", sal_f, "-f", out])
+    o_ref, s_ref = O.Rag(labels).merge_order_bc(cfg, O.make_forest(forest, -1))
+    probs = np.array([float("%.6g" % v) for v in s_ref])           # the saliency file holds 6 significant digits
+    lab, par, c0, c1, pot = O.tree_potentials(o_ref, probs)
+    picks = O.resolve_tree_greedy(par, c0, c1, pot)
+    ref = O.transform_image(labels, *O.label_transform(lab, c0, c1, picks, 1), fill_missing=True)
+    got = read_mha(out)
+    assert (got == ref).all() and 1 < len(np.unique(got)) <= len(np.unique(labels))
