@@ -75,6 +75,7 @@ struct BcCfg {
 
 __host__ __device__ inline int bc_rf_dim(const BcCfg& c) { return 4 + c.D + 2 * c.T + 5 * c.n_region + c.n_rlabel + 5 * c.n_boundary; }
 __host__ __device__ inline int bc_bf_dim(const BcCfg& c) { return 11 + 4 * c.T + 7 * c.n_region + 3 * c.n_rlabel + 5 * c.n_boundary; }
+__host__ __device__ inline int bc_full_dim(const BcCfg& c) { return bc_bf_dim(c) + 3 * bc_rf_dim(c); }
 __host__ __device__ inline int bc_feat_dim(const BcCfg& c) {
   return c.use_simple ? 5 + c.n_boundary + 4 * c.n_region + 2 * c.n_rlabel : bc_bf_dim(c) + 3 * bc_rf_dim(c);
 }
@@ -249,6 +250,143 @@ __device__ inline void bc_features(const BcCfg& c, const PStats& p0, const EStat
   for (int i = 0; i < c.rfdim; ++i) out[k++] = x1[i];
   for (int i = 0; i < c.rfdim; ++i) out[k++] = x2[i];
   for (int i = 0; i < c.rfdim; ++i) out[k++] = rf2[i];
+}
+
+
+// ---- the same vector without private arrays ------------------------------------------------------------------------
+// bc_features() above keeps four feature arrays and several statistics structs per thread; with run-time bin counts the
+// compiler places all of them in scratch memory, and the greedy loop then waits on scratch round trips (measured: 92 k
+// cycles per vector).  The variant below reads the statistics where they live, forms the merged sets on the fly, loops
+// over bins with compile-time bounds and writes every feature straight to its final slot of `out` (LDS in the loop).
+struct ImgSrc {               // an image-statistics set: hist = a + b - c (null pointers contribute nothing)
+  const uint32_t* ha; const uint32_t* hb; const uint32_t* hc;
+  uint32_t n; double sum, sq; float mn, mx;
+  __device__ __forceinline__ uint32_t h(int i) const { return (ha ? ha[i] : 0u) + (hb ? hb[i] : 0u) - (hc ? hc[i] : 0u); }
+};
+__device__ __forceinline__ ImgFeats image_feats_src(const ImgSrc& s, int bins) {
+  ImgFeats f;
+  double ent = 0.0;
+#pragma unroll
+  for (int i = 0; i < GLIA_HMT_MAX_BINS; ++i) {
+    if (i < bins) {
+      const double p = s.n ? s.h(i) / (double)s.n : 0.0;
+      if (!(fabs(p - 0.0) < 2.22e-16)) ent -= p * log2(p);
+    }
+  }
+  f.entropy = ent; f.mean = 0.0; f.stddev = 0.0; f.mn = 0.0; f.mx = 0.0;
+  const int ni = (int)s.n;
+  if (ni != 0) {
+    f.mean = s.sum / ni;
+    f.stddev = ssqrt(s.sq / ni - f.mean * f.mean, 0.0);
+    f.mn = (double)s.mn; f.mx = (double)s.mx;
+  }
+  return f;
+}
+struct RegionIn {             // what RegionFeats::generate reads of one region
+  uint32_t n, border; int lo[3], hi[3];
+  ImgSrc pimg;                // statistics over the region's voxels
+  uint32_t bn; uint32_t thr[GLIA_HMT_MAX_THRESH];
+  ImgSrc bimg;                // statistics over its boundary set
+};
+struct RegionOut { double area, perim; ImgFeats rimg; };
+__device__ __forceinline__ void region_feats_direct(const BcCfg& c, const RegionIn& r, double* out, RegionOut& aux) {
+  const int D = c.D, T = c.T;
+  double area = (double)r.n;
+  double perim = (double)((unsigned long long)r.bn + (unsigned long long)r.border);
+  const double compactness = sdiv(pow_perim(perim, D), area, 0.0);
+  area = sdiv(area, c.norm_area, 0.0);
+  perim = sdiv(perim, c.norm_len, 0.0);
+  double bboxArea = 1.0;
+  int k = 4;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    if (i < D) {
+      const double bb = (double)(unsigned long long)(r.hi[i] - r.lo[i]);
+      out[k++] = sdiv(bb, c.norm_len, 0.0);
+      bboxArea *= bb;
+    }
+  }
+  out[0] = area; out[1] = perim; out[2] = compactness; out[3] = sdiv(bboxArea, c.norm_area, 0.0);
+#pragma unroll
+  for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) if (i < T) out[k + i] = sdiv((double)r.thr[i], c.norm_len, 0.0);
+#pragma unroll
+  for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) if (i < T) out[k + T + i] = sdiv((double)r.thr[i], (double)r.bn, 0.0);
+  k += 2 * T;
+  aux.area = area; aux.perim = perim;
+  aux.rimg = image_feats_src(r.pimg, c.bins);           // entropy is shared by the region- and label-image features
+  if (c.n_region) { out[k++] = aux.rimg.entropy; out[k++] = aux.rimg.mean; out[k++] = aux.rimg.stddev; out[k++] = aux.rimg.mn; out[k++] = aux.rimg.mx; }
+  if (c.n_rlabel) out[k++] = aux.rimg.entropy;
+  if (c.n_boundary) {
+    const ImgFeats f = image_feats_src(r.bimg, c.bins);
+    out[k++] = f.entropy; out[k++] = f.mean; out[k++] = f.stddev; out[k++] = f.mn; out[k++] = f.mx;
+  }
+}
+
+// sh: shared boundary set (thresholds + image statistics); h0/n0, h1/n1: voxel histograms of the area-ordered regions
+__device__ __forceinline__ void boundary_feats_direct(const BcCfg& c, uint32_t shn, const uint32_t* shthr, const ImgSrc& shimg,
+                                                      const RegionOut& a0, const RegionOut& a1, const uint32_t* h0, uint32_t n0,
+                                                      const uint32_t* h1, uint32_t n1, double* out) {
+  const int T = c.T;
+  int k = 0;
+  const double areaDiff = fabs(a0.area - a1.area);
+  out[k++] = areaDiff; out[k++] = sdiv(areaDiff, a0.area, 0.0); out[k++] = sdiv(areaDiff, a1.area, 0.0);
+  const double perimDiff = fabs(a0.perim - a1.perim);
+  out[k++] = perimDiff; out[k++] = sdiv(perimDiff, a0.perim, 0.0); out[k++] = sdiv(perimDiff, a1.perim, 0.0);
+  const double bl = sdiv(ceil(shn / 2.0), c.norm_len, 0.0);
+  out[k++] = bl; out[k++] = sdiv(bl, a0.area, 0.0); out[k++] = sdiv(bl, a1.area, 0.0);
+  out[k++] = sdiv(bl, a0.perim, 0.0); out[k++] = sdiv(bl, a1.perim, 0.0);
+#pragma unroll
+  for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) {
+    if (i < T) {
+      const double vbl = sdiv(ceil(shthr[i] / 2.0), c.norm_len, 0.0);
+      out[k + i] = vbl; out[k + T + i] = sdiv(vbl, bl, 0.0);
+      out[k + 2 * T + i] = sdiv(vbl, a0.perim, 0.0); out[k + 3 * T + i] = sdiv(vbl, a1.perim, 0.0);
+    }
+  }
+  k += 4 * T;
+  if (c.n_region || c.n_rlabel) {
+    double l1 = 0.0, x2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < GLIA_HMT_MAX_BINS; ++i) {
+      if (i < c.bins) {
+        const double p0 = n0 ? h0[i] / (double)n0 : 0.0, p1 = n1 ? h1[i] / (double)n1 : 0.0;
+        const double d = p0 - p1;
+        l1 += fabs(d);
+        x2 += (d * d) / (p0 + p1 + 2.22e-16);
+      }
+    }
+    if (c.n_region) {
+      out[k++] = l1; out[k++] = x2; out[k++] = fabs(a0.rimg.entropy - a1.rimg.entropy);
+      out[k++] = fabs(a0.rimg.mean - a1.rimg.mean); out[k++] = fabs(a0.rimg.stddev - a1.rimg.stddev);
+      out[k++] = fabs(a0.rimg.mn - a1.rimg.mn); out[k++] = fabs(a0.rimg.mx - a1.rimg.mx);
+    }
+    if (c.n_rlabel) { out[k++] = l1; out[k++] = x2; out[k++] = fabs(a0.rimg.entropy - a1.rimg.entropy); }
+  }
+  if (c.n_boundary) {
+    const ImgFeats f = image_feats_src(shimg, c.bins);
+    out[k++] = f.entropy; out[k++] = f.mean; out[k++] = f.stddev; out[k++] = f.mn; out[k++] = f.mx;
+  }
+}
+
+// log() and selectFeatures applied in place to a vector laid out as [boundary | region 0 | region 1 | merged]
+__device__ __forceinline__ void finish_features(const BcCfg& c, double* out) {
+  if (c.use_log) {
+    boundary_log(c, out);
+    region_log(c, out + c.bfdim); region_log(c, out + c.bfdim + c.rfdim); region_log(c, out + c.bfdim + 2 * c.rfdim);
+  }
+  if (c.use_simple) {   // hmt/bc_feat.hxx:247-279; every source index lies beyond the slot it is copied to
+    const double* bf = out; const double* x1 = out + c.bfdim; const double* x2 = out + c.bfdim + c.rfdim;
+    const double v0 = x1[0], v1 = x2[0], v2 = x1[1], v3 = x2[1], v4 = bf[6];
+    const int bimg = 11 + 4 * c.T + 7 * c.n_region + 3 * c.n_rlabel, r = 11 + 4 * c.T, rl = 11 + 4 * c.T + 7 * c.n_region;
+    const double b1 = c.n_boundary ? bf[bimg + 1] : 0.0;
+    const double g3 = c.n_region ? bf[r + 3] : 0.0, g0 = c.n_region ? bf[r + 0] : 0.0, g1 = c.n_region ? bf[r + 1] : 0.0, g2 = c.n_region ? bf[r + 2] : 0.0;
+    const double l0 = c.n_rlabel ? bf[rl + 0] : 0.0, l1 = c.n_rlabel ? bf[rl + 1] : 0.0;
+    int k = 0;
+    out[k++] = v0; out[k++] = v1; out[k++] = v2; out[k++] = v3; out[k++] = v4;
+    if (c.n_boundary) out[k++] = b1;
+    if (c.n_region) { out[k++] = g3; out[k++] = g0; out[k++] = g1; out[k++] = g2; }
+    if (c.n_rlabel) { out[k++] = l0; out[k++] = l1; }
+  }
 }
 
 }  // namespace feat

@@ -109,27 +109,84 @@ __device__ void excl_minmax(const BcState& st, uint32_t r, uint32_t skip, float&
   }
 }
 
-// feature vector of record rec (regions `first`, `second` in the reference's orientation)
+// feature vector of record rec (regions `first`, `second` in the reference's orientation); `out` must hold
+// bc_full_dim doubles (the simple selection is compacted in place).  No private arrays: see bc_features.hpp.
 __device__ void edge_features(const BcState& st, uint32_t first, uint32_t second, uint32_t rec, float ex0mn, float ex0mx,
                               float ex1mn, float ex1mx, double* out) {
-  EStats b0 = st.Bt[first], b1 = st.Bt[second];
-  b0.mn = st.Bmn[first]; b0.mx = st.Bmx[first];
-  b1.mn = st.Bmn[second]; b1.mx = st.Bmx[second];
-  PStats p2 = st.pts[first];
-  pstats_add(p2, st.pts[second]);
-  EStats b2 = st.Bt[first];
-  estats_add(b2, st.Bt[second]);
-  b2.mn = fminf(ex0mn, ex1mn); b2.mx = fmaxf(ex0mx, ex1mx);
+#ifdef GLIA_HMT_PROFILE
+  const unsigned long long tq_in = __builtin_readcyclecounter();
+#endif
+  const BcCfg& c = st.cfg;
+  const PStats* P0 = &st.pts[first];
+  const PStats* P1 = &st.pts[second];
+  const EStats* B0 = &st.Bt[first];
+  const EStats* B1 = &st.Bt[second];
+  const EStats* A = rec != kNone ? &st.e_A[rec] : nullptr;     // kNone: no shared record (bc_feat on non-neighbours)
+  // shared boundary: mutual entries + always-alive non-mutual ones + the fragile ones whose target leaf is still alive
   EStats sh;
   estats_clear(sh);
-  if (rec != kNone) {      // kNone: the two regions share no record (bc_feat on an order that merges non-neighbours)
-    estats_sub_additive(b2, st.e_A[rec]);
-    sh = st.e_A[rec];
+  if (rec != kNone) {
+    sh = *A;
     estats_add(sh, st.e_NA[rec]);
     for (uint32_t f = st.e_fhead[rec]; f != kNone; f = st.le_next[f])
       if (leaf_alive(st, st.le_dst[f])) estats_add(sh, st.le_stats[f]);
   }
-  feat::bc_features(st.cfg, st.pts[first], b0, st.pts[second], b1, p2, b2, sh, out);
+  const uint32_t n0 = P0->n, n1 = P1->n;
+  // keep region 0 area <= region 1 area (main_merge_order_bc.cxx:77-80): decides the slots of the two region blocks
+  const bool swap = feat::sdiv((double)n0, c.norm_area, 0.0) > feat::sdiv((double)n1, c.norm_area, 0.0);
+  double* o_bf = out;
+  double* o_first = out + c.bfdim + (swap ? c.rfdim : 0);
+  double* o_second = out + c.bfdim + (swap ? 0 : c.rfdim);
+  double* o_merged = out + c.bfdim + 2 * c.rfdim;
+  feat::RegionOut a_first, a_second, a_merged;
+  {
+    feat::RegionIn r;
+    r.n = n0; r.border = P0->border;
+    for (int i = 0; i < 3; ++i) { r.lo[i] = P0->lo[i]; r.hi[i] = P0->hi[i]; }
+    r.pimg = feat::ImgSrc{P0->hist, nullptr, nullptr, n0, P0->sum, P0->sq, P0->mn, P0->mx};
+    r.bn = B0->n;
+    for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) r.thr[i] = B0->thr[i];
+    r.bimg = feat::ImgSrc{B0->hist, nullptr, nullptr, B0->n, B0->sum, B0->sq, st.Bmn[first], st.Bmx[first]};
+    feat::region_feats_direct(c, r, o_first, a_first);
+  }
+  {
+    feat::RegionIn r;
+    r.n = n1; r.border = P1->border;
+    for (int i = 0; i < 3; ++i) { r.lo[i] = P1->lo[i]; r.hi[i] = P1->hi[i]; }
+    r.pimg = feat::ImgSrc{P1->hist, nullptr, nullptr, n1, P1->sum, P1->sq, P1->mn, P1->mx};
+    r.bn = B1->n;
+    for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) r.thr[i] = B1->thr[i];
+    r.bimg = feat::ImgSrc{B1->hist, nullptr, nullptr, B1->n, B1->sum, B1->sq, st.Bmn[second], st.Bmx[second]};
+    feat::region_feats_direct(c, r, o_second, a_second);
+  }
+  {
+    // the scratch-merged region (TRegionMap::merge under key 0): voxel sets add, boundary sets add minus the mutual
+    // entries of the shared record
+    feat::RegionIn r;
+    r.n = n0 + n1; r.border = P0->border + P1->border;
+    for (int i = 0; i < 3; ++i) { r.lo[i] = P0->lo[i] < P1->lo[i] ? P0->lo[i] : P1->lo[i]; r.hi[i] = P0->hi[i] > P1->hi[i] ? P0->hi[i] : P1->hi[i]; }
+    r.pimg = feat::ImgSrc{P0->hist, P1->hist, nullptr, n0 + n1, P0->sum + P1->sum, P0->sq + P1->sq,
+                          P1->mn < P0->mn ? P1->mn : P0->mn, P1->mx > P0->mx ? P1->mx : P0->mx};
+    uint32_t bn = B0->n + B1->n;
+    double bsum = B0->sum + B1->sum, bsq = B0->sq + B1->sq;
+    for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) r.thr[i] = B0->thr[i] + B1->thr[i];
+    if (A) {
+      bn -= A->n; bsum -= A->sum; bsq -= A->sq;
+      for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) r.thr[i] -= A->thr[i];
+    }
+    r.bn = bn;
+    r.bimg = feat::ImgSrc{B0->hist, B1->hist, A ? A->hist : nullptr, bn, bsum, bsq, fminf(ex0mn, ex1mn), fmaxf(ex0mx, ex1mx)};
+    feat::region_feats_direct(c, r, o_merged, a_merged);
+  }
+  {
+    const feat::ImgSrc shimg{sh.hist, nullptr, nullptr, sh.n, sh.sum, sh.sq, sh.mn, sh.mx};
+    if (swap) feat::boundary_feats_direct(c, sh.n, sh.thr, shimg, a_second, a_first, P1->hist, n1, P0->hist, n0, o_bf);
+    else feat::boundary_feats_direct(c, sh.n, sh.thr, shimg, a_first, a_second, P0->hist, n0, P1->hist, n1, o_bf);
+  }
+  feat::finish_features(c, out);
+#ifdef GLIA_HMT_PROFILE
+  if (threadIdx.x == 0) { g_pqprof[25] += __builtin_readcyclecounter() - tq_in; g_pqprof[26] += 1; }
+#endif
 }
 
 __device__ __forceinline__ int forest_vote(const DeviceForest& f, int tree, const double* x) {
@@ -284,6 +341,7 @@ struct BcShared {
   uint32_t ex[4];
   int votes[kChunk];
   int model[kChunk];
+  float exmn[kChunk], exmx[kChunk];   // per new record: min / max of rs's boundary set without what it sends along the record
   double feat[kFeatDoubles];          // feature vectors of the chunk being scored, stride fdim
   PqWork pq;
 };
@@ -489,19 +547,43 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
 
     PH(3);
     // ---- score the new table edges: features (one thread per edge) -> forest ((edge, tree) per thread) ----
-    const uint32_t chunk = min((uint32_t)kChunk, (uint32_t)(kFeatDoubles / fdim));
+    const int fstride = bc_full_dim(st.cfg);      // vectors are assembled at full length, the simple selection is compacted in place
+    const uint32_t chunk = min((uint32_t)kChunk, (uint32_t)(kFeatDoubles / fstride));
     for (uint32_t c0 = 0; c0 < (forced ? 0u : newcount); c0 += chunk) {
       const uint32_t cn = min(chunk, newcount - c0);
+      {
+        // excl_minmax of every new record's neighbour region, 16 lanes per record: the scan of rs's incident list is
+        // a chain of dependent loads per entry, far too slow for the one thread that assembles the feature vector
+        const uint32_t sub = (uint32_t)tid >> 4, l16 = (uint32_t)tid & 15u;
+        for (uint32_t j = sub; j < cn; j += kBcThreads / 16) {
+          const uint32_t rec = (uint32_t)ne + c0 + j;
+          float mn = __builtin_inff(), mx = -__builtin_inff();
+          if (st.e_table[rec]) {
+            const uint32_t rs = st.e_u[rec];
+            const uint32_t off = st.adj_off[rs], len = st.adj_len[rs];
+            for (uint32_t i = l16; i < len; i += 16) {
+              const uint32_t e2 = st.pool[off + i];
+              if (e2 == rec || !st.e_alive[e2]) continue;
+              const float* d = &st.e_dir[(size_t)e2 * 4 + (st.e_u[e2] == rs ? 0 : 2)];
+              mn = fminf(mn, d[0]); mx = fmaxf(mx, d[1]);
+            }
+            if (l16 == 0) { mn = fminf(mn, st.Bn[rs].mn); mx = fmaxf(mx, st.Bn[rs].mx); }
+          }
+#pragma unroll
+          for (int o = 8; o >= 1; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o, 16)); mx = fmaxf(mx, __shfl_xor(mx, o, 16)); }
+          if (l16 == 0) { s.exmn[j] = mn; s.exmx[j] = mx; }
+        }
+      }
+      __syncthreads();
       if ((uint32_t)tid < cn) {
         const uint32_t rec = (uint32_t)ne + c0 + tid;
         s.votes[tid] = 0; s.model[tid] = -1;
         if (st.e_table[rec]) {
           const uint32_t rs = st.e_u[rec];
-          float a, b;
-          excl_minmax(st, rs, rec, a, b);
+          const float a = s.exmn[tid], b = s.exmx[tid];
           const float c = fminf(bnmn, rec == arg_mn ? second_mn : best_mn);
           const float d = fmaxf(bnmx, rec == arg_mx ? second_mx : best_mx);
-          double* x = &s.feat[tid * fdim];
+          double* x = &s.feat[tid * fstride];
           edge_features(st, rs, r2, rec, a, b, c, d, x);        // updateFb passes (rs, r2)
           s.model[tid] = st.clf.kind == 1 ? 0 : pick_model(st.clf, x);
         }
@@ -514,14 +596,14 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
           const uint32_t j = i / ntree, t = i % ntree;
           const int m = s.model[j];
           if (m < 0) continue;
-          if (forest_vote(st.clf.f[m], (int)t, &s.feat[j * fdim])) atomicAdd(&s.votes[j], 1);
+          if (forest_vote(st.clf.f[m], (int)t, &s.feat[j * fstride])) atomicAdd(&s.votes[j], 1);
         }
       }
       __syncthreads();
       PH(5);
       if ((uint32_t)tid < cn && s.model[tid] >= 0) {
         const uint32_t rec = (uint32_t)ne + c0 + tid;
-        const double sal = st.clf.kind == 1 ? 1.0 - s.feat[tid * fdim + st.clf.stub_index]
+        const double sal = st.clf.kind == 1 ? 1.0 - s.feat[tid * fstride + st.clf.stub_index]
                                             : (double)s.votes[tid] / (double)st.clf.f[s.model[tid]].ntree;
         const uint32_t cat = st.e_posv[rec] >> 30;
         st.pq.leaf_sal[rec] = sal;
@@ -539,6 +621,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
   }
   if (tid == 0) { st.ctrl[0] = k; st.ctrl[1] = ne; st.ctrl[2] = pool_used; st.ctrl[3] = status; }
 #ifdef GLIA_HMT_PROFILE
+  if (tid == 0) printf("[bc profile] edge_features of thread 0: gather %llu  bc_features %llu  calls %llu (cycles)\n", g_pqprof[24], g_pqprof[25], g_pqprof[26]);
   if (tid == 0) printf("[bc profile] merges %llu: pop+feats_out %llu  region+mark %llu  build %llu  top2 %llu  features %llu  forest %llu  pq %llu  loop-top %llu (cycles)\n", k, tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], tph[6], tph[7]);
 #endif
 }
