@@ -261,16 +261,20 @@ __device__ inline void bc_features(const BcCfg& c, const PStats& p0, const EStat
 struct ImgSrc {               // an image-statistics set: hist = a + b - c (null pointers contribute nothing)
   const uint32_t* ha; const uint32_t* hb; const uint32_t* hc;
   uint32_t n; double sum, sq; float mn, mx;
+  const double* ent;          // entropy computed beforehand (lane-parallel pass of the greedy loop), or null
   __device__ __forceinline__ uint32_t h(int i) const { return (ha ? ha[i] : 0u) + (hb ? hb[i] : 0u) - (hc ? hc[i] : 0u); }
 };
 __device__ __forceinline__ ImgFeats image_feats_src(const ImgSrc& s, int bins) {
   ImgFeats f;
   double ent = 0.0;
+  if (s.ent) ent = *s.ent;
+  else {
 #pragma unroll
-  for (int i = 0; i < GLIA_HMT_MAX_BINS; ++i) {
-    if (i < bins) {
-      const double p = s.n ? s.h(i) / (double)s.n : 0.0;
-      if (!(fabs(p - 0.0) < 2.22e-16)) ent -= p * log2(p);
+    for (int i = 0; i < GLIA_HMT_MAX_BINS; ++i) {
+      if (i < bins) {
+        const double p = s.n ? s.h(i) / (double)s.n : 0.0;
+        if (!(fabs(p - 0.0) < 2.22e-16)) ent -= p * log2(p);
+      }
     }
   }
   f.entropy = ent; f.mean = 0.0; f.stddev = 0.0; f.mn = 0.0; f.mx = 0.0;
@@ -325,7 +329,7 @@ __device__ __forceinline__ void region_feats_direct(const BcCfg& c, const Region
 // sh: shared boundary set (thresholds + image statistics); h0/n0, h1/n1: voxel histograms of the area-ordered regions
 __device__ __forceinline__ void boundary_feats_direct(const BcCfg& c, uint32_t shn, const uint32_t* shthr, const ImgSrc& shimg,
                                                       const RegionOut& a0, const RegionOut& a1, const uint32_t* h0, uint32_t n0,
-                                                      const uint32_t* h1, uint32_t n1, double* out) {
+                                                      const uint32_t* h1, uint32_t n1, const double* l1x2, double* out) {
   const int T = c.T;
   int k = 0;
   const double areaDiff = fabs(a0.area - a1.area);
@@ -346,13 +350,16 @@ __device__ __forceinline__ void boundary_feats_direct(const BcCfg& c, uint32_t s
   k += 4 * T;
   if (c.n_region || c.n_rlabel) {
     double l1 = 0.0, x2 = 0.0;
+    if (l1x2) { l1 = l1x2[0]; x2 = l1x2[1]; }
+    else {
 #pragma unroll
-    for (int i = 0; i < GLIA_HMT_MAX_BINS; ++i) {
-      if (i < c.bins) {
-        const double p0 = n0 ? h0[i] / (double)n0 : 0.0, p1 = n1 ? h1[i] / (double)n1 : 0.0;
-        const double d = p0 - p1;
-        l1 += fabs(d);
-        x2 += (d * d) / (p0 + p1 + 2.22e-16);
+      for (int i = 0; i < GLIA_HMT_MAX_BINS; ++i) {
+        if (i < c.bins) {
+          const double p0 = n0 ? h0[i] / (double)n0 : 0.0, p1 = n1 ? h1[i] / (double)n1 : 0.0;
+          const double d = p0 - p1;
+          l1 += fabs(d);
+          x2 += (d * d) / (p0 + p1 + 2.22e-16);
+        }
       }
     }
     if (c.n_region) {
@@ -366,6 +373,18 @@ __device__ __forceinline__ void boundary_feats_direct(const BcCfg& c, uint32_t s
     const ImgFeats f = image_feats_src(shimg, c.bins);
     out[k++] = f.entropy; out[k++] = f.mean; out[k++] = f.stddev; out[k++] = f.mn; out[k++] = f.mx;
   }
+}
+
+// one bin's term of an entropy sum / of the two histogram distances (the lane-parallel pass adds them in bin order)
+__device__ __forceinline__ double entropy_term(uint32_t cnt, uint32_t n) {
+  const double p = n ? cnt / (double)n : 0.0;
+  return (fabs(p - 0.0) < 2.22e-16) ? 0.0 : p * log2(p);
+}
+__device__ __forceinline__ void dist_terms(uint32_t c0, uint32_t n0, uint32_t c1, uint32_t n1, double& tl, double& tx) {
+  const double p0 = n0 ? c0 / (double)n0 : 0.0, p1 = n1 ? c1 / (double)n1 : 0.0;
+  const double d = p0 - p1;
+  tl = fabs(d);
+  tx = (d * d) / (p0 + p1 + 2.22e-16);
 }
 
 // log() and selectFeatures applied in place to a vector laid out as [boundary | region 0 | region 1 | merged]

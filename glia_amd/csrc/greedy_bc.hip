@@ -36,8 +36,8 @@
 namespace glia {
 
 constexpr int kBcThreads = 1024;
-constexpr int kChunk = 128;             // new edges scored per round (their feature vectors live in LDS)
-constexpr int kFeatDoubles = 128 * 104;  // LDS budget for them: 104 KiB (128 edges at the usual D_f = 104)
+constexpr int kChunk = 96;              // new edges scored per round (their feature vectors live in LDS)
+constexpr int kFeatDoubles = 96 * 104;   // LDS budget for them: 104 KiB (128 edges at the usual D_f = 104)
 
 struct BcState {
   uint32_t R0;
@@ -67,7 +67,10 @@ struct BcState {
   uint32_t* nm_out;              // [R0] non-mutual out-entries per leaf
   uint32_t *mark0, *mark1;       // [2*R0]
   uint32_t* order; double* sal_out; double* feats_out;
-  double* featbuf;               // [kChunk][fdim]
+  double* featbuf;               // [kChunk][full feature dim]: the chunk's vectors for the helper workgroups
+  uint32_t* hctl;                // helper protocol: [0] job sequence (0xFFFFFFFF = quit), [1] helpers done, [2] records in the job
+  int* hvotes; int* hmodel;      // [kChunk]
+  uint32_t n_helpers;            // workgroups 1..n_helpers evaluate the forest; 0 = the loop's own workgroup does
   unsigned long long* ctrl;
   unsigned long long max_iters;
   const uint32_t* forced;        // bc_feat mode: [forced_n][2] region pairs to merge, in this order (no queue, no scoring)
@@ -111,8 +114,19 @@ __device__ void excl_minmax(const BcState& st, uint32_t r, uint32_t skip, float&
 
 // feature vector of record rec (regions `first`, `second` in the reference's orientation); `out` must hold
 // bc_full_dim doubles (the simple selection is compacted in place).  No private arrays: see bc_features.hpp.
+// pre (optional): [0..6] entropies of first.voxels, first.boundary, second.voxels, second.boundary, merged.voxels,
+// merged.boundary, shared boundary; [7], [8] the L1 / chi-square histogram distances; sh_pre (optional): the shared set
+__device__ void shared_boundary(const BcState& st, uint32_t rec, EStats& sh) {
+  estats_clear(sh);
+  if (rec != kNone) {
+    sh = st.e_A[rec];
+    estats_add(sh, st.e_NA[rec]);
+    for (uint32_t f = st.e_fhead[rec]; f != kNone; f = st.le_next[f])
+      if (leaf_alive(st, st.le_dst[f])) estats_add(sh, st.le_stats[f]);
+  }
+}
 __device__ void edge_features(const BcState& st, uint32_t first, uint32_t second, uint32_t rec, float ex0mn, float ex0mx,
-                              float ex1mn, float ex1mx, double* out) {
+                              float ex1mn, float ex1mx, double* out, const double* pre = nullptr, const EStats* sh_pre = nullptr) {
 #ifdef GLIA_HMT_PROFILE
   const unsigned long long tq_in = __builtin_readcyclecounter();
 #endif
@@ -123,14 +137,9 @@ __device__ void edge_features(const BcState& st, uint32_t first, uint32_t second
   const EStats* B1 = &st.Bt[second];
   const EStats* A = rec != kNone ? &st.e_A[rec] : nullptr;     // kNone: no shared record (bc_feat on non-neighbours)
   // shared boundary: mutual entries + always-alive non-mutual ones + the fragile ones whose target leaf is still alive
-  EStats sh;
-  estats_clear(sh);
-  if (rec != kNone) {
-    sh = *A;
-    estats_add(sh, st.e_NA[rec]);
-    for (uint32_t f = st.e_fhead[rec]; f != kNone; f = st.le_next[f])
-      if (leaf_alive(st, st.le_dst[f])) estats_add(sh, st.le_stats[f]);
-  }
+  EStats sh_local;
+  if (!sh_pre) shared_boundary(st, rec, sh_local);
+  const EStats& sh = sh_pre ? *sh_pre : sh_local;
   const uint32_t n0 = P0->n, n1 = P1->n;
   // keep region 0 area <= region 1 area (main_merge_order_bc.cxx:77-80): decides the slots of the two region blocks
   const bool swap = feat::sdiv((double)n0, c.norm_area, 0.0) > feat::sdiv((double)n1, c.norm_area, 0.0);
@@ -143,20 +152,20 @@ __device__ void edge_features(const BcState& st, uint32_t first, uint32_t second
     feat::RegionIn r;
     r.n = n0; r.border = P0->border;
     for (int i = 0; i < 3; ++i) { r.lo[i] = P0->lo[i]; r.hi[i] = P0->hi[i]; }
-    r.pimg = feat::ImgSrc{P0->hist, nullptr, nullptr, n0, P0->sum, P0->sq, P0->mn, P0->mx};
+    r.pimg = feat::ImgSrc{P0->hist, nullptr, nullptr, n0, P0->sum, P0->sq, P0->mn, P0->mx, pre ? pre + 0 : nullptr};
     r.bn = B0->n;
     for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) r.thr[i] = B0->thr[i];
-    r.bimg = feat::ImgSrc{B0->hist, nullptr, nullptr, B0->n, B0->sum, B0->sq, st.Bmn[first], st.Bmx[first]};
+    r.bimg = feat::ImgSrc{B0->hist, nullptr, nullptr, B0->n, B0->sum, B0->sq, st.Bmn[first], st.Bmx[first], pre ? pre + 1 : nullptr};
     feat::region_feats_direct(c, r, o_first, a_first);
   }
   {
     feat::RegionIn r;
     r.n = n1; r.border = P1->border;
     for (int i = 0; i < 3; ++i) { r.lo[i] = P1->lo[i]; r.hi[i] = P1->hi[i]; }
-    r.pimg = feat::ImgSrc{P1->hist, nullptr, nullptr, n1, P1->sum, P1->sq, P1->mn, P1->mx};
+    r.pimg = feat::ImgSrc{P1->hist, nullptr, nullptr, n1, P1->sum, P1->sq, P1->mn, P1->mx, pre ? pre + 2 : nullptr};
     r.bn = B1->n;
     for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) r.thr[i] = B1->thr[i];
-    r.bimg = feat::ImgSrc{B1->hist, nullptr, nullptr, B1->n, B1->sum, B1->sq, st.Bmn[second], st.Bmx[second]};
+    r.bimg = feat::ImgSrc{B1->hist, nullptr, nullptr, B1->n, B1->sum, B1->sq, st.Bmn[second], st.Bmx[second], pre ? pre + 3 : nullptr};
     feat::region_feats_direct(c, r, o_second, a_second);
   }
   {
@@ -166,7 +175,7 @@ __device__ void edge_features(const BcState& st, uint32_t first, uint32_t second
     r.n = n0 + n1; r.border = P0->border + P1->border;
     for (int i = 0; i < 3; ++i) { r.lo[i] = P0->lo[i] < P1->lo[i] ? P0->lo[i] : P1->lo[i]; r.hi[i] = P0->hi[i] > P1->hi[i] ? P0->hi[i] : P1->hi[i]; }
     r.pimg = feat::ImgSrc{P0->hist, P1->hist, nullptr, n0 + n1, P0->sum + P1->sum, P0->sq + P1->sq,
-                          P1->mn < P0->mn ? P1->mn : P0->mn, P1->mx > P0->mx ? P1->mx : P0->mx};
+                          P1->mn < P0->mn ? P1->mn : P0->mn, P1->mx > P0->mx ? P1->mx : P0->mx, pre ? pre + 4 : nullptr};
     uint32_t bn = B0->n + B1->n;
     double bsum = B0->sum + B1->sum, bsq = B0->sq + B1->sq;
     for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) r.thr[i] = B0->thr[i] + B1->thr[i];
@@ -175,13 +184,14 @@ __device__ void edge_features(const BcState& st, uint32_t first, uint32_t second
       for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) r.thr[i] -= A->thr[i];
     }
     r.bn = bn;
-    r.bimg = feat::ImgSrc{B0->hist, B1->hist, A ? A->hist : nullptr, bn, bsum, bsq, fminf(ex0mn, ex1mn), fmaxf(ex0mx, ex1mx)};
+    r.bimg = feat::ImgSrc{B0->hist, B1->hist, A ? A->hist : nullptr, bn, bsum, bsq, fminf(ex0mn, ex1mn), fmaxf(ex0mx, ex1mx), pre ? pre + 5 : nullptr};
     feat::region_feats_direct(c, r, o_merged, a_merged);
   }
   {
-    const feat::ImgSrc shimg{sh.hist, nullptr, nullptr, sh.n, sh.sum, sh.sq, sh.mn, sh.mx};
-    if (swap) feat::boundary_feats_direct(c, sh.n, sh.thr, shimg, a_second, a_first, P1->hist, n1, P0->hist, n0, o_bf);
-    else feat::boundary_feats_direct(c, sh.n, sh.thr, shimg, a_first, a_second, P0->hist, n0, P1->hist, n1, o_bf);
+    const feat::ImgSrc shimg{sh.hist, nullptr, nullptr, sh.n, sh.sum, sh.sq, sh.mn, sh.mx, pre ? pre + 6 : nullptr};
+    const double* l1x2 = pre ? pre + 7 : nullptr;          // both distances are symmetric in the two regions
+    if (swap) feat::boundary_feats_direct(c, sh.n, sh.thr, shimg, a_second, a_first, P1->hist, n1, P0->hist, n0, l1x2, o_bf);
+    else feat::boundary_feats_direct(c, sh.n, sh.thr, shimg, a_first, a_second, P0->hist, n0, P1->hist, n1, l1x2, o_bf);
   }
   feat::finish_features(c, out);
 #ifdef GLIA_HMT_PROFILE
@@ -341,14 +351,71 @@ struct BcShared {
   uint32_t ex[4];
   int votes[kChunk];
   int model[kChunk];
-  float exmn[kChunk], exmx[kChunk];   // per new record: min / max of rs's boundary set without what it sends along the record
+  float exmn[kChunk], exmx[kChunk];
+  EStats shs[kChunk];                 // shared boundary set of every record of the chunk
+  double fx[kChunk][9];               // its seven entropies and two histogram distances (lane-parallel pass)   // per new record: min / max of rs's boundary set without what it sends along the record
   double feat[kFeatDoubles];          // feature vectors of the chunk being scored, stride fdim
   PqWork pq;
 };
 
+constexpr unsigned long long kHelperSpinLimit = 1ull << 27;     // polls (with s_sleep) before a side gives up: ~60 s
+
+__device__ __forceinline__ uint32_t ld_relaxed(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void fence_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+__device__ __forceinline__ void st_release(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Forest evaluation on the rest of the chip.  The contraction loop is one workgroup; scoring its new records is a
+// gather over ~100 records x 255 trees x ~12 levels that a single CU can only run at its own load-issue rate.  Helper
+// workgroups wait for a job (the chunk's feature vectors in global memory), take the records h, h + H, ... and walk one
+// tree per thread.  Hand-off in both directions is release/acquire at agent scope (the XCDs' L2s are not coherent).
+__device__ void bc_helper_loop(const BcState& st, BcShared& s) {
+  const int tid = threadIdx.x;
+  const uint32_t H = gridDim.x - 1u, h = blockIdx.x - 1u;
+  const int fstride = bc_full_dim(st.cfg);
+  uint32_t last = 0;
+  for (;;) {
+    if (tid == 0) {
+      uint32_t v = last;
+      // poll relaxed (an acquire per poll would invalidate the XCD's caches every time), acquire once it changed
+      for (unsigned long long spins = 0; spins < kHelperSpinLimit; ++spins) {
+        v = ld_relaxed(&st.hctl[0]);
+        if (v != last) break;
+        __builtin_amdgcn_s_sleep(4);
+      }
+      fence_acquire();
+      s.ex[0] = v;
+    }
+    __syncthreads();
+    const uint32_t v = s.ex[0];
+    if (v == last || v == 0xFFFFFFFFu) return;          // gave up waiting / the loop is over
+    last = v;
+    const uint32_t cn = st.hctl[2];
+    if (h >= cn) continue;                              // nothing for this workgroup in the job: it does not report either
+    for (uint32_t j = h; j < cn; j += H) {
+      const int m = st.hmodel[j];
+      if (m < 0) continue;
+      for (int i = tid; i < fstride; i += kBcThreads) s.feat[i] = st.featbuf[(size_t)j * fstride + i];
+      if (tid == 0) s.votes[0] = 0;
+      __syncthreads();
+      const DeviceForest& f = st.clf.f[m];
+      int mine = 0;
+      for (int t = tid; t < f.ntree; t += kBcThreads) mine += forest_vote(f, t, s.feat);
+      if (mine) atomicAdd(&s.votes[0], mine);
+      __syncthreads();
+      if (tid == 0) st.hvotes[j] = s.votes[0];
+      __syncthreads();
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(&st.hctl[1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
   __shared__ BcShared s;
+  if (blockIdx.x != 0) { bc_helper_loop(st, s); return; }
   const int tid = threadIdx.x;
+  uint32_t hseq = 0;
   unsigned long long k = st.ctrl[0], ne = st.ctrl[1], pool_used = st.ctrl[2];
   uint32_t status = ST_RUN;
   const int fdim = st.cfg.fdim;
@@ -357,7 +424,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
   __syncthreads();
 
 #ifdef GLIA_HMT_PROFILE
-  unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+  unsigned long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
 #define PH(i) do { if (tid == 0) { unsigned long long tn = __builtin_readcyclecounter(); tph[i] += tn - tlast; tlast = tn; } } while (0)
 #else
 #define PH(i) do {} while (0)
@@ -574,7 +641,53 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
           if (l16 == 0) { s.exmn[j] = mn; s.exmx[j] = mx; }
         }
       }
+      PH(8);
+      if ((uint32_t)tid < cn) {
+        const uint32_t rec = (uint32_t)ne + c0 + tid;
+        if (st.e_table[rec]) shared_boundary(st, rec, s.shs[tid]);
+      }
       __syncthreads();
+      PH(9);
+      {
+        // entropies and histogram distances, one lane per bin (16 lanes per record): the fifty-odd log2 and divisions of a
+        // vector are by far its longest serial stretch.  Lane 0 adds the bins' terms in bin order, as the reference does.
+        const uint32_t sub = (uint32_t)tid >> 4, l16 = (uint32_t)tid & 15u;
+        const int bins = st.cfg.bins;
+        for (uint32_t j = sub; j < cn; j += kBcThreads / 16) {
+          const uint32_t rec = (uint32_t)ne + c0 + j;
+          const bool on = st.e_table[rec] != 0;              // uniform over the 16 lanes
+          double t[7], tl = 0.0, tx = 0.0;
+#pragma unroll
+          for (int q = 0; q < 7; ++q) t[q] = 0.0;
+          if (on && (int)l16 < bins) {
+            const uint32_t rs = st.e_u[rec];
+            const PStats* P0 = &st.pts[rs]; const PStats* P1 = &st.pts[r2];
+            const EStats* B0 = &st.Bt[rs]; const EStats* B1 = &st.Bt[r2];
+            const EStats* A = &st.e_A[rec];
+            const uint32_t h0 = P0->hist[l16], h1 = P1->hist[l16], g0 = B0->hist[l16], g1 = B1->hist[l16];
+            t[0] = feat::entropy_term(h0, P0->n); t[1] = feat::entropy_term(g0, B0->n);
+            t[2] = feat::entropy_term(h1, P1->n); t[3] = feat::entropy_term(g1, B1->n);
+            t[4] = feat::entropy_term(h0 + h1, P0->n + P1->n);
+            t[5] = feat::entropy_term(g0 + g1 - A->hist[l16], B0->n + B1->n - A->n);
+            t[6] = feat::entropy_term(s.shs[j].hist[l16], s.shs[j].n);
+            feat::dist_terms(h0, P0->n, h1, P1->n, tl, tx);
+          }
+          double acc[9];
+#pragma unroll
+          for (int q = 0; q < 9; ++q) acc[q] = 0.0;
+          for (int b = 0; b < bins; ++b) {
+#pragma unroll
+            for (int q = 0; q < 7; ++q) acc[q] -= __shfl(t[q], b, 16);
+            acc[7] += __shfl(tl, b, 16); acc[8] += __shfl(tx, b, 16);
+          }
+          if (l16 == 0) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) s.fx[j][q] = acc[q];
+          }
+        }
+      }
+      __syncthreads();
+      PH(10);
       if ((uint32_t)tid < cn) {
         const uint32_t rec = (uint32_t)ne + c0 + tid;
         s.votes[tid] = 0; s.model[tid] = -1;
@@ -584,13 +697,32 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
           const float c = fminf(bnmn, rec == arg_mn ? second_mn : best_mn);
           const float d = fmaxf(bnmx, rec == arg_mx ? second_mx : best_mx);
           double* x = &s.feat[tid * fstride];
-          edge_features(st, rs, r2, rec, a, b, c, d, x);        // updateFb passes (rs, r2)
+          edge_features(st, rs, r2, rec, a, b, c, d, x, s.fx[tid], &s.shs[tid]);        // updateFb passes (rs, r2)
           s.model[tid] = st.clf.kind == 1 ? 0 : pick_model(st.clf, x);
         }
       }
       __syncthreads();
       PH(4);
-      if (st.clf.kind == 0) {
+      if (st.clf.kind == 0 && st.n_helpers) {
+        // hand the chunk to the helper workgroups and wait for their votes
+        for (uint32_t i = tid; i < cn * (uint32_t)fstride; i += kBcThreads) st.featbuf[i] = s.feat[i];
+        if ((uint32_t)tid < cn) st.hmodel[tid] = s.model[tid];
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) {
+          st.hctl[2] = cn; st.hctl[1] = 0u;
+          st_release(&st.hctl[0], ++hseq);
+          unsigned long long spins = 0;
+          const uint32_t expect = cn < st.n_helpers ? cn : st.n_helpers;              // helpers h < cn report
+          while (ld_relaxed(&st.hctl[1]) < expect) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kHelperSpinLimit) { s.stop = ST_BAD_SALIENCY; break; }     // helpers lost: reported as a failed run
+          }
+          fence_acquire();
+        }
+        __syncthreads();
+        if ((uint32_t)tid < cn && s.model[tid] >= 0) s.votes[tid] = st.hvotes[tid];
+      } else if (st.clf.kind == 0) {
         const int ntree = st.clf.f[0].ntree;    // the three ensemble members are required to have equal size
         for (uint32_t i = tid; i < cn * (uint32_t)ntree; i += kBcThreads) {
           const uint32_t j = i / ntree, t = i % ntree;
@@ -619,9 +751,11 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
     PH(6);
     k += 1; ne += newcount; pool_used += total;
   }
+  if (tid == 0 && st.n_helpers) st_release(&st.hctl[0], 0xFFFFFFFFu);
   if (tid == 0) { st.ctrl[0] = k; st.ctrl[1] = ne; st.ctrl[2] = pool_used; st.ctrl[3] = status; }
 #ifdef GLIA_HMT_PROFILE
   if (tid == 0) printf("[bc profile] edge_features of thread 0: gather %llu  bc_features %llu  calls %llu (cycles)\n", g_pqprof[24], g_pqprof[25], g_pqprof[26]);
+  if (tid == 0) printf("[bc profile] scoring: neighbour min/max %llu  shared sets %llu  entropies %llu  assemble %llu (cycles)\n", tph[8], tph[9], tph[10], tph[4]);
   if (tid == 0) printf("[bc profile] merges %llu: pop+feats_out %llu  region+mark %llu  build %llu  top2 %llu  features %llu  forest %llu  pq %llu  loop-top %llu (cycles)\n", k, tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], tph[6], tph[7]);
 #endif
 }
@@ -738,7 +872,18 @@ int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& cl
   if ((rc = buf.get(&st.order, 3 * (size_t)R, false, stream))) return rc;
   if ((rc = buf.get(&st.sal_out, (size_t)R, false, stream))) return rc;
   if (h_feats) { if ((rc = buf.get(&st.feats_out, (size_t)R * cfg.fdim, false, stream))) return rc; }
-  if ((rc = buf.get(&st.featbuf, (size_t)kChunk * cfg.fdim, false, stream))) return rc;
+  if ((rc = buf.get(&st.featbuf, (size_t)kChunk * bc_full_dim(cfg), false, stream))) return rc;
+  if ((rc = buf.get(&st.hctl, 4, true, stream))) return rc;
+  if ((rc = buf.get(&st.hvotes, kChunk, true, stream))) return rc;
+  if ((rc = buf.get(&st.hmodel, kChunk, true, stream))) return rc;
+  {
+    // helper workgroups for the forest (only a real forest in a scoring run needs them); GLIA_HMT_HELPERS overrides
+    const char* env = getenv("GLIA_HMT_HELPERS");
+    int nh = env ? atoi(env) : 63;
+    if (nh < 0) nh = 0;
+    if (nh > 200) nh = 200;
+    st.n_helpers = (clf.kind == 0 && !h_forced && !init_only) ? (uint32_t)nh : 0u;
+  }
   if ((rc = buf.get(&st.ctrl, 8, true, stream))) return rc;
   uint32_t* cursor;
   if ((rc = buf.get(&cursor, R2, true, stream))) return rc;
@@ -787,7 +932,8 @@ int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& cl
   }
   st.max_iters = 1ull << 14;
   while (true) {
-    hipLaunchKernelGGL(greedy_bc_kernel, dim3(1), dim3(kBcThreads), 0, stream, st);
+    GLIA_HIP_TRY(hipMemsetAsync(st.hctl, 0, 4 * sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(greedy_bc_kernel, dim3(1 + st.n_helpers), dim3(kBcThreads), 0, stream, st);
     GLIA_HIP_TRY(hipGetLastError());
     GLIA_HIP_TRY(hipMemcpyAsync(ctrl, st.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, stream));
     GLIA_HIP_TRY(hipStreamSynchronize(stream));
