@@ -1,6 +1,6 @@
 // cli/bc_feat.cpp -- drop-in for hmt/main_bc_feat.cxx: boundary-classifier feature rows of a GIVEN merge order.
 //   bc_feat -s seg.mha -o order.txt --pb pb.mha [--rbi/--rbb/--rbl/--rbu ...] [--bt ...] [-n b] [-l b] [--simpf b] -b feats.txt
-// Not supported yet: the saliency features (-y/--s0/--sb), masks, more than one image volume.
+// Not supported yet: the saliency features (-y/--s0/--sb).
 #include "common.hpp"
 
 using namespace cli;

@@ -190,25 +190,33 @@ struct FeatInputs {
   Volume seg, pb;
   uint32_t* dLab = nullptr;
   float* dPb = nullptr;
+  std::map<std::string, float*> volumes;      // every distinct image file is read and uploaded once
   glia_hmt_feat_config cfg;
 };
 inline void loadFeatInputs(const Args& a, FeatInputs& f) {
   const std::string pbFile = a.str("pb");
-  std::set<std::string> files = {pbFile};
-  for (const char* k : {"rbi", "rli", "ri", "bi"}) for (auto& x : a.all(k)) files.insert(x);
-  if (files.size() != 1) perr("Error: the MI355X path supports a single image volume shared by --pb/--rbi in this version...");
   f.seg = readMetaImage(a.str("segImage"), false);
   f.pb = readMetaImage(pbFile, true);
   if (f.seg.dim != f.pb.dim || f.seg.size() != f.pb.size()) perr("Error: image sizes do not match...");
   f.dLab = upload(f.seg.u32);
   f.dPb = upload(f.pb.f32);
+  f.volumes[pbFile] = f.dPb;
+  auto volume = [&](const std::string& file) -> float* {
+    auto it = f.volumes.find(file);
+    if (it != f.volumes.end()) return it->second;
+    Volume v = readMetaImage(file, true);
+    if (v.size() != f.seg.size()) perr("Error: image sizes do not match...");
+    float* d = upload(v.f32);
+    f.volumes[file] = d;
+    return d;
+  };
   memset(&f.cfg, 0, sizeof(f.cfg));
   auto addAll = [&](const char* ki, const char* kb, const char* kl, const char* ku, glia_hmt_image* list, int& n) {
     auto im = a.all(ki), b = a.all(kb), l = a.all(kl), u = a.all(ku);
     for (size_t i = 0; i < im.size(); ++i) {
       if (i >= b.size() || i >= l.size() || i >= u.size()) perr("Error: histogram parameters missing for an input image...");
       if (n >= GLIA_HMT_MAX_IMAGES) perr("Error: too many input images...");
-      list[n].d_image = f.dPb; list[n].bins = atoi(b[i].c_str()); list[n].lo = atof(l[i].c_str()); list[n].hi = atof(u[i].c_str()); ++n;
+      list[n].d_image = volume(im[i]); list[n].bins = atoi(b[i].c_str()); list[n].lo = atof(l[i].c_str()); list[n].hi = atof(u[i].c_str()); ++n;
     }
   };
   // --rbi images are appended to BOTH the region and the boundary list, before the exclusive ones

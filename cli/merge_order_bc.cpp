@@ -2,7 +2,7 @@
 //   merge_order_bc --bct 1 --bcm model.bin [--bcm m1 --bcm m2 --bcmd d0 --bcmd d1 --bcmd thr] -s seg.mha --pb pb.mha
 //                  [--rbi img --rbb bins --rbl lo --rbu hi] [--bt t0 t1 ..] [-n 0|1] [-l 0|1] [--simpf 0|1]
 //                  -o order.txt [--sal saliency.txt] [-b feats.txt]
-// Limits of this round: all image lists must name ONE volume (the --rbi pb --pb pb configuration).
+// Limits: at most four images per list and four distinct (volume, histogram) channels in total.
 #include "common.hpp"
 
 using namespace cli;

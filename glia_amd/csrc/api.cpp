@@ -83,6 +83,7 @@ struct glia_hmt_rag {
   bool has_cfg = false;
   VolumeRef vol;                 // whole-volume builds only: the caller keeps the volumes alive while the handle lives
   uint32_t* d_folded = nullptr;  // labels with the mask folded in (owned)
+  int map_region[GLIA_HMT_MAX_IMAGES] = {0}, map_rlabel[GLIA_HMT_MAX_IMAGES] = {0}, map_boundary[GLIA_HMT_MAX_IMAGES] = {0};   // list entry -> channel
 };
 
 static int free_tables(glia_hmt_ctx* c) {
@@ -199,45 +200,64 @@ static int rag_build_impl(glia_hmt_ctx* c, int dim, const int64_t dims[3], int64
     return GLIA_HMT_ERR_ARG;
   }
   GLIA_HIP_TRY(hipSetDevice(c->device));
-  const float* img = d_pb;
-  int bins = 8;
-  double lo = 0.0, hi = 1.0;
+  // ---- channels: one accumulation pass per distinct (volume, bins, lo, hi) over the three feature lists; channel 0
+  // is the boundary-probability volume (thresholded counts, pb linkages) ----
+  struct Chan { const float* img; int bins; double lo, hi; };
+  std::vector<Chan> chans;
+  int map_region[GLIA_HMT_MAX_IMAGES] = {0}, map_rlabel[GLIA_HMT_MAX_IMAGES] = {0}, map_boundary[GLIA_HMT_MAX_IMAGES] = {0};
   int nthr = 0;
   double thr[GLIA_HMT_MAX_THRESH] = {0, 0, 0, 0};
   if (cfg) {
-    // first implementation: one image volume shared by every list (the --rbi pb configuration of SURVEY.md 8d)
-    const glia_hmt_image* ref = nullptr;
-    auto check = [&](const glia_hmt_image* lst, int n) -> bool {
-      for (int i = 0; i < n; ++i) {
-        if (!ref) ref = &lst[i];
-        if (lst[i].d_image != ref->d_image || lst[i].bins != ref->bins || lst[i].lo != ref->lo || lst[i].hi != ref->hi)
-          return false;
-      }
-      return true;
-    };
-    if (cfg->n_region < 0 || cfg->n_rlabel < 0 || cfg->n_boundary < 0 || cfg->n_region > GLIA_HMT_MAX_IMAGES ||
-        cfg->n_rlabel > GLIA_HMT_MAX_IMAGES || cfg->n_boundary > GLIA_HMT_MAX_IMAGES ||
+    if (cfg->n_region < 0 || cfg->n_rlabel < 0 || cfg->n_boundary < 0 || cfg->n_region > kMaxListed ||
+        cfg->n_rlabel > kMaxListed || cfg->n_boundary > kMaxListed ||
         cfg->n_thresholds < 0 || cfg->n_thresholds > GLIA_HMT_MAX_THRESH) {
-      set_error("rag_build: feature configuration out of range");
+      set_error("rag_build: feature configuration out of range (at most 4 images per list, 4 thresholds)");
       return GLIA_HMT_ERR_ARG;
     }
-    bool same = check(cfg->region, cfg->n_region) && check(cfg->rlabel, cfg->n_rlabel) &&
-                check(cfg->boundary, cfg->n_boundary);
-    if (!same || cfg->n_region > 1 || cfg->n_rlabel > 1 || cfg->n_boundary > 1 ||
-        (ref && cfg->d_pb && ref->d_image != cfg->d_pb)) {
-      set_error("rag_build: only a single image volume shared by --pb/--rbi is supported yet");
-      return GLIA_HMT_ERR_UNSUPPORTED;
+    const float* pbv = cfg->d_pb ? cfg->d_pb : d_pb;
+    auto same = [](const Chan& c, const glia_hmt_image& g) { return c.img == g.d_image && c.bins == g.bins && c.lo == g.lo && c.hi == g.hi; };
+    // channel 0: the first listed image that IS the pb volume (its histogram spec comes along), else pb with 8 bins on [0,1]
+    const glia_hmt_image* lists[3] = {cfg->region, cfg->rlabel, cfg->boundary};
+    const int counts[3] = {cfg->n_region, cfg->n_rlabel, cfg->n_boundary};
+    for (int l = 0; l < 3 && chans.empty(); ++l)
+      for (int i = 0; i < counts[l] && chans.empty(); ++i)
+        if (pbv && lists[l][i].d_image == pbv) chans.push_back(Chan{pbv, lists[l][i].bins, lists[l][i].lo, lists[l][i].hi});
+    if (chans.empty()) {
+      if (pbv) chans.push_back(Chan{pbv, 8, 0.0, 1.0});
+      else if (counts[0] + counts[1] + counts[2] > 0) {      // no pb at all: thresholds count on the first image
+        const glia_hmt_image& g = counts[0] ? cfg->region[0] : (counts[1] ? cfg->rlabel[0] : cfg->boundary[0]);
+        chans.push_back(Chan{g.d_image, g.bins, g.lo, g.hi});
+      }
     }
-    img = cfg->d_pb ? cfg->d_pb : (ref ? ref->d_image : d_pb);
-    if (ref) { bins = ref->bins; lo = ref->lo; hi = ref->hi; }
+    int* maps[3] = {map_region, map_rlabel, map_boundary};
+    for (int l = 0; l < 3; ++l)
+      for (int i = 0; i < counts[l]; ++i) {
+        const glia_hmt_image& g = lists[l][i];
+        if (!g.d_image) { set_error("rag_build: null image in a feature list"); return GLIA_HMT_ERR_ARG; }
+        int k = -1;
+        for (size_t q = 0; q < chans.size(); ++q) if (same(chans[q], g)) { k = (int)q; break; }
+        if (k < 0) {
+          if ((int)chans.size() >= kMaxChannels) { set_error("rag_build: more than 4 distinct (image volume, histogram) channels"); return GLIA_HMT_ERR_UNSUPPORTED; }
+          chans.push_back(Chan{g.d_image, g.bins, g.lo, g.hi});
+          k = (int)chans.size() - 1;
+        }
+        maps[l][i] = k;
+      }
     nthr = cfg->n_thresholds;
     for (int i = 0; i < nthr; ++i) thr[i] = cfg->thresholds[i];
+  } else if (d_pb) chans.push_back(Chan{d_pb, 8, 0.0, 1.0});
+  if (chans.empty()) { set_error("rag_build: no image volume given"); return GLIA_HMT_ERR_ARG; }
+  for (const Chan& ch : chans)
+    if (ch.bins < 1 || ch.bins > GLIA_HMT_MAX_BINS || !(ch.hi > ch.lo)) {
+      set_error("rag_build: histogram bins must be 1..16 and hi > lo");
+      return GLIA_HMT_ERR_ARG;
+    }
+  if (chans.size() > 1 && !(zb == 0 && ze == nz && gz0 == 0 && gnz == nz)) {
+    set_error("rag_build_slab: slab builds take a single image channel");
+    return GLIA_HMT_ERR_UNSUPPORTED;
   }
-  if (!img) { set_error("rag_build: no image volume given"); return GLIA_HMT_ERR_ARG; }
-  if (bins < 1 || bins > GLIA_HMT_MAX_BINS || !(hi > lo)) {
-    set_error("rag_build: histogram bins must be 1..16 and hi > lo");
-    return GLIA_HMT_ERR_ARG;
-  }
+  const float* img = chans[0].img;
+  const int bins = chans[0].bins;
 
   const int64_t N = nx * ny * nz;
   uint32_t rcap = c->hint_rcap ? c->hint_rcap : next_pow2(std::max<int64_t>(1 << 12, N / 128));
@@ -262,17 +282,22 @@ static int rag_build_impl(glia_hmt_ctx* c, int dim, const int64_t dims[3], int64
     rag->vol.nx = nx; rag->vol.ny = ny; rag->vol.nz = nz;
   }
 
+  memcpy(rag->map_region, map_region, sizeof(map_region)); memcpy(rag->map_rlabel, map_rlabel, sizeof(map_rlabel));
+  memcpy(rag->map_boundary, map_boundary, sizeof(map_boundary));
+  double pass_ms_total = 0.0;
+  for (size_t ci = 0; ci < chans.size(); ++ci) {
+  RagArrays pass_arr;
   for (int attempt = 0;; ++attempt) {
     int rc = ensure_tables(c, rcap, pcap);
     if (rc) { glia_hmt_rag_free(rag); return rc; }
     AccParams p;
-    p.lab = lab_nb; p.lab_c = lab_c; p.masked = d_mask ? 1 : 0; p.img = img;
+    p.lab = lab_nb; p.lab_c = lab_c; p.masked = d_mask ? 1 : 0; p.img = chans[ci].img;
     p.nx = nx; p.ny = ny; p.nz = nz; p.dim = dim;
     p.gz0 = gz0; p.gnz = gnz; p.zb = zb; p.ze = ze;
     p.nbx = (int)((nx + kTileX - 1) / kTileX);
     p.nby = (int)((ny + kTileY - 1) / kTileY);
     p.nbz = (int)((ze - zb + kTZ - 1) / kTZ);
-    p.hist = make_hist_spec(bins, lo, hi);
+    p.hist = make_hist_spec(chans[ci].bins, chans[ci].lo, chans[ci].hi);
     p.nthr = nthr;
     for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) p.thr_f[i] = i < nthr ? ceil_f32(thr[i]) : std::numeric_limits<float>::infinity();
     p.rkeys = c->rkeys; p.rrec = c->rrec; p.rmask = c->rcap - 1;
@@ -290,12 +315,13 @@ static int rag_build_impl(glia_hmt_ctx* c, int dim, const int64_t dims[3], int64
     if (e != hipSuccess) { glia_hmt_rag_free(rag); set_error(std::string("rag_build: ") + hipGetErrorString(e)); return GLIA_HMT_ERR_HIP; }
     float ms = 0;
     (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
-    rag->pass_ms = ms;
+    pass_ms_total += ms;
+    rag->pass_ms = pass_ms_total;
     if (p.debug & 32) {
       fprintf(stderr, "[glia_hmt debug] region runs %u (lds-miss %u), pair runs %u (lds-miss %u), drains %u\n", flags[2], flags[4], flags[3], flags[5], flags[6]);
       (void)hipMemsetAsync(c->flags, 0, 64, c->stream);
     }
-    rag->alg_bytes = (double)(nx * ny * (ze - zb)) * 8.0;
+    rag->alg_bytes = (double)(nx * ny * (ze - zb)) * 8.0 * (double)chans.size();
     if (flags[0] || flags[1]) {
       // a table filled up: drop the partial result, grow and redo the pass
       if (attempt >= 6) { glia_hmt_rag_free(rag); set_error("rag_build: hash tables keep overflowing"); return GLIA_HMT_ERR_HIP; }
@@ -306,9 +332,21 @@ static int rag_build_impl(glia_hmt_ctx* c, int dim, const int64_t dims[3], int64
       if (flags[1]) pcap = c->pcap * 4;
       continue;
     }
-    rc = compact_tables(p, c->rcap, c->pcap, &rag->arr, c->stream);
+    rc = compact_tables(p, c->rcap, c->pcap, &pass_arr, c->stream);
     if (rc) { glia_hmt_rag_free(rag); return rc; }
     break;
+  }
+  if (ci == 0) rag->arr = pass_arr;
+  else {
+    // the keys depend on the labels only: every pass yields the same sorted key arrays
+    (void)hipFree(pass_arr.d_rlabel); (void)hipFree(pass_arr.d_pa); (void)hipFree(pass_arr.d_pb);
+    if (pass_arr.R != rag->arr.R || pass_arr.P != rag->arr.P) {
+      (void)hipFree(pass_arr.d_rrec); (void)hipFree(pass_arr.d_prec);
+      glia_hmt_rag_free(rag); set_error("rag_build: channel passes disagree on the region set"); return GLIA_HMT_ERR_HIP;
+    }
+  }
+  rag->arr.c_rrec[ci] = pass_arr.d_rrec; rag->arr.c_prec[ci] = pass_arr.d_prec; rag->arr.c_bins[ci] = chans[ci].bins;
+  rag->arr.K = (int)ci + 1;
   }
   *out = rag;
   return GLIA_HMT_OK;
@@ -353,6 +391,8 @@ int glia_hmt_rag_merge(glia_hmt_ctx* c, glia_hmt_rag* const* parts, int n_parts,
   rag->pass_ms = 0; rag->alg_bytes = 0;
   for (int i = 0; i < n_parts; ++i) { rag->pass_ms += parts[i]->pass_ms; rag->alg_bytes += parts[i]->alg_bytes; }
   int rc = merge_rag_arrays(arrs.data(), n_parts, &rag->arr, c->stream);
+  rag->arr.K = 1; rag->arr.c_rrec[0] = rag->arr.d_rrec; rag->arr.c_prec[0] = rag->arr.d_prec; rag->arr.c_bins[0] = rag->bins;
+  rag->d_folded = nullptr; rag->vol = VolumeRef();
   if (rc) { delete rag; return rc; }
   *out = rag;
   return GLIA_HMT_OK;
@@ -394,6 +434,7 @@ int glia_hmt_rag_from_arrays(glia_hmt_ctx* c, const glia_hmt_rag* like, int64_t 
   GLIA_HIP_TRY(hipSetDevice(c->device));
   glia_hmt_rag* rag = new glia_hmt_rag(*like);
   rag->ctx = c;
+  rag->d_folded = nullptr; rag->vol = VolumeRef();      // the copy owns neither the folded labels nor a whole volume
   rag->arr = RagArrays();
   rag->arr.R = n_regions; rag->arr.P = n_pairs;
   auto dup = [&](uint32_t** dst, const uint32_t* src, size_t n) -> int {
@@ -405,6 +446,7 @@ int glia_hmt_rag_from_arrays(glia_hmt_ctx* c, const glia_hmt_rag* like, int64_t 
   if ((rc = dup(&rag->arr.d_rlabel, d_region_label, (size_t)n_regions)) || (rc = dup(&rag->arr.d_rrec, d_region_rec, (size_t)n_regions * kRegionWords)) ||
       (rc = dup(&rag->arr.d_pa, d_pair_a, (size_t)n_pairs)) || (rc = dup(&rag->arr.d_pb, d_pair_b, (size_t)n_pairs)) ||
       (rc = dup(&rag->arr.d_prec, d_pair_rec, (size_t)n_pairs * kPairWords))) { glia_hmt_rag_free(rag); return rc; }
+  rag->arr.K = 1; rag->arr.c_rrec[0] = rag->arr.d_rrec; rag->arr.c_prec[0] = rag->arr.d_prec; rag->arr.c_bins[0] = rag->bins;
   GLIA_HIP_TRY(hipStreamSynchronize(c->stream));
   *out = rag;
   return GLIA_HMT_OK;
@@ -415,6 +457,7 @@ void glia_hmt_rag_free(glia_hmt_rag* r) {
   (void)hipSetDevice(r->ctx->device);
   (void)hipFree(r->arr.d_rlabel); (void)hipFree(r->arr.d_rrec);
   (void)hipFree(r->arr.d_pa); (void)hipFree(r->arr.d_pb); (void)hipFree(r->arr.d_prec);
+  for (int k = 1; k < r->arr.K; ++k) { (void)hipFree(r->arr.c_rrec[k]); (void)hipFree(r->arr.c_prec[k]); }
   if (r->d_folded) (void)hipFree(r->d_folded);
   delete r;
 }
@@ -612,8 +655,12 @@ void glia_hmt_forest_free(glia_hmt_forest* f) {
 static bool make_bc_cfg(const glia_hmt_rag* rag, BcCfg* c) {
   if (!rag->has_cfg) return false;
   const glia_hmt_feat_config& g = rag->cfg;
+  memset(c, 0, sizeof(*c));
   c->D = rag->dim; c->T = g.n_thresholds; c->bins = rag->bins;
+  c->K = rag->arr.K;
+  for (int k = 0; k < kMaxChannels; ++k) c->cbins[k] = k < rag->arr.K ? rag->arr.c_bins[k] : 0;
   c->n_region = g.n_region; c->n_rlabel = g.n_rlabel; c->n_boundary = g.n_boundary;
+  for (int i = 0; i < kMaxListed; ++i) { c->rc[i] = rag->map_region[i]; c->lc[i] = rag->map_rlabel[i]; c->bc[i] = rag->map_boundary[i]; }
   c->use_log = g.use_log_shape; c->use_simple = g.use_simple_features;
   c->norm_area = g.normalizing_area; c->norm_len = g.normalizing_length;
   c->rfdim = bc_rf_dim(*c); c->bfdim = bc_bf_dim(*c); c->fdim = bc_feat_dim(*c);

@@ -37,30 +37,37 @@ namespace glia {
 
 constexpr int kBcThreads = 1024;
 constexpr int kChunk = 96;              // new edges scored per round (their feature vectors live in LDS)
-constexpr int kFeatDoubles = 96 * 104;   // LDS budget for them: 104 KiB (128 edges at the usual D_f = 104)
 
-struct BcState {
-  uint32_t R0;
+// statistics of one image channel (a distinct volume + histogram among the feature lists); channel 0 = boundary
+// probability: its counts and thresholded counts also serve the shape features
+struct BcChan {
   // regions [2*R0]
   PStats* pts;
   EStats* Bn;          // non-mutual out-entries of the region's leaves
   EStats* Bt;          // additive totals of the whole boundary set (min/max fields unused)
   float* Bmn; float* Bmx;   // min / max over the whole boundary set
+  // records [Ecap]
+  EStats* e_A;         // mutual entries, both directions
+  EStats* e_NA;        // always-alive non-mutual entries, both directions
+  float* e_dir;        // [Ecap][4]  mutual u->v min,max ; v->u min,max
+  // leaf entries [P]
+  EStats* le_stats;
+};
+
+struct BcState {
+  uint32_t R0;
+  BcChan ch[kMaxChannels];
   uint32_t* parent;    // merge forest (find -> current region of a leaf)
   uint32_t* adj_off; uint32_t* adj_len; uint32_t* pool; unsigned long long pool_cap;
   // records [Ecap]
   uint32_t Ecap;
   uint32_t *e_u, *e_v, *e_posu, *e_posv;
   uint8_t *e_alive, *e_table, *e_orient;    // orient: 1 = features take (u, v), 0 = (v, u)
-  EStats* e_A;         // mutual entries, both directions
-  EStats* e_NA;        // always-alive non-mutual entries, both directions
-  float* e_dir;        // [Ecap][4]  mutual u->v min,max ; v->u min,max
   uint32_t *e_fhead, *e_ftail;   // fragile non-mutual leaf entries (linked through le_next), kNone = empty
   PqTree pq;
   // leaf entries [P] (directed label pairs, ascending (a,b))
   long long P;
   uint32_t *le_src, *le_dst;     // dense leaf ids
-  EStats* le_stats;
   uint32_t* le_next;
   uint8_t* le_mutual;
   uint32_t* le_start;            // [R0+1] first out-entry of each leaf
@@ -100,46 +107,49 @@ __device__ bool leaf_alive(const BcState& st, uint32_t x) {
   return false;
 }
 
-// min / max over region r's boundary set without the mutual entries it sends along record `skip`
-__device__ void excl_minmax(const BcState& st, uint32_t r, uint32_t skip, float& mn, float& mx) {
-  mn = st.Bn[r].mn; mx = st.Bn[r].mx;
+// min / max (channel c) over region r's boundary set without the mutual entries it sends along record `skip`
+__device__ void excl_minmax(const BcState& st, int c, uint32_t r, uint32_t skip, float& mn, float& mx) {
+  const BcChan& ch = st.ch[c];
+  mn = ch.Bn[r].mn; mx = ch.Bn[r].mx;
   const uint32_t off = st.adj_off[r], len = st.adj_len[r];
   for (uint32_t i = 0; i < len; ++i) {
     const uint32_t e = st.pool[off + i];
     if (e == skip || !st.e_alive[e]) continue;
-    const float* d = &st.e_dir[(size_t)e * 4 + (st.e_u[e] == r ? 0 : 2)];
+    const float* d = &ch.e_dir[(size_t)e * 4 + (st.e_u[e] == r ? 0 : 2)];
     mn = fminf(mn, d[0]); mx = fmaxf(mx, d[1]);
+  }
+}
+
+// shared boundary of the two regions of record rec on channel c: mutual entries + always-alive non-mutual ones + the
+// fragile ones whose target leaf is still alive
+__device__ void shared_boundary(const BcState& st, int c, uint32_t rec, EStats& sh) {
+  estats_clear(sh);
+  if (rec != kNone) {
+    const BcChan& ch = st.ch[c];
+    sh = ch.e_A[rec];
+    estats_add(sh, ch.e_NA[rec]);
+    for (uint32_t f = st.e_fhead[rec]; f != kNone; f = st.le_next[f])
+      if (leaf_alive(st, st.le_dst[f])) estats_add(sh, ch.le_stats[f]);
   }
 }
 
 // feature vector of record rec (regions `first`, `second` in the reference's orientation); `out` must hold
 // bc_full_dim doubles (the simple selection is compacted in place).  No private arrays: see bc_features.hpp.
-// pre (optional): [0..6] entropies of first.voxels, first.boundary, second.voxels, second.boundary, merged.voxels,
-// merged.boundary, shared boundary; [7], [8] the L1 / chi-square histogram distances; sh_pre (optional): the shared set
-__device__ void shared_boundary(const BcState& st, uint32_t rec, EStats& sh) {
-  estats_clear(sh);
-  if (rec != kNone) {
-    sh = st.e_A[rec];
-    estats_add(sh, st.e_NA[rec]);
-    for (uint32_t f = st.e_fhead[rec]; f != kNone; f = st.le_next[f])
-      if (leaf_alive(st, st.le_dst[f])) estats_add(sh, st.le_stats[f]);
-  }
-}
-__device__ void edge_features(const BcState& st, uint32_t first, uint32_t second, uint32_t rec, float ex0mn, float ex0mx,
-                              float ex1mn, float ex1mx, double* out, const double* pre = nullptr, const EStats* sh_pre = nullptr) {
+// ex: per channel {min, max of first's boundary set without the record's mutual entries, the same for second};
+// pre (optional): values of the lane-parallel pass (feat::pre_region / pre_boundary); sh_pre (optional): the shared
+// boundary set of every channel
+__device__ void edge_features(const BcState& st, uint32_t first, uint32_t second, uint32_t rec, const float* ex, double* out,
+                              const double* pre = nullptr, const EStats* sh_pre = nullptr) {
 #ifdef GLIA_HMT_PROFILE
   const unsigned long long tq_in = __builtin_readcyclecounter();
 #endif
   const BcCfg& c = st.cfg;
-  const PStats* P0 = &st.pts[first];
-  const PStats* P1 = &st.pts[second];
-  const EStats* B0 = &st.Bt[first];
-  const EStats* B1 = &st.Bt[second];
-  const EStats* A = rec != kNone ? &st.e_A[rec] : nullptr;     // kNone: no shared record (bc_feat on non-neighbours)
-  // shared boundary: mutual entries + always-alive non-mutual ones + the fragile ones whose target leaf is still alive
-  EStats sh_local;
-  if (!sh_pre) shared_boundary(st, rec, sh_local);
-  const EStats& sh = sh_pre ? *sh_pre : sh_local;
+  const BcChan& c0 = st.ch[0];
+  const PStats* P0 = &c0.pts[first];
+  const PStats* P1 = &c0.pts[second];
+  const EStats* B0 = &c0.Bt[first];
+  const EStats* B1 = &c0.Bt[second];
+  const EStats* A0 = rec != kNone ? &c0.e_A[rec] : nullptr;     // kNone: no shared record (bc_feat on non-neighbours)
   const uint32_t n0 = P0->n, n1 = P1->n;
   // keep region 0 area <= region 1 area (main_merge_order_bc.cxx:77-80): decides the slots of the two region blocks
   const bool swap = feat::sdiv((double)n0, c.norm_area, 0.0) > feat::sdiv((double)n1, c.norm_area, 0.0);
@@ -147,51 +157,71 @@ __device__ void edge_features(const BcState& st, uint32_t first, uint32_t second
   double* o_first = out + c.bfdim + (swap ? c.rfdim : 0);
   double* o_second = out + c.bfdim + (swap ? 0 : c.rfdim);
   double* o_merged = out + c.bfdim + 2 * c.rfdim;
-  feat::RegionOut a_first, a_second, a_merged;
+  // statistics sources of one region (which = 0 first, 1 second) and of the scratch-merged region (which = 2)
+  auto src_of = [&](int which) {
+    return [&st, &c, first, second, rec, ex, pre, which](int kind, int i) -> feat::ImgSrc {
+      const int cc = kind == 0 ? c.rc[i] : (kind == 1 ? c.lc[i] : c.bc[i]);
+      const BcChan& ch = st.ch[cc];
+      const double* pe = nullptr;
+      if (pre) pe = kind < 2 ? pre + feat::pre_region(c, kind, i) + which : pre + feat::pre_boundary(c, i) + which;
+      if (kind < 2) {
+        const PStats* p0 = &ch.pts[first]; const PStats* p1 = &ch.pts[second];
+        if (which == 0) return feat::ImgSrc{p0->hist, nullptr, nullptr, p0->n, p0->sum, p0->sq, p0->mn, p0->mx, pe};
+        if (which == 1) return feat::ImgSrc{p1->hist, nullptr, nullptr, p1->n, p1->sum, p1->sq, p1->mn, p1->mx, pe};
+        return feat::ImgSrc{p0->hist, p1->hist, nullptr, p0->n + p1->n, p0->sum + p1->sum, p0->sq + p1->sq,
+                            p1->mn < p0->mn ? p1->mn : p0->mn, p1->mx > p0->mx ? p1->mx : p0->mx, pe};
+      }
+      const EStats* b0 = &ch.Bt[first]; const EStats* b1 = &ch.Bt[second];
+      if (which == 0) return feat::ImgSrc{b0->hist, nullptr, nullptr, b0->n, b0->sum, b0->sq, ch.Bmn[first], ch.Bmx[first], pe};
+      if (which == 1) return feat::ImgSrc{b1->hist, nullptr, nullptr, b1->n, b1->sum, b1->sq, ch.Bmn[second], ch.Bmx[second], pe};
+      // the merged boundary set: both sets minus the mutual entries of the shared record
+      const EStats* a = rec != kNone ? &ch.e_A[rec] : nullptr;
+      uint32_t bn = b0->n + b1->n;
+      double bsum = b0->sum + b1->sum, bsq = b0->sq + b1->sq;
+      if (a) { bn -= a->n; bsum -= a->sum; bsq -= a->sq; }
+      return feat::ImgSrc{b0->hist, b1->hist, a ? a->hist : nullptr, bn, bsum, bsq, fminf(ex[4 * cc + 0], ex[4 * cc + 2]),
+                          fmaxf(ex[4 * cc + 1], ex[4 * cc + 3]), pe};
+    };
+  };
+  double ar_first, pe_first, ar_second, pe_second, ar_m, pe_m;
   {
-    feat::RegionIn r;
-    r.n = n0; r.border = P0->border;
+    feat::ShapeIn r;
+    r.n = n0; r.border = P0->border; r.bn = B0->n;
     for (int i = 0; i < 3; ++i) { r.lo[i] = P0->lo[i]; r.hi[i] = P0->hi[i]; }
-    r.pimg = feat::ImgSrc{P0->hist, nullptr, nullptr, n0, P0->sum, P0->sq, P0->mn, P0->mx, pre ? pre + 0 : nullptr};
-    r.bn = B0->n;
     for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) r.thr[i] = B0->thr[i];
-    r.bimg = feat::ImgSrc{B0->hist, nullptr, nullptr, B0->n, B0->sum, B0->sq, st.Bmn[first], st.Bmx[first], pre ? pre + 1 : nullptr};
-    feat::region_feats_direct(c, r, o_first, a_first);
+    feat::region_feats_multi(c, r, src_of(0), o_first, ar_first, pe_first);
   }
   {
-    feat::RegionIn r;
-    r.n = n1; r.border = P1->border;
+    feat::ShapeIn r;
+    r.n = n1; r.border = P1->border; r.bn = B1->n;
     for (int i = 0; i < 3; ++i) { r.lo[i] = P1->lo[i]; r.hi[i] = P1->hi[i]; }
-    r.pimg = feat::ImgSrc{P1->hist, nullptr, nullptr, n1, P1->sum, P1->sq, P1->mn, P1->mx, pre ? pre + 2 : nullptr};
-    r.bn = B1->n;
     for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) r.thr[i] = B1->thr[i];
-    r.bimg = feat::ImgSrc{B1->hist, nullptr, nullptr, B1->n, B1->sum, B1->sq, st.Bmn[second], st.Bmx[second], pre ? pre + 3 : nullptr};
-    feat::region_feats_direct(c, r, o_second, a_second);
+    feat::region_feats_multi(c, r, src_of(1), o_second, ar_second, pe_second);
   }
   {
-    // the scratch-merged region (TRegionMap::merge under key 0): voxel sets add, boundary sets add minus the mutual
-    // entries of the shared record
-    feat::RegionIn r;
+    // the scratch-merged region (TRegionMap::merge under key 0)
+    feat::ShapeIn r;
     r.n = n0 + n1; r.border = P0->border + P1->border;
     for (int i = 0; i < 3; ++i) { r.lo[i] = P0->lo[i] < P1->lo[i] ? P0->lo[i] : P1->lo[i]; r.hi[i] = P0->hi[i] > P1->hi[i] ? P0->hi[i] : P1->hi[i]; }
-    r.pimg = feat::ImgSrc{P0->hist, P1->hist, nullptr, n0 + n1, P0->sum + P1->sum, P0->sq + P1->sq,
-                          P1->mn < P0->mn ? P1->mn : P0->mn, P1->mx > P0->mx ? P1->mx : P0->mx, pre ? pre + 4 : nullptr};
-    uint32_t bn = B0->n + B1->n;
-    double bsum = B0->sum + B1->sum, bsq = B0->sq + B1->sq;
+    r.bn = B0->n + B1->n;
     for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) r.thr[i] = B0->thr[i] + B1->thr[i];
-    if (A) {
-      bn -= A->n; bsum -= A->sum; bsq -= A->sq;
-      for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) r.thr[i] -= A->thr[i];
-    }
-    r.bn = bn;
-    r.bimg = feat::ImgSrc{B0->hist, B1->hist, A ? A->hist : nullptr, bn, bsum, bsq, fminf(ex0mn, ex1mn), fmaxf(ex0mx, ex1mx), pre ? pre + 5 : nullptr};
-    feat::region_feats_direct(c, r, o_merged, a_merged);
+    if (A0) { r.bn -= A0->n; for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) r.thr[i] -= A0->thr[i]; }
+    feat::region_feats_multi(c, r, src_of(2), o_merged, ar_m, pe_m);
   }
   {
-    const feat::ImgSrc shimg{sh.hist, nullptr, nullptr, sh.n, sh.sum, sh.sq, sh.mn, sh.mx, pre ? pre + 6 : nullptr};
-    const double* l1x2 = pre ? pre + 7 : nullptr;          // both distances are symmetric in the two regions
-    if (swap) feat::boundary_feats_direct(c, sh.n, sh.thr, shimg, a_second, a_first, P1->hist, n1, P0->hist, n0, l1x2, o_bf);
-    else feat::boundary_feats_direct(c, sh.n, sh.thr, shimg, a_first, a_second, P0->hist, n0, P1->hist, n1, l1x2, o_bf);
+    // shared boundary: counts from channel 0, image statistics from each boundary-list channel
+    EStats sh_local;
+    if (!sh_pre) shared_boundary(st, 0, rec, sh_local);
+    const EStats& sh0 = sh_pre ? sh_pre[0] : sh_local;
+    EStats sh_tmp;
+    auto srcSh = [&](int i) -> feat::ImgSrc {
+      const int cc = c.bc[i];
+      const EStats* sh = &sh0;
+      if (cc != 0) { if (sh_pre) sh = &sh_pre[cc]; else { shared_boundary(st, cc, rec, sh_tmp); sh = &sh_tmp; } }
+      return feat::ImgSrc{sh->hist, nullptr, nullptr, sh->n, sh->sum, sh->sq, sh->mn, sh->mx, pre ? pre + feat::pre_boundary(c, i) + 3 : nullptr};
+    };
+    if (swap) feat::boundary_feats_multi(c, sh0.n, sh0.thr, ar_second, pe_second, ar_first, pe_first, src_of(1), src_of(0), srcSh, pre, o_bf);
+    else feat::boundary_feats_multi(c, sh0.n, sh0.thr, ar_first, pe_first, ar_second, pe_second, src_of(0), src_of(1), srcSh, pre, o_bf);
   }
   feat::finish_features(c, out);
 #ifdef GLIA_HMT_PROFILE
@@ -223,16 +253,20 @@ __device__ double classify_serial(const DeviceClassifier& c, const double* x) {
 }
 
 // ---- initialisation kernels ---------------------------------------------------------------------------
-__global__ void bc_leaf_entries(BcState st, const uint32_t* pa, const uint32_t* pb, const uint32_t* prec,
+// per channel c; the structural fields are written by the channel-0 launch
+__global__ void bc_leaf_entries(BcState st, int c, const uint32_t* pa, const uint32_t* pb, const uint32_t* prec,
                                 const uint32_t* rlabel, long long* partner, int bins, int nthr) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= st.P) return;
-  const uint32_t a = pa[i], b = pb[i];
-  const long long j = find_pair(pa, pb, st.P, b, a);
-  partner[i] = j;
-  st.le_mutual[i] = j >= 0;
-  const uint32_t src = find_label(rlabel, st.R0, a), dst = find_label(rlabel, st.R0, b);
-  st.le_src[i] = src; st.le_dst[i] = dst; st.le_next[i] = kNone;
+  if (c == 0) {
+    const uint32_t a = pa[i], b = pb[i];
+    const long long j = find_pair(pa, pb, st.P, b, a);
+    partner[i] = j;
+    st.le_mutual[i] = j >= 0;
+    const uint32_t src = find_label(rlabel, st.R0, a), dst = find_label(rlabel, st.R0, b);
+    st.le_src[i] = src; st.le_dst[i] = dst; st.le_next[i] = kNone;
+    if (j < 0) atomicAdd(&st.nm_out[src], 1u);
+  }
   const uint32_t* w = &prec[(size_t)i * kPairWords];
   EStats s;
   estats_clear(s);
@@ -241,8 +275,7 @@ __global__ void bc_leaf_entries(BcState st, const uint32_t* pa, const uint32_t* 
   s.mn = ord_float(~w[P_MIN]); s.mx = ord_float(w[P_MAX]);
   memcpy(&s.sum, &w[P_SUM], 8); memcpy(&s.sq, &w[P_SQ], 8);
   for (int k = 0; k < bins; ++k) s.hist[k] = w[P_HIST + k];
-  st.le_stats[i] = s;
-  if (j < 0) atomicAdd(&st.nm_out[src], 1u);
+  st.ch[c].le_stats[i] = s;
 }
 
 // first out-entry of every leaf (pairs ascend by source label): lower bound of the leaf's label in pa
@@ -256,9 +289,10 @@ __global__ void bc_leaf_starts(BcState st, const uint32_t* pa, const uint32_t* r
   st.le_start[r] = (uint32_t)lo;
 }
 
-__global__ void bc_leaf_regions(BcState st, const uint32_t* rrec, int bins) {
+__global__ void bc_leaf_regions(BcState st, int c, const uint32_t* rrec, int bins) {
   uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= st.R0) return;
+  const BcChan& ch = st.ch[c];
   const uint32_t* w = &rrec[(size_t)r * kRegionWords];
   PStats p;
   p.n = w[R_CNT]; p.border = w[R_BORDER];
@@ -266,15 +300,15 @@ __global__ void bc_leaf_regions(BcState st, const uint32_t* rrec, int bins) {
   p.mn = ord_float(~w[R_MIN]); p.mx = ord_float(w[R_MAX]);
   memcpy(&p.sum, &w[R_SUM], 8); memcpy(&p.sq, &w[R_SQ], 8);
   for (int k = 0; k < GLIA_HMT_MAX_BINS; ++k) p.hist[k] = k < bins ? w[R_HIST + k] : 0;
-  st.pts[r] = p;
+  ch.pts[r] = p;
   EStats bn, bt;
   estats_clear(bn); estats_clear(bt);
   for (uint32_t i = st.le_start[r]; i < st.le_start[r + 1]; ++i) {
-    estats_add(bt, st.le_stats[i]);
-    if (!st.le_mutual[i]) estats_add(bn, st.le_stats[i]);
+    estats_add(bt, ch.le_stats[i]);
+    if (!st.le_mutual[i]) estats_add(bn, ch.le_stats[i]);
   }
-  st.Bn[r] = bn; st.Bt[r] = bt; st.Bmn[r] = bt.mn; st.Bmx[r] = bt.mx;
-  st.parent[r] = r;
+  ch.Bn[r] = bn; ch.Bt[r] = bt; ch.Bmn[r] = bt.mn; ch.Bmx[r] = bt.mx;
+  if (c == 0) st.parent[r] = r;
 }
 
 __global__ void bc_record_flags(BcState st, const uint32_t* pa, const uint32_t* pb, uint32_t* flag) {
@@ -284,34 +318,38 @@ __global__ void bc_record_flags(BcState st, const uint32_t* pa, const uint32_t* 
   flag[i] = (pa[i] < pb[i] || !st.le_mutual[i]) ? 1u : 0u;
 }
 
-__global__ void bc_record_fill(BcState st, const uint32_t* flag, const uint32_t* eidx, const long long* partner,
+__global__ void bc_record_fill(BcState st, int c, const uint32_t* flag, const uint32_t* eidx, const long long* partner,
                                const uint32_t* rank, uint32_t* deg) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= st.P || !flag[i]) return;
+  const BcChan& ch = st.ch[c];
   const uint32_t e = eidx[i];
   const uint32_t src = st.le_src[i], dst = st.le_dst[i];
   const uint32_t u = src < dst ? src : dst, v = src < dst ? dst : src;
-  st.e_u[e] = u; st.e_v[e] = v; st.e_alive[e] = 1;
-  st.e_orient[e] = rank[u] < rank[v] ? 1 : 0;
   EStats A, NA;
   estats_clear(A); estats_clear(NA);
-  float* d = &st.e_dir[(size_t)e * 4];
+  float* d = &ch.e_dir[(size_t)e * 4];
   d[0] = d[2] = __builtin_inff(); d[1] = d[3] = -__builtin_inff();
-  st.e_fhead[e] = st.e_ftail[e] = kNone;
   const long long j = partner[i];
   if (j >= 0) {            // mutual pair: i = (u -> v), j = (v -> u)
-    const EStats& si = st.le_stats[i];
-    const EStats& sj = st.le_stats[j];
+    const EStats& si = ch.le_stats[i];
+    const EStats& sj = ch.le_stats[j];
     A = si; estats_add(A, sj);
     d[0] = si.mn; d[1] = si.mx; d[2] = sj.mn; d[3] = sj.mx;
+  } else if (st.nm_out[dst]) NA = ch.le_stats[i];
+  ch.e_A[e] = A; ch.e_NA[e] = NA;
+  if (c != 0) return;
+  // structure (once)
+  st.e_u[e] = u; st.e_v[e] = v; st.e_alive[e] = 1;
+  st.e_orient[e] = rank[u] < rank[v] ? 1 : 0;
+  st.e_fhead[e] = st.e_ftail[e] = kNone;
+  if (j >= 0) {
     st.e_table[e] = 1;
     st.pq.leaf_seq[e] = (unsigned long long)i + 1ull;      // lexicographic (u,v) order of the table edges
   } else {
     st.e_table[e] = 0;
-    if (st.nm_out[dst]) NA = st.le_stats[i];
-    else { st.e_fhead[e] = st.e_ftail[e] = (uint32_t)i; }
+    if (!st.nm_out[dst]) { st.e_fhead[e] = st.e_ftail[e] = (uint32_t)i; }
   }
-  st.e_A[e] = A; st.e_NA[e] = NA;
   atomicAdd(&deg[u], 1u);
   atomicAdd(&deg[v], 1u);
 }
@@ -336,27 +374,45 @@ __global__ void bc_init_score(BcState st, uint32_t E0) {
   if (e >= E0 || !st.e_table[e]) return;
   const uint32_t u = st.e_u[e], v = st.e_v[e];
   const uint32_t first = st.e_orient[e] ? u : v, second = st.e_orient[e] ? v : u;
-  float a, b, c, d;
-  excl_minmax(st, first, e, a, b);
-  excl_minmax(st, second, e, c, d);
+  float ex[4 * kMaxChannels];
+#pragma unroll
+  for (int c = 0; c < kMaxChannels; ++c) {
+    if (c < st.cfg.K) { excl_minmax(st, c, first, e, ex[4 * c + 0], ex[4 * c + 1]); excl_minmax(st, c, second, e, ex[4 * c + 2], ex[4 * c + 3]); }
+    else { ex[4 * c + 0] = ex[4 * c + 1] = ex[4 * c + 2] = ex[4 * c + 3] = 0.f; }
+  }
   double x[kMaxFeat];
-  edge_features(st, first, second, e, a, b, c, d, x);
+  edge_features(st, first, second, e, ex, x);
   st.pq.leaf_sal[e] = classify_serial(st.clf, x);
 }
 
 // ---- the loop ----------------------------------------------------------------------------------------------
+constexpr int kPoolBytes = 112 * 1024;   // LDS workspace of the scoring phase, partitioned at run time (bc_layout)
 struct BcShared {
   uint32_t r0, r1, e, stop, len0, len1, off0, off1, newcount;
-  unsigned long long best_mn, best_mx, second_mn, second_mx;    // ord(value) << 32 | record, over r2's new records
-  uint32_t ex[4];
+  // per channel: ord(value) << 32 | record over r2's new records (their r2 -> rs extremes), best and runner-up
+  unsigned long long best_mn[kMaxChannels], best_mx[kMaxChannels], second_mn[kMaxChannels], second_mx[kMaxChannels];
+  uint32_t ex[kMaxChannels][4];
   int votes[kChunk];
   int model[kChunk];
-  float exmn[kChunk], exmx[kChunk];
-  EStats shs[kChunk];                 // shared boundary set of every record of the chunk
-  double fx[kChunk][9];               // its seven entropies and two histogram distances (lane-parallel pass)   // per new record: min / max of rs's boundary set without what it sends along the record
-  double feat[kFeatDoubles];          // feature vectors of the chunk being scored, stride fdim
   PqWork pq;
+  __attribute__((aligned(16))) unsigned char pool[kPoolBytes];
 };
+// workspace of one scoring round of `chunk` records: feature vectors | precomputed entropies/distances | shared
+// boundary sets per channel | neighbour extremes per channel
+struct BcLayout { uint32_t chunk; int fstride, npre; double* feat; double* fx; EStats* shs; float* exmn; float* exmx; };
+__device__ __forceinline__ BcLayout bc_layout(const BcCfg& c, unsigned char* pool) {
+  BcLayout L;
+  L.fstride = bc_full_dim(c); L.npre = feat::pre_count(c);
+  const uint32_t per = 8u * (uint32_t)L.fstride + 8u * (uint32_t)L.npre + (uint32_t)sizeof(EStats) * (uint32_t)c.K + 8u * (uint32_t)c.K;
+  uint32_t chunk = (uint32_t)kPoolBytes / per;
+  L.chunk = chunk < (uint32_t)kChunk ? chunk : (uint32_t)kChunk;
+  L.feat = reinterpret_cast<double*>(pool);
+  L.fx = L.feat + (size_t)L.chunk * L.fstride;
+  L.shs = reinterpret_cast<EStats*>(L.fx + (size_t)L.chunk * L.npre);
+  L.exmn = reinterpret_cast<float*>(L.shs + (size_t)L.chunk * c.K);
+  L.exmx = L.exmn + (size_t)L.chunk * c.K;
+  return L;
+}
 
 constexpr unsigned long long kHelperSpinLimit = 1ull << 27;     // polls (with s_sleep) before a side gives up: ~60 s
 
@@ -383,10 +439,10 @@ __device__ void bc_helper_loop(const BcState& st, BcShared& s) {
         __builtin_amdgcn_s_sleep(4);
       }
       fence_acquire();
-      s.ex[0] = v;
+      s.ex[0][0] = v;
     }
     __syncthreads();
-    const uint32_t v = s.ex[0];
+    const uint32_t v = s.ex[0][0];
     if (v == last || v == 0xFFFFFFFFu) return;          // gave up waiting / the loop is over
     last = v;
     const uint32_t cn = st.hctl[2];
@@ -394,12 +450,13 @@ __device__ void bc_helper_loop(const BcState& st, BcShared& s) {
     for (uint32_t j = h; j < cn; j += H) {
       const int m = st.hmodel[j];
       if (m < 0) continue;
-      for (int i = tid; i < fstride; i += kBcThreads) s.feat[i] = st.featbuf[(size_t)j * fstride + i];
+      double* hfeat = reinterpret_cast<double*>(s.pool);
+      for (int i = tid; i < fstride; i += kBcThreads) hfeat[i] = st.featbuf[(size_t)j * fstride + i];
       if (tid == 0) s.votes[0] = 0;
       __syncthreads();
       const DeviceForest& f = st.clf.f[m];
       int mine = 0;
-      for (int t = tid; t < f.ntree; t += kBcThreads) mine += forest_vote(f, t, s.feat);
+      for (int t = tid; t < f.ntree; t += kBcThreads) mine += forest_vote(f, t, hfeat);
       if (mine) atomicAdd(&s.votes[0], mine);
       __syncthreads();
       if (tid == 0) st.hvotes[j] = s.votes[0];
@@ -419,6 +476,8 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
   unsigned long long k = st.ctrl[0], ne = st.ctrl[1], pool_used = st.ctrl[2];
   uint32_t status = ST_RUN;
   const int fdim = st.cfg.fdim;
+  const int K = st.cfg.K;
+  const BcLayout L = bc_layout(st.cfg, s.pool);
   if (tid == 0) { s.pq.wln[0] = s.pq.wln[1] = 0; s.pq.ovf = 0; s.pq.spill = 0; }
   for (int i = tid; i < kSetSlots; i += blockDim.x) { s.pq.set[0][i] = 0; s.pq.set[1][i] = 0; }
   __syncthreads();
@@ -434,8 +493,10 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
     if (tid == 0) {
       const PqLevel& root = st.pq.lv[st.pq.nlevels - 1];
       s.stop = ST_RUN; s.newcount = 0;
-      s.best_mn = s.second_mn = ~0ull; s.best_mx = s.second_mx = 0ull;
-      s.ex[0] = s.ex[2] = 0xFFFFFFFFu; s.ex[1] = s.ex[3] = 0u;
+      for (int c = 0; c < kMaxChannels; ++c) {
+        s.best_mn[c] = s.second_mn[c] = ~0ull; s.best_mx[c] = s.second_mx[c] = 0ull;
+        s.ex[c][0] = s.ex[c][2] = 0xFFFFFFFFu; s.ex[c][1] = s.ex[c][3] = 0u;
+      }
       const bool forced = st.forced != nullptr;
       if (forced ? (k >= st.forced_n) : (root.seq[0] == 0)) s.stop = ST_DONE;
       else {
@@ -478,17 +539,29 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
         const uint32_t r = side1 ? r1 : r0;
         const uint32_t eid = st.pool[side1 ? off1 + (i - len0) : off0 + i];
         if (eid == e || !st.e_alive[eid]) continue;
-        const float* d = &st.e_dir[(size_t)eid * 4 + (st.e_u[eid] == r ? 0 : 2)];
-        atomicMin(&s.ex[side1 ? 2 : 0], float_ord(d[0]));
-        atomicMax(&s.ex[side1 ? 3 : 1], float_ord(d[1]));
+        const int sel = st.e_u[eid] == r ? 0 : 2;
+        for (int c = 0; c < K; ++c) {
+          const float* d = &st.ch[c].e_dir[(size_t)eid * 4 + sel];
+          atomicMin(&s.ex[c][side1 ? 2 : 0], float_ord(d[0]));
+          atomicMax(&s.ex[c][side1 ? 3 : 1], float_ord(d[1]));
+        }
       }
       __syncthreads();
       if (tid == 0) {
-        float m0 = fminf(st.Bn[r0].mn, ord_float(s.ex[0])), x0 = fmaxf(st.Bn[r0].mx, ord_float(s.ex[1]));
-        float m1 = fminf(st.Bn[r1].mn, ord_float(s.ex[2])), x1 = fmaxf(st.Bn[r1].mx, ord_float(s.ex[3]));
+        const bool keep = forced || st.e_orient[e];        // bc_feat: (x0, x1) as given
+        float ex[4 * kMaxChannels];
+#pragma unroll
+        for (int c = 0; c < kMaxChannels; ++c) {
+          float m0 = 0.f, x0 = 0.f, m1 = 0.f, x1 = 0.f;
+          if (c < K) {
+            m0 = fminf(st.ch[c].Bn[r0].mn, ord_float(s.ex[c][0])); x0 = fmaxf(st.ch[c].Bn[r0].mx, ord_float(s.ex[c][1]));
+            m1 = fminf(st.ch[c].Bn[r1].mn, ord_float(s.ex[c][2])); x1 = fmaxf(st.ch[c].Bn[r1].mx, ord_float(s.ex[c][3]));
+          }
+          ex[4 * c + 0] = keep ? m0 : m1; ex[4 * c + 1] = keep ? x0 : x1; ex[4 * c + 2] = keep ? m1 : m0; ex[4 * c + 3] = keep ? x1 : x0;
+        }
         double x[kMaxFeat];
-        if (forced || st.e_orient[e]) edge_features(st, r0, r1, e, m0, x0, m1, x1, x);   // bc_feat: (x0, x1) as given
-        else edge_features(st, r1, r0, e, m1, x1, m0, x0, x);
+        if (keep) edge_features(st, r0, r1, e, ex, x);
+        else edge_features(st, r1, r0, e, ex, x);
         for (int i = 0; i < fdim; ++i) st.feats_out[(size_t)k * fdim + i] = x[i];
       }
       __syncthreads();
@@ -497,16 +570,19 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
     PH(0);
     // ---- the merged region (TRegionMap::merge, type/region_map.hxx:113-118) ----
     if (tid == 0) {
-      PStats p = st.pts[r0];
-      pstats_add(p, st.pts[r1]);
-      st.pts[r2] = p;
-      EStats bn = st.Bn[r0];
-      estats_add(bn, st.Bn[r1]);
-      st.Bn[r2] = bn;
-      EStats bt = st.Bt[r0];
-      estats_add(bt, st.Bt[r1]);
-      if (e != kNone) estats_sub_additive(bt, st.e_A[e]);
-      st.Bt[r2] = bt;
+      for (int c = 0; c < K; ++c) {
+        const BcChan& ch = st.ch[c];
+        PStats p = ch.pts[r0];
+        pstats_add(p, ch.pts[r1]);
+        ch.pts[r2] = p;
+        EStats bn = ch.Bn[r0];
+        estats_add(bn, ch.Bn[r1]);
+        ch.Bn[r2] = bn;
+        EStats bt = ch.Bt[r0];
+        estats_add(bt, ch.Bt[r1]);
+        if (e != kNone) estats_sub_additive(bt, ch.e_A[e]);
+        ch.Bt[r2] = bt;
+      }
       st.parent[r0] = r2; st.parent[r1] = r2; st.parent[r2] = r2;
       if (e != kNone) { st.e_alive[e] = 0; if (!forced) { st.pq.leaf_seq[e] = 0; pq_leaf_removed(st.pq, s.pq, e); } }
     }
@@ -545,20 +621,34 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
       }
       const uint32_t idx = atomicAdd(&s.newcount, 1u);
       const uint32_t newE = (uint32_t)ne + idx;
-      EStats A, NA;
-      estats_clear(A); estats_clear(NA);
-      float d[4] = {__builtin_inff(), -__builtin_inff(), __builtin_inff(), -__builtin_inff()};   // rs->r2, r2->rs
+      // image statistics of the new record, channel by channel
+      for (int c = 0; c < K; ++c) {
+        const BcChan& ch = st.ch[c];
+        EStats A, NA;
+        estats_clear(A); estats_clear(NA);
+        float d[4] = {__builtin_inff(), -__builtin_inff(), __builtin_inff(), -__builtin_inff()};   // rs->r2, r2->rs
+        for (int side = 0; side < 2; ++side) {
+          const uint32_t o = side ? e1s : e0s;
+          if (o == kNone) continue;
+          estats_add(A, ch.e_A[o]);
+          estats_add(NA, ch.e_NA[o]);
+          const float* od = &ch.e_dir[(size_t)o * 4];
+          const bool rsIsU = st.e_u[o] == rs;          // od[0..1] = u->v
+          d[0] = fminf(d[0], od[rsIsU ? 0 : 2]); d[1] = fmaxf(d[1], od[rsIsU ? 1 : 3]);
+          d[2] = fminf(d[2], od[rsIsU ? 2 : 0]); d[3] = fmaxf(d[3], od[rsIsU ? 3 : 1]);
+        }
+        ch.e_A[newE] = A; ch.e_NA[newE] = NA;
+        float* nd = &ch.e_dir[(size_t)newE * 4];
+        nd[0] = d[0]; nd[1] = d[1]; nd[2] = d[2]; nd[3] = d[3];
+        // r2's mutual boundary extremes (entries r2 -> rs) for B(r2) and the "all but one" queries
+        atomicMin(&s.best_mn[c], ((unsigned long long)float_ord(d[2]) << 32) | newE);
+        atomicMax(&s.best_mx[c], ((unsigned long long)float_ord(d[3]) << 32) | newE);
+      }
       uint32_t fh = kNone, ft = kNone;
       bool t0 = false, t1 = false;
       for (int side = 0; side < 2; ++side) {
         const uint32_t o = side ? e1s : e0s;
         if (o == kNone) continue;
-        estats_add(A, st.e_A[o]);
-        estats_add(NA, st.e_NA[o]);
-        const float* od = &st.e_dir[(size_t)o * 4];
-        const bool rsIsU = st.e_u[o] == rs;          // od[0..1] = u->v
-        d[0] = fminf(d[0], od[rsIsU ? 0 : 2]); d[1] = fmaxf(d[1], od[rsIsU ? 1 : 3]);
-        d[2] = fminf(d[2], od[rsIsU ? 2 : 0]); d[3] = fmaxf(d[3], od[rsIsU ? 3 : 1]);
         const uint32_t oh = st.e_fhead[o];
         if (oh != kNone) {
           if (fh == kNone) { fh = oh; ft = st.e_ftail[o]; }
@@ -572,9 +662,6 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
       const uint32_t posRs = (st.e_u[old] == rs) ? st.e_posu[old] : st.e_posv[old];
       st.e_u[newE] = rs; st.e_v[newE] = r2; st.e_posu[newE] = posRs; st.e_posv[newE] = idx;
       st.e_alive[newE] = 1; st.e_table[newE] = (t0 || t1) ? 1 : 0; st.e_orient[newE] = 1;
-      st.e_A[newE] = A; st.e_NA[newE] = NA;
-      float* nd = &st.e_dir[(size_t)newE * 4];
-      nd[0] = d[0]; nd[1] = d[1]; nd[2] = d[2]; nd[3] = d[3];
       st.e_fhead[newE] = fh; st.e_ftail[newE] = ft;
       // queue position (only meaningful for table edges): reference visit order, see greedy.hip
       const uint32_t cat = rs < r0 ? 0u : (t0 ? 1u : 2u);
@@ -584,9 +671,6 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
       st.pool[r2off + idx] = newE;
       // stash the category in posv's upper bits? no: recompute it when scoring -- keep it in model[] later
       st.e_posv[newE] = idx | (cat << 30);
-      // r2's mutual boundary extremes (entries r2 -> rs) for B(r2) and the "all but one" queries
-      atomicMin(&s.best_mn, ((unsigned long long)float_ord(d[2]) << 32) | newE);
-      atomicMax(&s.best_mx, ((unsigned long long)float_ord(d[3]) << 32) | newE);
     }
     __syncthreads();
     PH(2);
@@ -595,27 +679,34 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
       const uint32_t rec = (uint32_t)ne + j;
       const uint32_t rs = st.e_u[rec];
       st.mark0[rs] = 0; st.mark1[rs] = 0;
-      const float* nd = &st.e_dir[(size_t)rec * 4];
-      if (rec != (uint32_t)(s.best_mn & 0xFFFFFFFFull)) atomicMin(&s.second_mn, ((unsigned long long)float_ord(nd[2]) << 32) | rec);
-      if (rec != (uint32_t)(s.best_mx & 0xFFFFFFFFull)) atomicMax(&s.second_mx, ((unsigned long long)float_ord(nd[3]) << 32) | rec);
+      for (int c = 0; c < K; ++c) {
+        const float* nd = &st.ch[c].e_dir[(size_t)rec * 4];
+        if (rec != (uint32_t)(s.best_mn[c] & 0xFFFFFFFFull)) atomicMin(&s.second_mn[c], ((unsigned long long)float_ord(nd[2]) << 32) | rec);
+        if (rec != (uint32_t)(s.best_mx[c] & 0xFFFFFFFFull)) atomicMax(&s.second_mx[c], ((unsigned long long)float_ord(nd[3]) << 32) | rec);
+      }
     }
     __syncthreads();
-    const float bnmn = st.Bn[r2].mn, bnmx = st.Bn[r2].mx;
-    const float best_mn = newcount ? ord_float((uint32_t)(s.best_mn >> 32)) : __builtin_inff();
-    const float best_mx = newcount ? ord_float((uint32_t)(s.best_mx >> 32)) : -__builtin_inff();
-    const float second_mn = (s.second_mn != ~0ull) ? ord_float((uint32_t)(s.second_mn >> 32)) : __builtin_inff();
-    const float second_mx = (s.second_mx != 0ull) ? ord_float((uint32_t)(s.second_mx >> 32)) : -__builtin_inff();
-    const uint32_t arg_mn = (uint32_t)(s.best_mn & 0xFFFFFFFFull), arg_mx = (uint32_t)(s.best_mx & 0xFFFFFFFFull);
+    // per channel: extremes of r2's boundary set with all / all but one of its new records
+    auto r2_extremes = [&](int c, uint32_t rec, float& mn, float& mx) {
+      const float bnmn = st.ch[c].Bn[r2].mn, bnmx = st.ch[c].Bn[r2].mx;
+      const float best_mn = newcount ? ord_float((uint32_t)(s.best_mn[c] >> 32)) : __builtin_inff();
+      const float best_mx = newcount ? ord_float((uint32_t)(s.best_mx[c] >> 32)) : -__builtin_inff();
+      const float second_mn = (s.second_mn[c] != ~0ull) ? ord_float((uint32_t)(s.second_mn[c] >> 32)) : __builtin_inff();
+      const float second_mx = (s.second_mx[c] != 0ull) ? ord_float((uint32_t)(s.second_mx[c] >> 32)) : -__builtin_inff();
+      const uint32_t arg_mn = (uint32_t)(s.best_mn[c] & 0xFFFFFFFFull), arg_mx = (uint32_t)(s.best_mx[c] & 0xFFFFFFFFull);
+      mn = fminf(bnmn, rec == arg_mn ? second_mn : best_mn);
+      mx = fmaxf(bnmx, rec == arg_mx ? second_mx : best_mx);
+    };
     if (tid == 0) {
       st.adj_off[r2] = r2off; st.adj_len[r2] = newcount;
-      st.Bmn[r2] = fminf(bnmn, best_mn); st.Bmx[r2] = fmaxf(bnmx, best_mx);
+      for (int c = 0; c < K; ++c) { float mn, mx; r2_extremes(c, kNone, mn, mx); st.ch[c].Bmn[r2] = mn; st.ch[c].Bmx[r2] = mx; }
     }
     __syncthreads();
 
     PH(3);
     // ---- score the new table edges: features (one thread per edge) -> forest ((edge, tree) per thread) ----
-    const int fstride = bc_full_dim(st.cfg);      // vectors are assembled at full length, the simple selection is compacted in place
-    const uint32_t chunk = min((uint32_t)kChunk, (uint32_t)(kFeatDoubles / fstride));
+    const int fstride = L.fstride;      // vectors are assembled at full length, the simple selection is compacted in place
+    const uint32_t chunk = L.chunk;
     for (uint32_t c0 = 0; c0 < (forced ? 0u : newcount); c0 += chunk) {
       const uint32_t cn = min(chunk, newcount - c0);
       {
@@ -624,65 +715,97 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
         const uint32_t sub = (uint32_t)tid >> 4, l16 = (uint32_t)tid & 15u;
         for (uint32_t j = sub; j < cn; j += kBcThreads / 16) {
           const uint32_t rec = (uint32_t)ne + c0 + j;
-          float mn = __builtin_inff(), mx = -__builtin_inff();
+          float mn[kMaxChannels], mx[kMaxChannels];
+#pragma unroll
+          for (int c = 0; c < kMaxChannels; ++c) { mn[c] = __builtin_inff(); mx[c] = -__builtin_inff(); }
           if (st.e_table[rec]) {
             const uint32_t rs = st.e_u[rec];
             const uint32_t off = st.adj_off[rs], len = st.adj_len[rs];
             for (uint32_t i = l16; i < len; i += 16) {
               const uint32_t e2 = st.pool[off + i];
               if (e2 == rec || !st.e_alive[e2]) continue;
-              const float* d = &st.e_dir[(size_t)e2 * 4 + (st.e_u[e2] == rs ? 0 : 2)];
-              mn = fminf(mn, d[0]); mx = fmaxf(mx, d[1]);
+              const int sel = st.e_u[e2] == rs ? 0 : 2;
+#pragma unroll
+              for (int c = 0; c < kMaxChannels; ++c) {
+                if (c < K) {
+                  const float* d = &st.ch[c].e_dir[(size_t)e2 * 4 + sel];
+                  mn[c] = fminf(mn[c], d[0]); mx[c] = fmaxf(mx[c], d[1]);
+                }
+              }
             }
-            if (l16 == 0) { mn = fminf(mn, st.Bn[rs].mn); mx = fmaxf(mx, st.Bn[rs].mx); }
+            if (l16 == 0) {
+#pragma unroll
+              for (int c = 0; c < kMaxChannels; ++c) if (c < K) { mn[c] = fminf(mn[c], st.ch[c].Bn[rs].mn); mx[c] = fmaxf(mx[c], st.ch[c].Bn[rs].mx); }
+            }
           }
 #pragma unroll
-          for (int o = 8; o >= 1; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o, 16)); mx = fmaxf(mx, __shfl_xor(mx, o, 16)); }
-          if (l16 == 0) { s.exmn[j] = mn; s.exmx[j] = mx; }
+          for (int c = 0; c < kMaxChannels; ++c) {
+            if (c < K) {
+              float a = mn[c], b = mx[c];
+#pragma unroll
+              for (int o = 8; o >= 1; o >>= 1) { a = fminf(a, __shfl_xor(a, o, 16)); b = fmaxf(b, __shfl_xor(b, o, 16)); }
+              if (l16 == 0) { L.exmn[j * K + c] = a; L.exmx[j * K + c] = b; }
+            }
+          }
         }
       }
       PH(8);
-      if ((uint32_t)tid < cn) {
-        const uint32_t rec = (uint32_t)ne + c0 + tid;
-        if (st.e_table[rec]) shared_boundary(st, rec, s.shs[tid]);
+      for (uint32_t w = tid; w < cn * (uint32_t)K; w += kBcThreads) {
+        const uint32_t j = w / (uint32_t)K; const int c = (int)(w % (uint32_t)K);
+        const uint32_t rec = (uint32_t)ne + c0 + j;
+        if (st.e_table[rec]) shared_boundary(st, c, rec, L.shs[j * K + c]);
       }
       __syncthreads();
       PH(9);
       {
-        // entropies and histogram distances, one lane per bin (16 lanes per record): the fifty-odd log2 and divisions of a
-        // vector are by far its longest serial stretch.  Lane 0 adds the bins' terms in bin order, as the reference does.
+        // entropies and histogram distances, one lane per bin (16 lanes per record): the log2 and divisions of a vector
+        // are by far its longest serial stretch.  Lane 0 adds the bins' terms in bin order, as the reference does.
         const uint32_t sub = (uint32_t)tid >> 4, l16 = (uint32_t)tid & 15u;
-        const int bins = st.cfg.bins;
+        const BcCfg& cf = st.cfg;
         for (uint32_t j = sub; j < cn; j += kBcThreads / 16) {
           const uint32_t rec = (uint32_t)ne + c0 + j;
           const bool on = st.e_table[rec] != 0;              // uniform over the 16 lanes
-          double t[7], tl = 0.0, tx = 0.0;
-#pragma unroll
-          for (int q = 0; q < 7; ++q) t[q] = 0.0;
-          if (on && (int)l16 < bins) {
-            const uint32_t rs = st.e_u[rec];
-            const PStats* P0 = &st.pts[rs]; const PStats* P1 = &st.pts[r2];
-            const EStats* B0 = &st.Bt[rs]; const EStats* B1 = &st.Bt[r2];
-            const EStats* A = &st.e_A[rec];
-            const uint32_t h0 = P0->hist[l16], h1 = P1->hist[l16], g0 = B0->hist[l16], g1 = B1->hist[l16];
-            t[0] = feat::entropy_term(h0, P0->n); t[1] = feat::entropy_term(g0, B0->n);
-            t[2] = feat::entropy_term(h1, P1->n); t[3] = feat::entropy_term(g1, B1->n);
-            t[4] = feat::entropy_term(h0 + h1, P0->n + P1->n);
-            t[5] = feat::entropy_term(g0 + g1 - A->hist[l16], B0->n + B1->n - A->n);
-            t[6] = feat::entropy_term(s.shs[j].hist[l16], s.shs[j].n);
-            feat::dist_terms(h0, P0->n, h1, P1->n, tl, tx);
+          const uint32_t rs = st.e_u[rec];
+          double* fx = L.fx + (size_t)j * L.npre;
+          // lane 0 adds the 16 lanes' terms in bin order
+          auto bin_sum = [&](double t, int bins, bool negate) -> double {
+            double acc = 0.0;
+            for (int b = 0; b < bins; ++b) { const double v = __shfl(t, b, 16); acc = negate ? acc - v : acc + v; }
+            return acc;
+          };
+          for (int kind = 0; kind < 2; ++kind) {
+            const int cnt = kind ? cf.n_rlabel : cf.n_region;
+            for (int i = 0; i < cnt; ++i) {
+              const int cc = kind ? cf.lc[i] : cf.rc[i];
+              const int bins = cf.cbins[cc];
+              double t0 = 0.0, t1 = 0.0, t2 = 0.0, tl = 0.0, tx = 0.0;
+              if (on && (int)l16 < bins) {
+                const PStats* P0 = &st.ch[cc].pts[rs]; const PStats* P1 = &st.ch[cc].pts[r2];
+                const uint32_t h0 = P0->hist[l16], h1 = P1->hist[l16];
+                t0 = feat::entropy_term(h0, P0->n); t1 = feat::entropy_term(h1, P1->n);
+                t2 = feat::entropy_term(h0 + h1, P0->n + P1->n);
+                feat::dist_terms(h0, P0->n, h1, P1->n, tl, tx);
+              }
+              const double e0 = bin_sum(t0, bins, true), e1 = bin_sum(t1, bins, true), e2 = bin_sum(t2, bins, true);
+              const double dl = bin_sum(tl, bins, false), dx = bin_sum(tx, bins, false);
+              if (l16 == 0) { double* q = fx + feat::pre_region(cf, kind, i); q[0] = e0; q[1] = e1; q[2] = e2; q[3] = dl; q[4] = dx; }
+            }
           }
-          double acc[9];
-#pragma unroll
-          for (int q = 0; q < 9; ++q) acc[q] = 0.0;
-          for (int b = 0; b < bins; ++b) {
-#pragma unroll
-            for (int q = 0; q < 7; ++q) acc[q] -= __shfl(t[q], b, 16);
-            acc[7] += __shfl(tl, b, 16); acc[8] += __shfl(tx, b, 16);
-          }
-          if (l16 == 0) {
-#pragma unroll
-            for (int q = 0; q < 9; ++q) s.fx[j][q] = acc[q];
+          for (int i = 0; i < cf.n_boundary; ++i) {
+            const int cc = cf.bc[i];
+            const int bins = cf.cbins[cc];
+            double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+            if (on && (int)l16 < bins) {
+              const EStats* B0 = &st.ch[cc].Bt[rs]; const EStats* B1 = &st.ch[cc].Bt[r2];
+              const EStats* A = &st.ch[cc].e_A[rec];
+              const EStats* sh = &L.shs[j * K + cc];
+              const uint32_t g0 = B0->hist[l16], g1 = B1->hist[l16];
+              t0 = feat::entropy_term(g0, B0->n); t1 = feat::entropy_term(g1, B1->n);
+              t2 = feat::entropy_term(g0 + g1 - A->hist[l16], B0->n + B1->n - A->n);
+              t3 = feat::entropy_term(sh->hist[l16], sh->n);
+            }
+            const double e0 = bin_sum(t0, bins, true), e1 = bin_sum(t1, bins, true), e2 = bin_sum(t2, bins, true), e3 = bin_sum(t3, bins, true);
+            if (l16 == 0) { double* q = fx + feat::pre_boundary(cf, i); q[0] = e0; q[1] = e1; q[2] = e2; q[3] = e3; }
           }
         }
       }
@@ -693,11 +816,15 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
         s.votes[tid] = 0; s.model[tid] = -1;
         if (st.e_table[rec]) {
           const uint32_t rs = st.e_u[rec];
-          const float a = s.exmn[tid], b = s.exmx[tid];
-          const float c = fminf(bnmn, rec == arg_mn ? second_mn : best_mn);
-          const float d = fmaxf(bnmx, rec == arg_mx ? second_mx : best_mx);
-          double* x = &s.feat[tid * fstride];
-          edge_features(st, rs, r2, rec, a, b, c, d, x, s.fx[tid], &s.shs[tid]);        // updateFb passes (rs, r2)
+          float ex[4 * kMaxChannels];
+#pragma unroll
+          for (int c = 0; c < kMaxChannels; ++c) {
+            float a = 0.f, b = 0.f, cm = 0.f, dm = 0.f;
+            if (c < K) { a = L.exmn[tid * K + c]; b = L.exmx[tid * K + c]; r2_extremes(c, rec, cm, dm); }
+            ex[4 * c + 0] = a; ex[4 * c + 1] = b; ex[4 * c + 2] = cm; ex[4 * c + 3] = dm;
+          }
+          double* x = &L.feat[tid * fstride];
+          edge_features(st, rs, r2, rec, ex, x, L.fx + (size_t)tid * L.npre, &L.shs[tid * K]);        // updateFb passes (rs, r2)
           s.model[tid] = st.clf.kind == 1 ? 0 : pick_model(st.clf, x);
         }
       }
@@ -705,7 +832,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
       PH(4);
       if (st.clf.kind == 0 && st.n_helpers) {
         // hand the chunk to the helper workgroups and wait for their votes
-        for (uint32_t i = tid; i < cn * (uint32_t)fstride; i += kBcThreads) st.featbuf[i] = s.feat[i];
+        for (uint32_t i = tid; i < cn * (uint32_t)fstride; i += kBcThreads) st.featbuf[i] = L.feat[i];
         if ((uint32_t)tid < cn) st.hmodel[tid] = s.model[tid];
         __threadfence();
         __syncthreads();
@@ -728,14 +855,14 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
           const uint32_t j = i / ntree, t = i % ntree;
           const int m = s.model[j];
           if (m < 0) continue;
-          if (forest_vote(st.clf.f[m], (int)t, &s.feat[j * fstride])) atomicAdd(&s.votes[j], 1);
+          if (forest_vote(st.clf.f[m], (int)t, &L.feat[j * fstride])) atomicAdd(&s.votes[j], 1);
         }
       }
       __syncthreads();
       PH(5);
       if ((uint32_t)tid < cn && s.model[tid] >= 0) {
         const uint32_t rec = (uint32_t)ne + c0 + tid;
-        const double sal = st.clf.kind == 1 ? 1.0 - s.feat[tid * fstride + st.clf.stub_index]
+        const double sal = st.clf.kind == 1 ? 1.0 - L.feat[tid * fstride + st.clf.stub_index]
                                             : (double)s.votes[tid] / (double)st.clf.f[s.model[tid]].ntree;
         const uint32_t cat = st.e_posv[rec] >> 30;
         st.pq.leaf_sal[rec] = sal;
@@ -814,7 +941,7 @@ int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& cl
 
   if ((rc = buf.get(&st.le_src, P, false, stream))) return rc;
   if ((rc = buf.get(&st.le_dst, P, false, stream))) return rc;
-  if ((rc = buf.get(&st.le_stats, P, false, stream))) return rc;
+  for (int c = 0; c < cfg.K; ++c) if ((rc = buf.get(&st.ch[c].le_stats, P, false, stream))) return rc;
   if ((rc = buf.get(&st.le_next, P, false, stream))) return rc;
   if ((rc = buf.get(&st.le_mutual, P, false, stream))) return rc;
   if ((rc = buf.get(&st.le_start, (size_t)R + 1, false, stream))) return rc;
@@ -824,8 +951,9 @@ int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& cl
   if ((rc = buf.get(&flag, P + 1, true, stream))) return rc;
   if ((rc = buf.get(&eidx, P + 1, false, stream))) return rc;
   const unsigned gP = (unsigned)((P + 255) / 256);
-  hipLaunchKernelGGL(bc_leaf_entries, dim3(gP), dim3(256), 0, stream, st, rag.d_pa, rag.d_pb, rag.d_prec, rag.d_rlabel, partner,
-                     cfg.bins, cfg.T);
+  for (int c = 0; c < cfg.K; ++c)
+    hipLaunchKernelGGL(bc_leaf_entries, dim3(gP), dim3(256), 0, stream, st, c, rag.d_pa, rag.d_pb, rag.c_prec[c], rag.d_rlabel, partner,
+                       cfg.cbins[c], cfg.T);
   hipLaunchKernelGGL(bc_leaf_starts, dim3((R + 256) / 256), dim3(256), 0, stream, st, rag.d_pa, rag.d_rlabel);
   hipLaunchKernelGGL(bc_record_flags, dim3(gP), dim3(256), 0, stream, st, rag.d_pa, rag.d_pb, flag);
   {
@@ -843,11 +971,17 @@ int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& cl
   st.Ecap = (uint32_t)std::min<unsigned long long>(0xFFFFFF00ull, (unsigned long long)E0 * 6ull + (1u << 16));
   st.pool_cap = (unsigned long long)E0 * 12ull + (1u << 16);
   const size_t R2 = 2 * (size_t)R;
-  if ((rc = buf.get(&st.pts, R2, false, stream))) return rc;
-  if ((rc = buf.get(&st.Bn, R2, false, stream))) return rc;
-  if ((rc = buf.get(&st.Bt, R2, false, stream))) return rc;
-  if ((rc = buf.get(&st.Bmn, R2, false, stream))) return rc;
-  if ((rc = buf.get(&st.Bmx, R2, false, stream))) return rc;
+  for (int c = 0; c < cfg.K; ++c) {
+    BcChan& ch = st.ch[c];
+    if ((rc = buf.get(&ch.pts, R2, false, stream))) return rc;
+    if ((rc = buf.get(&ch.Bn, R2, false, stream))) return rc;
+    if ((rc = buf.get(&ch.Bt, R2, false, stream))) return rc;
+    if ((rc = buf.get(&ch.Bmn, R2, false, stream))) return rc;
+    if ((rc = buf.get(&ch.Bmx, R2, false, stream))) return rc;
+    if ((rc = buf.get(&ch.e_A, st.Ecap, false, stream))) return rc;
+    if ((rc = buf.get(&ch.e_NA, st.Ecap, false, stream))) return rc;
+    if ((rc = buf.get(&ch.e_dir, (size_t)st.Ecap * 4, false, stream))) return rc;
+  }
   if ((rc = buf.get(&st.parent, R2, false, stream))) return rc;
   if ((rc = buf.get(&st.adj_off, R2, true, stream))) return rc;
   if ((rc = buf.get(&st.adj_len, R2 + 1, true, stream))) return rc;
@@ -859,9 +993,6 @@ int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& cl
   if ((rc = buf.get(&st.e_alive, st.Ecap, false, stream))) return rc;
   if ((rc = buf.get(&st.e_table, st.Ecap, false, stream))) return rc;
   if ((rc = buf.get(&st.e_orient, st.Ecap, false, stream))) return rc;
-  if ((rc = buf.get(&st.e_A, st.Ecap, false, stream))) return rc;
-  if ((rc = buf.get(&st.e_NA, st.Ecap, false, stream))) return rc;
-  if ((rc = buf.get(&st.e_dir, (size_t)st.Ecap * 4, false, stream))) return rc;
   if ((rc = buf.get(&st.e_fhead, st.Ecap, false, stream))) return rc;
   if ((rc = buf.get(&st.e_ftail, st.Ecap, false, stream))) return rc;
   st.pq.nleaves = st.Ecap;
@@ -889,8 +1020,10 @@ int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& cl
   if ((rc = buf.get(&cursor, R2, true, stream))) return rc;
 
   hipLaunchKernelGGL(bc_init_dead, dim3((st.Ecap + 255) / 256), dim3(256), 0, stream, st, 0u);
-  hipLaunchKernelGGL(bc_leaf_regions, dim3((R + 255) / 256), dim3(256), 0, stream, st, rag.d_rrec, cfg.bins);
-  hipLaunchKernelGGL(bc_record_fill, dim3(gP), dim3(256), 0, stream, st, flag, eidx, partner, d_rank, st.adj_len);
+  for (int c = 0; c < cfg.K; ++c) {
+    hipLaunchKernelGGL(bc_leaf_regions, dim3((R + 255) / 256), dim3(256), 0, stream, st, c, rag.c_rrec[c], cfg.cbins[c]);
+    hipLaunchKernelGGL(bc_record_fill, dim3(gP), dim3(256), 0, stream, st, c, flag, eidx, partner, d_rank, st.adj_len);
+  }
   {
     size_t tmp = 0;
     GLIA_HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, st.adj_len, st.adj_off, 0u, (size_t)R, rocprim::plus<uint32_t>(), stream));
@@ -954,9 +1087,11 @@ int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& cl
       if ((rc = buf.grow(&st.e_alive, ocap, ncap, stream))) return rc;
       if ((rc = buf.grow(&st.e_table, ocap, ncap, stream))) return rc;
       if ((rc = buf.grow(&st.e_orient, ocap, ncap, stream))) return rc;
-      if ((rc = buf.grow(&st.e_A, ocap, ncap, stream))) return rc;
-      if ((rc = buf.grow(&st.e_NA, ocap, ncap, stream))) return rc;
-      if ((rc = buf.grow(&st.e_dir, (size_t)ocap * 4, (size_t)ncap * 4, stream))) return rc;
+      for (int c = 0; c < cfg.K; ++c) {
+        if ((rc = buf.grow(&st.ch[c].e_A, ocap, ncap, stream))) return rc;
+        if ((rc = buf.grow(&st.ch[c].e_NA, ocap, ncap, stream))) return rc;
+        if ((rc = buf.grow(&st.ch[c].e_dir, (size_t)ocap * 4, (size_t)ncap * 4, stream))) return rc;
+      }
       if ((rc = buf.grow(&st.e_fhead, ocap, ncap, stream))) return rc;
       if ((rc = buf.grow(&st.e_ftail, ocap, ncap, stream))) return rc;
       if ((rc = buf.grow(&st.pq.leaf_sal, ocap, ncap, stream))) return rc;

@@ -73,6 +73,9 @@ struct AccParams {
   uint32_t debug;                    // ablation switches for profiling builds (GLIA_HMT_DEBUG), 0 in production
 };
 
+constexpr int kMaxChannels = 4;     // distinct (image volume, histogram) pairs over all feature lists
+constexpr int kMaxListed = 4;       // images per feature list (region / label / boundary)
+
 // compact, sorted RAG as produced by the edge-table step
 struct RagArrays {
   int64_t R = 0, P = 0;       // regions, directed pairs
@@ -81,6 +84,12 @@ struct RagArrays {
   uint32_t* d_pa = nullptr;       // [P] label a (ascending (a,b))
   uint32_t* d_pb = nullptr;       // [P]
   uint32_t* d_prec = nullptr;     // [P][kPairWords]
+  // Feature lists with several image volumes: one accumulation pass per distinct (volume, histogram) CHANNEL.  Channel
+  // 0 is the boundary-probability volume (d_rrec / d_prec above = c_rrec[0] / c_prec[0]); the keys are common.
+  int K = 1;
+  uint32_t* c_rrec[kMaxChannels] = {nullptr, nullptr, nullptr, nullptr};
+  uint32_t* c_prec[kMaxChannels] = {nullptr, nullptr, nullptr, nullptr};
+  int c_bins[kMaxChannels] = {0, 0, 0, 0};
 };
 
 int launch_accumulate(const AccParams& p, hipStream_t stream);

@@ -148,3 +148,81 @@ def test_classifier_linkage_with_mask(ctx):
     o_ref, s_ref, f_ref = O.Rag(labels, mask=mask).merge_order_bc(ocfg, None, stub_index=stub, want_feats=True)
     assert order.shape == o_ref.shape and (order == o_ref).all()
     assert (sal == s_ref).all() and _feat_close(feats, f_ref)
+
+
+def _aux_images(shape, seed):
+    """two extra Q8 volumes (a smooth 'raw intensity' and a blocky 'texton label' image)"""
+    rng = np.random.default_rng(seed)
+    z = np.indices(shape).astype(np.float64)
+    raw = 0.5 + 0.25 * np.sin(z[0] / 3.0) * np.cos(z[-1] / 4.0) + 0.2 * rng.random(shape)
+    raw = (np.clip(np.round(raw * 255), 0, 255) / 256.0).astype(np.float32)
+    tex = ((z[0] // 3 + 2 * (z[-1] // 5) + (z[1] // 4 if len(shape) == 3 else 0)) % 7).astype(np.float32)
+    return raw, tex
+
+
+@pytest.mark.parametrize("layout", ["rb2", "split", "pb_unlisted", "four"])
+@pytest.mark.parametrize("shape,S,G", [((32, 32, 32), 8, 16), ((48, 40), 4, 16)])
+def test_feature_lists_with_several_image_volumes(ctx, layout, shape, S, G):
+    """prepareImages (hmt/hmt_util.hxx:17-56): --rbi images feed both lists, --ri / --bi / --rli one each; every distinct
+    (volume, histogram) is a channel of its own accumulation pass.  Orders, saliencies, feature rows vs the oracle."""
+    import torch
+    from glia_amd import hmt
+    from oracle import pyoracle as O
+    labels, pb = O.synth(shape, S, G)
+    raw, tex = _aux_images(shape, 21)
+    d = lambda a: torch.from_numpy(a).cuda()
+    d_lab = torch.from_numpy(labels.view(np.int32)).cuda()
+    d_pb, d_raw, d_tex = d(pb), d(raw), d(tex)
+    if layout == "rb2":            # --rbi raw --rbi pb
+        kw = dict(rb=[("raw", 8, 0.0, 1.0), ("pb", 8, 0.0, 1.0)])
+    elif layout == "split":        # --ri raw --bi pb --rli textons (16 bins over the label range)
+        kw = dict(r=[("raw", 8, 0.0, 1.0)], b=[("pb", 8, 0.0, 1.0)], rl=[("tex", 16, -0.5, 7.5)])
+    elif layout == "pb_unlisted":  # pb only drives the shape features
+        kw = dict(rb=[("raw", 16, 0.0, 1.0)])
+    else:                          # the same volume with two histogram specs + everything else
+        kw = dict(rb=[("pb", 8, 0.0, 1.0), ("raw", 8, 0.0, 1.0)], r=[("pb", 4, 0.0, 1.0)], rl=[("tex", 8, -0.5, 7.5)])
+    host = {"raw": raw, "pb": pb, "tex": tex}
+    dev = {"raw": d_raw, "pb": d_pb, "tex": d_tex}
+    okw = {k: [(host[n], b, lo, hi) for n, b, lo, hi in v] for k, v in kw.items()}
+    dkw = {k: [(dev[n], b, lo, hi) for n, b, lo, hi in v] for k, v in kw.items()}
+    cfg = hmt.make_config(d_pb, **dkw)
+    ocfg = O.make_cfg(pb, **okw)
+    rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, cfg=cfg)
+    dimf = rm.feat_dim()
+    assert dimf == O.feat_dim(len(shape), ocfg)
+    stub = 11 + 4 * 3 + 1          # a histogram distance of the first region / label image
+    order, sal, feats = rm.merge_order_bc(hmt.FeatureStubClassifier(ctx, stub), want_feats=True)
+    o_ref, s_ref, f_ref = O.Rag(labels).merge_order_bc(ocfg, None, stub_index=stub, want_feats=True)
+    assert order.shape == o_ref.shape and (order == o_ref).all()
+    assert (sal == s_ref).all() and _feat_close(feats, f_ref)
+    # bc_feat for the given order goes through the forced-order mode of the same kernel
+    f2 = rm.bc_feat(order)
+    assert _feat_close(f2, O.Rag(labels).bc_feat(ocfg, o_ref))
+    rm.close()
+
+
+def test_several_image_volumes_with_a_forest_and_simple_features(ctx):
+    import torch
+    from glia_amd import hmt
+    from oracle import pyoracle as O
+    import _rf
+    shape = (32, 32, 32)
+    labels, pb = O.synth(shape, 8, 16)
+    raw, tex = _aux_images(shape, 5)
+    d_lab = torch.from_numpy(labels.view(np.int32)).cuda()
+    d_pb, d_raw, d_tex = (torch.from_numpy(a).cuda() for a in (pb, raw, tex))
+    for simple in (False, True):
+        ocfg = O.make_cfg(pb, rb=[(raw, 8, 0.0, 1.0), (pb, 8, 0.0, 1.0)], rl=[(tex, 8, -0.5, 7.5)], use_simple=simple)
+        cfg = hmt.make_config(d_pb, rb=[(d_raw, 8, 0.0, 1.0), (d_pb, 8, 0.0, 1.0)], rl=[(d_tex, 8, -0.5, 7.5)], use_simple_features=simple)
+        _, _, f0 = O.Rag(labels).merge_order_bc(ocfg, None, stub_index=4, want_feats=True)
+        forest = _rf.random_forest(np.random.default_rng(9), 63, 7, f0)
+        with tempfile.TemporaryDirectory() as dd:
+            path = os.path.join(dd, "model.bin")
+            _rf.write_model(path, forest)
+            clf = hmt.RandomForest(ctx, path, predict_label=-1)
+        rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, cfg=cfg)
+        order, sal, feats = rm.merge_order_bc(clf, want_feats=True)
+        o_ref, s_ref, f_ref = O.Rag(labels).merge_order_bc(ocfg, O.make_forest(forest, -1), want_feats=True)
+        assert order.shape == o_ref.shape and (order == o_ref).all()
+        assert (sal == s_ref).all() and _feat_close(feats, f_ref)
+        rm.close()

@@ -167,3 +167,30 @@ def test_end_to_end_classifier_tree_to_final_segmentation(tools, tmp_path):
     ref = O.transform_image(labels, *O.label_transform(lab, c0, c1, picks, 1), fill_missing=True)
     got = read_mha(out)
     assert (got == ref).all() and 1 < len(np.unique(got)) <= len(np.unique(labels))
+
+
+def test_merge_order_bc_cli_with_two_volumes(tools, tmp_path):
+    """--rbi raw --rbi pb (both lists get both images) + --rli textons, through files"""
+    from oracle import pyoracle as O
+    import _rf
+    shape = (32, 32, 32)
+    labels, pb = O.synth(shape, 8, 16)
+    rng = np.random.default_rng(4)
+    raw = (np.round(rng.random(shape) * 255) / 256.0).astype(np.float32)
+    tex = (np.indices(shape).sum(0) % 5).astype(np.float32)
+    ocfg = O.make_cfg(pb, rb=[(raw, 8, 0.0, 1.0), (pb, 8, 0.0, 1.0)], rl=[(tex, 8, -0.5, 4.5)])
+    _, _, f0 = O.Rag(labels).merge_order_bc(ocfg, None, stub_index=31, want_feats=True)
+    forest = _rf.random_forest(np.random.default_rng(3), 31, 6, f0)
+    files = {n: str(tmp_path / n) for n in ("model.bin", "seg.mha", "pb.mha", "raw.mha", "tex.mha", "order.txt", "sal.txt", "bfeat.txt")}
+    _rf.write_model(files["model.bin"], forest)
+    for n, a in (("seg.mha", labels), ("pb.mha", pb), ("raw.mha", raw), ("tex.mha", tex)):
+        write_mha(files[n], a)
+    subprocess.check_call([os.path.join(tools, "merge_order_bc"), "--bct", "1", "--bcm", files["model.bin"], "-s", files["seg.mha"], "--pb", files["pb.mha"],
+                           "--rbi", files["raw.mha"], "--rbb", "8", "--rbl", "0", "--rbu", "1",
+                           "--rbi", files["pb.mha"], "--rbb", "8", "--rbl", "0", "--rbu", "1",
+                           "--rli", files["tex.mha"], "--rlb", "8", "--rll", "-0.5", "--rlu", "4.5",
+                           "--bt", "0.2", "0.5", "0.8", "-o", files["order.txt"], "--sal", files["sal.txt"], "-b", files["bfeat.txt"]])
+    o_ref, s_ref, f_ref = O.Rag(labels).merge_order_bc(ocfg, O.make_forest(forest, -1), want_feats=True)
+    assert (np.loadtxt(files["order.txt"], dtype=np.int64).reshape(-1, 3) == o_ref).all()
+    got = np.array([[float(x) for x in ln.split(" ")[:-1]] for ln in open(files["bfeat.txt"]).read().split("\n")[:-1]])
+    assert got.shape == f_ref.shape and np.allclose(got, f_ref, rtol=6e-8, atol=1e-12)
