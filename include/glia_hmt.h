@@ -60,7 +60,8 @@ typedef struct {
 
 /* Feature configuration = the image lists prepareImages builds (hmt/hmt_util.hxx:17-56: an --rbi
  * image is appended to BOTH the region and the boundary list) plus the scalar flags of
- * hmt/main_merge_order_bc.cxx:172-242. */
+ * hmt/main_merge_order_bc.cxx:172-242.  At most 4 entries per list; every distinct (d_image, bins, lo, hi) over
+ * all lists is one accumulation pass over the volume (at most 4 distinct ones). */
 typedef struct {
   int n_region;  glia_hmt_image region[GLIA_HMT_MAX_IMAGES];         /* rImages  */
   int n_rlabel;  glia_hmt_image rlabel[GLIA_HMT_MAX_IMAGES];         /* rlImages */
