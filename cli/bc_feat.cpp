@@ -1,6 +1,5 @@
 // cli/bc_feat.cpp -- drop-in for hmt/main_bc_feat.cxx: boundary-classifier feature rows of a GIVEN merge order.
 //   bc_feat -s seg.mha -o order.txt --pb pb.mha [--rbi/--rbb/--rbl/--rbu ...] [--bt ...] [-n b] [-l b] [--simpf b] -b feats.txt
-// Not supported yet: the saliency features (-y/--s0/--sb).
 #include "common.hpp"
 
 using namespace cli;
@@ -14,7 +13,6 @@ int main(int argc, char* argv[]) {
                  known, usage);
   for (const char* req : {"segImage", "mergeOrder", "pb"})
     if (!a.has(req)) { std::cerr << "Error: the option '--" << req << "' is required but missing\n" << usage; perr("Error: unable to parse input arguments"); }
-  if (a.has("saliency")) perr("Error: saliency features (-y) are not supported by the MI355X path yet...");
   FeatInputs f;
   loadFeatInputs(a, f);
   std::vector<uint32_t> order = readOrder(a.str("mergeOrder"));
@@ -24,9 +22,18 @@ int main(int argc, char* argv[]) {
   check(glia_hmt_ctx_create(0, nullptr, &ctx));
   uint32_t* dMask = loadMask(a, "maskImage", f.seg.size());
   check(glia_hmt_rag_build(ctx, f.seg.dim, f.seg.dims, f.dLab, dMask, /*only_contour=*/0, f.dPb, &f.cfg, &rag));
-  const int d = glia_hmt_feat_dim(rag);
+  std::vector<double> sal;
+  if (a.has("saliency")) {                                                        // :50-55
+    std::ifstream is(a.str("saliency"));
+    if (!is) perr("Error: invalid data file dimension in " + a.str("saliency"));
+    double x;
+    while (is >> x) sal.push_back(x);
+    if ((int64_t)sal.size() < n) perr("Error: too few saliencies...");
+  }
+  const int d = glia_hmt_bc_feat_dim(rag, sal.empty() ? 0 : 1);
   std::vector<double> feats((size_t)(n ? n : 1) * d);
-  check(glia_hmt_bc_feat(ctx, rag, order.data(), n, feats.data()));
+  check(glia_hmt_bc_feat_saliency(ctx, rag, order.data(), n, sal.empty() ? nullptr : sal.data(), atof(a.str("s0", "1.0").c_str()),
+                                  atof(a.str("sb", "1.0").c_str()), feats.data()));
   writeRows(a.str("bfeat"), feats.data(), n, d, /*FLT_PREC*/ 8);                  // :103-110
   glia_hmt_rag_free(rag); glia_hmt_ctx_destroy(ctx);
   (void)hipFree(f.dLab); (void)hipFree(f.dPb);

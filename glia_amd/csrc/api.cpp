@@ -652,6 +652,8 @@ void glia_hmt_forest_free(glia_hmt_forest* f) {
   delete f;
 }
 
+static inline double sdivide_host(double l, double r) { return std::fabs(r) >= 2.22e-16 ? l / r : 0.0; }   // glia_base.hxx:77-78
+
 static bool make_bc_cfg(const glia_hmt_rag* rag, BcCfg* c) {
   if (!rag->has_cfg) return false;
   const glia_hmt_feat_config& g = rag->cfg;
@@ -743,6 +745,17 @@ int glia_hmt_pre_merge(glia_hmt_ctx* c, glia_hmt_rag* rag, const int* size_thres
 }
 
 int glia_hmt_bc_feat(glia_hmt_ctx* c, glia_hmt_rag* rag, const uint32_t* h_order, int64_t n_merges, double* h_feats) {
+  return glia_hmt_bc_feat_saliency(c, rag, h_order, n_merges, nullptr, 1.0, 1.0, h_feats);
+}
+
+int glia_hmt_bc_feat_dim(const glia_hmt_rag* rag, int with_saliency) {
+  BcCfg cfg;
+  if (!rag || !make_bc_cfg(rag, &cfg)) return -1;
+  return cfg.fdim + ((with_saliency && !cfg.use_simple) ? 5 : 0);
+}
+
+int glia_hmt_bc_feat_saliency(glia_hmt_ctx* c, glia_hmt_rag* rag, const uint32_t* h_order, int64_t n_merges,
+                              const double* h_saliencies, double init_saliency, double saliency_bias, double* h_feats) {
   if (!c || !rag || !h_order || !h_feats || n_merges < 0 || rag->ctx != c) { set_error("bc_feat: invalid argument"); return GLIA_HMT_ERR_ARG; }
   BcCfg cfg;
   if (!make_bc_cfg(rag, &cfg) || rag->only_contour) {
@@ -782,7 +795,45 @@ int glia_hmt_bc_feat(glia_hmt_ctx* c, glia_hmt_rag* rag, const uint32_t* h_order
                      &rag->ms_loop, &rag->n_scored, false, forced.data(), n_merges);
   if (rc) return rc;
   if (n != n_merges) { set_error("bc_feat: internal error, merges not completed"); return GLIA_HMT_ERR_HIP; }
-  memcpy(h_feats, feats.data(), sizeof(double) * (size_t)n * cfg.fdim);
+  if (!h_saliencies || cfg.use_simple) {       // selectFeatures carries no saliency (hmt/bc_feat.hxx:247-279)
+    memcpy(h_feats, feats.data(), sizeof(double) * (size_t)n * cfg.fdim);
+    return GLIA_HMT_OK;
+  }
+  // Saliency features (hmt/main_bc_feat.cxx:50-55): every region of the order carries a number -- initSal for the
+  // regions that are only merged, saliency + bias for the region a merge creates (genSaliencyMap, hmt/bc_feat.hxx:12-26).
+  // They do not depend on the image: each region block gets its number appended (bc_feat.hxx:76), the boundary block
+  // (min, max) of |s(x1) - s(x3)|, |s(x2) - s(x3)| (:163-166, :208-213).  Which region is x1 follows the area rule of
+  // main_bc_feat.cxx:88-91, for which the voxel counts of the tree nodes are summed up here.
+  std::vector<uint32_t> rrec((size_t)R * kRegionWords);
+  GLIA_HIP_TRY(hipMemcpy(rrec.data(), rag->arr.d_rrec, sizeof(uint32_t) * kRegionWords * R, hipMemcpyDeviceToHost));
+  std::vector<unsigned long long> area((size_t)R + n_merges);
+  for (int64_t i = 0; i < R; ++i) area[i] = rrec[(size_t)i * kRegionWords + R_CNT];
+  std::unordered_map<uint32_t, double> smap;
+  for (int64_t i = 0; i < n_merges; ++i) {
+    if (!smap.count(h_order[3 * i])) smap[h_order[3 * i]] = init_saliency;
+    if (!smap.count(h_order[3 * i + 1])) smap[h_order[3 * i + 1]] = init_saliency;
+    smap[h_order[3 * i + 2]] = h_saliencies[i] + saliency_bias;
+  }
+  const int od = cfg.fdim + 5;
+  for (int64_t i = 0; i < n_merges; ++i) {
+    const uint32_t a = forced[2 * i], b = forced[2 * i + 1];
+    area[R + i] = area[a] + area[b];
+    const bool swap = sdivide_host((double)area[a], cfg.norm_area) > sdivide_host((double)area[b], cfg.norm_area);
+    const double s0 = smap[h_order[3 * i]], s1 = smap[h_order[3 * i + 1]], s2 = smap[h_order[3 * i + 2]];
+    const double sx1 = swap ? s1 : s0, sx2 = swap ? s0 : s1;
+    const double d02 = std::fabs(sx1 - s2), d12 = std::fabs(sx2 - s2);
+    const double* in = &feats[(size_t)i * cfg.fdim];
+    double* out = &h_feats[(size_t)i * od];
+    int k = 0;
+    for (int q = 0; q < cfg.bfdim; ++q) out[k++] = in[q];
+    out[k++] = std::min(d02, d12); out[k++] = std::max(d02, d12);
+    for (int q = 0; q < cfg.rfdim; ++q) out[k++] = in[cfg.bfdim + q];
+    out[k++] = sx1;
+    for (int q = 0; q < cfg.rfdim; ++q) out[k++] = in[cfg.bfdim + cfg.rfdim + q];
+    out[k++] = sx2;
+    for (int q = 0; q < cfg.rfdim; ++q) out[k++] = in[cfg.bfdim + 2 * cfg.rfdim + q];
+    out[k++] = s2;
+  }
   return GLIA_HMT_OK;
 }
 

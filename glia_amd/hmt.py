@@ -425,11 +425,14 @@ class RegionMap:
                                         _np(order), _np(sal), C.c_int64(cap), C.byref(n)))
         return order[:n.value].copy(), sal[:n.value].copy()
 
-    def bc_feat(self, order):
-        """hmt/main_bc_feat.cxx: feature rows for a given merge order."""
+    def bc_feat(self, order, saliencies=None, init_sal=1.0, sal_bias=1.0):
+        """hmt/main_bc_feat.cxx: feature rows of a given merge order; with `saliencies` (-y) also the saliency features."""
         order = np.ascontiguousarray(order, dtype=np.uint32)
-        feats = np.empty((len(order), self.feat_dim()), np.float64)
-        _check(lib().glia_hmt_bc_feat(self.ctx.h, self.h, _np(order), C.c_int64(len(order)), _np(feats)))
+        d = lib().glia_hmt_bc_feat_dim(self.h, C.c_int(1 if saliencies is not None else 0))
+        feats = np.empty((len(order), d), np.float64)
+        sal = None if saliencies is None else np.ascontiguousarray(saliencies, dtype=np.float64)
+        _check(lib().glia_hmt_bc_feat_saliency(self.ctx.h, self.h, _np(order), C.c_int64(len(order)), _np(sal),
+                                               C.c_double(init_sal), C.c_double(sal_bias), _np(feats)))
         return feats
 
     def score_initial_edges(self, classifier):

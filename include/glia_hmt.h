@@ -175,9 +175,15 @@ int glia_hmt_pre_merge(glia_hmt_ctx* ctx, glia_hmt_rag* rag, const int* size_thr
 
 /* Replaces the bc_feat pipeline (hmt/main_bc_feat.cxx:27-112) for a GIVEN merge order: RegionMap(seg, mask, order,
  * false) + RegionFeats of every tree node + BoundaryFeats of every merge (the OpenMP parfor loops of :59-101),
- * without the optional saliency features (-y).  h_order: n_merges triples (x0, x1, x2); h_feats: [n_merges][feat_dim],
+ * without the optional saliency features (see glia_hmt_bc_feat_saliency).  h_order: n_merges triples (x0, x1, x2); h_feats: [n_merges][feat_dim],
  * row i = features of merge i with regions in the file's orientation and the area-ordered swap of :88-91. */
 int glia_hmt_bc_feat(glia_hmt_ctx* ctx, glia_hmt_rag* rag, const uint32_t* h_order, int64_t n_merges, double* h_feats);
+/* The same with the saliency features of bc_feat -y/--s0/--sb (hmt/main_bc_feat.cxx:50-55, genSaliencyMap
+ * hmt/bc_feat.hxx:12-26): h_saliencies[i] belongs to merge i; rows then have glia_hmt_bc_feat_dim(rag, 1) columns
+ * (5 more: two in the boundary block, one per region block; none for the simple selection). */
+int glia_hmt_bc_feat_saliency(glia_hmt_ctx* ctx, glia_hmt_rag* rag, const uint32_t* h_order, int64_t n_merges,
+                              const double* h_saliencies, double init_saliency, double saliency_bias, double* h_feats);
+int glia_hmt_bc_feat_dim(const glia_hmt_rag* rag, int with_saliency);
 
 /* ---- the step after the merge path: tree resolution (hmt/main_segment_greedy.cxx:33-86), host-only ----
  * glia_hmt_tree_potentials = genTree / genTreeWithNodePotentials (hmt/tree_build.hxx:12-63): array tree of the merge

@@ -528,7 +528,10 @@ struct RegionFeats {
     for (auto const& p : region) p.serialize(f);
     for (auto const& p : labelRegion) p.serialize(f);
     for (auto const& p : boundary) p.serialize(f);
+    if (hasSaliency) f.push_back(saliency);          // bc_feat.hxx:76
   }
+  bool hasSaliency = false;                          // bc_feat.hxx:53,125-126 (pSaliency)
+  double saliency = 0.0;
 };
 
 // hmt/bc_feat.hxx:131-214 with type/feat.hxx:94-187, 507-590, 643-670, 769-811, 856-883
@@ -613,7 +616,18 @@ struct BoundaryFeats {
     }
     for (auto const& d : labelRegion) { f.push_back(d.l1); f.push_back(d.x2); f.push_back(d.ed); }
     for (auto const& p : boundary) p.serialize(f);
+    if (hasSaliency) { f.push_back(salFirst); f.push_back(salSecond); }     // bc_feat.hxx:163-166
   }
+  // bc_feat.hxx:208-213
+  void setSaliency(RegionFeats const& rf0, RegionFeats const& rf1, RegionFeats const& rf2) {
+    if (rf0.hasSaliency && rf1.hasSaliency && rf2.hasSaliency) {
+      double dsal02 = std::fabs(rf0.saliency - rf2.saliency);
+      double dsal12 = std::fabs(rf1.saliency - rf2.saliency);
+      hasSaliency = true; salFirst = std::min(dsal02, dsal12); salSecond = std::max(dsal02, dsal12);
+    }
+  }
+  bool hasSaliency = false;
+  double salFirst = 0.0, salSecond = 0.0;
 };
 
 // hmt/bc_feat.hxx:247-279
@@ -1014,16 +1028,37 @@ int64_t orc_merge_order_bc(orc_rag* h, const orc_feat_cfg* c, const orc_forest* 
   return n;
 }
 
+int64_t orc_bc_feat_sal(orc_rag* h, const orc_feat_cfg* c, const orc_label* order, int64_t n_merges, const double* saliencies,
+                        double init_sal, double sal_bias, double* feats_out);
 int64_t orc_bc_feat(orc_rag* h, const orc_feat_cfg* c, const orc_label* order, int64_t n_merges,
                     double* feats_out) {
+  return orc_bc_feat_sal(h, c, order, n_merges, nullptr, 1.0, 1.0, feats_out);
+}
+// with the saliency features of main_bc_feat.cxx:50-55 when `saliencies` is given; rows have dim + 5 columns then
+// (none for the simple selection)
+int64_t orc_bc_feat_sal(orc_rag* h, const orc_feat_cfg* c, const orc_label* order, int64_t n_merges, const double* saliencies,
+                        double init_sal, double sal_bias, double* feats_out) {
   if (h->onlyContour) return -1;
   RegionMap& rmap = h->rmap;
   Cfg cfg = makeCfg(&h->vol, c);
+  std::unordered_map<Label, double> saliencyMap;       // genSaliencyMap, bc_feat.hxx:12-26
+  if (saliencies) {
+    for (int64_t i = 0; i < n_merges; ++i) {
+      if (saliencyMap.count(order[3 * i]) == 0) saliencyMap[order[3 * i]] = init_sal;
+      if (saliencyMap.count(order[3 * i + 1]) == 0) saliencyMap[order[3 * i + 1]] = init_sal;
+      saliencyMap[order[3 * i + 2]] = saliencies[i] + sal_bias;
+    }
+  }
   // main_bc_feat.cxx:57: RegionMap(seg, mask, order, false) -> set(order) (region_map.hxx:67-68)
   for (int64_t i = 0; i < n_merges; ++i) rmap.merge(order[3 * i], order[3 * i + 1], order[3 * i + 2]);
   std::unordered_map<Label, RegionFeats> rfmap;
-  for (auto const& rp : rmap) rfmap[rp.first].generate(rp.second, cfg);           // :59-71
-  int d = orc_feat_dim(h->vol.D, c);
+  for (auto const& rp : rmap) {                                                    // :59-71
+    RegionFeats& rf = rfmap[rp.first];
+    rf.generate(rp.second, cfg);
+    auto sit = saliencyMap.find(rp.first);
+    if (sit != saliencyMap.end()) { rf.hasSaliency = true; rf.saliency = sit->second; }
+  }
+  int d = orc_feat_dim(h->vol.D, c) + ((saliencies && !c->use_simple) ? 5 : 0);
   std::vector<BoundaryFeats> bfeats(n_merges);
   std::vector<std::array<RegionFeats*, 3>> xs(n_merges);
   for (int64_t i = 0; i < n_merges; ++i) {                                           // :76-95
@@ -1035,6 +1070,7 @@ int64_t orc_bc_feat(orc_rag* h, const orc_feat_cfg* c, const orc_label* order, i
     PtrPairMap b;
     getBoundary(b, rmap.find(r0)->second, rmap.find(r1)->second);
     bfeats[i].generate(b, *x1, *x2, cfg);
+    bfeats[i].setSaliency(*x1, *x2, *x3);
     xs[i] = {x1, x2, x3};
   }
   if (c->use_log) {                                                                  // :97-102

@@ -124,6 +124,9 @@ int orc_feat_dim(int dim, const orc_feat_cfg*);
 int64_t orc_bc_feat(orc_rag*, const orc_feat_cfg*, const orc_label* order, int64_t n_merges,
                     double* feats_out);
 
+int64_t orc_bc_feat_sal(orc_rag*, const orc_feat_cfg*, const orc_label* order, int64_t n_merges, const double* saliencies,
+                        double init_sal, double sal_bias, double* feats_out);
+
 // pre_merge condition engine (gadget/main_pre_merge.cxx:27-76)
 int64_t orc_pre_merge(orc_rag*, const float* pb, const int* size_thresholds, int n_thresholds,
                       double rpb_threshold, orc_label* order, double* sal, int64_t cap);

@@ -218,11 +218,16 @@ class Rag:
             return order[:n].copy(), sal[:n].copy(), feats[:n].copy()
         return order[:n].copy(), sal[:n].copy()
 
-    def bc_feat(self, cfg, order):
+    def bc_feat(self, cfg, order, saliencies=None, init_sal=1.0, sal_bias=1.0):
         order = np.ascontiguousarray(order, dtype=np.uint32)
         d = lib().orc_feat_dim(C.c_int(self.dim), C.byref(cfg))
+        if saliencies is not None and not cfg.use_simple:
+            d += 5
         feats = np.empty((len(order), d), np.float64)
-        n = lib().orc_bc_feat(self.h, C.byref(cfg), _p(order), C.c_int64(len(order)), _p(feats))
+        sal = None if saliencies is None else np.ascontiguousarray(saliencies, dtype=np.float64)
+        lib().orc_bc_feat_sal.restype = C.c_int64
+        n = lib().orc_bc_feat_sal(self.h, C.byref(cfg), _p(order), C.c_int64(len(order)), _p(sal) if sal is not None else None,
+                                  C.c_double(init_sal), C.c_double(sal_bias), _p(feats))
         if n < 0:
             raise RuntimeError("orc_bc_feat failed")
         return feats

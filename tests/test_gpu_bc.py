@@ -226,3 +226,23 @@ def test_several_image_volumes_with_a_forest_and_simple_features(ctx):
         assert order.shape == o_ref.shape and (order == o_ref).all()
         assert (sal == s_ref).all() and _feat_close(feats, f_ref)
         rm.close()
+
+
+@pytest.mark.parametrize("use_log", [False, True])
+def test_bc_feat_with_saliency_features(ctx, use_log):
+    """bc_feat -y: genSaliencyMap + the five saliency columns (hmt/bc_feat.hxx:12-26,76,163-166,208-213)"""
+    import torch
+    from glia_amd import hmt
+    from oracle import pyoracle as O
+    labels, pb = O.synth((32, 32, 32), 8, 16)
+    d_lab = torch.from_numpy(labels.view(np.int32)).cuda()
+    d_pb = torch.from_numpy(pb).cuda()
+    cfg = hmt.make_config(d_pb, rb=[(d_pb, 8, 0.0, 1.0)], use_log_shape=use_log)
+    ocfg = O.make_cfg(pb, rb=[(pb, 8, 0.0, 1.0)], use_log=use_log)
+    order, sal = O.Rag(labels, only_contour=True).merge_order_pb(pb, type=2)
+    rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, cfg=cfg)
+    got = rm.bc_feat(order, saliencies=sal, init_sal=0.75, sal_bias=1.5)
+    ref = O.Rag(labels).bc_feat(ocfg, order, saliencies=sal, init_sal=0.75, sal_bias=1.5)
+    assert got.shape == ref.shape == (len(order), 104 + 5) and _feat_close(got, ref)
+    assert (got[:, 35] <= got[:, 36]).all()               # (min, max) of the two saliency differences
+    rm.close()

@@ -111,6 +111,17 @@ def test_bc_feat_cli(tools, tmp_path):
     f_ref = O.Rag(labels).bc_feat(cfg, order)
     got = np.array([[float(x) for x in ln.split(" ")[:-1]] for ln in open(feat_f).read().split("\n")[:-1]])
     assert got.shape == f_ref.shape and np.allclose(got, f_ref, rtol=6e-8, atol=1e-12)
+    # -y: saliency file -> five more columns
+    _, sal = O.Rag(labels, only_contour=True).merge_order_pb(pb, type=2)
+    sal_f = str(tmp_path / "sal.txt")
+    with open(sal_f, "w") as f:
+        for v in sal:
+            f.write("%.17g\n" % v)
+    subprocess.check_call([os.path.join(tools, "bc_feat"), "-s", seg, "-o", order_f, "-y", sal_f, "--s0", "0.5", "--sb", "2.0", "--pb", pbf, "--rbi", pbf,
+                           "--rbb", "8", "--rbl", "0", "--rbu", "1", "--bt", "0.2", "0.5", "0.8", "-l", "1", "-b", feat_f])
+    f_ref = O.Rag(labels).bc_feat(cfg, order, saliencies=sal, init_sal=0.5, sal_bias=2.0)
+    got = np.array([[float(x) for x in ln.split(" ")[:-1]] for ln in open(feat_f).read().split("\n")[:-1]])
+    assert got.shape == f_ref.shape and np.allclose(got, f_ref, rtol=6e-8, atol=1e-12)
 
 
 @pytest.mark.parametrize("relabel,w16", [(0, 0), (1, 1)])
