@@ -536,11 +536,15 @@ int glia_hmt_merge_order_pb(glia_hmt_ctx* c, glia_hmt_rag* rag, int type, uint32
     set_error("merge_order_pb: invalid argument");
     return GLIA_HMT_ERR_ARG;
   }
-  if (type == 1 && !rag->vol.lab) {
+  if (type == 3 && rag->only_contour) {
+    set_error("merge_order_pb: the median x min-size linkage needs region sizes (only_contour = 0)");
+    return GLIA_HMT_ERR_ARG;
+  }
+  if ((type == 1 || type == 3) && !rag->vol.lab) {
     set_error("merge_order_pb: median linkage needs the volumes the RAG was built from (whole-volume build)");
     return GLIA_HMT_ERR_UNSUPPORTED;
   }
-  if (type != 1 && type != 2) {   // hmt/main_merge_order_pb.cxx:36
+  if (type != 1 && type != 2 && type != 3) {   // hmt/main_merge_order_pb.cxx:36 (3: this library's name for ...AndMinSize)
     set_error("Error: unsupported boundary stats type...");
     return GLIA_HMT_ERR_ARG;
   }
@@ -552,7 +556,7 @@ int glia_hmt_merge_order_pb(glia_hmt_ctx* c, glia_hmt_rag* rag, int type, uint32
   std::vector<double> sal((size_t)R);
   int64_t n = 0;
   int rc = greedy_mean(rag->arr, c->stream, order.data(), sal.data(), R, &n, &rag->ms_table, &rag->ms_loop,
-                       &rag->n_scored, 0, nullptr, 0.0, type == 1 ? &rag->vol : nullptr);
+                       &rag->n_scored, 0, nullptr, 0.0, (type == 1 || type == 3) ? &rag->vol : nullptr, type == 3);
   if (rc) return rc;
   if (n > capacity) { set_error("merge_order_pb: output capacity too small"); return GLIA_HMT_ERR_CAPACITY; }
   // dense id -> key.  Leaves: i-th label ascending.  Merged regions: maxKey + 1 + k (util/struct_merge.hxx:19,27-31),

@@ -79,6 +79,7 @@ struct GreedyState {
   unsigned long long vals_cap;
   unsigned long long* e_off;      // [Ecap] start of the edge's run
   unsigned long long* rbv;        // [2*R0] values held by the region's incident edges (capacity pre-check)
+  int size_weight;                // ...AndMinSize linkage (util/struct_merge.hxx:141-185): saliency = -median * min(region sizes)
   PqTree pq;
   // pre_merge condition (gadget/main_pre_merge.cxx:27-76); cond_n == 0: f_true
   int cond_n; unsigned long long cond_t0, cond_t1; double cond_rpb;
@@ -298,7 +299,8 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
         const unsigned long long seq = ((k + 1ull) << 32) | ((unsigned long long)cat << 30) | rs;
         st.e_u[newE] = rs; st.e_v[newE] = r2; st.e_posu[newE] = posRs; st.e_posv[newE] = idx;
         st.e_mean[newE] = first; st.e_n[newE] = second;
-        pq.leaf_sal[newE] = -first; pq.leaf_seq[newE] = seq;
+        pq.leaf_sal[newE] = (MEDIAN && st.size_weight) ? -first * (double)min(st.rsz[rs], st.rsz[r2]) : -first;
+        pq.leaf_seq[newE] = seq;
         st.pool[offRs + posRs] = make_uint2(newE, r2);
         st.pool[r2off + idx] = make_uint2(newE, rs);
         pq_leaf_added(pq, s.pq, newE);
@@ -372,7 +374,8 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
             const uint32_t newE = jobs.newE[tid];
             const unsigned long long off = vals_used + jobs.off[tid];
             const double med = (double)st.vals[off + (uint32_t)st.e_n[newE] / 2u];   // util/stats.hxx:83-91
-            st.e_off[newE] = off; st.e_mean[newE] = med; pq.leaf_sal[newE] = -med;
+            st.e_off[newE] = off; st.e_mean[newE] = med;
+            pq.leaf_sal[newE] = st.size_weight ? -med * (double)min(st.rsz[st.e_u[newE]], st.rsz[r2]) : -med;
           }
           vals_used += tot;
           __syncthreads();
@@ -502,7 +505,8 @@ __global__ void median_init(GreedyState st, uint32_t E0) {
   if (e >= E0) return;
   const uint32_t n = (uint32_t)st.e_n[e];
   const double med = (double)st.vals[st.e_off[e] + n / 2u];      // amedian, util/stats.hxx:83-91
-  st.e_mean[e] = med; st.pq.leaf_sal[e] = -med;
+  st.e_mean[e] = med;
+  st.pq.leaf_sal[e] = st.size_weight ? -med * (double)min(st.rsz[st.e_u[e]], st.rsz[st.e_v[e]]) : -med;
   atomicAdd(&st.rbv[st.e_u[e]], (unsigned long long)n);
   atomicAdd(&st.rbv[st.e_v[e]], (unsigned long long)n);
 }
@@ -518,7 +522,7 @@ __global__ void fill_leaves_dead(PqTree t, uint32_t from) {
 // merged region R+k); the caller maps them to keys.
 int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, double* h_sal, int64_t capacity,
                 int64_t* n_merges, double* ms_table, double* ms_loop, int64_t* n_scored, int cond_n,
-                const long long* cond_sizes, double cond_rpb, const VolumeRef* median_of) {
+                const long long* cond_sizes, double cond_rpb, const VolumeRef* median_of, bool size_weight) {
   const long long P = rag.P;
   const uint32_t R = (uint32_t)rag.R;
   *n_merges = 0;
@@ -564,7 +568,7 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
   if ((rc = buf.get(&st.pq.leaf_seq, st.Ecap, false, stream))) return rc;
   if ((rc = buf.get(&st.rsz, 2 * (size_t)R, true, stream))) return rc;
   if ((rc = buf.get(&st.rsum, 2 * (size_t)R, true, stream))) return rc;
-  st.cond_n = cond_n; st.cond_rpb = cond_rpb;
+  st.cond_n = cond_n; st.cond_rpb = cond_rpb; st.size_weight = size_weight ? 1 : 0;
   st.cond_t0 = cond_n > 0 ? (unsigned long long)cond_sizes[0] : 0; st.cond_t1 = cond_n > 1 ? (unsigned long long)cond_sizes[1] : 0;
   hipLaunchKernelGGL(region_sizes, dim3((R + 255) / 256), dim3(256), 0, stream, rag.d_rrec, R, st.rsz, st.rsum);
   if ((rc = buf.get(&st.mark0, 2 * (size_t)R, true, stream))) return rc;

@@ -111,7 +111,8 @@ struct VolumeRef {
 };
 int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, double* h_sal, int64_t capacity,
                 int64_t* n_merges, double* ms_table, double* ms_loop, int64_t* n_scored, int cond_n = 0,
-                const long long* cond_sizes = nullptr, double cond_rpb = 0.0, const VolumeRef* median_of = nullptr);
+                const long long* cond_sizes = nullptr, double cond_rpb = 0.0, const VolumeRef* median_of = nullptr,
+                bool size_weight = false);
 struct BcCfg;
 struct DeviceClassifier;
 int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& clf, hipStream_t stream, uint32_t* h_order,

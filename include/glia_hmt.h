@@ -134,7 +134,9 @@ int glia_hmt_rag_last_pass(const glia_hmt_rag* rag, double* ms, double* algorith
  * Output: h_order[3*i..] = (x0, x1, x2) of merge i (TTriple, type/tuple.hxx:8-29),
  * h_saliency[i] = popped queue key.  *n_merges <= capacity.  Type 1 (the tool's default) keeps, per table edge, the
  * SORTED run of its boundary voxels' values; a contraction merges runs (merge path) and reads the order statistic
- * n/2 (stats::amedian, util/stats.hxx:83-91).  It needs a handle built by glia_hmt_rag_build (whole volume). */
+ * n/2 (stats::amedian, util/stats.hxx:83-91).  It needs a handle built by glia_hmt_rag_build (whole volume).
+ * Type 3 (no tool of the reference calls it) = genMergeOrderGreedyUsingPbApproxMedianAndMinSize (:141-185): saliency
+ * -median * min(size of the two regions), regions merged as the loop goes; needs only_contour = 0. */
 int glia_hmt_merge_order_pb(glia_hmt_ctx* ctx, glia_hmt_rag* rag, int type, uint32_t* h_order,
                             double* h_saliency, int64_t capacity, int64_t* n_merges);
 

@@ -969,6 +969,26 @@ int64_t orc_merge_order_pb(orc_rag* h, const float* pb, int type, int update_reg
       else if (p1) splice1(d2, *p1);
     };
     genMergeOrderGreedy<ItemData>(order, sal, rmap, update_region != 0, initFb, fsal, updateFb, fsal, ftrue);
+  } else if (type == 3) {
+    // util/struct_merge.hxx:141-185: median x min(region sizes), updateRegion = true
+    typedef std::vector<double> ItemData;
+    auto initFb = [&](ItemData& data, Label r0, Label r1) {
+      PtrPairMap b;
+      getBoundary(b, rmap.find(r0)->second, rmap.find(r1)->second);
+      data.reserve(mapSize(b));
+      traverse(b, [&](int64_t p) { data.push_back(pb[p]); });
+    };
+    auto fsal = [&](ItemData& data, Label r0, Label r1) -> double {
+      double p = amedian(data);
+      if (p == DUMMY) bad = true;
+      return -p * std::min(rmap.find(r0)->second.size(), rmap.find(r1)->second.size());
+    };
+    auto updateFb = [](ItemData& d2, Label, Label, Label, Label, ItemData* p0, ItemData* p1) {
+      if (p0 && p1) splice2(d2, *p0, *p1);
+      else if (p0) splice1(d2, *p0);
+      else if (p1) splice1(d2, *p1);
+    };
+    genMergeOrderGreedy<ItemData>(order, sal, rmap, true, initFb, fsal, updateFb, fsal, ftrue);
   } else return -1;   // hmt/main_merge_order_pb.cxx:36 "unsupported boundary stats type"
   if (bad) return -2;  // "invalid boundary saliency" (struct_merge.hxx:58-59)
   return emit(order, sal, order_out, sal_out, cap);

@@ -198,3 +198,14 @@ def test_merge_order_with_mask(ctx, shape, S, G, type):
     o_ref, s_ref = O.Rag(labels, mask=mask, only_contour=True).merge_order_pb(pb, type=type)
     assert order.shape == o_ref.shape and (order == o_ref).all() and (sal == s_ref).all()
     rm.close()
+
+
+@pytest.mark.parametrize("shape,S,G,variant", [((32, 32, 32), 8, 16, 0), ((40, 36, 28), 6, 12, 1), ((64, 64), 4, 16, 0)])
+def test_median_times_min_size_linkage(ctx, shape, S, G, variant):
+    """genMergeOrderGreedyUsingPbApproxMedianAndMinSize (util/struct_merge.hxx:141-185; no reference tool calls it):
+    saliency = -median * min(region sizes) with the regions merged as the loop goes"""
+    from oracle import pyoracle as O
+    labels, pb = O.synth(shape, S, G, variant=variant)
+    order, sal = _gpu_order(ctx, labels, pb, only_contour=False, type=3)
+    o_ref, s_ref = O.Rag(labels, only_contour=False).merge_order_pb(pb, type=3, update_region=True)
+    assert order.shape == o_ref.shape and (order == o_ref).all() and (sal == s_ref).all()
