@@ -412,7 +412,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
   __syncthreads();
   if (tid == 0) { st.ctrl[0] = k; st.ctrl[1] = ne; st.ctrl[2] = pool_used; st.ctrl[3] = status; st.ctrl[4] = vals_used; }
 #ifdef GLIA_HMT_PROFILE
-  if (tid == 0) printf("[greedy profile] pq levels: cycles %llu %llu %llu %llu  nodes %llu %llu %llu %llu  spilled %llu %llu %llu %llu\n", g_pqprof[0], g_pqprof[1], g_pqprof[2],
+  if (tid == 0) printf("[greedy profile] pq levels (wave 0): recompute %llu %llu %llu %llu  barrier-wait %llu %llu %llu %llu  active %llu %llu %llu %llu\n", g_pqprof[0], g_pqprof[1], g_pqprof[2],
                        g_pqprof[3], g_pqprof[8], g_pqprof[9], g_pqprof[10], g_pqprof[11], g_pqprof[16], g_pqprof[17], g_pqprof[18], g_pqprof[19]);
   if (tid == 0) printf("[greedy profile] by degree (<=64, <=512, <=1408, more): merges %llu %llu %llu %llu  cycles %llu %llu %llu %llu  entries %llu %llu %llu %llu\n",
                        nb[0], nb[1], nb[2], nb[3], tb[0], tb[1], tb[2], tb[3], db[0], db[1], db[2], db[3]);

@@ -140,13 +140,22 @@ __device__ __forceinline__ void pq_propagate(const PqTree& t, PqWork& w, int tid
     }
     for (int l = 0; l < t.nlevels; ++l) {
       uint32_t parent = kNone;
+#ifdef GLIA_HMT_PROFILE
+      const unsigned long long tf0 = __builtin_readcyclecounter();
+#endif
       if (node != kNone) {
         const bool changed = pq_recompute_node(t, l, node, lane, false);
         const bool ch = __shfl((int)changed, 0) != 0;
         if (ch && l + 1 < t.nlevels) parent = node / kFan;
       }
+#ifdef GLIA_HMT_PROFILE
+      const unsigned long long tf1 = __builtin_readcyclecounter();
+#endif
       if (lane == 0) w.fast[l & 1][wave] = parent;
       __syncthreads();
+#ifdef GLIA_HMT_PROFILE
+      if (tid == 0) { g_pqprof[l] += tf1 - tf0; g_pqprof[8 + l] += __builtin_readcyclecounter() - tf1; g_pqprof[16 + l] += (node != kNone); }
+#endif
       if (parent != kNone) for (int j = 0; j < wave; ++j) if (w.fast[l & 1][j] == parent) { parent = kNone; break; }
       node = parent;
     }
