@@ -47,7 +47,7 @@ def cpu_baseline(size, S, bc_size):
     return out
 
 
-def slab_phase(ctx, hmt, dist, torch, size, S, world, rank):
+def slab_phase(ctx, hmt, dist, torch, size, S, world, rank, clf):
     """SURVEY.md 8e / BASELINE config 4: ONE volume z-split across the ranks -- every rank accumulates its slab (one halo
     plane per cut), the compact partial records cross RCCL once (all_gather), every rank merges them by key.  Timed
     apart from `value` (the merge loop does not shard); rank 0 checks the result against its single-pass build."""
@@ -71,6 +71,19 @@ def slab_phase(ctx, hmt, dist, torch, size, S, world, rank):
     t = torch.tensor([time.time() - t0], dtype=torch.float64, device="cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     out = {"ms": float(t.item()) * 1e3, "slab_planes_per_rank": ze - zb, "regions": merged.num_regions, "pairs": merged.num_pairs}
+    # K7 on the merged map, sharded by record (independent per edge): every rank scores 1/world of the initial edges,
+    # one all_gather of the scores, element-wise max
+    dist.barrier(); torch.cuda.synchronize(); ctx.sync()
+    t0 = time.time()
+    mine = torch.from_numpy(merged.score_initial_edges_shard(clf, rank, world)).cuda()
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    scores = torch.stack(parts).max(dim=0).values
+    dist.barrier(); torch.cuda.synchronize(); ctx.sync()
+    t = torch.tensor([time.time() - t0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    out["sharded_edge_scoring_ms"] = float(t.item()) * 1e3
+    out["edges_scored"] = int(torch.isfinite(scores).sum().item())
     if rank == 0:
         wcfg = hmt.make_config(pb, rb=[(pb, 8, 0.0, 1.0)], thresholds=(0.2, 0.5, 0.8))
         whole = hmt.RegionMap(ctx, labels, pb=pb, cfg=wcfg)
@@ -78,6 +91,8 @@ def slab_phase(ctx, hmt, dist, torch, size, S, world, rank):
         ra, rb = whole.regions(), merged.regions()
         out["identical_to_single_pass"] = bool(all((a[k] == b[k]).all() for k in a) and all((ra[k] == rb[k]).all() for k in ra))
         out["ms_single_gpu_accumulate"] = whole.last_pass()[0]
+        full = torch.from_numpy(whole.score_initial_edges_shard(clf, 0, 1)).cuda()
+        out["scores_identical_to_single_gpu"] = bool(torch.equal(full, scores))
         whole.close()
     merged.close()
     return out
@@ -224,7 +239,7 @@ def main():
         try:
             del labels, pb, cfg
             torch.cuda.empty_cache()
-            slab_info = slab_phase(ctx, hmt, dist, torch, args.size, args.S, world, rank)
+            slab_info = slab_phase(ctx, hmt, dist, torch, args.size, args.S, world, rank, clf)
         except Exception as e:          # noqa: BLE001
             slab_info = {"error": "%s: %s" % (type(e).__name__, e)}
         dog.cancel()

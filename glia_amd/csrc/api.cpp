@@ -911,6 +911,35 @@ int glia_hmt_score_initial_edges(glia_hmt_ctx* c, glia_hmt_rag* rag, const glia_
   return GLIA_HMT_OK;
 }
 
+int glia_hmt_score_initial_edges_shard(glia_hmt_ctx* c, glia_hmt_rag* rag, const glia_hmt_forest* forest, int shard, int n_shards,
+                                       double* h_scores, int64_t capacity, int64_t* n_records) {
+  if (!c || !rag || !forest || rag->ctx != c || n_shards < 1 || shard < 0 || shard >= n_shards || !n_records) {
+    set_error("score_initial_edges_shard: invalid argument");
+    return GLIA_HMT_ERR_ARG;
+  }
+  BcCfg cfg;
+  if (!make_bc_cfg(rag, &cfg) || rag->only_contour) {
+    set_error("score_initial_edges: the region map must be built with a feature configuration and with region points");
+    return GLIA_HMT_ERR_ARG;
+  }
+  if (forest->max_var >= cfg.fdim) { set_error("score_initial_edges: the classifier reads features beyond the vector"); return GLIA_HMT_ERR_ARG; }
+  GLIA_HIP_TRY(hipSetDevice(c->device));
+  // one record per unordered leaf pair; the count is needed before the scores can be copied out
+  std::vector<double> scores;
+  int64_t n = 0;
+  const int64_t upper = rag->arr.P;            // records <= directed pairs
+  scores.assign((size_t)(upper ? upper : 1), 0.0);
+  int rc = greedy_bc(rag->arr, cfg, forest->dc, c->stream, nullptr, nullptr, nullptr, 0, &n, &rag->ms_table, &rag->ms_init,
+                     &rag->ms_loop, &rag->n_scored, true, nullptr, 0, shard, n_shards, scores.data());
+  if (rc) return rc;
+  *n_records = n;
+  if (h_scores) {
+    if (n > capacity) { set_error("score_initial_edges_shard: output capacity too small"); return GLIA_HMT_ERR_CAPACITY; }
+    memcpy(h_scores, scores.data(), sizeof(double) * (size_t)n);
+  }
+  return GLIA_HMT_OK;
+}
+
 int glia_hmt_last_merge_timing(const glia_hmt_rag* r, double* ms_table, double* ms_init, double* ms_loop,
                                int64_t* n_scored) {
   if (!r) return GLIA_HMT_ERR_ARG;

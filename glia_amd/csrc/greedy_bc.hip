@@ -78,6 +78,7 @@ struct BcState {
   uint32_t* hctl;                // helper protocol: [0] job sequence (0xFFFFFFFF = quit), [1] helpers done, [2] records in the job
   int* hvotes; int* hmodel;      // [kChunk]
   uint32_t n_helpers;            // workgroups 1..n_helpers evaluate the forest; 0 = the loop's own workgroup does
+  uint32_t shard, n_shards;      // initial scoring: this call scores the records e with e % n_shards == shard (multi-GPU K7)
   unsigned long long* ctrl;
   unsigned long long max_iters;
   const uint32_t* forced;        // bc_feat mode: [forced_n][2] region pairs to merge, in this order (no queue, no scoring)
@@ -371,7 +372,7 @@ __global__ void bc_init_dead(BcState st, uint32_t from) {
 // initFb + initFsal of every initial table edge (util/struct_merge_bc.hxx:18-27)
 __global__ void bc_init_score(BcState st, uint32_t E0) {
   uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E0 || !st.e_table[e]) return;
+  if (e >= E0 || !st.e_table[e] || e % st.n_shards != st.shard) return;
   const uint32_t u = st.e_u[e], v = st.e_v[e];
   const uint32_t first = st.e_orient[e] ? u : v, second = st.e_orient[e] ? v : u;
   float ex[4 * kMaxChannels];
@@ -913,7 +914,7 @@ static void rmap_ranks(const std::vector<uint32_t>& labels, const std::vector<lo
 int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& clf, hipStream_t stream,
               uint32_t* h_order, double* h_sal, double* h_feats, int64_t capacity, int64_t* n_merges,
               double* ms_table, double* ms_init, double* ms_loop, int64_t* n_scored, bool init_only,
-              const uint32_t* h_forced, int64_t n_forced) {
+              const uint32_t* h_forced, int64_t n_forced, int shard, int n_shards, double* h_scores) {
   const long long P = rag.P;
   const uint32_t R = (uint32_t)rag.R;
   *n_merges = 0;
@@ -927,6 +928,7 @@ int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& cl
   BcState st;
   memset(&st, 0, sizeof(st));
   st.R0 = R; st.P = P; st.cfg = cfg; st.clf = clf;
+  st.shard = (uint32_t)shard; st.n_shards = (uint32_t)(n_shards > 0 ? n_shards : 1);
 
   // host side: reference region-map iteration order
   std::vector<uint32_t> lab(R), rrec((size_t)R * kRegionWords), rank;
@@ -1061,6 +1063,8 @@ int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& cl
     int64_t nt = 0;
     for (uint8_t t : tab) nt += t;
     *n_scored = nt;
+    *n_merges = (int64_t)E0;            // init-only calls report the number of records here
+    if (h_scores) GLIA_HIP_TRY(hipMemcpy(h_scores, st.pq.leaf_sal, sizeof(double) * E0, hipMemcpyDeviceToHost));
     return GLIA_HMT_OK;
   }
   st.max_iters = 1ull << 14;

@@ -118,7 +118,7 @@ struct DeviceClassifier;
 int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& clf, hipStream_t stream, uint32_t* h_order,
               double* h_sal, double* h_feats, int64_t capacity, int64_t* n_merges, double* ms_table, double* ms_init,
               double* ms_loop, int64_t* n_scored, bool init_only, const uint32_t* h_forced = nullptr,
-              int64_t n_forced = 0);
+              int64_t n_forced = 0, int shard = 0, int n_shards = 1, double* h_scores = nullptr);
 int compact_tables(const AccParams& p, uint32_t rcap, uint32_t pcap, RagArrays* out, hipStream_t stream);
 int transform_keys(const uint32_t* order, int64_t n, std::vector<uint32_t>* src, std::vector<uint32_t>* dst);
 int transform_image(uint32_t* d_lab, int64_t n, const uint32_t* h_src, const uint32_t* h_dst, int64_t m, const uint32_t* d_mask,

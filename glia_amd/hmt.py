@@ -440,6 +440,15 @@ class RegionMap:
         _check(lib().glia_hmt_score_initial_edges(self.ctx.h, self.h, classifier.h, C.byref(n), C.byref(ms)))
         return n.value, ms.value
 
+    def score_initial_edges_shard(self, classifier, shard, n_shards):
+        """scores of the initial records e with e % n_shards == shard (-inf elsewhere); max over shards = all scores"""
+        cap = max(self.num_pairs, 1)
+        out = np.empty(cap, np.float64)
+        n = C.c_int64(0)
+        _check(lib().glia_hmt_score_initial_edges_shard(self.ctx.h, self.h, classifier.h, C.c_int(shard), C.c_int(n_shards), _np(out),
+                                                        C.c_int64(cap), C.byref(n)))
+        return out[:n.value].copy()
+
     def last_merge_timing(self):
         a, b, c, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
         _check(lib().glia_hmt_last_merge_timing(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))

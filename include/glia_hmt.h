@@ -236,6 +236,12 @@ int64_t glia_hmt_gen_tree(const uint32_t* h_order, int64_t n_merges, uint32_t* n
  * *ms = device time of the feature + forest kernel. */
 int glia_hmt_score_initial_edges(glia_hmt_ctx* ctx, glia_hmt_rag* rag, const glia_hmt_forest* forest,
                                  int64_t* n_edges, double* ms);
+/* The same, sharded for several GPUs (scoring of the initial edges is independent per edge): this call
+ * scores the records e with e % n_shards == shard.  h_scores[e] (e < *n_records, one record per unordered adjacent
+ * leaf pair in lexicographic order) = P(merge) for the table edges of the shard, -inf for every other record; the
+ * element-wise maximum over the shards is the full result.  h_scores may be NULL to query *n_records (<= directed pairs). */
+int glia_hmt_score_initial_edges_shard(glia_hmt_ctx* ctx, glia_hmt_rag* rag, const glia_hmt_forest* forest, int shard,
+                                       int n_shards, double* h_scores, int64_t capacity, int64_t* n_records);
 
 /* Phase timings of the last merge_order_* call on this rag (ms): edge-table build, init, greedy loop. */
 int glia_hmt_last_merge_timing(const glia_hmt_rag* rag, double* ms_table, double* ms_init, double* ms_loop,

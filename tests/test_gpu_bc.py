@@ -246,3 +246,33 @@ def test_bc_feat_with_saliency_features(ctx, use_log):
     assert got.shape == ref.shape == (len(order), 104 + 5) and _feat_close(got, ref)
     assert (got[:, 35] <= got[:, 36]).all()               # (min, max) of the two saliency differences
     rm.close()
+
+
+def test_sharded_initial_edge_scoring(ctx):
+    """the scores of the initial edges are independent, so ranks can own residue classes of the records"""
+    import torch
+    from glia_amd import hmt
+    from oracle import pyoracle as O
+    import _rf
+    labels, pb = O.synth((32, 32, 32), 8, 16)
+    d_lab = torch.from_numpy(labels.view(np.int32)).cuda()
+    d_pb = torch.from_numpy(pb).cuda()
+    cfg = hmt.make_config(d_pb, rb=[(d_pb, 8, 0.0, 1.0)])
+    ocfg = O.make_cfg(pb, rb=[(pb, 8, 0.0, 1.0)])
+    _, _, f0 = O.Rag(labels).merge_order_bc(ocfg, None, stub_index=31, want_feats=True)
+    forest = _rf.random_forest(np.random.default_rng(7), 31, 6, f0)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "model.bin")
+        _rf.write_model(path, forest)
+        clf = hmt.RandomForest(ctx, path, predict_label=-1)
+    rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, cfg=cfg)
+    full = rm.score_initial_edges_shard(clf, 0, 1)
+    parts = [rm.score_initial_edges_shard(clf, r, 3) for r in range(3)]
+    assert all(len(p) == len(full) for p in parts)
+    assert (np.maximum.reduce(parts) == full).all()
+    fin = [np.isfinite(p) for p in parts]
+    assert not (fin[0] & fin[1]).any() and not (fin[1] & fin[2]).any() and np.isfinite(full).sum() == sum(f.sum() for f in fin)
+    # the first merge of the classifier loop takes the best initial score
+    order, sal = rm.merge_order_bc(clf)
+    assert sal[0] == full[np.isfinite(full)].max()
+    rm.close()
