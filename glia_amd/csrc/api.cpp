@@ -67,6 +67,7 @@ struct glia_hmt_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   uint32_t hint_rcap = 0, hint_pcap = 0;
   double transform_ms = 0;
+  int tz = kTZ;                  // tile depth of the accumulation pass; halved when the LDS tables of a pass overflowed a lot
 };
 
 struct glia_hmt_rag {
@@ -296,7 +297,8 @@ static int rag_build_impl(glia_hmt_ctx* c, int dim, const int64_t dims[3], int64
     p.gz0 = gz0; p.gnz = gnz; p.zb = zb; p.ze = ze;
     p.nbx = (int)((nx + kTileX - 1) / kTileX);
     p.nby = (int)((ny + kTileY - 1) / kTileY);
-    p.nbz = (int)((ze - zb + kTZ - 1) / kTZ);
+    p.tz = c->tz;
+    p.nbz = (int)((ze - zb + p.tz - 1) / p.tz);
     p.hist = make_hist_spec(chans[ci].bins, chans[ci].lo, chans[ci].hi);
     p.nthr = nthr;
     for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) p.thr_f[i] = i < nthr ? ceil_f32(thr[i]) : std::numeric_limits<float>::infinity();
@@ -322,6 +324,10 @@ static int rag_build_impl(glia_hmt_ctx* c, int dim, const int64_t dims[3], int64
       (void)hipMemsetAsync(c->flags, 0, 64, c->stream);
     }
     rag->alg_bytes = (double)(nx * ny * (ze - zb)) * 8.0 * (double)chans.size();
+    // runs that found the tile's LDS tables full went to the global tables one by one (exact, slow): with more than one
+    // such run per 256 voxels the supervoxels are too small for this tile depth -- use shallower tiles from now on
+    if (c->tz > 4 && (double)flags[7] * 256.0 > (double)(nx * ny * (ze - zb))) c->tz /= 2;
+    if (flags[7]) (void)hipMemsetAsync(c->flags + 7, 0, sizeof(uint32_t), c->stream);
     if (flags[0] || flags[1]) {
       // a table filled up: drop the partial result, grow and redo the pass
       if (attempt >= 6) { glia_hmt_rag_free(rag); set_error("rag_build: hash tables keep overflowing"); return GLIA_HMT_ERR_HIP; }

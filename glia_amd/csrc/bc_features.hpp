@@ -103,32 +103,8 @@ __device__ inline double pow_perim(double x, int D) {
   return ph + (pl + x * sl);
 }
 
-// histogram -> entropy (normalised by the set's voxel count), also returns the normalised histogram
-__device__ inline double hist_entropy(const uint32_t* hc, uint32_t n, int bins, double* h) {
-  double ent = 0.0;
-  for (int i = 0; i < bins; ++i) {
-    double p = n ? hc[i] / (double)n : 0.0;
-    h[i] = p;
-    if (!(fabs(p - 0.0) < 2.22e-16)) ent -= p * log2(p);
-  }
-  return ent;
-}
-
 // the five ImageFeats numbers (entropy, mean, std, min, max) of a voxel set
 struct ImgFeats { double entropy, mean, stddev, mn, mx; };
-__device__ inline ImgFeats image_feats(const uint32_t* hc, uint32_t n, double sum, double sq, float mn, float mx, int bins,
-                                       double* h) {
-  ImgFeats f;
-  f.entropy = hist_entropy(hc, n, bins, h);
-  f.mean = 0.0; f.stddev = 0.0; f.mn = 0.0; f.mx = 0.0;
-  const int ni = (int)n;
-  if (ni != 0) {
-    f.mean = sum / ni;
-    f.stddev = ssqrt(sq / ni - f.mean * f.mean, 0.0);
-    f.mn = (double)mn; f.mx = (double)mx;
-  }
-  return f;
-}
 
 __device__ inline void region_log(const BcCfg& c, double* rf) {    // feat.hxx:46-52, 463-467
   rf[0] = slog(rf[0], 0.0); rf[1] = slog(rf[1], 0.0); rf[3] = slog(rf[3], 0.0);

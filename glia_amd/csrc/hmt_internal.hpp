@@ -60,6 +60,7 @@ struct AccParams {
   int64_t zb, ze;                    // local planes [zb, ze) are accumulated (the halo planes only feed the neighbour rule)
   int dim;
   int nbx, nby, nbz;
+  int tz;                            // planes a workgroup marches through: kTZ, or fewer when supervoxels are small
   HistSpec hist;
   int nthr;
   float thr_f[GLIA_HMT_MAX_THRESH];  // smallest float >= threshold (val >= thr <=> val >= thr_f)

@@ -190,7 +190,9 @@ __device__ __attribute__((noinline)) void drain_ring(Lds<BINS>& s, uint32_t* rin
     }
     return;
   }
-  // LDS table saturated (tile with very many tiny supervoxels): straight to the global tables (slow, exact)
+  // LDS table saturated (tile with very many tiny supervoxels): straight to the global tables (slow, exact).  The host
+  // watches the count and gives the next pass shallower tiles.
+  atomicAdd(&p.flags[7], 1u);
   if (isRegion) {
     int g = global_region_slot(p, a.x);
     if (g < 0) return;
@@ -277,12 +279,12 @@ __global__ __launch_bounds__(kThreads, 2) void rag_accumulate_kernel(const AccPa
   const int lane = tid & 63, wave = tid >> 6;
   const int64_t nx = p.nx, ny = p.ny, nz = p.nz;
   Tile tile;
-  tile.x0 = (int64_t)bx * kTileX; tile.y0 = (int64_t)by * kTileY; tile.z0 = p.zb + (int64_t)bz * kTZ;
+  tile.x0 = (int64_t)bx * kTileX; tile.y0 = (int64_t)by * kTileY; tile.z0 = p.zb + (int64_t)bz * p.tz;
   const int xrel0 = (lane % kLanesPerRow) * kVX;
   const int yrel = wave * kRowsPerWave + (lane / kLanesPerRow);
   const int64_t x0 = tile.x0 + xrel0;
   const int64_t y = tile.y0 + yrel;
-  const int64_t z1 = (tile.z0 + kTZ < p.ze) ? tile.z0 + kTZ : p.ze;
+  const int64_t z1 = (tile.z0 + p.tz < p.ze) ? tile.z0 + p.tz : p.ze;
   const int64_t gz0 = p.gz0, gnz = p.gnz;
   const bool rowOk = (y < ny) && (x0 < nx);
   const int64_t sy = nx, sz = nx * ny;
