@@ -50,6 +50,8 @@ struct BcChan {
   EStats* e_A;         // mutual entries, both directions
   EStats* e_NA;        // always-alive non-mutual entries, both directions
   float* e_dir;        // [Ecap][4]  mutual u->v min,max ; v->u min,max
+  float2* pool_dir;    // [pool_cap] parallel to the incident lists: (min, max) the list's owner sends along that entry's
+                       // record, (+inf, -inf) for dead entries -- the "all but one record" scans read it contiguously
   // leaf entries [P]
   EStats* le_stats;
 };
@@ -362,6 +364,11 @@ __global__ void bc_adj_fill(BcState st, uint32_t E0, uint32_t* cursor) {
   const uint32_t pu = atomicAdd(&cursor[u], 1u), pv = atomicAdd(&cursor[v], 1u);
   st.pool[st.adj_off[u] + pu] = e; st.e_posu[e] = pu;
   st.pool[st.adj_off[v] + pv] = e; st.e_posv[e] = pv;
+  for (int c = 0; c < st.cfg.K; ++c) {
+    const float* d = &st.ch[c].e_dir[(size_t)e * 4];
+    st.ch[c].pool_dir[st.adj_off[u] + pu] = make_float2(d[0], d[1]);
+    st.ch[c].pool_dir[st.adj_off[v] + pv] = make_float2(d[2], d[3]);
+  }
 }
 
 __global__ void bc_init_dead(BcState st, uint32_t from) {
@@ -622,6 +629,11 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
       }
       const uint32_t idx = atomicAdd(&s.newcount, 1u);
       const uint32_t newE = (uint32_t)ne + idx;
+      const uint32_t old = (e0s != kNone) ? e0s : e1s;
+      const uint32_t posRs = (st.e_u[old] == rs) ? st.e_posu[old] : st.e_posv[old];
+      const uint32_t offRs = st.adj_off[rs];
+      // rs held two entries when it touched both r0 and r1: the new record reuses one, the other one is dead from now on
+      const uint32_t posDead = (e0s != kNone && e1s != kNone) ? ((st.e_u[e1s] == rs) ? st.e_posu[e1s] : st.e_posv[e1s]) : kNone;
       // image statistics of the new record, channel by channel
       for (int c = 0; c < K; ++c) {
         const BcChan& ch = st.ch[c];
@@ -641,6 +653,9 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
         ch.e_A[newE] = A; ch.e_NA[newE] = NA;
         float* nd = &ch.e_dir[(size_t)newE * 4];
         nd[0] = d[0]; nd[1] = d[1]; nd[2] = d[2]; nd[3] = d[3];
+        ch.pool_dir[offRs + posRs] = make_float2(d[0], d[1]);
+        ch.pool_dir[r2off + idx] = make_float2(d[2], d[3]);
+        if (posDead != kNone) ch.pool_dir[offRs + posDead] = make_float2(__builtin_inff(), -__builtin_inff());
         // r2's mutual boundary extremes (entries r2 -> rs) for B(r2) and the "all but one" queries
         atomicMin(&s.best_mn[c], ((unsigned long long)float_ord(d[2]) << 32) | newE);
         atomicMax(&s.best_mx[c], ((unsigned long long)float_ord(d[3]) << 32) | newE);
@@ -659,8 +674,6 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
         st.e_alive[o] = 0;
         if (st.e_table[o] && !forced) { st.pq.leaf_seq[o] = 0; pq_leaf_removed(st.pq, s.pq, o); }
       }
-      const uint32_t old = (e0s != kNone) ? e0s : e1s;
-      const uint32_t posRs = (st.e_u[old] == rs) ? st.e_posu[old] : st.e_posv[old];
       st.e_u[newE] = rs; st.e_v[newE] = r2; st.e_posu[newE] = posRs; st.e_posv[newE] = idx;
       st.e_alive[newE] = 1; st.e_table[newE] = (t0 || t1) ? 1 : 0; st.e_orient[newE] = 1;
       st.e_fhead[newE] = fh; st.e_ftail[newE] = ft;
@@ -668,7 +681,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
       const uint32_t cat = rs < r0 ? 0u : (t0 ? 1u : 2u);
       st.pq.leaf_seq[newE] = 0;
       st.pq.leaf_sal[newE] = -__builtin_inf();
-      st.pool[st.adj_off[rs] + posRs] = newE;
+      st.pool[offRs + posRs] = newE;
       st.pool[r2off + idx] = newE;
       // stash the category in posv's upper bits? no: recompute it when scoring -- keep it in model[] later
       st.e_posv[newE] = idx | (cat << 30);
@@ -722,15 +735,14 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
           if (st.e_table[rec]) {
             const uint32_t rs = st.e_u[rec];
             const uint32_t off = st.adj_off[rs], len = st.adj_len[rs];
+            const uint32_t own = st.e_posu[rec];             // the record's own slot in rs's list (e_u = rs)
             for (uint32_t i = l16; i < len; i += 16) {
-              const uint32_t e2 = st.pool[off + i];
-              if (e2 == rec || !st.e_alive[e2]) continue;
-              const int sel = st.e_u[e2] == rs ? 0 : 2;
+              if (i == own) continue;
 #pragma unroll
               for (int c = 0; c < kMaxChannels; ++c) {
                 if (c < K) {
-                  const float* d = &st.ch[c].e_dir[(size_t)e2 * 4 + sel];
-                  mn[c] = fminf(mn[c], d[0]); mx[c] = fmaxf(mx[c], d[1]);
+                  const float2 d = st.ch[c].pool_dir[off + i];     // dead entries hold (+inf, -inf)
+                  mn[c] = fminf(mn[c], d.x); mx[c] = fmaxf(mx[c], d.y);
                 }
               }
             }
@@ -750,6 +762,9 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
           }
         }
       }
+#ifdef GLIA_HMT_PROFILE
+      __syncthreads();          // attribution only: the phases below would otherwise absorb the stragglers of this one
+#endif
       PH(8);
       for (uint32_t w = tid; w < cn * (uint32_t)K; w += kBcThreads) {
         const uint32_t j = w / (uint32_t)K; const int c = (int)(w % (uint32_t)K);
@@ -983,6 +998,7 @@ int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& cl
     if ((rc = buf.get(&ch.e_A, st.Ecap, false, stream))) return rc;
     if ((rc = buf.get(&ch.e_NA, st.Ecap, false, stream))) return rc;
     if ((rc = buf.get(&ch.e_dir, (size_t)st.Ecap * 4, false, stream))) return rc;
+    if ((rc = buf.get(&ch.pool_dir, (size_t)st.pool_cap, false, stream))) return rc;
   }
   if ((rc = buf.get(&st.parent, R2, false, stream))) return rc;
   if ((rc = buf.get(&st.adj_off, R2, true, stream))) return rc;
@@ -1079,6 +1095,7 @@ int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& cl
     if (ctrl[3] == ST_NEED_POOL) {
       const unsigned long long ncap = st.pool_cap * 2;
       if ((rc = buf.grow(&st.pool, (size_t)st.pool_cap, (size_t)ncap, stream))) return rc;
+      for (int c = 0; c < cfg.K; ++c) if ((rc = buf.grow(&st.ch[c].pool_dir, (size_t)st.pool_cap, (size_t)ncap, stream))) return rc;
       st.pool_cap = ncap;
     } else if (ctrl[3] == ST_NEED_EDGES) {
       if (st.Ecap >= 0xFFFFFF00u) { set_error("greedy: more than 2^32 edge slots needed"); return GLIA_HMT_ERR_ARG; }
