@@ -7,7 +7,11 @@
 
 namespace glia {
 
-constexpr int kFan = 64;
+#ifndef GLIA_PQ_LANE_CHILDREN
+#define GLIA_PQ_LANE_CHILDREN 8
+#endif
+constexpr int kLaneChildren = GLIA_PQ_LANE_CHILDREN;   // children of a node per lane
+constexpr int kFan = 64 * kLaneChildren;              // fewer, fatter levels: every level is a dependent round trip
 constexpr int kMaxLevels = 6;
 constexpr int kGreedyThreads = 512;
 constexpr int kWorkCap = 2048;       // >= kSetSlots: every list entry owns a set entry, so the set fills up first
@@ -58,17 +62,25 @@ struct PqTree {
 __device__ __forceinline__ bool pq_recompute_node(const PqTree& t, int l, uint32_t j, int lane, bool force = false) {
   Key k;
   k.sal = -__builtin_inf(); k.seq = 0; k.arg = 0;
-  uint32_t ci = j * kFan + lane;
-  if (l == 0) {
-    if (ci < t.nleaves) {
-      const unsigned long long q = t.leaf_seq[ci];
-      const double v = t.leaf_sal[ci];            // independent loads (one round trip)
-      k.seq = q; k.sal = q ? v : -__builtin_inf(); k.arg = ci;
+  // every lane takes kLaneChildren children, all loads in flight together (one round trip)
+  Key kk[kLaneChildren];
+#pragma unroll
+  for (int c = 0; c < kLaneChildren; ++c) {
+    const uint32_t ci = j * kFan + c * 64 + lane;
+    kk[c].sal = -__builtin_inf(); kk[c].seq = 0; kk[c].arg = 0;
+    if (l == 0) {
+      if (ci < t.nleaves) {
+        const unsigned long long q = t.leaf_seq[ci];
+        const double v = t.leaf_sal[ci];
+        kk[c].seq = q; kk[c].sal = q ? v : -__builtin_inf(); kk[c].arg = ci;
+      }
+    } else {
+      const PqLevel& cl = t.lv[l - 1];
+      if (ci < cl.size) { kk[c].sal = cl.sal[ci]; kk[c].seq = cl.seq[ci]; kk[c].arg = cl.arg[ci]; }
     }
-  } else {
-    const PqLevel& c = t.lv[l - 1];
-    if (ci < c.size) { k.sal = c.sal[ci]; k.seq = c.seq[ci]; k.arg = c.arg[ci]; }
   }
+#pragma unroll
+  for (int c = 0; c < kLaneChildren; ++c) if (better(kk[c], k)) k = kk[c];
   const PqLevel& d = t.lv[l];
   // the node's previous key, fetched alongside the children (same round trip)
   const unsigned long long oseq = d.seq[j];
