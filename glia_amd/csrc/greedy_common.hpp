@@ -8,7 +8,7 @@
 namespace glia {
 
 #ifndef GLIA_PQ_LANE_CHILDREN
-#define GLIA_PQ_LANE_CHILDREN 8
+#define GLIA_PQ_LANE_CHILDREN 4
 #endif
 constexpr int kLaneChildren = GLIA_PQ_LANE_CHILDREN;   // children of a node per lane
 constexpr int kFan = 64 * kLaneChildren;              // fewer, fatter levels: every level is a dependent round trip
