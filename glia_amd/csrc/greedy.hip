@@ -273,6 +273,11 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
         const uint32_t old = (e0s != kNone) ? e0s : e1s;
         const uint32_t posRs = (st.e_u[old] == rs) ? st.e_posu[old] : st.e_posv[old];
         const uint32_t offRs = st.adj_off[rs];
+        // everything this record will read, requested before its first store: a wave's loads queue behind its own
+        // earlier stores (vmcnt is in order), so a load issued after the stores below costs a second round trip
+        const unsigned long long seq0 = e0s != kNone ? pq.leaf_seq[e0s] : 0ull, seq1 = e1s != kNone ? pq.leaf_seq[e1s] : 0ull;
+        const uint32_t top0 = e0s != kNone ? pq.lv[0].arg[e0s / kFan] : kNone, top1 = e1s != kNone ? pq.lv[0].arg[e1s / kFan] : kNone;
+        const uint32_t pos1 = (e0s != kNone && e1s != kNone) ? ((st.e_u[e1s] == rs) ? st.e_posu[e1s] : st.e_posv[e1s]) : kNone;
         double first = 0.0;
         int second = 0;
         if (!MEDIAN) {
@@ -290,11 +295,8 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
             jobs.newE[j] = newE; jobs.e0[j] = e0s; jobs.e1[j] = e1s;
           } else { first = st.e_mean[old]; st.e_off[newE] = st.e_off[old]; }
         }
-        if (e0s != kNone && e1s != kNone) {
-          // rs held two entries (to r0 and to r1): one is reused for the new edge, the other becomes a tombstone
-          const uint32_t pos1 = (st.e_u[e1s] == rs) ? st.e_posu[e1s] : st.e_posv[e1s];
-          st.pool[offRs + pos1] = make_uint2(kNone, 0u);
-        }
+        // rs held two entries (to r0 and to r1): one is reused for the new edge, the other becomes a tombstone
+        if (pos1 != kNone) st.pool[offRs + pos1] = make_uint2(kNone, 0u);
         const uint32_t cat = rs < r0 ? 0u : (e0s != kNone ? 1u : 2u);
         const unsigned long long seq = ((k + 1ull) << 32) | ((unsigned long long)cat << 30) | rs;
         st.e_u[newE] = rs; st.e_v[newE] = r2; st.e_posu[newE] = posRs; st.e_posv[newE] = idx;
@@ -304,8 +306,9 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
         st.pool[offRs + posRs] = make_uint2(newE, r2);
         st.pool[r2off + idx] = make_uint2(newE, rs);
         pq_leaf_added(pq, s.pq, newE);
-        if (e0s != kNone && pq.leaf_seq[e0s]) { pq.leaf_seq[e0s] = 0; pq_leaf_removed(pq, s.pq, e0s); }
-        if (e1s != kNone && pq.leaf_seq[e1s]) { pq.leaf_seq[e1s] = 0; pq_leaf_removed(pq, s.pq, e1s); }
+        // a dying leaf only matters to the tree if it is the current maximum of its level-0 node (see pq_leaf_removed)
+        if (seq0) { pq.leaf_seq[e0s] = 0; if (top0 == e0s) pq_touch(pq, s.pq, 0, 0, e0s); }
+        if (seq1) { pq.leaf_seq[e1s] = 0; if (top1 == e1s) pq_touch(pq, s.pq, 0, 0, e1s); }
       } while (false);
       if (MEDIAN) {
         __syncthreads();

@@ -13,7 +13,10 @@ namespace glia {
 constexpr int kLaneChildren = GLIA_PQ_LANE_CHILDREN;   // children of a node per lane
 constexpr int kFan = 64 * kLaneChildren;              // fewer, fatter levels: every level is a dependent round trip
 constexpr int kMaxLevels = 6;
-constexpr int kGreedyThreads = 512;
+#ifndef GLIA_GREEDY_THREADS
+#define GLIA_GREEDY_THREADS 512
+#endif
+constexpr int kGreedyThreads = GLIA_GREEDY_THREADS;
 constexpr int kWorkCap = 2048;       // >= kSetSlots: every list entry owns a set entry, so the set fills up first
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
