@@ -1,0 +1,89 @@
+"""Randomised cross-check of the HIP path against the oracle (small volumes, many configurations).
+usage: fuzz_gpu.py [seconds] [seed]   -- stops at the first mismatch with the configuration printed."""
+import os, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+from glia_amd import hmt
+from oracle import pyoracle as O
+import _rf
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+ctx = hmt.Context(0)
+t_end = time.time() + budget
+n = 0
+close = lambda a, b: a.shape == b.shape and np.allclose(a, b, rtol=1e-5, atol=1e-12)
+while time.time() < t_end:
+    dim = int(rng.choice([2, 3], p=[0.3, 0.7]))
+    shape = tuple(int(rng.integers(6, 70 if dim == 2 else 44)) for _ in range(dim))
+    S = int(rng.integers(3, 10)); G = int(rng.integers(2, 4)) * S
+    variant = int(rng.integers(0, 2))
+    labels, pb = O.synth(shape, S, G, seed=int(rng.integers(1, 1 << 60)), variant=variant) if "seed" in O.synth.__code__.co_varnames else O.synth(shape, S, G, variant=variant)
+    if rng.random() < 0.3:       # coarse quantisation: many exact ties
+        q = int(rng.choice([2, 4, 8]))
+        pb = (np.floor(pb * q) / q).astype(np.float32)
+    mask = None
+    if rng.random() < 0.35:
+        mask = (rng.random(shape) > rng.uniform(0.05, 0.4)).astype(np.uint32)
+    cfgdesc = dict(shape=shape, S=S, G=G, variant=variant, masked=mask is not None)
+    d_lab = torch.from_numpy(labels.view(np.int32)).cuda()
+    d_pb = torch.from_numpy(pb).cuda()
+    d_mask = torch.from_numpy(mask.view(np.int32)).cuda() if mask is not None else None
+    try:
+        # pb linkages
+        for typ in (1, 2):
+            rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, mask=d_mask, only_contour=True)
+            o, s = rm.merge_order_pb(type=typ); rm.close()
+            ro, rs = O.Rag(labels, mask=mask, only_contour=True).merge_order_pb(pb, type=typ)
+            assert o.shape == ro.shape and (o == ro).all(), "pb order type %d" % typ
+            assert (s == rs).all() if (variant == 0 or typ == 1) else np.allclose(s, rs, rtol=0, atol=1e-12), "pb saliency type %d" % typ
+        rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, mask=d_mask, only_contour=False)
+        if rng.random() < 0.5:
+            o, s = rm.merge_order_pb(type=3)
+            ro, rs = O.Rag(labels, mask=mask).merge_order_pb(pb, type=3, update_region=True)
+            assert o.shape == ro.shape and (o == ro).all() and (s == rs).all(), "median x size"
+        sizes = sorted(int(x) for x in rng.integers(2, 4 * S ** dim, size=int(rng.integers(1, 3))))
+        rpb = float(rng.uniform(0.1, 0.5))
+        o, s = rm.pre_merge(sizes, rpb); rm.close()
+        ro, rs = O.Rag(labels, mask=mask).pre_merge(pb, sizes, rpb)
+        assert o.shape == ro.shape and (o == ro).all(), "pre_merge %s %g" % (sizes, rpb)
+        # classifier linkage, random image lists
+        raw = (np.round(rng.random(shape) * 255) / 256.0).astype(np.float32)
+        d_raw = torch.from_numpy(raw).cuda()
+        lay = int(rng.integers(0, 4))
+        bins = int(rng.choice([4, 8, 16]))
+        if lay == 0: okw, dkw = dict(rb=[(pb, bins, 0.0, 1.0)]), dict(rb=[(d_pb, bins, 0.0, 1.0)])
+        elif lay == 1: okw, dkw = dict(rb=[(raw, bins, 0.0, 1.0), (pb, 8, 0.0, 1.0)]), dict(rb=[(d_raw, bins, 0.0, 1.0), (d_pb, 8, 0.0, 1.0)])
+        elif lay == 2: okw, dkw = dict(r=[(raw, bins, 0.0, 1.0)], b=[(pb, 8, 0.0, 1.0)], rl=[(raw, 4, 0.0, 1.0)]), dict(r=[(d_raw, bins, 0.0, 1.0)], b=[(d_pb, 8, 0.0, 1.0)], rl=[(d_raw, 4, 0.0, 1.0)])
+        else: okw, dkw = dict(b=[(raw, bins, 0.0, 1.0)]), dict(b=[(d_raw, bins, 0.0, 1.0)])
+        flags = dict(use_log=bool(rng.random() < 0.3), use_simple=bool(rng.random() < 0.2))
+        ocfg = O.make_cfg(pb, **okw, **flags)
+        cfg = hmt.make_config(d_pb, **dkw, use_log_shape=flags["use_log"], use_simple_features=flags["use_simple"])
+        cfgdesc.update(layout=lay, bins=bins, **flags)
+        rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, mask=d_mask, cfg=cfg)
+        fd = rm.feat_dim()
+        stub = int(rng.integers(0, fd))
+        ro, rs, rf = O.Rag(labels, mask=mask).merge_order_bc(ocfg, None, stub_index=stub, want_feats=True)
+        o, s, f = rm.merge_order_bc(hmt.FeatureStubClassifier(ctx, stub), want_feats=True)
+        if variant == 0:
+            assert o.shape == ro.shape and (o == ro).all(), "bc order (stub %d)" % stub
+            assert close(f, rf), "bc feats"
+        if len(ro) > 4 and variant == 0:
+            forest = _rf.random_forest(rng, int(rng.choice([7, 31, 63])), int(rng.integers(3, 8)), rf)
+            with tempfile.TemporaryDirectory() as d:
+                path = os.path.join(d, "m.bin"); _rf.write_model(path, forest)
+                clf = hmt.RandomForest(ctx, path, predict_label=-1)
+            o, s = rm.merge_order_bc(clf)
+            ro, rs = O.Rag(labels, mask=mask).merge_order_bc(ocfg, O.make_forest(forest, -1))
+            assert o.shape == ro.shape and (o == ro).all() and (s == rs).all(), "bc forest"
+        rm.close()
+    except AssertionError as e:
+        print("MISMATCH after %d cases: %s  config %s" % (n, e, cfgdesc), flush=True)
+        np.savez_compressed(os.path.join(ROOT, "gpurun_out", "fuzz_fail.npz"), labels=labels, pb=pb, mask=mask if mask is not None else np.zeros(0))
+        sys.exit(1)
+    n += 1
+    if n % 20 == 0:
+        print("%d cases ok (%.0f s left)" % (n, t_end - time.time()), flush=True)
+print("fuzz: %d random configurations, all identical to the oracle" % n)
