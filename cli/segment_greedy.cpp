@@ -1,7 +1,7 @@
-// cli/segment_greedy.cpp -- drop-in for hmt/main_segment_greedy.cxx with ONE merge tree: node potentials from the merge
+// cli/segment_greedy.cpp -- drop-in for hmt/main_segment_greedy.cxx: node potentials from the merge
 // (and optional region) probabilities, greedy tree resolution, final label image.
 //   segment_greedy -s seg.mha -o order.txt [-p mergeProbs.txt] [-n regionProbs.txt] [-m mask.mha] [-i 0|1] [-r b] [-u b] -f out.mha
-// Not supported: several trees (-o given more than once), the boundary-confidence image (-b).
+// Several -o / -p / -n files = several trees resolved jointly.  Not supported: the boundary-confidence image (-b).
 #include "common.hpp"
 
 using namespace cli;
@@ -23,32 +23,51 @@ int main(int argc, char* argv[]) {
                  {"segImage", "mergeOrders", "mergeProbs", "regionProbs", "maskImage", "ignore", "relabel", "write16", "compress", "finalSegImage", "bcImage"}, usage);
   for (const char* req : {"segImage", "mergeOrders"})
     if (!a.has(req)) { std::cerr << "Error: the option '--" << req << "' is required but missing\n" << usage; return EXIT_FAILURE; }
-  if (a.all("mergeOrders").size() != 1) perr("Error: the MI355X path resolves a single merge tree in this version...");
   if (a.has("bcImage")) perr("Error: the boundary confidence image is not supported by the MI355X path yet...");
   if (flagOf(a, "compress")) perr("Error: compressed output is not supported...");
-  std::vector<uint32_t> order = readOrder(a.str("mergeOrders"));
-  const int64_t n = (int64_t)order.size() / 3, cap = 3 * n + 1;
-  std::vector<double> mprobs, rprobs;
-  if (a.has("mergeProbs")) { mprobs = readDoubles(a.str("mergeProbs")); if ((int64_t)mprobs.size() < n) perr("Error: too few merge probabilities..."); }
-  std::vector<uint32_t> lab(cap), src(cap), dst(cap);
-  std::vector<int32_t> par(cap), c0(cap), c1(cap), picks(cap);
-  std::vector<double> pot(cap);
-  if (a.has("regionProbs")) rprobs = readDoubles(a.str("regionProbs"));
-  // potentials need the node count first when region probabilities are given (one per node)
-  int64_t nn = glia_hmt_tree_potentials(order.data(), n, mprobs.empty() ? nullptr : mprobs.data(), nullptr, lab.data(), par.data(), c0.data(),
-                                        c1.data(), pot.data(), cap);
-  if (nn < 0) perr(glia_hmt_last_error());
-  if (!rprobs.empty()) {
-    if ((int64_t)rprobs.size() < nn) perr("Error: too few region probabilities...");
-    nn = glia_hmt_tree_potentials(order.data(), n, mprobs.empty() ? nullptr : mprobs.data(), rprobs.data(), lab.data(), par.data(), c0.data(),
-                                  c1.data(), pot.data(), cap);
-    if (nn < 0) perr(glia_hmt_last_error());
+  // one tree per merge order file (main_segment_greedy.cxx:33-60)
+  const auto orderFiles = a.all("mergeOrders"), probFiles = a.all("mergeProbs"), rprobFiles = a.all("regionProbs");
+  const int nTree = (int)orderFiles.size();
+  struct Tree { std::vector<uint32_t> lab; std::vector<int32_t> par, c0, c1; std::vector<double> pot; int64_t n = 0; };
+  std::vector<Tree> trees((size_t)nTree);
+  for (int t = 0; t < nTree; ++t) {
+    std::vector<uint32_t> order = readOrder(orderFiles[t]);
+    const int64_t n = (int64_t)order.size() / 3, cap = 3 * n + 1;
+    std::vector<double> mprobs, rprobs;
+    if ((int)probFiles.size() > t) { mprobs = readDoubles(probFiles[t]); if ((int64_t)mprobs.size() < n) perr("Error: too few merge probabilities..."); }
+    if (!rprobFiles.empty()) { if ((int)rprobFiles.size() <= t) perr("Error: too few region probability files..."); rprobs = readDoubles(rprobFiles[t]); }
+    Tree& T = trees[t];
+    T.lab.resize(cap); T.par.resize(cap); T.c0.resize(cap); T.c1.resize(cap); T.pot.resize(cap);
+    // region probabilities come one per node: the node count is known after a first pass
+    T.n = glia_hmt_tree_potentials(order.data(), n, mprobs.empty() ? nullptr : mprobs.data(), nullptr, T.lab.data(), T.par.data(), T.c0.data(),
+                                   T.c1.data(), T.pot.data(), cap);
+    if (T.n < 0) perr(glia_hmt_last_error());
+    if (!rprobs.empty()) {
+      if ((int64_t)rprobs.size() < T.n) perr("Error: too few region probabilities...");
+      T.n = glia_hmt_tree_potentials(order.data(), n, mprobs.empty() ? nullptr : mprobs.data(), rprobs.data(), T.lab.data(), T.par.data(),
+                                     T.c0.data(), T.c1.data(), T.pot.data(), cap);
+      if (T.n < 0) perr(glia_hmt_last_error());
+    }
   }
   if (!a.has("finalSegImage")) return EXIT_SUCCESS;
-  const int64_t np = glia_hmt_resolve_tree_greedy(par.data(), c0.data(), c1.data(), pot.data(), nn, picks.data(), cap);   // :72-76
+  int64_t total = 0;
+  std::vector<int64_t> nn; std::vector<const uint32_t*> pl; std::vector<const int32_t*> pp, p0, p1; std::vector<const double*> pq;
+  for (auto& T : trees) { total += T.n; nn.push_back(T.n); pl.push_back(T.lab.data()); pp.push_back(T.par.data()); p0.push_back(T.c0.data());
+                          p1.push_back(T.c1.data()); pq.push_back(T.pot.data()); }
+  std::vector<int32_t> pickTree((size_t)(total ? total : 1)), pickNode((size_t)(total ? total : 1));
+  const int64_t np = glia_hmt_resolve_trees_greedy(nTree, nn.data(), pl.data(), pp.data(), p0.data(), p1.data(), pq.data(), pickTree.data(),
+                                                   pickNode.data(), total);                                            // :72-76
   if (np < 0) perr(glia_hmt_last_error());
-  const int64_t m = glia_hmt_label_transform(lab.data(), c0.data(), c1.data(), nn, picks.data(), np, 1u, src.data(), dst.data(), cap);
-  if (m < 0) perr(glia_hmt_last_error());
+  // genLabelTransform (hmt/tree_segment.hxx:24-35): the leaves below pick k get the label 1 + k
+  std::vector<uint32_t> src, dst, s1((size_t)(total ? total : 1)), d1((size_t)(total ? total : 1));
+  for (int64_t k = 0; k < np; ++k) {
+    const Tree& T = trees[pickTree[k]];
+    const int64_t m1 = glia_hmt_label_transform(T.lab.data(), T.c0.data(), T.c1.data(), T.n, &pickNode[k], 1, (uint32_t)(1 + k), s1.data(), d1.data(),
+                                                (int64_t)s1.size());
+    if (m1 < 0) perr(glia_hmt_last_error());
+    src.insert(src.end(), s1.begin(), s1.begin() + m1); dst.insert(dst.end(), d1.begin(), d1.begin() + m1);
+  }
+  const int64_t m = (int64_t)src.size();
   Volume seg = readMetaImage(a.str("segImage"), false);
   uint32_t* dLab = upload(seg.u32);
   uint32_t* dMask = loadMask(a, "maskImage", seg.size());

@@ -74,6 +74,66 @@ int64_t glia_hmt_resolve_tree_greedy(const int32_t* parent, const int32_t* child
   return np;
 }
 
+// resolveTreeGreedy over several trees (hmt/tree_greedy.hxx:76-92, 104-152): one pick sequence over all trees (first
+// maximum in (tree, node) order); a pick invalidates its ancestors and descendants and, for every LEAF below it, the
+// leaf of the same label in each other tree (as far as that leaf hangs below the tree's last node, :114-119) together
+// with that leaf's ancestors.
+int64_t glia_hmt_resolve_trees_greedy(int n_trees, const int64_t* n_nodes, const uint32_t* const* node_label,
+                                      const int32_t* const* parent, const int32_t* const* child0, const int32_t* const* child1,
+                                      const double* const* potential, int32_t* h_pick_tree, int32_t* h_pick_node, int64_t capacity) {
+  if (n_trees < 1 || !n_nodes || !node_label || !parent || !child0 || !child1 || !potential || !h_pick_tree || !h_pick_node) {
+    set_error("resolve_trees_greedy: invalid argument");
+    return GLIA_HMT_ERR_ARG;
+  }
+  struct Item { double p; int32_t t, i; };
+  auto worse = [](const Item& a, const Item& b) { return a.p < b.p || (a.p == b.p && (a.t > b.t || (a.t == b.t && a.i > b.i))); };
+  std::priority_queue<Item, std::vector<Item>, decltype(worse)> heap(worse);
+  std::vector<std::vector<char>> valid((size_t)n_trees);
+  std::vector<std::unordered_map<uint32_t, int32_t>> lnmap((size_t)n_trees);
+  std::vector<int32_t> stack;
+  for (int t = 0; t < n_trees; ++t) {
+    valid[t].assign((size_t)n_nodes[t], 1);
+    for (int64_t i = 0; i < n_nodes[t]; ++i) heap.push(Item{potential[t][i], (int32_t)t, (int32_t)i});
+    if (n_nodes[t] > 0) {                       // leaves below root() = the last node
+      stack.assign(1, (int32_t)n_nodes[t] - 1);
+      while (!stack.empty()) {
+        const int32_t x = stack.back(); stack.pop_back();
+        if (child0[t][x] < 0) lnmap[t][node_label[t][x]] = x;
+        else { stack.push_back(child0[t][x]); stack.push_back(child1[t][x]); }
+      }
+    }
+  }
+  int64_t np = 0;
+  std::vector<uint32_t> llabels;
+  while (!heap.empty()) {
+    const Item it = heap.top();
+    heap.pop();
+    if (!valid[it.t][it.i]) continue;
+    if (np >= capacity) { set_error("resolve_trees_greedy: output capacity too small"); return GLIA_HMT_ERR_CAPACITY; }
+    h_pick_tree[np] = it.t; h_pick_node[np] = it.i; ++np;
+    valid[it.t][it.i] = 0;
+    for (int32_t a = parent[it.t][it.i]; a >= 0; a = parent[it.t][a]) valid[it.t][a] = 0;
+    llabels.clear();
+    stack.clear();
+    for (int32_t c : {child0[it.t][it.i], child1[it.t][it.i]}) if (c >= 0) stack.push_back(c);
+    while (!stack.empty()) {
+      const int32_t x = stack.back(); stack.pop_back();
+      valid[it.t][x] = 0;
+      if (child0[it.t][x] < 0) llabels.push_back(node_label[it.t][x]);
+      else { stack.push_back(child0[it.t][x]); stack.push_back(child1[it.t][x]); }
+    }
+    for (uint32_t l : llabels)
+      for (int t = 0; t < n_trees; ++t) {
+        if (t == it.t) continue;
+        auto nit = lnmap[t].find(l);
+        if (nit == lnmap[t].end()) continue;
+        valid[t][nit->second] = 0;
+        for (int32_t a = parent[t][nit->second]; a >= 0; a = parent[t][a]) valid[t][a] = 0;
+      }
+  }
+  return np;
+}
+
 int64_t glia_hmt_label_transform(const uint32_t* node_label, const int32_t* child0, const int32_t* child1, int64_t n_nodes,
                                  const int32_t* h_picks, int64_t n_picks, uint32_t key_to_assign, uint32_t* h_src,
                                  uint32_t* h_dst, int64_t capacity) {

@@ -200,6 +200,11 @@ int64_t glia_hmt_tree_potentials(const uint32_t* h_order, int64_t n_merges, cons
  * h_picks receives node indices in pick order; returns their number. */
 int64_t glia_hmt_resolve_tree_greedy(const int32_t* parent, const int32_t* child0, const int32_t* child1,
                                      const double* potential, int64_t n_nodes, int32_t* h_picks, int64_t capacity);
+/* The same over several trees (alternative merge orders of overlapping supervoxel sets; hmt/tree_greedy.hxx:104-152):
+ * per-tree arrays are passed as arrays of pointers; picks come out as (tree, node) pairs in pick order. */
+int64_t glia_hmt_resolve_trees_greedy(int n_trees, const int64_t* n_nodes, const uint32_t* const* node_label,
+                                      const int32_t* const* parent, const int32_t* const* child0, const int32_t* const* child1,
+                                      const double* const* potential, int32_t* h_pick_tree, int32_t* h_pick_node, int64_t capacity);
 /* genLabelTransform (hmt/tree_segment.hxx:10-21): every leaf label under pick k maps to key_to_assign + k.  The pairs
  * feed glia_hmt_transform_image (fill_missing = 1 reproduces segment_greedy's default --ignore true). */
 int64_t glia_hmt_label_transform(const uint32_t* node_label, const int32_t* child0, const int32_t* child1, int64_t n_nodes,

@@ -1311,6 +1311,57 @@ int64_t orc_resolve_tree_greedy(const int32_t* parent, const int32_t* child0, co
   return np;
 }
 
+// hmt/tree_greedy.hxx:76-92 + 104-152, several trees: full scan per pick over all trees in order, BFS traversals
+int64_t orc_resolve_trees_greedy(int n_trees, const int64_t* n_nodes, const orc_label* const* node_label, const int32_t* const* parent,
+                                 const int32_t* const* child0, const int32_t* const* child1, const double* const* potential,
+                                 int32_t* pick_tree, int32_t* pick_node, int64_t cap) {
+  std::vector<std::vector<bool>> validity(n_trees);
+  std::vector<std::unordered_map<Label, int>> lnmap(n_trees);
+  auto bfs = [&](int t, int root, std::function<void(int)> f) {
+    std::queue<int> q; q.push(root);
+    while (!q.empty()) { int x = q.front(); q.pop(); f(x); for (int c : {child0[t][x], child1[t][x]}) if (c >= 0) q.push(c); }
+  };
+  for (int i = 0; i < n_trees; ++i) {
+    validity[i].assign((size_t)n_nodes[i], true);
+    if (n_nodes[i] > 0) {
+      int root = (int)n_nodes[i] - 1;
+      if (child0[i][root] < 0) lnmap[i][node_label[i][root]] = root;
+      else for (int c : {child0[i][root], child1[i][root]}) bfs(i, c, [&](int x) { if (child0[i][x] < 0) lnmap[i][node_label[i][x]] = x; });
+    }
+  }
+  auto pickNode = [&]() {
+    std::pair<int, int> ret(-1, -1);
+    for (int i = 0; i < n_trees; ++i)
+      for (int x = 0; x < n_nodes[i]; ++x)
+        if (validity[i][x] && (ret.first < 0 || potential[ret.first][ret.second] < potential[i][x])) ret = {i, x};
+    return ret;
+  };
+  int64_t np = 0;
+  auto pick = pickNode();
+  std::vector<Label> llabels;
+  while (pick.first >= 0) {
+    if (np >= cap) return -1;
+    pick_tree[np] = pick.first; pick_node[np] = pick.second; ++np;
+    const int t = pick.first;
+    validity[t][pick.second] = false;
+    for (int a = parent[t][pick.second]; a >= 0; a = parent[t][a]) validity[t][a] = false;
+    llabels.clear();
+    for (int c : {child0[t][pick.second], child1[t][pick.second]})
+      if (c >= 0) bfs(t, c, [&](int x) { validity[t][x] = false; if (child0[t][x] < 0) llabels.push_back(node_label[t][x]); });
+    for (Label l : llabels)
+      for (int i = 0; i < n_trees; ++i)
+        if (i != t) {
+          auto nit = lnmap[i].find(l);
+          if (nit != lnmap[i].end()) {
+            validity[i][nit->second] = false;
+            for (int a = parent[i][nit->second]; a >= 0; a = parent[i][a]) validity[i][a] = false;
+          }
+        }
+    pick = pickNode();
+  }
+  return np;
+}
+
 // hmt/tree_segment.hxx:10-21: pairs sorted by source label (the reference fills an unordered_map)
 int64_t orc_label_transform(const orc_label* node_label, const int32_t* child0, const int32_t* child1, int64_t n,
                             const int32_t* picks, int64_t n_picks, orc_label key, orc_label* src, orc_label* dst, int64_t cap) {

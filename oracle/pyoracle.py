@@ -332,3 +332,22 @@ def resolve_tree_greedy(par, c0, c1, pot):
 
 def label_transform(lab, c0, c1, picks, key=1):
     return _label_transform(lib(), "orc_", lab, c0, c1, picks, key, _p)
+
+
+def _resolve_trees(L, prefix, trees, ptr):
+    """trees: list of (label, parent, child0, child1, potential)"""
+    nt = len(trees)
+    keep = [[np.ascontiguousarray(t[0], np.uint32), np.ascontiguousarray(t[1], np.int32), np.ascontiguousarray(t[2], np.int32),
+             np.ascontiguousarray(t[3], np.int32), np.ascontiguousarray(t[4], np.float64)] for t in trees]
+    nn = (C.c_int64 * nt)(*[len(k[0]) for k in keep])
+    arr = lambda j: (C.c_void_p * nt)(*[k[j].ctypes.data for k in keep])
+    tot = sum(len(k[0]) for k in keep)
+    pt = np.empty(max(tot, 1), np.int32); pn = np.empty(max(tot, 1), np.int32)
+    f = getattr(L, prefix + "resolve_trees_greedy"); f.restype = C.c_int64
+    n = f(C.c_int(nt), nn, arr(0), arr(1), arr(2), arr(3), arr(4), ptr(pt), ptr(pn), C.c_int64(len(pt)))
+    assert n >= 0
+    return pt[:n].copy(), pn[:n].copy()
+
+
+def resolve_trees_greedy(trees):
+    return _resolve_trees(lib(), "orc_", trees, _p)

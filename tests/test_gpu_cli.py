@@ -205,3 +205,33 @@ def test_merge_order_bc_cli_with_two_volumes(tools, tmp_path):
     assert (np.loadtxt(files["order.txt"], dtype=np.int64).reshape(-1, 3) == o_ref).all()
     got = np.array([[float(x) for x in ln.split(" ")[:-1]] for ln in open(files["bfeat.txt"]).read().split("\n")[:-1]])
     assert got.shape == f_ref.shape and np.allclose(got, f_ref, rtol=6e-8, atol=1e-12)
+
+
+def test_segment_greedy_cli_with_two_trees(tools, tmp_path):
+    """two merge orders of the same supervoxels resolved jointly (-o a -o b -p pa -p pb)"""
+    from oracle import pyoracle as O
+    labels, pb = O.synth((32, 32, 32), 8, 16)
+    seg, out = str(tmp_path / "seg.mha"), str(tmp_path / "final.mha")
+    write_mha(seg, labels)
+    trees, args = [], []
+    for k, typ in enumerate((2, 1)):
+        o, s = O.Rag(labels, only_contour=True).merge_order_pb(pb, type=typ)
+        probs = np.clip(1.0 + 2.5 * s, 0.0, 1.0)
+        of, pf = str(tmp_path / ("order%d.txt" % k)), str(tmp_path / ("prob%d.txt" % k))
+        with open(of, "w") as f:
+            for r in o:
+                f.write("%d %d %d\n" % tuple(r))
+        with open(pf, "w") as f:
+            for v in probs:
+                f.write("%.17g\n" % v)
+        args += ["-o", of, "-p", pf]
+        trees.append(O.tree_potentials(o, probs))
+    subprocess.check_call([os.path.join(tools, "segment_greedy"), "-s", seg] + args + ["-f", out])
+    pt, pn = O.resolve_trees_greedy(trees)
+    src, dst = [], []
+    for k in range(len(pt)):
+        lab, par, c0, c1, pot = trees[pt[k]]
+        s1, d1 = O.label_transform(lab, c0, c1, np.array([pn[k]], np.int32), 1 + k)
+        src += s1.tolist(); dst += d1.tolist()
+    ref = O.transform_image(labels, np.array(src, np.uint32), np.array(dst, np.uint32), fill_missing=True)
+    assert (read_mha(out) == ref).all()

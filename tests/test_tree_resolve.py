@@ -54,3 +54,24 @@ def test_constant_probabilities_tie_rule_and_forest():
         s1 = hmt.label_transform(a[0], a[2], a[3], picks, 5)
         s2 = O.label_transform(b[0], b[2], b[3], picks, 5)
         assert (s1[0] == s2[0]).all() and (s1[1] == s2[1]).all()
+
+
+def test_several_trees_share_leaves():
+    """two alternative merge orders over the same supervoxels + a third tree over a subset: picks in one tree take the
+    leaves away from the others (hmt/tree_greedy.hxx:104-152)"""
+    labels, pb = O.synth((24, 24, 24), 6, 12)
+    rag = O.Rag(labels, only_contour=True)
+    o1, s1 = rag.merge_order_pb(pb, type=2)
+    o2, s2 = O.Rag(labels, only_contour=True).merge_order_pb(pb, type=1)
+    sub = (labels[:12] if True else labels)
+    o3, s3 = O.Rag(np.ascontiguousarray(sub), only_contour=True).merge_order_pb(np.ascontiguousarray(pb[:12]), type=2)
+    trees = []
+    for o, s in ((o1, s1), (o2, s2), (o3, s3)):
+        lab, par, c0, c1, pot = hmt.tree_potentials(o, np.clip(1.0 + 2.5 * s, 0.0, 1.0))
+        trees.append((lab, par, c0, c1, pot))
+    pt, pn = hmt.resolve_trees_greedy(trees)
+    ot, on = O.resolve_trees_greedy(trees)
+    assert (pt == ot).all() and (pn == on).all() and len(pt) > 3
+    # with one tree the joint resolver degenerates to the single-tree one (apart from leaf picks, which behave the same)
+    pt1, pn1 = hmt.resolve_trees_greedy(trees[:1])
+    assert (pt1 == 0).all() and (pn1 == hmt.resolve_tree_greedy(*trees[0][1:])).all()
