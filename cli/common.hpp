@@ -164,6 +164,15 @@ inline void writeMetaImage(const std::string& file, int dim, const int64_t dims[
   } else os.write((const char*)v.data(), v.size() * 4);
 }
 
+inline void writeMetaImageFloat(const std::string& file, int dim, const int64_t dims[3], const std::vector<float>& v) {
+  std::ofstream os(file, std::ios::binary);
+  if (!os) perr("Error: cannot create file " + file);
+  os << "ObjectType = Image\nNDims = " << dim << "\nBinaryData = True\nBinaryDataByteOrderMSB = False\nCompressedData = False\nDimSize =";
+  for (int i = 0; i < dim; ++i) os << " " << dims[i];
+  os << "\nElementType = MET_FLOAT\nElementDataFile = LOCAL\n";
+  os.write((const char*)v.data(), v.size() * 4);
+}
+
 // readData(order, file, true) of util/text_io.hxx:193-213 for TTriple<Label> (type/tuple.hxx:26-28)
 inline std::vector<uint32_t> readOrder(const std::string& file) {
   std::ifstream is(file);

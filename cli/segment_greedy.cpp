@@ -1,7 +1,7 @@
 // cli/segment_greedy.cpp -- drop-in for hmt/main_segment_greedy.cxx: node potentials from the merge
 // (and optional region) probabilities, greedy tree resolution, final label image.
 //   segment_greedy -s seg.mha -o order.txt [-p mergeProbs.txt] [-n regionProbs.txt] [-m mask.mha] [-i 0|1] [-r b] [-u b] -f out.mha
-// Several -o / -p / -n files = several trees resolved jointly.  Not supported: the boundary-confidence image (-b).
+// Several -o / -p / -n files = several trees resolved jointly; -b writes the boundary-confidence image (float).
 #include "common.hpp"
 
 using namespace cli;
@@ -23,7 +23,6 @@ int main(int argc, char* argv[]) {
                  {"segImage", "mergeOrders", "mergeProbs", "regionProbs", "maskImage", "ignore", "relabel", "write16", "compress", "finalSegImage", "bcImage"}, usage);
   for (const char* req : {"segImage", "mergeOrders"})
     if (!a.has(req)) { std::cerr << "Error: the option '--" << req << "' is required but missing\n" << usage; return EXIT_FAILURE; }
-  if (a.has("bcImage")) perr("Error: the boundary confidence image is not supported by the MI355X path yet...");
   if (flagOf(a, "compress")) perr("Error: compressed output is not supported...");
   // one tree per merge order file (main_segment_greedy.cxx:33-60)
   const auto orderFiles = a.all("mergeOrders"), probFiles = a.all("mergeProbs"), rprobFiles = a.all("regionProbs");
@@ -49,11 +48,28 @@ int main(int argc, char* argv[]) {
       if (T.n < 0) perr(glia_hmt_last_error());
     }
   }
-  if (!a.has("finalSegImage")) return EXIT_SUCCESS;
   int64_t total = 0;
   std::vector<int64_t> nn; std::vector<const uint32_t*> pl; std::vector<const int32_t*> pp, p0, p1; std::vector<const double*> pq;
   for (auto& T : trees) { total += T.n; nn.push_back(T.n); pl.push_back(T.lab.data()); pp.push_back(T.par.data()); p0.push_back(T.c0.data());
                           p1.push_back(T.c1.data()); pq.push_back(T.pot.data()); }
+  if (a.has("bcImage")) {                                                                                   // :62-70
+    Volume segb = readMetaImage(a.str("segImage"), false);
+    uint32_t* dL = upload(segb.u32);
+    uint32_t* dM = loadMask(a, "maskImage", segb.size());
+    std::vector<float> zeros(segb.size(), 0.0f);
+    float* dZ = upload(zeros);                                       // the contour-only map needs an image volume; its values are not used
+    float* dOut = upload(zeros);
+    glia_hmt_ctx* cx; glia_hmt_rag* rag;
+    check(glia_hmt_ctx_create(0, nullptr, &cx));
+    check(glia_hmt_rag_build(cx, segb.dim, segb.dims, dL, dM, /*only_contour=*/1, dZ, nullptr, &rag));
+    check(glia_hmt_boundary_confidence(cx, rag, nTree, nn.data(), pl.data(), pp.data(), p0.data(), pq.data(), dOut));
+    hipCheck(hipMemcpy(zeros.data(), dOut, zeros.size() * 4, hipMemcpyDeviceToHost));
+    writeMetaImageFloat(a.str("bcImage"), segb.dim, segb.dims, zeros);
+    glia_hmt_rag_free(rag); glia_hmt_ctx_destroy(cx);
+    (void)hipFree(dL); (void)hipFree(dZ); (void)hipFree(dOut);
+    if (dM) (void)hipFree(dM);
+  }
+  if (!a.has("finalSegImage")) return EXIT_SUCCESS;
   std::vector<int32_t> pickTree((size_t)(total ? total : 1)), pickNode((size_t)(total ? total : 1));
   const int64_t np = glia_hmt_resolve_trees_greedy(nTree, nn.data(), pl.data(), pp.data(), p0.data(), p1.data(), pq.data(), pickTree.data(),
                                                    pickNode.data(), total);                                            // :72-76

@@ -872,6 +872,26 @@ int glia_hmt_relabel_image(glia_hmt_ctx* c, uint32_t* d_labels, int64_t n_voxels
   return relabel_image(d_labels, n_voxels, min_size, n_labels, c->stream);
 }
 
+int glia_hmt_boundary_confidence(glia_hmt_ctx* c, glia_hmt_rag* rag, int n_trees, const int64_t* n_nodes, const uint32_t* const* node_label,
+                                 const int32_t* const* parent, const int32_t* const* child0, const double* const* potential, float* d_out) {
+  if (!c || !rag || rag->ctx != c || n_trees < 1 || !n_nodes || !node_label || !parent || !child0 || !potential || !d_out) {
+    set_error("boundary_confidence: invalid argument");
+    return GLIA_HMT_ERR_ARG;
+  }
+  if (!rag->vol.lab) { set_error("boundary_confidence: needs the volumes the region map was built from (whole-volume build)"); return GLIA_HMT_ERR_UNSUPPORTED; }
+  GLIA_HIP_TRY(hipSetDevice(c->device));
+  const int64_t P = rag->arr.P;
+  std::vector<uint32_t> pa((size_t)(P ? P : 1)), pb((size_t)(P ? P : 1));
+  if (P) {
+    GLIA_HIP_TRY(hipMemcpy(pa.data(), rag->arr.d_pa, sizeof(uint32_t) * P, hipMemcpyDeviceToHost));
+    GLIA_HIP_TRY(hipMemcpy(pb.data(), rag->arr.d_pb, sizeof(uint32_t) * P, hipMemcpyDeviceToHost));
+  }
+  std::vector<float> val;
+  int rc = boundary_confidence_values(n_trees, n_nodes, node_label, parent, child0, potential, pa.data(), pb.data(), P, &val);
+  if (rc) return rc;
+  return paint_pair_values(rag->vol, rag->arr.d_pa, rag->arr.d_pb, P, val.data(), d_out, c->stream);
+}
+
 double glia_hmt_last_transform_ms(const glia_hmt_ctx* c) { return c ? c->transform_ms : 0.0; }
 
 int64_t glia_hmt_gen_tree(const uint32_t* h_order, int64_t n_merges, uint32_t* node_label, int32_t* parent, int32_t* child0,

@@ -125,6 +125,11 @@ int transform_keys(const uint32_t* order, int64_t n, std::vector<uint32_t>* src,
 int transform_image(uint32_t* d_lab, int64_t n, const uint32_t* h_src, const uint32_t* h_dst, int64_t m, const uint32_t* d_mask,
                     int fill_missing, hipStream_t stream, double* ms);
 int relabel_image(uint32_t* d_lab, int64_t n, int64_t min_size, uint32_t* n_labels, hipStream_t stream);
+int paint_pair_values(const VolumeRef& vol, const uint32_t* d_pa, const uint32_t* d_pb, int64_t P, const float* h_val, float* d_out,
+                      hipStream_t stream);
+int boundary_confidence_values(int n_trees, const int64_t* n_nodes, const uint32_t* const* node_label, const int32_t* const* parent,
+                               const int32_t* const* child0, const double* const* potential, const uint32_t* pa, const uint32_t* pb,
+                               int64_t P, std::vector<float>* out);
 int merge_rag_arrays(const RagArrays* parts, int n_parts, RagArrays* out, hipStream_t stream);
 
 __host__ __device__ inline uint32_t float_ord(float f) {

@@ -69,7 +69,52 @@ __global__ void count_labels_kernel(const uint32_t* lab, long long n, unsigned l
   atomicAdd(&cnt[cur], run);
 }
 
+// genBoundaryConfidenceImage (hmt/tree_segment.hxx:145-171): every voxel of a directed boundary receives the value of its
+// leaf pair; all other voxels 0.  The voxel's pair is re-derived with the neighbour rule of the accumulation pass.
+__global__ void paint_pairs_kernel(VolumeRef vol, const uint32_t* pa, const uint32_t* pb, long long P, const float* val, float* out) {
+  const long long N = vol.nx * vol.ny * vol.nz;
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= N) return;
+  float r = 0.0f;
+  const uint32_t t = vol.lab[p];
+  if (t != kMaskedLabel) {
+    const long long x = p % vol.nx, y = (p / vol.nx) % vol.ny, z = p / (vol.nx * vol.ny);
+    const long long sy = vol.nx, sz = vol.nx * vol.ny;
+    const uint32_t* L = vol.lab_nb;
+    uint32_t nb = t, q;
+    do {
+      if (x > 0 && (q = L[p - 1]) != t && q != kMaskedLabel) { nb = q; break; }
+      if (x + 1 < vol.nx && (q = L[p + 1]) != t && q != kMaskedLabel) { nb = q; break; }
+      if (y > 0 && (q = L[p - sy]) != t && q != kMaskedLabel) { nb = q; break; }
+      if (y + 1 < vol.ny && (q = L[p + sy]) != t && q != kMaskedLabel) { nb = q; break; }
+      if (vol.dim == 3) {
+        if (z > 0 && (q = L[p - sz]) != t && q != kMaskedLabel) { nb = q; break; }
+        if (z + 1 < vol.nz && (q = L[p + sz]) != t && q != kMaskedLabel) { nb = q; break; }
+      }
+    } while (false);
+    if (nb != t) {
+      long long lo = 0, hi = P;
+      while (lo < hi) { const long long mid = (lo + hi) >> 1; if (pa[mid] < t || (pa[mid] == t && pb[mid] < nb)) lo = mid + 1; else hi = mid; }
+      if (lo < P && pa[lo] == t && pb[lo] == nb && val[lo] > 0.0f) r = val[lo];
+    }
+  }
+  out[p] = r;
+}
+
 }  // namespace
+
+int paint_pair_values(const VolumeRef& vol, const uint32_t* d_pa, const uint32_t* d_pb, int64_t P, const float* h_val, float* d_out,
+                      hipStream_t stream) {
+  float* d_val = nullptr;
+  GLIA_HIP_TRY(hipMalloc(&d_val, sizeof(float) * (size_t)(P ? P : 1)));
+  GLIA_HIP_TRY(hipMemcpyAsync(d_val, h_val, sizeof(float) * (size_t)P, hipMemcpyHostToDevice, stream));
+  const long long N = vol.nx * vol.ny * vol.nz;
+  hipLaunchKernelGGL(paint_pairs_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, vol, d_pa, d_pb, (long long)P, d_val, d_out);
+  GLIA_HIP_TRY(hipGetLastError());
+  GLIA_HIP_TRY(hipStreamSynchronize(stream));
+  (void)hipFree(d_val);
+  return GLIA_HMT_OK;
+}
 
 // transformKeys: for every merged key that is not itself created by a merge, the key it ends up in
 int transform_keys(const uint32_t* order, int64_t n, std::vector<uint32_t>* src, std::vector<uint32_t>* dst) {

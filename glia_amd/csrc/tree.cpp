@@ -5,6 +5,7 @@
 // hmt/main_segment_greedy.cxx:33-86.  The reference re-scans every node for each pick (O(n^2)); here the same pick
 // sequence comes out of a heap ordered by (potential descending, node index ascending) with lazy invalidation.
 #include <algorithm>
+#include <limits>
 #include <queue>
 #include <unordered_map>
 #include <vector>
@@ -12,6 +13,92 @@
 #include "hmt_internal.hpp"
 
 using namespace glia;
+
+namespace glia {
+
+// genBoundaryConfidenceMap with all nodes (hmt/tree_segment.hxx:66-143): for every unordered leaf pair the largest
+// (float) potential over the tree nodes whose region still holds a directed entry of the pair.  A node N holds a -> b
+// iff a is below N and the entry has not been cancelled there: a non-mutual entry never is (type/region.hxx:66-75), a
+// mutual one is as soon as b is below N too.  So a non-mutual entry sees a and ALL its ancestors, a mutual one the path
+// from a up to just below the lowest common ancestor.  Path maxima come from binary lifting; out[i] belongs to directed
+// pair i and is shared by both directions.
+int boundary_confidence_values(int n_trees, const int64_t* n_nodes, const uint32_t* const* node_label, const int32_t* const* parent,
+                               const int32_t* const* child0, const double* const* potential, const uint32_t* pa, const uint32_t* pb,
+                               int64_t P, std::vector<float>* out) {
+  out->assign((size_t)P, 0.0f);
+  std::vector<char> seen((size_t)P, 0);
+  // partner (b -> a) of every directed pair (pairs are sorted by (a, b))
+  std::vector<int64_t> partner((size_t)P, -1);
+  for (int64_t i = 0; i < P; ++i) {
+    int64_t lo = 0, hi = P;
+    const uint32_t a = pb[i], b = pa[i];
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (pa[mid] < a || (pa[mid] == a && pb[mid] < b)) lo = mid + 1; else hi = mid; }
+    if (lo < P && pa[lo] == a && pb[lo] == b) partner[i] = lo;
+  }
+  for (int t = 0; t < n_trees; ++t) {
+    const int64_t n = n_nodes[t];
+    if (n <= 0) continue;
+    int LOG = 1;
+    while ((1ll << LOG) < n) ++LOG;
+    std::vector<int32_t> depth((size_t)n, 0), root((size_t)n, 0);
+    std::vector<std::vector<int32_t>> up((size_t)LOG, std::vector<int32_t>((size_t)n));
+    std::vector<std::vector<float>> mx((size_t)LOG, std::vector<float>((size_t)n));      // max over 2^k nodes starting at x going up
+    std::vector<float> maxUp((size_t)n);
+    for (int64_t x = n - 1; x >= 0; --x) {                 // parents have larger indices than children
+      const int32_t p = parent[t][x];
+      const float v = (float)potential[t][x];
+      depth[x] = p >= 0 ? depth[p] + 1 : 0;
+      root[x] = p >= 0 ? root[p] : (int32_t)x;
+      maxUp[x] = p >= 0 ? std::max(v, maxUp[p]) : v;
+      up[0][x] = p >= 0 ? p : (int32_t)x;
+      mx[0][x] = v;
+    }
+    for (int k = 1; k < LOG; ++k)
+      for (int64_t x = 0; x < n; ++x) {
+        const int32_t h = up[k - 1][x];
+        up[k][x] = up[k - 1][h];
+        mx[k][x] = std::max(mx[k - 1][x], mx[k - 1][h]);
+      }
+    std::unordered_map<uint32_t, int32_t> leaf;
+    for (int64_t x = 0; x < n; ++x) if (child0[t][x] < 0) leaf[node_label[t][x]] = (int32_t)x;
+    // max potential over x and its `steps - 1` nearest ancestors
+    auto path_max = [&](int32_t x, int32_t steps) {
+      float m = -std::numeric_limits<float>::infinity();
+      for (int k = 0; steps > 0; ++k, steps >>= 1)
+        if (steps & 1) { m = std::max(m, mx[k][x]); x = up[k][x]; }
+      return m;
+    };
+    auto lca_depth = [&](int32_t x, int32_t y) {
+      if (depth[x] < depth[y]) std::swap(x, y);
+      int32_t d = depth[x] - depth[y];
+      for (int k = 0; d > 0; ++k, d >>= 1) if (d & 1) x = up[k][x];
+      if (x == y) return depth[x];
+      for (int k = LOG - 1; k >= 0; --k) if (up[k][x] != up[k][y]) { x = up[k][x]; y = up[k][y]; }
+      return depth[x] - 1;
+    };
+    for (int64_t i = 0; i < P; ++i) {
+      auto la = leaf.find(pa[i]);
+      if (la == leaf.end()) continue;
+      const int32_t xa = la->second;
+      float v;
+      auto lb = partner[i] >= 0 ? leaf.find(pb[i]) : leaf.end();
+      if (lb != leaf.end() && root[lb->second] == root[xa]) v = path_max(xa, depth[xa] - lca_depth(xa, lb->second));
+      else v = maxUp[xa];
+      // the pair's value is shared by both directions (key normalised to (min, max), tree_segment.hxx:76-83)
+      const int64_t j = partner[i];
+      const float cur = seen[i] ? (*out)[i] : -std::numeric_limits<float>::infinity();
+      const float nv = std::max(cur, v);
+      (*out)[i] = nv; seen[i] = 1;
+      if (j >= 0) { (*out)[j] = seen[j] ? std::max((*out)[j], nv) : nv; seen[j] = 1; if ((*out)[j] > (*out)[i]) (*out)[i] = (*out)[j]; }
+    }
+  }
+  // both directions of a pair hold the same maximum
+  for (int64_t i = 0; i < P; ++i) if (partner[i] >= 0) { const float m = std::max((*out)[i], (*out)[partner[i]]); (*out)[i] = m; (*out)[partner[i]] = m; }
+  for (int64_t i = 0; i < P; ++i) if (!seen[i]) (*out)[i] = 0.0f;
+  return GLIA_HMT_OK;
+}
+
+}  // namespace glia
 
 extern "C" {
 

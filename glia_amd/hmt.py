@@ -469,6 +469,18 @@ class RegionMap:
                                                         C.c_int64(cap), C.byref(n)))
         return out[:n.value].copy()
 
+    def boundary_confidence(self, trees):
+        """segment_greedy -b (genBoundaryConfidenceImage, all nodes): float32 CUDA tensor of the volume's shape"""
+        import torch
+        nt = len(trees)
+        keep = [[np.ascontiguousarray(t[0], np.uint32), np.ascontiguousarray(t[1], np.int32), np.ascontiguousarray(t[2], np.int32),
+                 np.ascontiguousarray(t[4], np.float64)] for t in trees]
+        nn = (C.c_int64 * nt)(*[len(k[0]) for k in keep])
+        arr = lambda j: (C.c_void_p * nt)(*[k[j].ctypes.data for k in keep])
+        out = torch.empty(self.shape, dtype=torch.float32, device=torch.device("cuda", self.ctx.device))
+        _check(lib().glia_hmt_boundary_confidence(self.ctx.h, self.h, C.c_int(nt), nn, arr(0), arr(1), arr(2), arr(3), C.c_void_p(out.data_ptr())))
+        return out
+
     def last_merge_timing(self):
         a, b, c, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
         _check(lib().glia_hmt_last_merge_timing(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))

@@ -211,6 +211,14 @@ int64_t glia_hmt_label_transform(const uint32_t* node_label, const int32_t* chil
                                  const int32_t* h_picks, int64_t n_picks, uint32_t key_to_assign, uint32_t* h_src,
                                  uint32_t* h_dst, int64_t capacity);
 
+/* genBoundaryConfidenceImage with all tree nodes (hmt/tree_segment.hxx:66-203; segment_greedy -b): every voxel on a
+ * directed boundary of two supervoxels receives the largest (float) node potential among the tree nodes whose region
+ * still owns an entry of that supervoxel pair; every other voxel 0.  rag: the region map of the segmentation image
+ * (glia_hmt_rag_build, whole volume); trees as produced by glia_hmt_tree_potentials; d_out: float volume. */
+int glia_hmt_boundary_confidence(glia_hmt_ctx* ctx, glia_hmt_rag* rag, int n_trees, const int64_t* n_nodes,
+                                 const uint32_t* const* node_label, const int32_t* const* parent, const int32_t* const* child0,
+                                 const double* const* potential, float* d_out);
+
 /* ---- label-volume rewrites either side of the path (gadget/main_pre_merge.cxx:77-79, gadget/main_apply_merges.cxx:28-34) ----
  * transformKeys (util/struct_merge.hxx:188-210): every key that is merged and is not itself created by a merge maps
  * to the key it finally ends up in.  Host-only; pairs come out sorted by source key.  Returns the number of pairs

@@ -1362,6 +1362,51 @@ int64_t orc_resolve_trees_greedy(int n_trees, const int64_t* n_nodes, const orc_
   return np;
 }
 
+// genBoundaryConfidenceMap / genBoundaryConfidenceImage with all nodes (hmt/tree_segment.hxx:66-203) as
+// main_segment_greedy.cxx:62-70 calls them: one copy of the contour-only region map per tree with the tree's merges
+// applied (type/region_map.hxx:67-68), every node's surviving boundary keys vote max(float potential), the first map
+// paints.  h must be a contour-only rag.
+int orc_boundary_confidence(orc_rag* h, int n_trees, const orc_label* const* orders, const int64_t* n_merges,
+                            const orc_label* const* node_label, const int64_t* n_nodes, const double* const* potential, float* out) {
+  if (!h->onlyContour) return -1;
+  typedef std::pair<Label, Label> KeyPair;
+  std::unordered_map<KeyPair, float, PairHash> pbmap;
+  auto fpb = [&](double val, KeyPair const& key01) {
+    KeyPair key10 = key01.first < key01.second ? key01 : std::make_pair(key01.second, key01.first);
+    auto pbit = pbmap.find(key10);
+    if (pbit == pbmap.end()) pbmap[key10] = (float)val;
+    else if (pbit->second < val) pbit->second = (float)val;
+  };
+  std::vector<RegionMap> rmaps(n_trees, h->rmap);
+  for (int i = 0; i < n_trees; ++i)
+    for (int64_t m = 0; m < n_merges[i]; ++m) rmaps[i].merge(orders[i][3 * m], orders[i][3 * m + 1], orders[i][3 * m + 2]);
+  for (int i = 0; i < n_trees; ++i)
+    for (int64_t x = 0; x < n_nodes[i]; ++x) {
+      float val = (float)potential[i][x];                     // the node functor returns Real (= float)
+      auto rit = rmaps[i].find(node_label[i][x]);
+      if (rit == rmaps[i].end()) continue;                    // (the reference would dereference end() here)
+      for (auto const& bp : rit->second.boundary) fpb(val, bp.first);
+    }
+  int64_t N = h->vol.size();
+  for (int64_t p = 0; p < N; ++p) out[p] = 0.0f;
+  RegionMap const& rmap = rmaps.front();
+  for (auto const& pbp : pbmap) {
+    KeyPair key = pbp.first;
+    auto rit = rmap.find(pbp.first.first);
+    if (rit != rmap.end()) {
+      auto bit = rit->second.boundary.find(key);
+      if (bit != rit->second.boundary.end()) for (auto p : *bit->second) if (out[p] < pbp.second) out[p] = pbp.second;
+    }
+    std::swap(key.first, key.second);
+    rit = rmap.find(pbp.first.second);
+    if (rit != rmap.end()) {
+      auto bit = rit->second.boundary.find(key);
+      if (bit != rit->second.boundary.end()) for (auto p : *bit->second) if (out[p] < pbp.second) out[p] = pbp.second;
+    }
+  }
+  return 0;
+}
+
 // hmt/tree_segment.hxx:10-21: pairs sorted by source label (the reference fills an unordered_map)
 int64_t orc_label_transform(const orc_label* node_label, const int32_t* child0, const int32_t* child1, int64_t n,
                             const int32_t* picks, int64_t n_picks, orc_label key, orc_label* src, orc_label* dst, int64_t cap) {

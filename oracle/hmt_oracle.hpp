@@ -147,6 +147,8 @@ int64_t orc_resolve_tree_greedy(const int32_t* parent, const int32_t* child0, co
 int64_t orc_resolve_trees_greedy(int n_trees, const int64_t* n_nodes, const orc_label* const* node_label, const int32_t* const* parent,
                                  const int32_t* const* child0, const int32_t* const* child1, const double* const* potential,
                                  int32_t* pick_tree, int32_t* pick_node, int64_t cap);
+int orc_boundary_confidence(orc_rag* h, int n_trees, const orc_label* const* orders, const int64_t* n_merges,
+                            const orc_label* const* node_label, const int64_t* n_nodes, const double* const* potential, float* out);
 int64_t orc_label_transform(const orc_label* node_label, const int32_t* child0, const int32_t* child1, int64_t n,
                             const int32_t* picks, int64_t n_picks, orc_label key, orc_label* src, orc_label* dst, int64_t cap);
 

@@ -232,6 +232,19 @@ class Rag:
             raise RuntimeError("orc_bc_feat failed")
         return feats
 
+    def boundary_confidence(self, orders, trees):
+        """segment_greedy -b: orders = list of merge orders, trees = list of (label, parent, child0, child1, potential)"""
+        nt = len(orders)
+        ko = [np.ascontiguousarray(o, np.uint32) for o in orders]
+        kl = [np.ascontiguousarray(t[0], np.uint32) for t in trees]
+        kp = [np.ascontiguousarray(t[4], np.float64) for t in trees]
+        arr = lambda ks: (C.c_void_p * nt)(*[k.ctypes.data for k in ks])
+        nm = (C.c_int64 * nt)(*[len(o) for o in ko]); nn = (C.c_int64 * nt)(*[len(k) for k in kl])
+        out = np.empty(self.shape, np.float32)
+        rc = lib().orc_boundary_confidence(self.h, C.c_int(nt), arr(ko), nm, arr(kl), nn, arr(kp), _p(out))
+        assert rc == 0
+        return out
+
     def pre_merge(self, pb, size_thresholds, rpb_threshold):
         cap = max(self.num_regions, 1)
         order = np.empty((cap, 3), np.uint32); sal = np.empty(cap, np.float64)

@@ -226,7 +226,12 @@ def test_segment_greedy_cli_with_two_trees(tools, tmp_path):
                 f.write("%.17g\n" % v)
         args += ["-o", of, "-p", pf]
         trees.append(O.tree_potentials(o, probs))
-    subprocess.check_call([os.path.join(tools, "segment_greedy"), "-s", seg] + args + ["-f", out])
+    bc = str(tmp_path / "bc.mha")
+    subprocess.check_call([os.path.join(tools, "segment_greedy"), "-s", seg] + args + ["-f", out, "-b", bc])
+    raw = open(bc, "rb").read()
+    got_bc = np.frombuffer(raw[raw.index(b"ElementDataFile = LOCAL\n") + 24:], dtype=np.float32).reshape(labels.shape)
+    orders = [np.loadtxt(args[i + 1], dtype=np.int64).reshape(-1, 3).astype(np.uint32) for i in range(0, len(args), 4)]
+    assert (got_bc == O.Rag(labels, only_contour=True).boundary_confidence(orders, trees)).all()
     pt, pn = O.resolve_trees_greedy(trees)
     src, dst = [], []
     for k in range(len(pt)):

@@ -103,3 +103,31 @@ def test_transform_image_full_size_properties(ctx):
     after = torch.bincount(work.view(-1).to(torch.int64))
     assert int(after.sum()) == int(before.sum()) and int((after > 0).sum()) == 101
     print("transform_image 512^3: %.3f ms -> %.0f GB/s" % (ms, 8 * 512 ** 3 / ms / 1e6))
+
+
+@pytest.mark.parametrize("shape,S,G,masked,two", [((32, 32, 32), 8, 16, False, False), ((40, 36, 28), 6, 12, True, False),
+                                                  ((64, 64), 4, 16, False, True)])
+def test_boundary_confidence_image(ctx, shape, S, G, masked, two):
+    """segment_greedy -b: genBoundaryConfidenceMap / Image over all tree nodes (hmt/tree_segment.hxx:66-203).  The library
+    derives the pair values from tree paths (binary lifting); the oracle applies the merges to a region map per tree and
+    lets every node vote, as the reference does."""
+    import torch
+    from glia_amd import hmt
+    from oracle import pyoracle as O
+    labels, pb = O.synth(shape, S, G)
+    mask = None
+    if masked:
+        mask = (np.random.default_rng(2).random(shape) > 0.2).astype(np.uint32)
+    d_lab = _dev(labels)
+    d_pb = torch.from_numpy(pb).cuda()
+    d_mask = _dev(mask) if masked else None
+    rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, mask=d_mask, only_contour=True)
+    orders, trees = [], []
+    for typ in ((2, 1) if two else (2,)):
+        o, s = O.Rag(labels, mask=mask, only_contour=True).merge_order_pb(pb, type=typ)
+        orders.append(o)
+        trees.append(O.tree_potentials(o, np.clip(1.0 + 2.5 * s, 0.0, 1.0)))
+    got = rm.boundary_confidence(trees).cpu().numpy()
+    ref = O.Rag(labels, mask=mask, only_contour=True).boundary_confidence(orders, trees)
+    assert (got == ref).all() and (got > 0).any() and (got[ref == 0] == 0).all()
+    rm.close()
