@@ -1,8 +1,8 @@
 """Randomised cross-check of the HIP path against the oracle (small volumes, many configurations).
-usage: fuzz_gpu.py [seconds] [seed]   -- stops at the first mismatch with the configuration printed."""
+usage: python tests/fuzz_gpu.py [seconds] [seed]   -- stops at the first mismatch with the configuration printed."""
 import os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))   # lives under tests/: it uses the oracle
 import numpy as np
 import torch
 from glia_amd import hmt
@@ -84,6 +84,6 @@ while time.time() < t_end:
         np.savez_compressed(os.path.join(ROOT, "gpurun_out", "fuzz_fail.npz"), labels=labels, pb=pb, mask=mask if mask is not None else np.zeros(0))
         sys.exit(1)
     n += 1
-    if n % 20 == 0:
+    if n % 5 == 0:
         print("%d cases ok (%.0f s left)" % (n, t_end - time.time()), flush=True)
 print("fuzz: %d random configurations, all identical to the oracle" % n)
