@@ -49,7 +49,10 @@ while time.time() < t_end:
         o, s = rm.pre_merge(sizes, rpb); rm.close()
         ro, rs = O.Rag(labels, mask=mask).pre_merge(pb, sizes, rpb)
         assert o.shape == ro.shape and (o == ro).all(), "pre_merge %s %g" % (sizes, rpb)
-        # classifier linkage, random image lists
+        # classifier linkage, random image lists (the oracle re-walks voxels per edge: keep it to a few hundred regions)
+        if len(np.unique(labels)) > 300:
+            n += 1
+            continue
         raw = (np.round(rng.random(shape) * 255) / 256.0).astype(np.float32)
         d_raw = torch.from_numpy(raw).cuda()
         lay = int(rng.integers(0, 4))
