@@ -36,6 +36,33 @@ def cpu_baseline(size, S, bc_size):
            "sample": "%d^3 synthetic volume, S=%d (%d regions): RAG %.2fs + greedy pb-mean %.2fs, oracle/hmt_oracle.cc; "
                      "edge features: classifier path on %d^3" % (size, S, len(order) + 1, t1 - t0, t2 - t1, bc_size),
            "merge_loop_only": len(order) / max(t2 - t1, 1e-9)}
+    # the reference's own engine (type/boundary_table.hxx, type/region_map.hxx, util/struct_merge.hxx:13-33 compiled in
+    # place into oracle/_ref/ref_engine, which travels prebuilt): same sample, fed the region map as a dump
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_engine")
+    if os.path.exists(ref):
+        try:
+            import subprocess
+            import tempfile
+            with tempfile.TemporaryDirectory() as d:
+                dump = os.path.join(d, "dump.txt")
+                rag.dump(pb, 2, False, dump)
+                with open(dump) as f:
+                    t3 = time.time()
+                    res = subprocess.run([ref], stdin=f, capture_output=True, text=True, check=True, timeout=600)
+                    t4 = time.time()
+            n_ref = len([l for l in res.stdout.split("\n") if l.strip()])
+            eng = [l for l in res.stderr.split("\n") if l.startswith("engine_seconds")]
+            if eng:
+                t4 = t3 + float(eng[-1].split()[1])     # the engine's own clock around genMergeOrderGreedy (no dump parsing)
+            if n_ref == len(order):
+                out.update({"value": n_ref / ((t1 - t0) + (t4 - t3)), "kind": "reference", "merge_loop_only": n_ref / (t4 - t3),
+                            "port_value": len(order) / (t2 - t0),
+                            "sample": "%d^3 synthetic volume, S=%d (%d regions): RAG %.2fs (oracle port) + the reference's own greedy engine "
+                                      "(oracle/_ref/ref_engine: boundary table + genMergeOrderGreedy headers built in place, reads a dump of the "
+                                      "region map) %.2fs; edge features: classifier path (port) on %d^3"
+                                      % (size, S, n_ref + 1, t1 - t0, t4 - t3, bc_size)})
+        except Exception:      # noqa: BLE001 -- the port's numbers stand
+            pass
     labels, pb = O.synth((bc_size,) * 3, S // 2, 4 * S)
     cfg = O.make_cfg(pb, rb=[(pb, 8, 0.0, 1.0)])
     rag = O.Rag(labels)

@@ -18,6 +18,7 @@
 //         B lines:  a b n  p0 p1 ...                  (directed boundary voxel ids)
 //         then N pb values (N = number of voxels, first line gives N)
 // stdout: one "x0 x1 x2 saliency" line per merge (saliency printed with %.17g)
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <cstdio>
@@ -82,8 +83,10 @@ int main() {
       if (p1) { d2.first += p1->first * p1->second; d2.second += p1->second; }
       d2.first = sdivide(d2.first, d2.second, 0.0);
     };
+    const auto t0 = std::chrono::steady_clock::now();
     genMergeOrderGreedy<ItemData>(order, sal, rmap, updateRegion != 0, initFb, fsal, updateFb, fsal,
                                   f_true<BT&, BT::iterator>);
+    fprintf(stderr, "engine_seconds %.6f\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
   } else {
     typedef std::vector<double> ItemData;
     typedef TBoundaryTable<ItemData, RegionMap> BT;
@@ -100,8 +103,10 @@ int main() {
       else if (p0) splice(d2, *p0);
       else if (p1) splice(d2, *p1);
     };
+    const auto t0 = std::chrono::steady_clock::now();
     genMergeOrderGreedy<ItemData>(order, sal, rmap, updateRegion != 0, initFb, fsal, updateFb, fsal,
                                   f_true<BT&, BT::iterator>);
+    fprintf(stderr, "engine_seconds %.6f\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
   }
   for (size_t i = 0; i < order.size(); ++i)
     printf("%u %u %u %.17g\n", order[i].x0, order[i].x1, order[i].x2, sal[i]);
