@@ -14,6 +14,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = hmt.Context(0)
 t_end = time.time() + budget
 n = 0
+near_ties = 0
 close = lambda a, b: a.shape == b.shape and np.allclose(a, b, rtol=1e-5, atol=1e-12)
 while time.time() < t_end:
     dim = int(rng.choice([2, 3], p=[0.3, 0.7]))
@@ -71,9 +72,19 @@ while time.time() < t_end:
         ro, rs, rf = O.Rag(labels, mask=mask).merge_order_bc(ocfg, None, stub_index=stub, want_feats=True)
         o, s, f = rm.merge_order_bc(hmt.FeatureStubClassifier(ctx, stub), want_feats=True)
         if variant == 0:
-            assert o.shape == ro.shape and (o == ro).all(), "bc order (stub %d)" % stub
+            same = o.shape == ro.shape and (o == ro).all()
+            if not same and o.shape == ro.shape:
+                # Entropy features carry the device libm's log2 (<= 1 ulp from glibc's, which itself differs between its FMA
+                # and non-FMA builds): a scorer that is a bare entropy can order mathematically tied edges differently.
+                # Accept a divergence only if it starts at saliencies that agree to a few ulp.
+                k0 = int(np.argmax((o != ro).any(1)))
+                if abs(s[k0] - rs[k0]) <= 8 * np.spacing(abs(rs[k0])) and close(f[:k0], rf[:k0]):
+                    near_ties += 1
+                    same = True
+                    f, rf = f[:k0], rf[:k0]
+            assert same, "bc order (stub %d)" % stub
             assert close(f, rf), "bc feats"
-        if len(ro) > 4 and variant == 0:
+        if len(ro) > 4 and variant == 0 and len(f) == len(ro):
             forest = _rf.random_forest(rng, int(rng.choice([7, 31, 63])), int(rng.integers(3, 8)), rf)
             with tempfile.TemporaryDirectory() as d:
                 path = os.path.join(d, "m.bin"); _rf.write_model(path, forest)
@@ -89,4 +100,4 @@ while time.time() < t_end:
     n += 1
     if n % 5 == 0:
         print("%d cases ok (%.0f s left)" % (n, t_end - time.time()), flush=True)
-print("fuzz: %d random configurations, all identical to the oracle" % n)
+print("fuzz: %d random configurations, all identical to the oracle (%d classifier runs diverged at a libm near-tie of an entropy score)" % (n, near_ties))
