@@ -186,3 +186,29 @@ def test_rag_with_mask_matches_oracle(ctx, shape, S, G, only_contour):
                 first[int(flat[i])] = i
         assert [first[int(l)] for l in reg["label"]] == reg["first"].tolist()
     rm.close()
+
+
+def test_error_paths_return_status_not_exit(ctx):
+    """the library reports through status codes + glia_hmt_last_error (the reference perr()s and exits)"""
+    torch = _torch()
+    from glia_amd import hmt
+    from oracle import pyoracle as O
+    labels, pb = O.synth((16, 16, 16), 4, 8)
+    d_lab = torch.from_numpy(labels.view(np.int32)).cuda()
+    d_pb = torch.from_numpy(pb).cuda()
+    imgs = [torch.from_numpy((pb * (i + 1) / 8).astype(np.float32)).cuda() for i in range(5)]
+    with pytest.raises(hmt.HmtError) as e:      # histogram bins out of range
+        hmt.RegionMap(ctx, d_lab, pb=d_pb, cfg=hmt.make_config(d_pb, rb=[(d_pb, 17, 0.0, 1.0)]))
+    assert e.value.code == -1 and "bins" in str(e.value)
+    with pytest.raises(hmt.HmtError) as e:      # five distinct channels
+        hmt.RegionMap(ctx, d_lab, pb=d_pb, cfg=hmt.make_config(d_pb, r=[(im, 8, 0.0, 1.0) for im in imgs[:4]], b=[(imgs[4], 8, 0.0, 1.0)]))
+    assert e.value.code == -3
+    rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, only_contour=True)
+    with pytest.raises(hmt.HmtError) as e:      # unsupported boundary stats type (main_merge_order_pb.cxx:36)
+        rm.merge_order_pb(type=7)
+    assert "unsupported boundary stats type" in str(e.value)
+    with pytest.raises(hmt.HmtError):           # classifier linkage needs a feature configuration and region points
+        rm.merge_order_bc(hmt.FeatureStubClassifier(ctx, 3))
+    with pytest.raises(hmt.HmtError):           # a model file that does not exist
+        hmt.RandomForest(ctx, "/nonexistent/model.bin")
+    rm.close()
