@@ -48,7 +48,7 @@ int pq_setup(DeviceBuffers& buf, PqTree& t, hipStream_t stream) {
     if ((rc = buf.get(&L.seq, n, false, stream))) return rc;
     if ((rc = buf.get(&L.arg, n, false, stream))) return rc;
     if ((rc = buf.get(&L.dirty, n, true, stream))) return rc;
-    if (n == 1) break;
+    if (n <= kTopMax) break;
   }
   {
     int rc;
@@ -155,9 +155,9 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
   if (tid == 0) { s.pq.wln[0] = s.pq.wln[1] = 0; s.pq.ovf = 0; s.pq.spill = 0; s.nitems = 0; }
   for (int i = tid; i < kSetSlots; i += blockDim.x) { s.pq.set[0][i] = 0; s.pq.set[1][i] = 0; }
   for (uint32_t i = tid; i < kMarkSlots; i += blockDim.x) { s.mk[i] = 0; s.mv0[i] = 0; s.mv1[i] = 0; }
-  // levels >= 2 of the priority tree move to LDS for the lifetime of this launch (written back at the end)
   const PqTree& pq = st.pq;
   __syncthreads();
+  pq_top<kGreedyThreads>(pq, s.pq, tid);      // the root lives in LDS: rebuilt at every launch
 
 #ifdef GLIA_HMT_PROFILE
   unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
@@ -170,13 +170,13 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
     // ---- pop (TBoundaryTable::top) ----
     PH(5);
     if (tid == 0) {
-      const PqLevel& root = pq.lv[pq.nlevels - 1];
+      const Key root = pq_root<kGreedyThreads>(s.pq);
       s.stop = ST_RUN;
       s.newcount = 0;
       s.reject = 0;
-      if (root.seq[0] == 0) s.stop = ST_DONE;
+      if (root.seq == 0) s.stop = ST_DONE;
       else {
-        uint32_t e = root.arg[0];
+        uint32_t e = root.arg;
         s.e = e; s.r0 = st.e_u[e]; s.r1 = st.e_v[e];
         if (st.cond_n > 0) {
           // TBoundaryTable::top(fcond) walks the queue from the best item down and returns the first one fcond accepts.
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
         else {
           if (MEDIAN) st.rbv[st.R0 + (uint32_t)k] = st.rbv[s.r0] + st.rbv[s.r1] - 2ull * (unsigned long long)st.e_n[e];
           st.order[3 * k + 0] = s.r0; st.order[3 * k + 1] = s.r1; st.order[3 * k + 2] = st.R0 + (uint32_t)k;
-          st.sal_out[k] = root.sal[0];
+          st.sal_out[k] = root.sal;
           st.rsz[st.R0 + (uint32_t)k] = st.rsz[s.r0] + st.rsz[s.r1];       // TRegionMap::merge (updateRegion)
           st.rsum[st.R0 + (uint32_t)k] = st.rsum[s.r0] + st.rsum[s.r1];
         }
@@ -415,6 +415,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
   __syncthreads();
   if (tid == 0) { st.ctrl[0] = k; st.ctrl[1] = ne; st.ctrl[2] = pool_used; st.ctrl[3] = status; st.ctrl[4] = vals_used; }
 #ifdef GLIA_HMT_PROFILE
+  if (tid == 0) printf("[greedy profile] pq top: loads %llu wave_max %llu barrier %llu calls %llu\n", g_pqprof[24], g_pqprof[25], g_pqprof[26], g_pqprof[27]);
   if (tid == 0) printf("[greedy profile] pq levels (wave 0): recompute %llu %llu %llu %llu  barrier-wait %llu %llu %llu %llu  active %llu %llu %llu %llu\n", g_pqprof[0], g_pqprof[1], g_pqprof[2],
                        g_pqprof[3], g_pqprof[8], g_pqprof[9], g_pqprof[10], g_pqprof[11], g_pqprof[16], g_pqprof[17], g_pqprof[18], g_pqprof[19]);
   if (tid == 0) printf("[greedy profile] by degree (<=64, <=512, <=1408, more): merges %llu %llu %llu %llu  cycles %llu %llu %llu %llu  entries %llu %llu %llu %llu\n",

@@ -489,6 +489,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
   if (tid == 0) { s.pq.wln[0] = s.pq.wln[1] = 0; s.pq.ovf = 0; s.pq.spill = 0; }
   for (int i = tid; i < kSetSlots; i += blockDim.x) { s.pq.set[0][i] = 0; s.pq.set[1][i] = 0; }
   __syncthreads();
+  pq_top<kBcThreads>(st.pq, s.pq, tid);      // the root lives in LDS: rebuilt at every launch
 
 #ifdef GLIA_HMT_PROFILE
   unsigned long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
@@ -499,16 +500,16 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
   for (unsigned long long it = 0; it < st.max_iters; ++it) {
     PH(7);
     if (tid == 0) {
-      const PqLevel& root = st.pq.lv[st.pq.nlevels - 1];
+      const Key root = pq_root<kBcThreads>(s.pq);
       s.stop = ST_RUN; s.newcount = 0;
       for (int c = 0; c < kMaxChannels; ++c) {
         s.best_mn[c] = s.second_mn[c] = ~0ull; s.best_mx[c] = s.second_mx[c] = 0ull;
         s.ex[c][0] = s.ex[c][2] = 0xFFFFFFFFu; s.ex[c][1] = s.ex[c][3] = 0u;
       }
       const bool forced = st.forced != nullptr;
-      if (forced ? (k >= st.forced_n) : (root.seq[0] == 0)) s.stop = ST_DONE;
+      if (forced ? (k >= st.forced_n) : (root.seq == 0)) s.stop = ST_DONE;
       else {
-        const uint32_t e = forced ? kNone : root.arg[0];
+        const uint32_t e = forced ? kNone : root.arg;
         s.e = e;
         if (forced) { s.r0 = st.forced[2 * k]; s.r1 = st.forced[2 * k + 1]; }
         else { s.r0 = st.e_u[e]; s.r1 = st.e_v[e]; }
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
         else if (pool_used + tot > st.pool_cap) s.stop = ST_NEED_POOL;
         else {
           st.order[3 * k + 0] = s.r0; st.order[3 * k + 1] = s.r1; st.order[3 * k + 2] = st.R0 + (uint32_t)k;
-          st.sal_out[k] = forced ? 0.0 : root.sal[0];
+          st.sal_out[k] = forced ? 0.0 : root.sal;
         }
       }
     }

@@ -1,8 +1,6 @@
 // glia_amd/csrc/greedy_common.hpp -- pieces shared by the greedy merge kernels (pb-mean and classifier linkage):
 // the 64-ary tournament tree used as priority queue and small host helpers.
 #pragma once
-#include <rocprim/warp/warp_reduce.hpp>
-
 #include "hmt_internal.hpp"
 
 namespace glia {
@@ -13,6 +11,7 @@ namespace glia {
 constexpr int kLaneChildren = GLIA_PQ_LANE_CHILDREN;   // children of a node per lane
 constexpr int kFan = 64 * kLaneChildren;              // fewer, fatter levels: every level is a dependent round trip
 constexpr int kMaxLevels = 6;
+constexpr uint32_t kTopMax = 4096;   // the last stored level has at most this many nodes: the whole workgroup reduces it in one step
 #ifndef GLIA_GREEDY_THREADS
 #define GLIA_GREEDY_THREADS 512
 #endif
@@ -37,18 +36,47 @@ __device__ __forceinline__ bool better(const Key& a, const Key& b) {
   return a.sal > b.sal || (a.sal == b.sal && a.seq > b.seq);
 }
 
-struct KeyMax { __device__ __forceinline__ Key operator()(const Key& a, const Key& b) const { return better(b, a) ? b : a; } };
-// 64-lane maximum by (saliency, seq); the result is valid in lane 0 (rocPRIM's DPP reduction: no LDS round trips)
+// 64-lane maximum by (saliency, seq), returned to every lane.  Hand-written over DPP: a generic reduction of the 20-byte
+// key selects between two structs through private memory (a scratch round trip per step, ~4000 cycles per call);
+// here every step is five v_mov_dpp plus compares and selects on registers.  max is idempotent, so the lanes a
+// row_bcast step does not write (row_mask) simply combine with themselves.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ void key_max_step(Key& k) {
+  const unsigned long long sb = (unsigned long long)__double_as_longlong(k.sal);
+  const uint32_t s_lo = dpp_u32<CTRL, ROW_MASK>((uint32_t)sb), s_hi = dpp_u32<CTRL, ROW_MASK>((uint32_t)(sb >> 32));
+  const uint32_t q_lo = dpp_u32<CTRL, ROW_MASK>((uint32_t)k.seq), q_hi = dpp_u32<CTRL, ROW_MASK>((uint32_t)(k.seq >> 32));
+  const uint32_t a = dpp_u32<CTRL, ROW_MASK>(k.arg);
+  const double osal = __longlong_as_double((long long)(((unsigned long long)s_hi << 32) | s_lo));
+  const unsigned long long oseq = ((unsigned long long)q_hi << 32) | q_lo;
+  const bool b = osal > k.sal || (osal == k.sal && oseq > k.seq);
+  k.sal = b ? osal : k.sal;
+  k.seq = b ? oseq : k.seq;
+  k.arg = b ? a : k.arg;
+}
 __device__ __forceinline__ Key wave_max(Key k) {
-  using WR = rocprim::warp_reduce<Key, 64>;
-  __shared__ typename WR::storage_type storage;       // empty for the DPP implementation
+  key_max_step<0xB1>(k);          // quad_perm [1,0,3,2]
+  key_max_step<0x4E>(k);          // quad_perm [2,3,0,1]
+  key_max_step<0x124>(k);         // row_ror 4
+  key_max_step<0x128>(k);         // row_ror 8: every lane holds its row's maximum
+  key_max_step<0x142, 0xa>(k);    // row_bcast 15 into rows 1 and 3
+  key_max_step<0x143, 0xc>(k);    // row_bcast 31 into rows 2 and 3: lane 63 holds the wave's maximum
+  const unsigned long long sb = (unsigned long long)__double_as_longlong(k.sal);
+  const uint32_t s_lo = __builtin_amdgcn_readlane((int)(uint32_t)sb, 63), s_hi = __builtin_amdgcn_readlane((int)(uint32_t)(sb >> 32), 63);
+  const uint32_t q_lo = __builtin_amdgcn_readlane((int)(uint32_t)k.seq, 63), q_hi = __builtin_amdgcn_readlane((int)(uint32_t)(k.seq >> 32), 63);
   Key out;
-  WR().reduce(k, out, storage, KeyMax());
+  out.sal = __longlong_as_double((long long)(((unsigned long long)s_hi << 32) | s_lo));
+  out.seq = ((unsigned long long)q_hi << 32) | q_lo;
+  out.arg = (uint32_t)__builtin_amdgcn_readlane((int)k.arg, 63);
   return out;
 }
 
 
-// The tree: level 0 nodes are the parents of the leaves (edge slots), the last level has one node.
+// The tree: level 0 nodes are the parents of the leaves (edge slots); the last stored level (<= kTopMax nodes) has no
+// stored parent -- pq_top() reduces it with the whole workgroup into PqWork::part (LDS), from where pop reads the root.
 struct PqTree {
   uint32_t nleaves;
   double* leaf_sal;
@@ -102,6 +130,7 @@ struct PqWork {            // lives in LDS
   uint32_t ovf;
   uint32_t spill;                 // some node went to the global lists
   uint32_t fast[2][16];           // small propagations: the node each wave handles on the next level
+  Key part[16];                   // per-wave maxima of the last stored level (pq_top); their maximum is the root
   uint32_t wln[2];
   uint32_t wl[2][kWorkCap];
   uint32_t set[2][kSetSlots];     // membership of wl[which] (node + 1, 0 = empty): no global round trip to dedupe
@@ -136,6 +165,50 @@ __device__ __forceinline__ void pq_touch(const PqTree& t, PqWork& w, int level, 
 #ifdef GLIA_HMT_PROFILE
 __device__ unsigned long long g_pqprof[32];     // [l] cycles of level l, [8+l] nodes recomputed at level l, [16+l] spilled nodes
 #endif
+// the root: one round trip over the last stored level by the whole workgroup (every thread calls; the caller has put a
+// barrier after the last store into that level; ends with a barrier)
+template <int THREADS>
+__device__ __forceinline__ void pq_top(const PqTree& t, PqWork& w, int tid) {
+  const PqLevel& cl = t.lv[t.nlevels - 1];
+  Key k;
+  k.sal = -__builtin_inf(); k.seq = 0; k.arg = 0;
+#ifdef GLIA_HMT_PROFILE
+  const unsigned long long tt0 = __builtin_readcyclecounter();
+#endif
+  constexpr int kBatch = 4;
+  for (uint32_t base = 0; base < cl.size; base += THREADS * kBatch) {
+    Key kk[kBatch];
+#pragma unroll
+    for (int c = 0; c < kBatch; ++c) {
+      const uint32_t ci = base + c * THREADS + tid;
+      kk[c].sal = -__builtin_inf(); kk[c].seq = 0; kk[c].arg = 0;
+      if (ci < cl.size) { kk[c].sal = cl.sal[ci]; kk[c].seq = cl.seq[ci]; kk[c].arg = cl.arg[ci]; }
+    }
+#pragma unroll
+    for (int c = 0; c < kBatch; ++c) if (better(kk[c], k)) k = kk[c];
+  }
+#ifdef GLIA_HMT_PROFILE
+  if (k.arg == 0xFFFFFFF0u) w.ovf = 1;      // keep the loads before the timestamp
+  const unsigned long long tt1 = __builtin_readcyclecounter();
+#endif
+  k = wave_max(k);
+#ifdef GLIA_HMT_PROFILE
+  const unsigned long long tt2 = __builtin_readcyclecounter();
+#endif
+  if ((tid & 63) == 0) w.part[tid >> 6] = k;
+  __syncthreads();
+#ifdef GLIA_HMT_PROFILE
+  if (tid == 0) { g_pqprof[24] += tt1 - tt0; g_pqprof[25] += tt2 - tt1; g_pqprof[26] += __builtin_readcyclecounter() - tt2; g_pqprof[27] += 1; }
+#endif
+}
+template <int THREADS>
+__device__ __forceinline__ Key pq_root(const PqWork& w) {
+  Key b = w.part[0];
+#pragma unroll
+  for (int j = 1; j < THREADS / 64; ++j) { const Key c = w.part[j]; if (better(c, b)) b = c; }
+  return b;
+}
+
 // apply all pending leaf changes level by level; every thread of the workgroup must call (contains barriers)
 template <int THREADS>
 __device__ __forceinline__ void pq_propagate(const PqTree& t, PqWork& w, int tid) {
@@ -175,7 +248,7 @@ __device__ __forceinline__ void pq_propagate(const PqTree& t, PqWork& w, int tid
       node = parent;
     }
     if (tid == 0) w.wln[0] = 0;
-    __syncthreads();
+    pq_top<THREADS>(t, w, tid);
     return;
   }
   int cur = 0;
@@ -224,7 +297,7 @@ __device__ __forceinline__ void pq_propagate(const PqTree& t, PqWork& w, int tid
   }
   __syncthreads();
   if (tid == 0) { w.ovf = 0; w.spill = 0; w.wln[0] = w.wln[1] = 0; }
-  __syncthreads();
+  pq_top<THREADS>(t, w, tid);
 }
 
 __global__ void pq_build_level_kernel(PqTree t, int l);
