@@ -265,11 +265,29 @@ __device__ __forceinline__ void boundary_feats_multi(const BcCfg& c, uint32_t sh
 }
 
 // log() and selectFeatures applied in place to a vector laid out as [boundary | region 0 | region 1 | merged]
+// the slots boundary_log / region_log touch, in order; returns their number (<= kMaxLogSlots)
+constexpr int kMaxLogSlots = 3 + GLIA_HMT_MAX_THRESH + 3 * (3 + 3 + GLIA_HMT_MAX_THRESH);
+template <class Out>
+__device__ __forceinline__ int log_slots(const BcCfg& c, Out* pos) {
+  int n = 0;
+  pos[n++] = 0; pos[n++] = 3; pos[n++] = 6;
+  for (int i = 0; i < c.T; ++i) pos[n++] = (Out)(11 + i);
+  for (int b = 0; b < 3; ++b) {
+    const int o = c.bfdim + b * c.rfdim;
+    pos[n++] = (Out)(o + 0); pos[n++] = (Out)(o + 1); pos[n++] = (Out)(o + 3);
+    for (int i = 0; i < c.D + c.T; ++i) pos[n++] = (Out)(o + 4 + i);
+  }
+  return n;
+}
+__device__ __forceinline__ void simple_selection(const BcCfg& c, double* out);
 __device__ __forceinline__ void finish_features(const BcCfg& c, double* out) {
   if (c.use_log) {
     boundary_log(c, out);
     region_log(c, out + c.bfdim); region_log(c, out + c.bfdim + c.rfdim); region_log(c, out + c.bfdim + 2 * c.rfdim);
   }
+  simple_selection(c, out);
+}
+__device__ __forceinline__ void simple_selection(const BcCfg& c, double* out) {
   if (c.use_simple) {   // hmt/bc_feat.hxx:247-279; every source index lies beyond the slot it is copied to
     const double* bf = out; const double* x1 = out + c.bfdim; const double* x2 = out + c.bfdim + c.rfdim;
     const double v0 = x1[0], v1 = x2[0], v2 = x1[1], v3 = x2[1], v4 = bf[6];

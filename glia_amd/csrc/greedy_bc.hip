@@ -141,8 +141,10 @@ __device__ void shared_boundary(const BcState& st, int c, uint32_t rec, EStats& 
 // ex: per channel {min, max of first's boundary set without the record's mutual entries, the same for second};
 // pre (optional): values of the lane-parallel pass (feat::pre_region / pre_boundary); sh_pre (optional): the shared
 // boundary set of every channel
+// parts: which blocks to write (1 first region, 2 second region, 4 merged region, 8 boundary block) -- the greedy loop
+// gives each block to a different wave; finish: apply the log / simple selection (the loop does both lane-parallel)
 __device__ void edge_features(const BcState& st, uint32_t first, uint32_t second, uint32_t rec, const float* ex, double* out,
-                              const double* pre = nullptr, const EStats* sh_pre = nullptr) {
+                              const double* pre = nullptr, const EStats* sh_pre = nullptr, int parts = 15, bool finish = true) {
 #ifdef GLIA_HMT_PROFILE
   const unsigned long long tq_in = __builtin_readcyclecounter();
 #endif
@@ -186,22 +188,27 @@ __device__ void edge_features(const BcState& st, uint32_t first, uint32_t second
                           fmaxf(ex[4 * cc + 1], ex[4 * cc + 3]), pe};
     };
   };
-  double ar_first, pe_first, ar_second, pe_second, ar_m, pe_m;
-  {
+  // area / perimeter as region_feats_multi normalises them (the boundary block needs both regions')
+  double ar_first = feat::sdiv((double)n0, c.norm_area, 0.0);
+  double pe_first = feat::sdiv((double)((unsigned long long)B0->n + (unsigned long long)P0->border), c.norm_len, 0.0);
+  double ar_second = feat::sdiv((double)n1, c.norm_area, 0.0);
+  double pe_second = feat::sdiv((double)((unsigned long long)B1->n + (unsigned long long)P1->border), c.norm_len, 0.0);
+  double ar_m, pe_m;
+  if (parts & 1) {
     feat::ShapeIn r;
     r.n = n0; r.border = P0->border; r.bn = B0->n;
     for (int i = 0; i < 3; ++i) { r.lo[i] = P0->lo[i]; r.hi[i] = P0->hi[i]; }
     for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) r.thr[i] = B0->thr[i];
     feat::region_feats_multi(c, r, src_of(0), o_first, ar_first, pe_first);
   }
-  {
+  if (parts & 2) {
     feat::ShapeIn r;
     r.n = n1; r.border = P1->border; r.bn = B1->n;
     for (int i = 0; i < 3; ++i) { r.lo[i] = P1->lo[i]; r.hi[i] = P1->hi[i]; }
     for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) r.thr[i] = B1->thr[i];
     feat::region_feats_multi(c, r, src_of(1), o_second, ar_second, pe_second);
   }
-  {
+  if (parts & 4) {
     // the scratch-merged region (TRegionMap::merge under key 0)
     feat::ShapeIn r;
     r.n = n0 + n1; r.border = P0->border + P1->border;
@@ -211,7 +218,7 @@ __device__ void edge_features(const BcState& st, uint32_t first, uint32_t second
     if (A0) { r.bn -= A0->n; for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) r.thr[i] -= A0->thr[i]; }
     feat::region_feats_multi(c, r, src_of(2), o_merged, ar_m, pe_m);
   }
-  {
+  if (parts & 8) {
     // shared boundary: counts from channel 0, image statistics from each boundary-list channel
     EStats sh_local;
     if (!sh_pre) shared_boundary(st, 0, rec, sh_local);
@@ -226,7 +233,7 @@ __device__ void edge_features(const BcState& st, uint32_t first, uint32_t second
     if (swap) feat::boundary_feats_multi(c, sh0.n, sh0.thr, ar_second, pe_second, ar_first, pe_first, src_of(1), src_of(0), srcSh, pre, o_bf);
     else feat::boundary_feats_multi(c, sh0.n, sh0.thr, ar_first, pe_first, ar_second, pe_second, src_of(0), src_of(1), srcSh, pre, o_bf);
   }
-  feat::finish_features(c, out);
+  if (finish) feat::finish_features(c, out);
 #ifdef GLIA_HMT_PROFILE
   if (threadIdx.x == 0) { g_pqprof[25] += __builtin_readcyclecounter() - tq_in; g_pqprof[26] += 1; }
 #endif
@@ -402,6 +409,8 @@ struct BcShared {
   uint32_t ex[kMaxChannels][4];
   int votes[kChunk];
   int model[kChunk];
+  uint32_t nlog;                 // slots of the full vector that take a logarithm
+  uint16_t logpos[feat::kMaxLogSlots];
   PqWork pq;
   __attribute__((aligned(16))) unsigned char pool[kPoolBytes];
 };
@@ -486,7 +495,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
   const int fdim = st.cfg.fdim;
   const int K = st.cfg.K;
   const BcLayout L = bc_layout(st.cfg, s.pool);
-  if (tid == 0) { s.pq.wln[0] = s.pq.wln[1] = 0; s.pq.ovf = 0; s.pq.spill = 0; }
+  if (tid == 0) { s.pq.wln[0] = s.pq.wln[1] = 0; s.pq.ovf = 0; s.pq.spill = 0; s.nlog = (uint32_t)feat::log_slots(st.cfg, s.logpos); }
   for (int i = tid; i < kSetSlots; i += blockDim.x) { s.pq.set[0][i] = 0; s.pq.set[1][i] = 0; }
   __syncthreads();
   pq_top<kBcThreads>(st.pq, s.pq, tid);      // the root lives in LDS: rebuilt at every launch
@@ -828,20 +837,43 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
       }
       __syncthreads();
       PH(10);
+      {
+        // one block of the vector per wave: waves 4g..4g+3 write the four blocks of the records 64g..64g+63
+        const int wave = tid >> 6, part = wave & 3;
+        const uint32_t slot = (uint32_t)(wave >> 2) * 64u + (uint32_t)(tid & 63);
+        if (slot < cn) {
+          const uint32_t rec = (uint32_t)ne + c0 + slot;
+          if (part == 0) { s.votes[slot] = 0; s.model[slot] = -1; }
+          if (st.e_table[rec]) {
+            const uint32_t rs = st.e_u[rec];
+            float ex[4 * kMaxChannels];
+#pragma unroll
+            for (int c = 0; c < kMaxChannels; ++c) {
+              float a = 0.f, b = 0.f, cm = 0.f, dm = 0.f;
+              if (c < K) { a = L.exmn[slot * K + c]; b = L.exmx[slot * K + c]; r2_extremes(c, rec, cm, dm); }
+              ex[4 * c + 0] = a; ex[4 * c + 1] = b; ex[4 * c + 2] = cm; ex[4 * c + 3] = dm;
+            }
+            edge_features(st, rs, r2, rec, ex, &L.feat[slot * fstride], L.fx + (size_t)slot * L.npre, &L.shs[slot * K], 1 << part, false);   // updateFb passes (rs, r2)
+          }
+        }
+      }
+      __syncthreads();
+      if (st.cfg.use_log) {
+        // feat.hxx:46-52, 103-106: the logarithms, one (record, slot) pair per thread
+        const uint32_t nlog = s.nlog;
+        for (uint32_t i = tid; i < cn * nlog; i += kBcThreads) {
+          const uint32_t j = i / nlog;
+          if (!st.e_table[(uint32_t)ne + c0 + j]) continue;
+          double* q = &L.feat[j * fstride + s.logpos[i - j * nlog]];
+          *q = feat::slog(*q, 0.0);
+        }
+        __syncthreads();
+      }
       if ((uint32_t)tid < cn) {
         const uint32_t rec = (uint32_t)ne + c0 + tid;
-        s.votes[tid] = 0; s.model[tid] = -1;
         if (st.e_table[rec]) {
-          const uint32_t rs = st.e_u[rec];
-          float ex[4 * kMaxChannels];
-#pragma unroll
-          for (int c = 0; c < kMaxChannels; ++c) {
-            float a = 0.f, b = 0.f, cm = 0.f, dm = 0.f;
-            if (c < K) { a = L.exmn[tid * K + c]; b = L.exmx[tid * K + c]; r2_extremes(c, rec, cm, dm); }
-            ex[4 * c + 0] = a; ex[4 * c + 1] = b; ex[4 * c + 2] = cm; ex[4 * c + 3] = dm;
-          }
           double* x = &L.feat[tid * fstride];
-          edge_features(st, rs, r2, rec, ex, x, L.fx + (size_t)tid * L.npre, &L.shs[tid * K]);        // updateFb passes (rs, r2)
+          feat::simple_selection(st.cfg, x);
           s.model[tid] = st.clf.kind == 1 ? 0 : pick_model(st.clf, x);
         }
       }
