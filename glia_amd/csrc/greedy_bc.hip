@@ -434,8 +434,23 @@ __device__ __forceinline__ BcLayout bc_layout(const BcCfg& c, unsigned char* poo
 constexpr unsigned long long kHelperSpinLimit = 1ull << 27;     // polls (with s_sleep) before a side gives up: ~60 s
 
 __device__ __forceinline__ uint32_t ld_relaxed(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void fence_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 __device__ __forceinline__ void st_release(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+// Everything the contraction workgroup and the helpers exchange goes through agent-scope accesses (write-through
+// stores, loads that miss the XCD-local caches), ordered by "my stores have completed" + a flag.  A full agent-scope
+// release / acquire pair would write back and INVALIDATE the whole L2 of the XCD at every chunk: the loop's working
+// set (and the helpers' forest nodes) would be re-fetched from memory each time.
+__device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_agent(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+// this wave's earlier stores have been acknowledged (and the compiler keeps later accesses behind this point)
+__device__ __forceinline__ void stores_done() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_waitcnt(0); }
+__device__ __forceinline__ void after_flag() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 
 // Forest evaluation on the rest of the chip.  The contraction loop is one workgroup; scoring its new records is a
 // gather over ~100 records x 255 trees x ~12 levels that a single CU can only run at its own load-issue rate.  Helper
@@ -455,20 +470,20 @@ __device__ void bc_helper_loop(const BcState& st, BcShared& s) {
         if (v != last) break;
         __builtin_amdgcn_s_sleep(4);
       }
-      fence_acquire();
+      after_flag();
       s.ex[0][0] = v;
     }
     __syncthreads();
     const uint32_t v = s.ex[0][0];
     if (v == last || v == 0xFFFFFFFFu) return;          // gave up waiting / the loop is over
     last = v;
-    const uint32_t cn = st.hctl[2];
+    const uint32_t cn = ld_relaxed(&st.hctl[2]);
     if (h >= cn) continue;                              // nothing for this workgroup in the job: it does not report either
     for (uint32_t j = h; j < cn; j += H) {
-      const int m = st.hmodel[j];
+      const int m = ld_agent(&st.hmodel[j]);
       if (m < 0) continue;
       double* hfeat = reinterpret_cast<double*>(s.pool);
-      for (int i = tid; i < fstride; i += kBcThreads) hfeat[i] = st.featbuf[(size_t)j * fstride + i];
+      for (int i = tid; i < fstride; i += kBcThreads) hfeat[i] = ld_agent(&st.featbuf[(size_t)j * fstride + i]);
       if (tid == 0) s.votes[0] = 0;
       __syncthreads();
       const DeviceForest& f = st.clf.f[m];
@@ -476,12 +491,10 @@ __device__ void bc_helper_loop(const BcState& st, BcShared& s) {
       for (int t = tid; t < f.ntree; t += kBcThreads) mine += forest_vote(f, t, hfeat);
       if (mine) atomicAdd(&s.votes[0], mine);
       __syncthreads();
-      if (tid == 0) st.hvotes[j] = s.votes[0];
+      if (tid == 0) st_agent(&st.hvotes[j], s.votes[0]);
       __syncthreads();
     }
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(&st.hctl[1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) { stores_done(); __hip_atomic_fetch_add(&st.hctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   }
 }
 
@@ -881,23 +894,24 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
       PH(4);
       if (st.clf.kind == 0 && st.n_helpers) {
         // hand the chunk to the helper workgroups and wait for their votes
-        for (uint32_t i = tid; i < cn * (uint32_t)fstride; i += kBcThreads) st.featbuf[i] = L.feat[i];
-        if ((uint32_t)tid < cn) st.hmodel[tid] = s.model[tid];
-        __threadfence();
+        for (uint32_t i = tid; i < cn * (uint32_t)fstride; i += kBcThreads) st_agent(&st.featbuf[i], L.feat[i]);
+        if ((uint32_t)tid < cn) st_agent(&st.hmodel[tid], s.model[tid]);
+        stores_done();
         __syncthreads();
         if (tid == 0) {
-          st.hctl[2] = cn; st.hctl[1] = 0u;
-          st_release(&st.hctl[0], ++hseq);
+          st_agent(&st.hctl[2], cn); st_agent(&st.hctl[1], 0u);
+          stores_done();
+          st_agent(&st.hctl[0], ++hseq);
           unsigned long long spins = 0;
           const uint32_t expect = cn < st.n_helpers ? cn : st.n_helpers;              // helpers h < cn report
           while (ld_relaxed(&st.hctl[1]) < expect) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > kHelperSpinLimit) { s.stop = ST_BAD_SALIENCY; break; }     // helpers lost: reported as a failed run
           }
-          fence_acquire();
+          after_flag();
         }
         __syncthreads();
-        if ((uint32_t)tid < cn && s.model[tid] >= 0) s.votes[tid] = st.hvotes[tid];
+        if ((uint32_t)tid < cn && s.model[tid] >= 0) s.votes[tid] = ld_agent(&st.hvotes[tid]);
       } else if (st.clf.kind == 0) {
         const int ntree = st.clf.f[0].ntree;    // the three ensemble members are required to have equal size
         for (uint32_t i = tid; i < cn * (uint32_t)ntree; i += kBcThreads) {
