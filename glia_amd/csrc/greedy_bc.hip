@@ -35,7 +35,10 @@
 
 namespace glia {
 
-constexpr int kBcThreads = 1024;
+#ifndef GLIA_BC_THREADS
+#define GLIA_BC_THREADS 512
+#endif
+constexpr int kBcThreads = GLIA_BC_THREADS;   // 512: 256 VGPRs per thread (1024 spilled into scratch, measured 8% slower); >= 512 needed: the feature blocks of a 96-record chunk take 8 waves
 constexpr int kChunk = 96;              // new edges scored per round (their feature vectors live in LDS)
 
 // statistics of one image channel (a distinct volume + histogram among the feature lists); channel 0 = boundary
@@ -498,7 +501,10 @@ __device__ void bc_helper_loop(const BcState& st, BcShared& s) {
   }
 }
 
-__global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(BcState st) {
+// The state comes through a pointer: device functions take it by reference, and a by-value kernel argument whose address
+// escapes is copied to private memory -- every st.pq.lv[l] / st.ch[c] then became a scratch load in front of the real one.
+__global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __restrict__ stp) {
+  const BcState& st = *stp;
   __shared__ BcShared s;
   if (blockIdx.x != 0) { bc_helper_loop(st, s); return; }
   const int tid = threadIdx.x;
@@ -1131,9 +1137,13 @@ int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& cl
     return GLIA_HMT_OK;
   }
   st.max_iters = 1ull << 14;
+  BcState* d_st = nullptr;
+  if ((rc = buf.get(&d_st, 1, false, stream))) return rc;
   while (true) {
     GLIA_HIP_TRY(hipMemsetAsync(st.hctl, 0, 4 * sizeof(uint32_t), stream));
-    hipLaunchKernelGGL(greedy_bc_kernel, dim3(1 + st.n_helpers), dim3(kBcThreads), 0, stream, st);
+    GLIA_HIP_TRY(hipMemcpyAsync(d_st, &st, sizeof(BcState), hipMemcpyHostToDevice, stream));
+    GLIA_HIP_TRY(hipStreamSynchronize(stream));       // st lives on this stack: the copy must have read it before it changes
+    hipLaunchKernelGGL(greedy_bc_kernel, dim3(1 + st.n_helpers), dim3(kBcThreads), 0, stream, (const BcState*)d_st);
     GLIA_HIP_TRY(hipGetLastError());
     GLIA_HIP_TRY(hipMemcpyAsync(ctrl, st.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, stream));
     GLIA_HIP_TRY(hipStreamSynchronize(stream));
