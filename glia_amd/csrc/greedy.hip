@@ -192,19 +192,24 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
           }
           if (!ok) { s.reject = 1; pq.leaf_seq[e] = 0; pq_leaf_removed(pq, s.pq, e); }
         }
-        s.len0 = st.adj_len[s.r0]; s.len1 = st.adj_len[s.r1];
-        s.off0 = st.adj_off[s.r0]; s.off1 = st.adj_off[s.r1];
-        unsigned long long tot = (unsigned long long)s.len0 + s.len1;
+        // one round trip for everything the two regions contribute (loads first: they would queue behind the stores)
+        const uint32_t len0 = st.adj_len[s.r0], len1 = st.adj_len[s.r1], off0 = st.adj_off[s.r0], off1 = st.adj_off[s.r1];
+        const unsigned long long z0 = st.rsz[s.r0], z1 = st.rsz[s.r1];
+        const double w0 = st.rsum[s.r0], w1 = st.rsum[s.r1];
+        const unsigned long long b0 = MEDIAN ? st.rbv[s.r0] : 0ull, b1 = MEDIAN ? st.rbv[s.r1] : 0ull;
+        const int en = MEDIAN ? st.e_n[e] : 0;
+        s.len0 = len0; s.len1 = len1; s.off0 = off0; s.off1 = off1;
+        unsigned long long tot = (unsigned long long)len0 + len1;
         if (s.reject) {}      // nothing is contracted: no capacity needed
         else if (ne + tot > st.Ecap) s.stop = ST_NEED_EDGES;
         else if (pool_used + tot > st.pool_cap) s.stop = ST_NEED_POOL;
-        else if (MEDIAN && vals_used + st.rbv[s.r0] + st.rbv[s.r1] > st.vals_cap) s.stop = ST_NEED_VALUES;
+        else if (MEDIAN && vals_used + b0 + b1 > st.vals_cap) s.stop = ST_NEED_VALUES;
         else {
-          if (MEDIAN) st.rbv[st.R0 + (uint32_t)k] = st.rbv[s.r0] + st.rbv[s.r1] - 2ull * (unsigned long long)st.e_n[e];
+          if (MEDIAN) st.rbv[st.R0 + (uint32_t)k] = b0 + b1 - 2ull * (unsigned long long)en;
           st.order[3 * k + 0] = s.r0; st.order[3 * k + 1] = s.r1; st.order[3 * k + 2] = st.R0 + (uint32_t)k;
           st.sal_out[k] = root.sal;
-          st.rsz[st.R0 + (uint32_t)k] = st.rsz[s.r0] + st.rsz[s.r1];       // TRegionMap::merge (updateRegion)
-          st.rsum[st.R0 + (uint32_t)k] = st.rsum[s.r0] + st.rsum[s.r1];
+          st.rsz[st.R0 + (uint32_t)k] = z0 + z1;       // TRegionMap::merge (updateRegion)
+          st.rsum[st.R0 + (uint32_t)k] = w0 + w1;
         }
       }
     }
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
     PH(0);
     if (s.stop != ST_RUN) { status = s.stop; break; }
     if (s.reject) { pq_propagate<kGreedyThreads>(pq, s.pq, tid); continue; }
-    const uint32_t r0 = s.r0, r1 = s.r1, e = s.e, len0 = s.len0, len1 = s.len1, off0 = s.off0, off1 = s.off1;
+    const uint32_t r0 = s.r0, e = s.e, len0 = s.len0, len1 = s.len1, off0 = s.off0, off1 = s.off1;
     const uint32_t r2 = st.R0 + (uint32_t)k;
     const uint32_t total = len0 + len1;
     const uint32_t r2off = (uint32_t)pool_used;
@@ -270,30 +275,39 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
         }
         const uint32_t idx = atomicAdd(&s.newcount, 1u);
         const uint32_t newE = (uint32_t)ne + idx;
-        const uint32_t old = (e0s != kNone) ? e0s : e1s;
-        const uint32_t posRs = (st.e_u[old] == rs) ? st.e_posu[old] : st.e_posv[old];
+        // Everything this record reads, requested up front and UNCONDITIONALLY (a missing side re-reads the other side's
+        // slot): a load inside a branch gets its own basic block and its own s_waitcnt, i.e. its own memory round trip,
+        // and a wave's loads queue behind its own earlier stores (vmcnt is in order).
+        const bool h0 = e0s != kNone, h1 = e1s != kNone;
+        const uint32_t a0 = h0 ? e0s : e1s, a1 = h1 ? e1s : e0s;
+        const uint32_t u0 = st.e_u[a0], pu0 = st.e_posu[a0], pv0 = st.e_posv[a0];
+        const uint32_t u1 = st.e_u[a1], pu1 = st.e_posu[a1], pv1 = st.e_posv[a1];
         const uint32_t offRs = st.adj_off[rs];
-        // everything this record will read, requested before its first store: a wave's loads queue behind its own
-        // earlier stores (vmcnt is in order), so a load issued after the stores below costs a second round trip
-        const unsigned long long seq0 = e0s != kNone ? pq.leaf_seq[e0s] : 0ull, seq1 = e1s != kNone ? pq.leaf_seq[e1s] : 0ull;
-        const uint32_t top0 = e0s != kNone ? pq.lv[0].arg[e0s / kFan] : kNone, top1 = e1s != kNone ? pq.lv[0].arg[e1s / kFan] : kNone;
-        const uint32_t pos1 = (e0s != kNone && e1s != kNone) ? ((st.e_u[e1s] == rs) ? st.e_posu[e1s] : st.e_posv[e1s]) : kNone;
+        const unsigned long long q0 = pq.leaf_seq[a0], q1 = pq.leaf_seq[a1];
+        const uint32_t t0 = pq.lv[0].arg[a0 / kFan], t1 = pq.lv[0].arg[a1 / kFan];
+        const int n0 = st.e_n[a0], n1 = st.e_n[a1];
+        const double m0 = st.e_mean[a0], m1 = st.e_mean[a1];
+        const unsigned long long eoff = MEDIAN ? st.e_off[a0] : 0ull;
+        const uint32_t posRs = (u0 == rs) ? pu0 : pv0;
+        const unsigned long long seq0 = h0 ? q0 : 0ull, seq1 = h1 ? q1 : 0ull;
+        const uint32_t top0 = h0 ? t0 : kNone, top1 = h1 ? t1 : kNone;
+        const uint32_t pos1 = (h0 && h1) ? ((u1 == rs) ? pu1 : pv1) : kNone;
         double first = 0.0;
         int second = 0;
         if (!MEDIAN) {
           // util/struct_merge.hxx:62-76
-          if (e0s != kNone) { const int n0 = st.e_n[e0s]; first += st.e_mean[e0s] * n0; second += n0; }
-          if (e1s != kNone) { const int n1 = st.e_n[e1s]; first += st.e_mean[e1s] * n1; second += n1; }
+          if (h0) { first += m0 * n0; second += n0; }
+          if (h1) { first += m1 * n1; second += n1; }
           first = sdivide(first, (double)second, 0.0);
           if (first == -1.0) bad = true;               // DUMMY -> "invalid boundary saliency" (:78-79)
         } else {
           // util/struct_merge.hxx:118-127: the value lists are spliced; one list alone is moved (its run is reused)
-          if (e0s != kNone) second += st.e_n[e0s];
-          if (e1s != kNone) second += st.e_n[e1s];
-          if (e0s != kNone && e1s != kNone) {
+          if (h0) second += n0;
+          if (h1) second += n1;
+          if (h0 && h1) {
             const uint32_t j = atomicAdd(&jobs.n, 1u);
             jobs.newE[j] = newE; jobs.e0[j] = e0s; jobs.e1[j] = e1s;
-          } else { first = st.e_mean[old]; st.e_off[newE] = st.e_off[old]; }
+          } else { first = m0; st.e_off[newE] = eoff; }
         }
         // rs held two entries (to r0 and to r1): one is reused for the new edge, the other becomes a tombstone
         if (pos1 != kNone) st.pool[offRs + pos1] = make_uint2(kNone, 0u);

@@ -93,21 +93,35 @@ struct PqTree {
 __device__ __forceinline__ bool pq_recompute_node(const PqTree& t, int l, uint32_t j, int lane, bool force = false) {
   Key k;
   k.sal = -__builtin_inf(); k.seq = 0; k.arg = 0;
-  // every lane takes kLaneChildren children, all loads in flight together (one round trip)
+  // every lane takes kLaneChildren children.  The loads are unconditional (index clamped, validity applied afterwards):
+  // a load inside `if (ci < size)` gets its own basic block and its own s_waitcnt -- the "one round trip" became one per
+  // child (measured: 4.6 k cycles per node instead of ~1.5 k).
   Key kk[kLaneChildren];
+  if (l == 0) {
+    unsigned long long q[kLaneChildren];
+    double v[kLaneChildren];
 #pragma unroll
-  for (int c = 0; c < kLaneChildren; ++c) {
-    const uint32_t ci = j * kFan + c * 64 + lane;
-    kk[c].sal = -__builtin_inf(); kk[c].seq = 0; kk[c].arg = 0;
-    if (l == 0) {
-      if (ci < t.nleaves) {
-        const unsigned long long q = t.leaf_seq[ci];
-        const double v = t.leaf_sal[ci];
-        kk[c].seq = q; kk[c].sal = q ? v : -__builtin_inf(); kk[c].arg = ci;
-      }
-    } else {
-      const PqLevel& cl = t.lv[l - 1];
-      if (ci < cl.size) { kk[c].sal = cl.sal[ci]; kk[c].seq = cl.seq[ci]; kk[c].arg = cl.arg[ci]; }
+    for (int c = 0; c < kLaneChildren; ++c) {
+      const uint32_t ci = j * kFan + c * 64 + lane, cj = ci < t.nleaves ? ci : t.nleaves - 1u;
+      q[c] = t.leaf_seq[cj]; v[c] = t.leaf_sal[cj];
+    }
+#pragma unroll
+    for (int c = 0; c < kLaneChildren; ++c) {
+      const uint32_t ci = j * kFan + c * 64 + lane;
+      const bool ok = ci < t.nleaves && q[c] != 0;
+      kk[c].seq = ok ? q[c] : 0ull; kk[c].sal = ok ? v[c] : -__builtin_inf(); kk[c].arg = ci < t.nleaves ? ci : 0u;
+    }
+  } else {
+    const PqLevel& cl = t.lv[l - 1];
+#pragma unroll
+    for (int c = 0; c < kLaneChildren; ++c) {
+      const uint32_t ci = j * kFan + c * 64 + lane, cj = ci < cl.size ? ci : cl.size - 1u;
+      kk[c].sal = cl.sal[cj]; kk[c].seq = cl.seq[cj]; kk[c].arg = cl.arg[cj];
+    }
+#pragma unroll
+    for (int c = 0; c < kLaneChildren; ++c) {
+      const uint32_t ci = j * kFan + c * 64 + lane;
+      if (ci >= cl.size) { kk[c].sal = -__builtin_inf(); kk[c].seq = 0; kk[c].arg = 0; }
     }
   }
 #pragma unroll
@@ -179,13 +193,16 @@ __device__ __forceinline__ void pq_top(const PqTree& t, PqWork& w, int tid) {
   for (uint32_t base = 0; base < cl.size; base += THREADS * kBatch) {
     Key kk[kBatch];
 #pragma unroll
-    for (int c = 0; c < kBatch; ++c) {
-      const uint32_t ci = base + c * THREADS + tid;
-      kk[c].sal = -__builtin_inf(); kk[c].seq = 0; kk[c].arg = 0;
-      if (ci < cl.size) { kk[c].sal = cl.sal[ci]; kk[c].seq = cl.seq[ci]; kk[c].arg = cl.arg[ci]; }
+    for (int c = 0; c < kBatch; ++c) {       // unconditional loads, see pq_recompute_node
+      const uint32_t ci = base + c * THREADS + tid, cj = ci < cl.size ? ci : cl.size - 1u;
+      kk[c].sal = cl.sal[cj]; kk[c].seq = cl.seq[cj]; kk[c].arg = cl.arg[cj];
     }
 #pragma unroll
-    for (int c = 0; c < kBatch; ++c) if (better(kk[c], k)) k = kk[c];
+    for (int c = 0; c < kBatch; ++c) {
+      const uint32_t ci = base + c * THREADS + tid;
+      if (ci >= cl.size) { kk[c].sal = -__builtin_inf(); kk[c].seq = 0; kk[c].arg = 0; }
+      if (better(kk[c], k)) k = kk[c];
+    }
   }
 #ifdef GLIA_HMT_PROFILE
   if (k.arg == 0xFFFFFFF0u) w.ovf = 1;      // keep the loads before the timestamp
