@@ -606,20 +606,30 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
 
     PH(0);
     // ---- the merged region (TRegionMap::merge, type/region_map.hxx:113-118) ----
-    if (tid == 0) {
-      for (int c = 0; c < K; ++c) {
-        const BcChan& ch = st.ch[c];
+    // one (channel, statistics set) pair per wave 1.. lane: each is two loads and a store, all in flight together
+    if (tid >= 64 && tid < 64 + 3 * K) {
+      const int c = (tid - 64) / 3, kind = (tid - 64) % 3;
+      const BcChan& ch = st.ch[c];
+      if (kind == 0) {
         PStats p = ch.pts[r0];
-        pstats_add(p, ch.pts[r1]);
+        const PStats q = ch.pts[r1];
+        pstats_add(p, q);
         ch.pts[r2] = p;
+      } else if (kind == 1) {
         EStats bn = ch.Bn[r0];
-        estats_add(bn, ch.Bn[r1]);
+        const EStats q = ch.Bn[r1];
+        estats_add(bn, q);
         ch.Bn[r2] = bn;
+      } else {
         EStats bt = ch.Bt[r0];
-        estats_add(bt, ch.Bt[r1]);
-        if (e != kNone) estats_sub_additive(bt, ch.e_A[e]);
+        const EStats q = ch.Bt[r1];
+        const EStats a = ch.e_A[e != kNone ? e : 0u];
+        estats_add(bt, q);
+        if (e != kNone) estats_sub_additive(bt, a);
         ch.Bt[r2] = bt;
       }
+    }
+    if (tid == 0) {
       st.parent[r0] = r2; st.parent[r1] = r2; st.parent[r2] = r2;
       if (e != kNone) { st.e_alive[e] = 0; if (!forced) { st.pq.leaf_seq[e] = 0; pq_leaf_removed(st.pq, s.pq, e); } }
     }
@@ -627,9 +637,10 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
     for (uint32_t i = tid; i < total; i += kBcThreads) {
       const bool side1 = i >= len0;
       const uint32_t eid = st.pool[side1 ? off1 + (i - len0) : off0 + i];
-      if (eid == e || !st.e_alive[eid]) continue;
-      const uint32_t r = side1 ? r1 : r0;
+      const uint8_t alive = st.e_alive[eid];           // unconditional loads: one round trip (see greedy_common.hpp)
       const uint32_t u = st.e_u[eid], v = st.e_v[eid];
+      if (eid == e || !alive) continue;
+      const uint32_t r = side1 ? r1 : r0;
       const uint32_t rs = (u == r) ? v : u;
       (side1 ? st.mark1 : st.mark0)[rs] = eid + 1u;
     }
@@ -637,51 +648,61 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
 
     PH(1);
     // ---- phase B: one new record (rs, r2) per distinct neighbour ----
+    // Loads are grouped into four unconditional round trips (pool entry; the record; the neighbour's marks; everything
+    // about the record and its partner): a load behind a branch costs a round trip of its own.
     for (uint32_t i = tid; i < total; i += kBcThreads) {
       const bool side1 = i >= len0;
       const uint32_t eid = st.pool[side1 ? off1 + (i - len0) : off0 + i];
       if (eid == e) continue;
-      const uint32_t u = st.e_u[eid], v = st.e_v[eid];
+      const uint32_t u = st.e_u[eid], v = st.e_v[eid], pu = st.e_posu[eid], pv = st.e_posv[eid];
       const uint32_t r = side1 ? r1 : r0;
       if (u != r && v != r) continue;
       const uint32_t rs = (u == r) ? v : u;
-      uint32_t e0s, e1s;
+      const uint32_t mk0 = st.mark0[rs], mk1 = st.mark1[rs], offRs = st.adj_off[rs];
+      // the record itself is the first (and maybe only) parent of the new record; a common neighbour is handled from
+      // the r0 side, where the r1-side record is the second parent
+      uint32_t partner = kNone;
       if (!side1) {
-        if (st.mark0[rs] != eid + 1u) continue;
-        e0s = eid;
-        const uint32_t m = st.mark1[rs];
-        e1s = m ? m - 1u : kNone;
+        if (mk0 != eid + 1u) continue;
+        if (mk1) partner = mk1 - 1u;
       } else {
-        if (st.mark1[rs] != eid + 1u) continue;
-        if (st.mark0[rs] != 0u) continue;
-        e0s = kNone; e1s = eid;
+        if (mk1 != eid + 1u) continue;
+        if (mk0 != 0u) continue;
       }
+      const bool both = partner != kNone;
+      const uint32_t a1 = both ? partner : eid;
       const uint32_t idx = atomicAdd(&s.newcount, 1u);
       const uint32_t newE = (uint32_t)ne + idx;
-      const uint32_t old = (e0s != kNone) ? e0s : e1s;
-      const uint32_t posRs = (st.e_u[old] == rs) ? st.e_posu[old] : st.e_posv[old];
-      const uint32_t offRs = st.adj_off[rs];
+      const uint32_t posRs = (u == rs) ? pu : pv;
+      const uint32_t u1 = st.e_u[a1], pu1 = st.e_posu[a1], pv1 = st.e_posv[a1];
+      const uint32_t fh1 = st.e_fhead[eid], ft1 = st.e_ftail[eid], fh2 = st.e_fhead[a1], ft2 = st.e_ftail[a1];
+      const uint8_t tb1 = st.e_table[eid], tb2 = st.e_table[a1];
+      const uint32_t top1 = st.pq.lv[0].arg[eid / kFan], top2 = st.pq.lv[0].arg[a1 / kFan];
       // rs held two entries when it touched both r0 and r1: the new record reuses one, the other one is dead from now on
-      const uint32_t posDead = (e0s != kNone && e1s != kNone) ? ((st.e_u[e1s] == rs) ? st.e_posu[e1s] : st.e_posv[e1s]) : kNone;
+      const uint32_t posDead = both ? ((u1 == rs) ? pu1 : pv1) : kNone;
       // image statistics of the new record, channel by channel
       for (int c = 0; c < K; ++c) {
         const BcChan& ch = st.ch[c];
+        const EStats A1 = ch.e_A[eid], N1 = ch.e_NA[eid];
+        const float4 d1 = *reinterpret_cast<const float4*>(&ch.e_dir[(size_t)eid * 4]);
+        const float4 d2 = *reinterpret_cast<const float4*>(&ch.e_dir[(size_t)a1 * 4]);
         EStats A, NA;
         estats_clear(A); estats_clear(NA);
+        estats_add(A, A1); estats_add(NA, N1);
+        if (both) { estats_add(A, ch.e_A[partner]); estats_add(NA, ch.e_NA[partner]); }
         float d[4] = {__builtin_inff(), -__builtin_inff(), __builtin_inff(), -__builtin_inff()};   // rs->r2, r2->rs
-        for (int side = 0; side < 2; ++side) {
-          const uint32_t o = side ? e1s : e0s;
-          if (o == kNone) continue;
-          estats_add(A, ch.e_A[o]);
-          estats_add(NA, ch.e_NA[o]);
-          const float* od = &ch.e_dir[(size_t)o * 4];
-          const bool rsIsU = st.e_u[o] == rs;          // od[0..1] = u->v
-          d[0] = fminf(d[0], od[rsIsU ? 0 : 2]); d[1] = fmaxf(d[1], od[rsIsU ? 1 : 3]);
-          d[2] = fminf(d[2], od[rsIsU ? 2 : 0]); d[3] = fmaxf(d[3], od[rsIsU ? 3 : 1]);
+        {
+          const bool rsIsU = u == rs;                   // d1.x, d1.y = u->v
+          d[0] = fminf(d[0], rsIsU ? d1.x : d1.z); d[1] = fmaxf(d[1], rsIsU ? d1.y : d1.w);
+          d[2] = fminf(d[2], rsIsU ? d1.z : d1.x); d[3] = fmaxf(d[3], rsIsU ? d1.w : d1.y);
+        }
+        if (both) {
+          const bool rsIsU = u1 == rs;
+          d[0] = fminf(d[0], rsIsU ? d2.x : d2.z); d[1] = fmaxf(d[1], rsIsU ? d2.y : d2.w);
+          d[2] = fminf(d[2], rsIsU ? d2.z : d2.x); d[3] = fmaxf(d[3], rsIsU ? d2.w : d2.y);
         }
         ch.e_A[newE] = A; ch.e_NA[newE] = NA;
-        float* nd = &ch.e_dir[(size_t)newE * 4];
-        nd[0] = d[0]; nd[1] = d[1]; nd[2] = d[2]; nd[3] = d[3];
+        *reinterpret_cast<float4*>(&ch.e_dir[(size_t)newE * 4]) = make_float4(d[0], d[1], d[2], d[3]);
         ch.pool_dir[offRs + posRs] = make_float2(d[0], d[1]);
         ch.pool_dir[r2off + idx] = make_float2(d[2], d[3]);
         if (posDead != kNone) ch.pool_dir[offRs + posDead] = make_float2(__builtin_inff(), -__builtin_inff());
@@ -689,30 +710,31 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
         atomicMin(&s.best_mn[c], ((unsigned long long)float_ord(d[2]) << 32) | newE);
         atomicMax(&s.best_mx[c], ((unsigned long long)float_ord(d[3]) << 32) | newE);
       }
+      // the fragile-entry chains of the parents, concatenated in (r0 side, r1 side) order
       uint32_t fh = kNone, ft = kNone;
-      bool t0 = false, t1 = false;
-      for (int side = 0; side < 2; ++side) {
-        const uint32_t o = side ? e1s : e0s;
-        if (o == kNone) continue;
-        const uint32_t oh = st.e_fhead[o];
-        if (oh != kNone) {
-          if (fh == kNone) { fh = oh; ft = st.e_ftail[o]; }
-          else { st.le_next[ft] = oh; ft = st.e_ftail[o]; }
-        }
-        if (st.e_table[o]) { if (side) t1 = true; else t0 = true; }
-        st.e_alive[o] = 0;
-        if (st.e_table[o] && !forced) { st.pq.leaf_seq[o] = 0; pq_leaf_removed(st.pq, s.pq, o); }
+      if (fh1 != kNone) { fh = fh1; ft = ft1; }
+      if (both && fh2 != kNone) {
+        if (fh == kNone) { fh = fh2; ft = ft2; }
+        else { st.le_next[ft] = fh2; ft = ft2; }
       }
-      st.e_u[newE] = rs; st.e_v[newE] = r2; st.e_posu[newE] = posRs; st.e_posv[newE] = idx;
+      // the record is the r1-side parent exactly when it was found from r1
+      const bool t0 = !side1 && tb1, t1 = side1 ? (tb1 != 0) : (both && tb2);
+      st.e_alive[eid] = 0;
+      if (tb1 && !forced) { st.pq.leaf_seq[eid] = 0; if (top1 == eid) pq_touch(st.pq, s.pq, 0, 0, eid); }
+      if (both) {
+        st.e_alive[partner] = 0;
+        if (tb2 && !forced) { st.pq.leaf_seq[partner] = 0; if (top2 == partner) pq_touch(st.pq, s.pq, 0, 0, partner); }
+      }
+      st.e_u[newE] = rs; st.e_v[newE] = r2; st.e_posu[newE] = posRs;
       st.e_alive[newE] = 1; st.e_table[newE] = (t0 || t1) ? 1 : 0; st.e_orient[newE] = 1;
       st.e_fhead[newE] = fh; st.e_ftail[newE] = ft;
-      // queue position (only meaningful for table edges): reference visit order, see greedy.hip
+      // queue position (only meaningful for table edges): reference visit order, see greedy.hip; the category rides in
+      // posv's upper bits until the record has been scored
       const uint32_t cat = rs < r0 ? 0u : (t0 ? 1u : 2u);
       st.pq.leaf_seq[newE] = 0;
       st.pq.leaf_sal[newE] = -__builtin_inf();
       st.pool[offRs + posRs] = newE;
       st.pool[r2off + idx] = newE;
-      // stash the category in posv's upper bits? no: recompute it when scoring -- keep it in model[] later
       st.e_posv[newE] = idx | (cat << 30);
     }
     __syncthreads();
