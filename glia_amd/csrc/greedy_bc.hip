@@ -783,23 +783,38 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
           float mn[kMaxChannels], mx[kMaxChannels];
 #pragma unroll
           for (int c = 0; c < kMaxChannels; ++c) { mn[c] = __builtin_inff(); mx[c] = -__builtin_inff(); }
-          if (st.e_table[rec]) {
+          {
+            // unconditional, batched loads (a load behind a branch is a round trip of its own): the record's fields,
+            // then rs's list header and set extremes, then the list four entries per lane at a time.  A clamped index
+            // re-reads the last entry (harmless for min / max), the record's own slot is masked out.
+            const bool on = st.e_table[rec] != 0;
             const uint32_t rs = st.e_u[rec];
-            const uint32_t off = st.adj_off[rs], len = st.adj_len[rs];
             const uint32_t own = st.e_posu[rec];             // the record's own slot in rs's list (e_u = rs)
-            for (uint32_t i = l16; i < len; i += 16) {
-              if (i == own) continue;
+            const uint32_t off = st.adj_off[rs], len = on ? st.adj_len[rs] : 0u;
+            float bmn[kMaxChannels], bmx[kMaxChannels];
+#pragma unroll
+            for (int c = 0; c < kMaxChannels; ++c) if (c < K) { bmn[c] = st.ch[c].Bn[rs].mn; bmx[c] = st.ch[c].Bn[rs].mx; }
+            for (uint32_t i0 = 0; i0 < len; i0 += 64) {
 #pragma unroll
               for (int c = 0; c < kMaxChannels; ++c) {
                 if (c < K) {
-                  const float2 d = st.ch[c].pool_dir[off + i];     // dead entries hold (+inf, -inf)
-                  mn[c] = fminf(mn[c], d.x); mx[c] = fmaxf(mx[c], d.y);
+                  float2 d[4];
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) {
+                    const uint32_t i = i0 + q * 16 + l16;
+                    d[q] = st.ch[c].pool_dir[off + (i < len ? i : len - 1u)];     // dead entries hold (+inf, -inf)
+                  }
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) {
+                    const uint32_t i = i0 + q * 16 + l16;
+                    if (i < len && i != own) { mn[c] = fminf(mn[c], d[q].x); mx[c] = fmaxf(mx[c], d[q].y); }
+                  }
                 }
               }
             }
-            if (l16 == 0) {
+            if (on && l16 == 0) {
 #pragma unroll
-              for (int c = 0; c < kMaxChannels; ++c) if (c < K) { mn[c] = fminf(mn[c], st.ch[c].Bn[rs].mn); mx[c] = fmaxf(mx[c], st.ch[c].Bn[rs].mx); }
+              for (int c = 0; c < kMaxChannels; ++c) if (c < K) { mn[c] = fminf(mn[c], bmn[c]); mx[c] = fmaxf(mx[c], bmx[c]); }
             }
           }
 #pragma unroll
@@ -820,7 +835,17 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
       for (uint32_t w = tid; w < cn * (uint32_t)K; w += kBcThreads) {
         const uint32_t j = w / (uint32_t)K; const int c = (int)(w % (uint32_t)K);
         const uint32_t rec = (uint32_t)ne + c0 + j;
-        if (st.e_table[rec]) shared_boundary(st, c, rec, L.shs[j * K + c]);
+        // shared_boundary() with its loads hoisted in front of the branch (one round trip instead of three)
+        const BcChan& ch = st.ch[c];
+        const uint8_t on = st.e_table[rec];
+        EStats sh = ch.e_A[rec];
+        const EStats na = ch.e_NA[rec];
+        uint32_t f = st.e_fhead[rec];
+        if (on) {
+          estats_add(sh, na);
+          for (; f != kNone; f = st.le_next[f]) if (leaf_alive(st, st.le_dst[f])) estats_add(sh, ch.le_stats[f]);
+          L.shs[j * K + c] = sh;
+        }
       }
       __syncthreads();
       PH(9);
@@ -834,10 +859,18 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
           const bool on = st.e_table[rec] != 0;              // uniform over the 16 lanes
           const uint32_t rs = st.e_u[rec];
           double* fx = L.fx + (size_t)j * L.npre;
-          // lane 0 adds the 16 lanes' terms in bin order
+          // The bins' terms are added in bin order, as the reference does: a 16-step chain over DPP row_shr:1 (lane l
+          // ends with t_0 .. t_l; lane 0's predecessor reads +0.0, the reference's start value), the lane of the last
+          // bin holds the sum.  (Sixteen broadcasts through ds_bpermute per sum were the longest stretch of the pass.)
           auto bin_sum = [&](double t, int bins, bool negate) -> double {
             double acc = 0.0;
-            for (int b = 0; b < bins; ++b) { const double v = __shfl(t, b, 16); acc = negate ? acc - v : acc + v; }
+            for (int b = 0; b < bins; ++b) {
+              const unsigned long long ab = (unsigned long long)__double_as_longlong(acc);
+              const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)ab, 0x111, 0xf, 0xf, true);
+              const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(ab >> 32), 0x111, 0xf, 0xf, true);
+              const double prev = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+              acc = negate ? prev - t : prev + t;
+            }
             return acc;
           };
           for (int kind = 0; kind < 2; ++kind) {
@@ -846,33 +879,33 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
               const int cc = kind ? cf.lc[i] : cf.rc[i];
               const int bins = cf.cbins[cc];
               double t0 = 0.0, t1 = 0.0, t2 = 0.0, tl = 0.0, tx = 0.0;
+              const PStats* P0 = &st.ch[cc].pts[rs]; const PStats* P1 = &st.ch[cc].pts[r2];
+              const uint32_t h0 = P0->hist[l16], h1 = P1->hist[l16], pn0 = P0->n, pn1 = P1->n;     // unconditional loads
               if (on && (int)l16 < bins) {
-                const PStats* P0 = &st.ch[cc].pts[rs]; const PStats* P1 = &st.ch[cc].pts[r2];
-                const uint32_t h0 = P0->hist[l16], h1 = P1->hist[l16];
-                t0 = feat::entropy_term(h0, P0->n); t1 = feat::entropy_term(h1, P1->n);
-                t2 = feat::entropy_term(h0 + h1, P0->n + P1->n);
-                feat::dist_terms(h0, P0->n, h1, P1->n, tl, tx);
+                t0 = feat::entropy_term(h0, pn0); t1 = feat::entropy_term(h1, pn1);
+                t2 = feat::entropy_term(h0 + h1, pn0 + pn1);
+                feat::dist_terms(h0, pn0, h1, pn1, tl, tx);
               }
               const double e0 = bin_sum(t0, bins, true), e1 = bin_sum(t1, bins, true), e2 = bin_sum(t2, bins, true);
               const double dl = bin_sum(tl, bins, false), dx = bin_sum(tx, bins, false);
-              if (l16 == 0) { double* q = fx + feat::pre_region(cf, kind, i); q[0] = e0; q[1] = e1; q[2] = e2; q[3] = dl; q[4] = dx; }
+              if ((int)l16 == bins - 1) { double* q = fx + feat::pre_region(cf, kind, i); q[0] = e0; q[1] = e1; q[2] = e2; q[3] = dl; q[4] = dx; }
             }
           }
           for (int i = 0; i < cf.n_boundary; ++i) {
             const int cc = cf.bc[i];
             const int bins = cf.cbins[cc];
             double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+            const EStats* B0 = &st.ch[cc].Bt[rs]; const EStats* B1 = &st.ch[cc].Bt[r2];
+            const EStats* A = &st.ch[cc].e_A[rec];
+            const EStats* sh = &L.shs[j * K + cc];
+            const uint32_t g0 = B0->hist[l16], g1 = B1->hist[l16], ga = A->hist[l16], bn0 = B0->n, bn1 = B1->n, an = A->n;
             if (on && (int)l16 < bins) {
-              const EStats* B0 = &st.ch[cc].Bt[rs]; const EStats* B1 = &st.ch[cc].Bt[r2];
-              const EStats* A = &st.ch[cc].e_A[rec];
-              const EStats* sh = &L.shs[j * K + cc];
-              const uint32_t g0 = B0->hist[l16], g1 = B1->hist[l16];
-              t0 = feat::entropy_term(g0, B0->n); t1 = feat::entropy_term(g1, B1->n);
-              t2 = feat::entropy_term(g0 + g1 - A->hist[l16], B0->n + B1->n - A->n);
+              t0 = feat::entropy_term(g0, bn0); t1 = feat::entropy_term(g1, bn1);
+              t2 = feat::entropy_term(g0 + g1 - ga, bn0 + bn1 - an);
               t3 = feat::entropy_term(sh->hist[l16], sh->n);
             }
             const double e0 = bin_sum(t0, bins, true), e1 = bin_sum(t1, bins, true), e2 = bin_sum(t2, bins, true), e3 = bin_sum(t3, bins, true);
-            if (l16 == 0) { double* q = fx + feat::pre_boundary(cf, i); q[0] = e0; q[1] = e1; q[2] = e2; q[3] = e3; }
+            if ((int)l16 == bins - 1) { double* q = fx + feat::pre_boundary(cf, i); q[0] = e0; q[1] = e1; q[2] = e2; q[3] = e3; }
           }
         }
       }
