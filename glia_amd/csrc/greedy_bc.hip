@@ -80,8 +80,9 @@ struct BcState {
   uint32_t *mark0, *mark1;       // [2*R0]
   uint32_t* order; double* sal_out; double* feats_out;
   double* featbuf;               // [kChunk][full feature dim]: the chunk's vectors for the helper workgroups
-  uint32_t* hctl;                // helper protocol: [0] job sequence (0xFFFFFFFF = quit), [1] helpers done, [2] records in the job
-  int* hvotes; int* hmodel;      // [kChunk]
+  uint32_t* hctl;                // helper protocol: [0] job word = sequence << 8 | records in the job (0xFFFFFFFF = quit)
+  unsigned long long* hvotes;    // [kChunk] sequence << 32 | votes: the contraction workgroup polls the slots it waits for
+  int* hmodel;                   // [kChunk]
   uint32_t n_helpers;            // workgroups 1..n_helpers evaluate the forest; 0 = the loop's own workgroup does
   uint32_t shard, n_shards;      // initial scoring: this call scores the records e with e % n_shards == shard (multi-GPU K7)
   unsigned long long* ctrl;
@@ -413,6 +414,7 @@ struct BcShared {
   int votes[kChunk];
   int model[kChunk];
   uint32_t nlog;                 // slots of the full vector that take a logarithm
+  uint32_t lost;                 // a helper did not answer in time
   uint16_t logpos[feat::kMaxLogSlots];
   PqWork pq;
   __attribute__((aligned(16))) unsigned char pool[kPoolBytes];
@@ -448,6 +450,8 @@ __device__ __forceinline__ void st_agent(double* p, double v) {
   __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double ld_agent(const double* p) {
   return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
@@ -480,24 +484,26 @@ __device__ void bc_helper_loop(const BcState& st, BcShared& s) {
     const uint32_t v = s.ex[0][0];
     if (v == last || v == 0xFFFFFFFFu) return;          // gave up waiting / the loop is over
     last = v;
-    const uint32_t cn = ld_relaxed(&st.hctl[2]);
-    if (h >= cn) continue;                              // nothing for this workgroup in the job: it does not report either
+    const uint32_t cn = v & 0xFFu, tag = v >> 8;
+    if (h >= cn) continue;                              // nothing for this workgroup in the job
     for (uint32_t j = h; j < cn; j += H) {
+      // the record's model and vector are requested together (agent-scope loads are long round trips)
       const int m = ld_agent(&st.hmodel[j]);
-      if (m < 0) continue;
       double* hfeat = reinterpret_cast<double*>(s.pool);
       for (int i = tid; i < fstride; i += kBcThreads) hfeat[i] = ld_agent(&st.featbuf[(size_t)j * fstride + i]);
       if (tid == 0) s.votes[0] = 0;
       __syncthreads();
-      const DeviceForest& f = st.clf.f[m];
-      int mine = 0;
-      for (int t = tid; t < f.ntree; t += kBcThreads) mine += forest_vote(f, t, hfeat);
-      if (mine) atomicAdd(&s.votes[0], mine);
+      if (m >= 0) {
+        const DeviceForest& f = st.clf.f[m];
+        int mine = 0;
+        for (int t = tid; t < f.ntree; t += kBcThreads) mine += forest_vote(f, t, hfeat);
+        if (mine) atomicAdd(&s.votes[0], mine);
+      }
       __syncthreads();
-      if (tid == 0) st_agent(&st.hvotes[j], s.votes[0]);
+      // the answer carries the job's sequence number: the contraction workgroup polls the slot itself, no counter
+      if (tid == 0 && m >= 0) st_agent(&st.hvotes[j], ((unsigned long long)tag << 32) | (unsigned long long)(uint32_t)s.votes[0]);
       __syncthreads();
     }
-    if (tid == 0) { stores_done(); __hip_atomic_fetch_add(&st.hctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   }
 }
 
@@ -514,7 +520,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
   const int fdim = st.cfg.fdim;
   const int K = st.cfg.K;
   const BcLayout L = bc_layout(st.cfg, s.pool);
-  if (tid == 0) { s.pq.wln[0] = s.pq.wln[1] = 0; s.pq.ovf = 0; s.pq.spill = 0; s.nlog = (uint32_t)feat::log_slots(st.cfg, s.logpos); }
+  if (tid == 0) { s.pq.wln[0] = s.pq.wln[1] = 0; s.pq.ovf = 0; s.pq.spill = 0; s.lost = 0; s.nlog = (uint32_t)feat::log_slots(st.cfg, s.logpos); }
   for (int i = tid; i < kSetSlots; i += blockDim.x) { s.pq.set[0][i] = 0; s.pq.set[1][i] = 0; }
   __syncthreads();
   pq_top<kBcThreads>(st.pq, s.pq, tid);      // the root lives in LDS: rebuilt at every launch
@@ -535,7 +541,8 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
         s.ex[c][0] = s.ex[c][2] = 0xFFFFFFFFu; s.ex[c][1] = s.ex[c][3] = 0u;
       }
       const bool forced = st.forced != nullptr;
-      if (forced ? (k >= st.forced_n) : (root.seq == 0)) s.stop = ST_DONE;
+      if (s.lost) s.stop = ST_BAD_SALIENCY;
+      else if (forced ? (k >= st.forced_n) : (root.seq == 0)) s.stop = ST_DONE;
       else {
         const uint32_t e = forced ? kNone : root.arg;
         s.e = e;
@@ -959,20 +966,19 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
         if ((uint32_t)tid < cn) st_agent(&st.hmodel[tid], s.model[tid]);
         stores_done();
         __syncthreads();
-        if (tid == 0) {
-          st_agent(&st.hctl[2], cn); st_agent(&st.hctl[1], 0u);
-          stores_done();
-          st_agent(&st.hctl[0], ++hseq);
-          unsigned long long spins = 0;
-          const uint32_t expect = cn < st.n_helpers ? cn : st.n_helpers;              // helpers h < cn report
-          while (ld_relaxed(&st.hctl[1]) < expect) {
+        hseq = hseq >= 0xFFFFFEu ? 1u : hseq + 1u;      // never 0 (the slots' initial tag), never the quit word
+        if (tid == 0) st_agent(&st.hctl[0], (hseq << 8) | cn);
+        if ((uint32_t)tid < cn && s.model[tid] >= 0) {
+          unsigned long long w = 0, spins = 0;
+          for (;;) {
+            w = ld_agent(&st.hvotes[tid]);
+            if ((uint32_t)(w >> 32) == hseq) break;
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > kHelperSpinLimit) { s.stop = ST_BAD_SALIENCY; break; }     // helpers lost: reported as a failed run
+            if (++spins > kHelperSpinLimit) { s.lost = 1u; break; }     // helpers lost: reported as a failed run at the next pop
           }
-          after_flag();
+          s.votes[tid] = (int)(uint32_t)w;
         }
         __syncthreads();
-        if ((uint32_t)tid < cn && s.model[tid] >= 0) s.votes[tid] = ld_agent(&st.hvotes[tid]);
       } else if (st.clf.kind == 0) {
         const int ntree = st.clf.f[0].ntree;    // the three ensemble members are required to have equal size
         for (uint32_t i = tid; i < cn * (uint32_t)ntree; i += kBcThreads) {
@@ -1196,6 +1202,7 @@ int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& cl
   if ((rc = buf.get(&d_st, 1, false, stream))) return rc;
   while (true) {
     GLIA_HIP_TRY(hipMemsetAsync(st.hctl, 0, 4 * sizeof(uint32_t), stream));
+    GLIA_HIP_TRY(hipMemsetAsync(st.hvotes, 0, kChunk * sizeof(unsigned long long), stream));
     GLIA_HIP_TRY(hipMemcpyAsync(d_st, &st, sizeof(BcState), hipMemcpyHostToDevice, stream));
     GLIA_HIP_TRY(hipStreamSynchronize(stream));       // st lives on this stack: the copy must have read it before it changes
     hipLaunchKernelGGL(greedy_bc_kernel, dim3(1 + st.n_helpers), dim3(kBcThreads), 0, stream, (const BcState*)d_st);
