@@ -190,7 +190,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
             if (sz0 < st.cond_t1 && sdivide(su0, (double)sz0, 0.0) > st.cond_rpb) ok = true;
             if (!ok && sz1 < st.cond_t1 && sdivide(su1, (double)sz1, 0.0) > st.cond_rpb) ok = true;
           }
-          if (!ok) { s.reject = 1; pq.leaf_seq[e] = 0; pq_leaf_removed(pq, s.pq, e); }
+          if (!ok) { s.reject = 1; pq.leaf_seq[e] = 0; pq_touch(pq, s.pq, 0, 0, e); /* e is the root, hence the maximum of its level-0 node */ }
         }
         // one round trip for everything the two regions contribute (loads first: they would queue behind the stores)
         const uint32_t len0 = st.adj_len[s.r0], len1 = st.adj_len[s.r1], off0 = st.adj_off[s.r0], off1 = st.adj_off[s.r1];
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
         }
       }
         }
-    if (tid == 0) { pq.leaf_seq[e] = 0; pq_leaf_removed(pq, s.pq, e); s.nitems = 0; }
+    if (tid == 0) { pq.leaf_seq[e] = 0; pq_touch(pq, s.pq, 0, 0, e);   /* the root is the maximum of its node: no need to look */ s.nitems = 0; }
     if (__syncthreads_or(bad ? 1 : 0)) { status = ST_BAD_SALIENCY; break; }
     PH(2);
 

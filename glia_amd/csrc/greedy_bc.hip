@@ -638,7 +638,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
     }
     if (tid == 0) {
       st.parent[r0] = r2; st.parent[r1] = r2; st.parent[r2] = r2;
-      if (e != kNone) { st.e_alive[e] = 0; if (!forced) { st.pq.leaf_seq[e] = 0; pq_leaf_removed(st.pq, s.pq, e); } }
+      if (e != kNone) { st.e_alive[e] = 0; if (!forced) { st.pq.leaf_seq[e] = 0; pq_touch(st.pq, s.pq, 0, 0, e);   /* the root is the maximum of its node */ } }
     }
     // ---- phase A: mark the neighbours of r0 / r1 with the record that reaches them ----
     for (uint32_t i = tid; i < total; i += kBcThreads) {
