@@ -111,11 +111,17 @@ struct MedianJobs {               // median linkage: the value runs to merge in 
   unsigned long long off[kGreedyThreads + 1];    // output offset of job j (elements)
   uint32_t toff[kGreedyThreads + 1];             // first tile of job j
   uint32_t tjob[kGreedyThreads], ta0[kGreedyThreads], ta1[kGreedyThreads];   // tiles of the current round
-  float buf[kGreedyThreads / 64][2 * kMergeTile];
+  // the two input runs of job j (lengths, offsets in the value pool) and its median, kept here so that neither the tile
+  // set-up nor the tiles nor the final pass go back to global memory for them
+  uint32_t na[kGreedyThreads], nb[kGreedyThreads];
+  unsigned long long oa[kGreedyThreads], ob[kGreedyThreads];
+  float med[kGreedyThreads];
+  float buf[kGreedyThreads / 64][2 * kMergeTile + 64];      // input pieces | output (padded: index + index / 16)
 };
 struct NoJobs {                   // mean linkage: never touched
-  uint32_t n, newE[1], e0[1], e1[1], toff[2], tjob[1], ta0[1], ta1[1];
-  unsigned long long off[2];
+  uint32_t n, newE[1], e0[1], e1[1], toff[2], tjob[1], ta0[1], ta1[1], na[1], nb[1];
+  unsigned long long off[2], oa[1], ob[1];
+  float med[1];
   float buf[kGreedyThreads / 64][2];
 };
 
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
         const uint32_t t0 = pq.lv[0].arg[a0 / kFan], t1 = pq.lv[0].arg[a1 / kFan];
         const int n0 = st.e_n[a0], n1 = st.e_n[a1];
         const double m0 = st.e_mean[a0], m1 = st.e_mean[a1];
-        const unsigned long long eoff = MEDIAN ? st.e_off[a0] : 0ull;
+        const unsigned long long eoff = MEDIAN ? st.e_off[a0] : 0ull, eoff1 = MEDIAN ? st.e_off[a1] : 0ull;
         const uint32_t posRs = (u0 == rs) ? pu0 : pv0;
         const unsigned long long seq0 = h0 ? q0 : 0ull, seq1 = h1 ? q1 : 0ull;
         const uint32_t top0 = h0 ? t0 : kNone, top1 = h1 ? t1 : kNone;
@@ -307,6 +313,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
           if (h0 && h1) {
             const uint32_t j = atomicAdd(&jobs.n, 1u);
             jobs.newE[j] = newE; jobs.e0[j] = e0s; jobs.e1[j] = e1s;
+            jobs.na[j] = (uint32_t)n0; jobs.nb[j] = (uint32_t)n1; jobs.oa[j] = eoff; jobs.ob[j] = eoff1;
           } else { first = m0; st.e_off[newE] = eoff; }
         }
         // rs held two entries (to r0 and to r1): one is reused for the new edge, the other becomes a tombstone
@@ -332,7 +339,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
             unsigned long long o = 0;
             uint32_t to = 0;
             for (uint32_t j = 0; j < J; ++j) {
-              const uint32_t n = (uint32_t)st.e_n[jobs.newE[j]];
+              const uint32_t n = jobs.na[j] + jobs.nb[j];
               jobs.off[j] = o; jobs.toff[j] = to;
               o += n; to += (n + kMergeTile - 1) / kMergeTile;
             }
@@ -350,10 +357,9 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
             if (q < ntiles) {
               uint32_t lo = 0, hi = J;
               while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (jobs.toff[mid] <= q) lo = mid; else hi = mid; }
-              const uint32_t ea = jobs.e0[lo], eb = jobs.e1[lo];
-              const uint32_t na = (uint32_t)st.e_n[ea], nb = (uint32_t)st.e_n[eb], n = na + nb;
-              const float* A = st.vals + st.e_off[ea];
-              const float* B = st.vals + st.e_off[eb];
+              const uint32_t na = jobs.na[lo], nb = jobs.nb[lo], n = na + nb;
+              const float* A = st.vals + jobs.oa[lo];
+              const float* B = st.vals + jobs.ob[lo];
               const uint32_t d0 = (q - jobs.toff[lo]) * kMergeTile, d1 = d0 + kMergeTile < n ? d0 + kMergeTile : n;
               jobs.tjob[tid] = lo;
               jobs.ta0[tid] = d0 == 0 ? 0u : merge_split(A, na, B, nb, d0);
@@ -365,23 +371,34 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
             float* ob = in + kMergeTile;
             for (uint32_t t = wave; t < cnt; t += kGreedyThreads / 64) {
               const uint32_t j = jobs.tjob[t], a0 = jobs.ta0[t], a1 = jobs.ta1[t];
-              const uint32_t ea = jobs.e0[j], eb = jobs.e1[j];
-              const uint32_t n = (uint32_t)st.e_n[ea] + (uint32_t)st.e_n[eb];
+              const uint32_t n = jobs.na[j] + jobs.nb[j];
               const uint32_t d0 = (round0 + t - jobs.toff[j]) * kMergeTile, d1 = d0 + kMergeTile < n ? d0 + kMergeTile : n;
-              const uint32_t b0 = d0 - a0, la = a1 - a0, lb = (d1 - a1) - b0;
-              const float* A = st.vals + st.e_off[ea] + a0;
-              const float* B = st.vals + st.e_off[eb] + b0;
+              const uint32_t b0 = d0 - a0, la = a1 - a0, lb = (d1 - a1) - b0, lt = la + lb;
+              const float* A = st.vals + jobs.oa[j] + a0;
+              const float* B = st.vals + jobs.ob[j] + b0;
               float* out = st.vals + vals_used + jobs.off[j] + d0;
               for (uint32_t i = lane; i < la; i += 64) in[i] = A[i];
               for (uint32_t i = lane; i < lb; i += 64) in[la + i] = B[i];
               wave_lds_sync();
-              for (uint32_t i = lane; i < la + lb; i += 64) {
-                const float v = in[i];
-                const uint32_t pos = i < la ? i + run_rank(in + la, lb, v, true) : (i - la) + run_rank(in, la, v, false);
-                ob[pos] = v;
+              {
+                // every lane merges 16 consecutive outputs sequentially from its merge-path split (a rank search per
+                // element cost ten dependent LDS reads each); the output index is padded against bank conflicts
+                const float* TA = in;
+                const float* TB = in + la;
+                const uint32_t o0 = (uint32_t)lane * 16u < lt ? (uint32_t)lane * 16u : lt, o1 = o0 + 16u < lt ? o0 + 16u : lt;
+                uint32_t ai = o0 == 0u ? 0u : (o0 >= lt ? la : merge_split(TA, la, TB, lb, o0));
+                uint32_t bi = o0 - ai;
+                float a = ai < la ? TA[ai] : 0.f, b = bi < lb ? TB[bi] : 0.f;
+                for (uint32_t o = o0; o < o1; ++o) {
+                  const bool ta = bi >= lb || (ai < la && a <= b);      // ties: the (r0, rs) run first
+                  ob[o + (o >> 4)] = ta ? a : b;
+                  if (ta) { ++ai; a = ai < la ? TA[ai] : 0.f; } else { ++bi; b = bi < lb ? TB[bi] : 0.f; }
+                }
               }
               wave_lds_sync();
-              for (uint32_t i = lane; i < la + lb; i += 64) out[i] = ob[i];
+              for (uint32_t i = lane; i < lt; i += 64) out[i] = ob[i + (i >> 4)];
+              const uint32_t mi = n / 2u;                               // util/stats.hxx:83-91
+              if (lane == 0 && mi >= d0 && mi < d1) jobs.med[j] = ob[(mi - d0) + ((mi - d0) >> 4)];
               wave_lds_sync();
             }
             __syncthreads();
@@ -390,7 +407,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
           if ((uint32_t)tid < J) {
             const uint32_t newE = jobs.newE[tid];
             const unsigned long long off = vals_used + jobs.off[tid];
-            const double med = (double)st.vals[off + (uint32_t)st.e_n[newE] / 2u];   // util/stats.hxx:83-91
+            const double med = (double)jobs.med[tid];
             st.e_off[newE] = off; st.e_mean[newE] = med;
             pq.leaf_sal[newE] = st.size_weight ? -med * (double)min(st.rsz[st.e_u[newE]], st.rsz[r2]) : -med;
           }
