@@ -369,16 +369,34 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
             const uint32_t cnt = ntiles - round0 < (uint32_t)kGreedyThreads ? ntiles - round0 : (uint32_t)kGreedyThreads;
             float* in = jobs.buf[wave];
             float* ob = in + kMergeTile;
+            // a tile's two input pieces travel global memory -> registers -> LDS; the registers of the NEXT tile are
+            // requested before the current one is merged, so the memory round trip overlaps the merge
+            constexpr int kPer = (int)(kMergeTile / 64);
+            float pre[kPer];
+            auto fetch = [&](uint32_t t) __attribute__((always_inline)) {
+              const uint32_t j = jobs.tjob[t], a0 = jobs.ta0[t], a1 = jobs.ta1[t];
+              const uint32_t n = jobs.na[j] + jobs.nb[j];
+              const uint32_t d0 = (round0 + t - jobs.toff[j]) * kMergeTile, d1 = d0 + kMergeTile < n ? d0 + kMergeTile : n;
+              const uint32_t b0 = d0 - a0, la = a1 - a0, lt = d1 - d0;
+              const float* A = st.vals + jobs.oa[j] + a0;
+              const float* B = st.vals + jobs.ob[j] + b0;
+#pragma unroll
+              for (int k = 0; k < kPer; ++k) {          // unconditional loads: a clamped index re-reads the last element
+                const uint32_t i = (uint32_t)lane + 64u * (uint32_t)k, ic = i < lt ? i : lt - 1u;
+                const float* src = ic < la ? A + ic : B + (ic - la);      // one load through a selected address
+                pre[k] = *src;
+              }
+            };
+            if ((uint32_t)wave < cnt) fetch((uint32_t)wave);
             for (uint32_t t = wave; t < cnt; t += kGreedyThreads / 64) {
               const uint32_t j = jobs.tjob[t], a0 = jobs.ta0[t], a1 = jobs.ta1[t];
               const uint32_t n = jobs.na[j] + jobs.nb[j];
               const uint32_t d0 = (round0 + t - jobs.toff[j]) * kMergeTile, d1 = d0 + kMergeTile < n ? d0 + kMergeTile : n;
               const uint32_t b0 = d0 - a0, la = a1 - a0, lb = (d1 - a1) - b0, lt = la + lb;
-              const float* A = st.vals + jobs.oa[j] + a0;
-              const float* B = st.vals + jobs.ob[j] + b0;
               float* out = st.vals + vals_used + jobs.off[j] + d0;
-              for (uint32_t i = lane; i < la; i += 64) in[i] = A[i];
-              for (uint32_t i = lane; i < lb; i += 64) in[la + i] = B[i];
+#pragma unroll
+              for (int k = 0; k < kPer; ++k) { const uint32_t i = (uint32_t)lane + 64u * (uint32_t)k; if (i < lt) in[i] = pre[k]; }
+              if (t + kGreedyThreads / 64 < cnt) fetch(t + kGreedyThreads / 64);
               wave_lds_sync();
               {
                 // every lane merges 16 consecutive outputs sequentially from its merge-path split (a rank search per
