@@ -464,6 +464,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
   __syncthreads();
   if (tid == 0) { st.ctrl[0] = k; st.ctrl[1] = ne; st.ctrl[2] = pool_used; st.ctrl[3] = status; st.ctrl[4] = vals_used; }
 #ifdef GLIA_HMT_PROFILE
+  if (tid == 0) printf("[greedy profile] pq propagations by dirty level-0 nodes (<=8, <=16, more): %llu %llu %llu\n", g_pqprof[28], g_pqprof[29], g_pqprof[30]);
   if (tid == 0) printf("[greedy profile] pq top: loads %llu wave_max %llu barrier %llu calls %llu\n", g_pqprof[24], g_pqprof[25], g_pqprof[26], g_pqprof[27]);
   if (tid == 0) printf("[greedy profile] pq levels (wave 0): recompute %llu %llu %llu %llu  barrier-wait %llu %llu %llu %llu  active %llu %llu %llu %llu\n", g_pqprof[0], g_pqprof[1], g_pqprof[2],
                        g_pqprof[3], g_pqprof[8], g_pqprof[9], g_pqprof[10], g_pqprof[11], g_pqprof[16], g_pqprof[17], g_pqprof[18], g_pqprof[19]);

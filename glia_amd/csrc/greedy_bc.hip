@@ -1011,6 +1011,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
   if (tid == 0 && st.n_helpers) st_release(&st.hctl[0], 0xFFFFFFFFu);
   if (tid == 0) { st.ctrl[0] = k; st.ctrl[1] = ne; st.ctrl[2] = pool_used; st.ctrl[3] = status; }
 #ifdef GLIA_HMT_PROFILE
+  if (tid == 0) printf("[bc profile] pq propagations by dirty level-0 nodes (<=8, <=16, more): %llu %llu %llu\n", g_pqprof[28], g_pqprof[29], g_pqprof[30]);
   if (tid == 0) printf("[bc profile] edge_features of thread 0: gather %llu  bc_features %llu  calls %llu (cycles)\n", g_pqprof[24], g_pqprof[25], g_pqprof[26]);
   if (tid == 0) printf("[bc profile] scoring: neighbour min/max %llu  shared sets %llu  entropies %llu  assemble %llu (cycles)\n", tph[8], tph[9], tph[10], tph[4]);
   if (tid == 0) printf("[bc profile] merges %llu: pop+feats_out %llu  region+mark %llu  build %llu  top2 %llu  features %llu  forest %llu  pq %llu  loop-top %llu (cycles)\n", k, tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], tph[6], tph[7]);

@@ -233,6 +233,9 @@ __device__ __forceinline__ void pq_propagate(const PqTree& t, PqWork& w, int tid
   constexpr int nwaves = THREADS / 64;
   static_assert(nwaves <= 16, "PqWork::fast");
   __syncthreads();
+#ifdef GLIA_HMT_PROFILE
+  if (tid == 0) { const uint32_t nd = w.wln[0]; g_pqprof[28 + (nd <= (uint32_t)nwaves ? 0 : (nd <= 2u * nwaves ? 1 : 2))] += 1; }
+#endif
   if (w.wln[0] <= (uint32_t)nwaves && !w.spill && !w.ovf) {
     // The usual case -- at most one dirty node per wave: every wave walks its node up the tree, one barrier per
     // level; waves whose node did not change, or whose parent is taken by a lower wave, drop out.
