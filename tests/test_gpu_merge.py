@@ -149,7 +149,9 @@ def test_median_reference_known_answers(ctx, N, B, dim, n, expect):
         assert sal[i] == pytest.approx(s, rel=0, abs=5e-9)
 
 
-@pytest.mark.parametrize("shape,S,G,variant", CASES + [((33, 30, 40), 5, 20, 1)])
+# the last case ends with contractions that merge several hundred thousand values: more than 512 tiles, i.e. more than
+# one round of the tile loop
+@pytest.mark.parametrize("shape,S,G,variant", CASES + [((33, 30, 40), 5, 20, 1), ((176, 176, 176), 16, 16, 0)])
 def test_median_order_matches_oracle(ctx, shape, S, G, variant):
     """Saliency = an order statistic of the f32 values: bit-identical for Q8 and for continuous pb alike."""
     from oracle import pyoracle as O
