@@ -747,6 +747,15 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
     __syncthreads();
     PH(2);
     const uint32_t newcount = s.newcount;
+    // the last thread publishes r2's list header and boundary extremes after the pass below; it requests what it needs
+    // from global memory now (Bn(r2) was written two barriers ago), not behind its own stores
+    float pre_mn[kMaxChannels], pre_mx[kMaxChannels];
+#pragma unroll
+    for (int c = 0; c < kMaxChannels; ++c) { pre_mn[c] = 0.f; pre_mx[c] = 0.f; }
+    if (tid == kBcThreads - 1) {
+#pragma unroll
+      for (int c = 0; c < kMaxChannels; ++c) if (c < K) { pre_mn[c] = st.ch[c].Bn[r2].mn; pre_mx[c] = st.ch[c].Bn[r2].mx; }
+    }
     for (uint32_t j = tid; j < newcount; j += kBcThreads) {
       const uint32_t rec = (uint32_t)ne + j;
       const uint32_t rs = st.e_u[rec];
@@ -759,8 +768,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
     }
     __syncthreads();
     // per channel: extremes of r2's boundary set with all / all but one of its new records
-    auto r2_extremes = [&](int c, uint32_t rec, float& mn, float& mx) {
-      const float bnmn = st.ch[c].Bn[r2].mn, bnmx = st.ch[c].Bn[r2].mx;
+    auto r2_extremes_of = [&](int c, uint32_t rec, float bnmn, float bnmx, float& mn, float& mx) {
       const float best_mn = newcount ? ord_float((uint32_t)(s.best_mn[c] >> 32)) : __builtin_inff();
       const float best_mx = newcount ? ord_float((uint32_t)(s.best_mx[c] >> 32)) : -__builtin_inff();
       const float second_mn = (s.second_mn[c] != ~0ull) ? ord_float((uint32_t)(s.second_mn[c] >> 32)) : __builtin_inff();
@@ -769,9 +777,14 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
       mn = fminf(bnmn, rec == arg_mn ? second_mn : best_mn);
       mx = fmaxf(bnmx, rec == arg_mx ? second_mx : best_mx);
     };
-    if (tid == 0) {
+    auto r2_extremes = [&](int c, uint32_t rec, float& mn, float& mx) {
+      r2_extremes_of(c, rec, st.ch[c].Bn[r2].mn, st.ch[c].Bn[r2].mx, mn, mx);
+    };
+    if (tid == kBcThreads - 1) {
       st.adj_off[r2] = r2off; st.adj_len[r2] = newcount;
-      for (int c = 0; c < K; ++c) { float mn, mx; r2_extremes(c, kNone, mn, mx); st.ch[c].Bmn[r2] = mn; st.ch[c].Bmx[r2] = mx; }
+#pragma unroll
+      for (int c = 0; c < kMaxChannels; ++c)
+        if (c < K) { float mn, mx; r2_extremes_of(c, kNone, pre_mn[c], pre_mx[c], mn, mx); st.ch[c].Bmn[r2] = mn; st.ch[c].Bmx[r2] = mx; }
     }
     __syncthreads();
 

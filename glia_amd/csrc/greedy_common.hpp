@@ -241,11 +241,7 @@ __device__ __forceinline__ void pq_propagate(const PqTree& t, PqWork& w, int tid
     // level; waves whose node did not change, or whose parent is taken by a lower wave, drop out.
     const uint32_t n0 = w.wln[0];
     uint32_t node = (uint32_t)wave < n0 ? w.wl[0][wave] : kNone;
-    if (node != kNone && lane == 0) {
-      uint32_t h = (node * 2654435761u) >> 22;
-      while (w.set[0][h] != node + 1u) h = (h + 1) & (kSetSlots - 1);
-      w.set[0][h] = 0;
-    }
+    const uint32_t node0 = node;
     for (int l = 0; l < t.nlevels; ++l) {
       uint32_t parent = kNone;
 #ifdef GLIA_HMT_PROFILE
@@ -266,6 +262,11 @@ __device__ __forceinline__ void pq_propagate(const PqTree& t, PqWork& w, int tid
 #endif
       if (parent != kNone) for (int j = 0; j < wave; ++j) if (w.fast[l & 1][j] == parent) { parent = kNone; break; }
       node = parent;
+    }
+    if (node0 != kNone && lane == 0) {      // consume the worklist entry's membership slot (off the loads' critical path)
+      uint32_t h = (node0 * 2654435761u) >> 22;
+      while (w.set[0][h] != node0 + 1u) h = (h + 1) & (kSetSlots - 1);
+      w.set[0][h] = 0;
     }
     if (tid == 0) w.wln[0] = 0;
     pq_top<THREADS>(t, w, tid);
