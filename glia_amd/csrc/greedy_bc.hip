@@ -79,10 +79,10 @@ struct BcState {
   uint32_t* nm_out;              // [R0] non-mutual out-entries per leaf
   uint32_t *mark0, *mark1;       // [2*R0]
   uint32_t* order; double* sal_out; double* feats_out;
-  double* featbuf;               // [kChunk][full feature dim]: the chunk's vectors for the helper workgroups
+  double* featbuf;               // [2][kChunk][full feature dim]: the chunk's vectors for the helper workgroups (two jobs in flight)
   uint32_t* hctl;                // helper protocol: [0] job word = sequence << 8 | records in the job (0xFFFFFFFF = quit)
-  unsigned long long* hvotes;    // [kChunk] sequence << 32 | votes: the contraction workgroup polls the slots it waits for
-  int* hmodel;                   // [kChunk]
+  unsigned long long* hvotes;    // [2][kChunk] sequence << 32 | votes: the contraction workgroup polls the slots it waits for
+  int* hmodel;                   // [2][kChunk]
   uint32_t n_helpers;            // workgroups 1..n_helpers evaluate the forest; 0 = the loop's own workgroup does
   uint32_t shard, n_shards;      // initial scoring: this call scores the records e with e % n_shards == shard (multi-GPU K7)
   unsigned long long* ctrl;
@@ -412,7 +412,7 @@ struct BcShared {
   unsigned long long best_mn[kMaxChannels], best_mx[kMaxChannels], second_mn[kMaxChannels], second_mx[kMaxChannels];
   uint32_t ex[kMaxChannels][4];
   int votes[kChunk];
-  int model[kChunk];
+  int model[2][kChunk];          // [job parity]: a job's models are needed again when its votes come back
   uint32_t nlog;                 // slots of the full vector that take a logarithm
   uint32_t lost;                 // a helper did not answer in time
   uint16_t logpos[feat::kMaxLogSlots];
@@ -488,9 +488,10 @@ __device__ void bc_helper_loop(const BcState& st, BcShared& s) {
     if (h >= cn) continue;                              // nothing for this workgroup in the job
     for (uint32_t j = h; j < cn; j += H) {
       // the record's model and vector are requested together (agent-scope loads are long round trips)
-      const int m = ld_agent(&st.hmodel[j]);
+      const uint32_t pj = (tag & 1u) * (uint32_t)kChunk + j;      // jobs alternate between two buffers (see the chunk loop)
+      const int m = ld_agent(&st.hmodel[pj]);
       double* hfeat = reinterpret_cast<double*>(s.pool);
-      for (int i = tid; i < fstride; i += kBcThreads) hfeat[i] = ld_agent(&st.featbuf[(size_t)j * fstride + i]);
+      for (int i = tid; i < fstride; i += kBcThreads) hfeat[i] = ld_agent(&st.featbuf[(size_t)pj * fstride + i]);
       if (tid == 0) s.votes[0] = 0;
       __syncthreads();
       if (m >= 0) {
@@ -501,7 +502,7 @@ __device__ void bc_helper_loop(const BcState& st, BcShared& s) {
       }
       __syncthreads();
       // the answer carries the job's sequence number: the contraction workgroup polls the slot itself, no counter
-      if (tid == 0 && m >= 0) st_agent(&st.hvotes[j], ((unsigned long long)tag << 32) | (unsigned long long)(uint32_t)s.votes[0]);
+      if (tid == 0 && m >= 0) st_agent(&st.hvotes[pj], ((unsigned long long)tag << 32) | (unsigned long long)(uint32_t)s.votes[0]);
       __syncthreads();
     }
   }
@@ -792,8 +793,42 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
     // ---- score the new table edges: features (one thread per edge) -> forest ((edge, tree) per thread) ----
     const int fstride = L.fstride;      // vectors are assembled at full length, the simple selection is compacted in place
     const uint32_t chunk = L.chunk;
+    // With helper workgroups the chunks are pipelined: the forest of chunk c runs in the helpers while this workgroup
+    // builds the vectors of chunk c + 1; the votes of c are collected (and its records enter the queue) just before
+    // c + 1 is handed over.  Jobs alternate between two global buffers and two model arrays (parity of the sequence).
+    bool pending = false;
+    uint32_t pend_c0 = 0, pend_cn = 0, pend_seq = 0;
+    int pend_par = 0;
+    auto score_records = [&](uint32_t c0r, uint32_t cnr, int par, bool stub_from_lds) __attribute__((always_inline)) {
+      if ((uint32_t)tid < cnr && s.model[par][tid] >= 0) {
+        const uint32_t rec = (uint32_t)ne + c0r + tid;
+        const double sal = stub_from_lds ? 1.0 - L.feat[tid * L.fstride + st.clf.stub_index]
+                                         : (double)s.votes[tid] / (double)st.clf.f[s.model[par][tid]].ntree;
+        const uint32_t cat = st.e_posv[rec] >> 30;
+        st.pq.leaf_sal[rec] = sal;
+        st.pq.leaf_seq[rec] = ((k + 1ull) << 32) | ((unsigned long long)cat << 30) | st.e_u[rec];
+        pq_leaf_added(st.pq, s.pq, rec);
+      }
+    };
+    auto collect_pending = [&]() __attribute__((always_inline)) {
+      if ((uint32_t)tid < pend_cn && s.model[pend_par][tid] >= 0) {
+        unsigned long long w = 0, spins = 0;
+        for (;;) {
+          w = ld_agent(&st.hvotes[pend_par * kChunk + tid]);
+          if ((uint32_t)(w >> 32) == pend_seq) break;
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > kHelperSpinLimit) { s.lost = 1u; break; }     // helpers lost: reported as a failed run at the next pop
+        }
+        s.votes[tid] = (int)(uint32_t)w;
+      }
+      score_records(pend_c0, pend_cn, pend_par, false);
+      __syncthreads();
+      pending = false;
+    };
     for (uint32_t c0 = 0; c0 < (forced ? 0u : newcount); c0 += chunk) {
       const uint32_t cn = min(chunk, newcount - c0);
+      const uint32_t nseq = hseq >= 0xFFFFFEu ? 1u : hseq + 1u;     // job sequence: never 0 (the slots' initial tag), never the quit word
+      const int cur = (int)(nseq & 1u);                             // consecutive jobs use different buffers
       {
         // excl_minmax of every new record's neighbour region, 16 lanes per record: the scan of rs's incident list is
         // a chain of dependent loads per entry, far too slow for the one thread that assembles the feature vector
@@ -937,7 +972,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
         const uint32_t slot = (uint32_t)(wave >> 2) * 64u + (uint32_t)(tid & 63);
         if (slot < cn) {
           const uint32_t rec = (uint32_t)ne + c0 + slot;
-          if (part == 0) { s.votes[slot] = 0; s.model[slot] = -1; }
+          if (part == 0) { s.votes[slot] = 0; s.model[cur][slot] = -1; }
           if (st.e_table[rec]) {
             const uint32_t rs = st.e_u[rec];
             float ex[4 * kMaxChannels];
@@ -968,52 +1003,39 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
         if (st.e_table[rec]) {
           double* x = &L.feat[tid * fstride];
           feat::simple_selection(st.cfg, x);
-          s.model[tid] = st.clf.kind == 1 ? 0 : pick_model(st.clf, x);
+          s.model[cur][tid] = st.clf.kind == 1 ? 0 : pick_model(st.clf, x);
         }
       }
       __syncthreads();
       PH(4);
       if (st.clf.kind == 0 && st.n_helpers) {
-        // hand the chunk to the helper workgroups and wait for their votes
-        for (uint32_t i = tid; i < cn * (uint32_t)fstride; i += kBcThreads) st_agent(&st.featbuf[i], L.feat[i]);
-        if ((uint32_t)tid < cn) st_agent(&st.hmodel[tid], s.model[tid]);
+        if (pending) collect_pending();           // the previous chunk's forest ran while this chunk's vectors were built
+        // hand the chunk to the helper workgroups
+        const size_t fb = (size_t)cur * kChunk * (size_t)fstride;
+        for (uint32_t i = tid; i < cn * (uint32_t)fstride; i += kBcThreads) st_agent(&st.featbuf[fb + i], L.feat[i]);
+        if ((uint32_t)tid < cn) st_agent(&st.hmodel[cur * kChunk + tid], s.model[cur][tid]);
         stores_done();
         __syncthreads();
-        hseq = hseq >= 0xFFFFFEu ? 1u : hseq + 1u;      // never 0 (the slots' initial tag), never the quit word
+        hseq = nseq;
         if (tid == 0) st_agent(&st.hctl[0], (hseq << 8) | cn);
-        if ((uint32_t)tid < cn && s.model[tid] >= 0) {
-          unsigned long long w = 0, spins = 0;
-          for (;;) {
-            w = ld_agent(&st.hvotes[tid]);
-            if ((uint32_t)(w >> 32) == hseq) break;
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > kHelperSpinLimit) { s.lost = 1u; break; }     // helpers lost: reported as a failed run at the next pop
-          }
-          s.votes[tid] = (int)(uint32_t)w;
-        }
-        __syncthreads();
+        pending = true; pend_c0 = c0; pend_cn = cn; pend_seq = hseq; pend_par = cur;
+        PH(5);
+        continue;
       } else if (st.clf.kind == 0) {
         const int ntree = st.clf.f[0].ntree;    // the three ensemble members are required to have equal size
         for (uint32_t i = tid; i < cn * (uint32_t)ntree; i += kBcThreads) {
           const uint32_t j = i / ntree, t = i % ntree;
-          const int m = s.model[j];
+          const int m = s.model[cur][j];
           if (m < 0) continue;
           if (forest_vote(st.clf.f[m], (int)t, &L.feat[j * fstride])) atomicAdd(&s.votes[j], 1);
         }
       }
       __syncthreads();
       PH(5);
-      if ((uint32_t)tid < cn && s.model[tid] >= 0) {
-        const uint32_t rec = (uint32_t)ne + c0 + tid;
-        const double sal = st.clf.kind == 1 ? 1.0 - L.feat[tid * fstride + st.clf.stub_index]
-                                            : (double)s.votes[tid] / (double)st.clf.f[s.model[tid]].ntree;
-        const uint32_t cat = st.e_posv[rec] >> 30;
-        st.pq.leaf_sal[rec] = sal;
-        st.pq.leaf_seq[rec] = ((k + 1ull) << 32) | ((unsigned long long)cat << 30) | st.e_u[rec];
-        pq_leaf_added(st.pq, s.pq, rec);
-      }
+      score_records(c0, cn, cur, st.clf.kind == 1);
       __syncthreads();
     }
+    if (pending) collect_pending();
     for (uint32_t j = tid; j < newcount; j += kBcThreads) st.e_posv[(uint32_t)ne + j] &= 0x3FFFFFFFu;
     PH(3);
     if (!forced) pq_propagate<kBcThreads>(st.pq, s.pq, tid);
@@ -1149,10 +1171,10 @@ int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& cl
   if ((rc = buf.get(&st.order, 3 * (size_t)R, false, stream))) return rc;
   if ((rc = buf.get(&st.sal_out, (size_t)R, false, stream))) return rc;
   if (h_feats) { if ((rc = buf.get(&st.feats_out, (size_t)R * cfg.fdim, false, stream))) return rc; }
-  if ((rc = buf.get(&st.featbuf, (size_t)kChunk * bc_full_dim(cfg), false, stream))) return rc;
+  if ((rc = buf.get(&st.featbuf, (size_t)2 * kChunk * bc_full_dim(cfg), false, stream))) return rc;      // two jobs in flight
   if ((rc = buf.get(&st.hctl, 4, true, stream))) return rc;
-  if ((rc = buf.get(&st.hvotes, kChunk, true, stream))) return rc;
-  if ((rc = buf.get(&st.hmodel, kChunk, true, stream))) return rc;
+  if ((rc = buf.get(&st.hvotes, 2 * kChunk, true, stream))) return rc;
+  if ((rc = buf.get(&st.hmodel, 2 * kChunk, true, stream))) return rc;
   {
     // helper workgroups for the forest (only a real forest in a scoring run needs them); GLIA_HMT_HELPERS overrides
     const char* env = getenv("GLIA_HMT_HELPERS");
@@ -1216,7 +1238,7 @@ int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& cl
   if ((rc = buf.get(&d_st, 1, false, stream))) return rc;
   while (true) {
     GLIA_HIP_TRY(hipMemsetAsync(st.hctl, 0, 4 * sizeof(uint32_t), stream));
-    GLIA_HIP_TRY(hipMemsetAsync(st.hvotes, 0, kChunk * sizeof(unsigned long long), stream));
+    GLIA_HIP_TRY(hipMemsetAsync(st.hvotes, 0, 2 * kChunk * sizeof(unsigned long long), stream));
     GLIA_HIP_TRY(hipMemcpyAsync(d_st, &st, sizeof(BcState), hipMemcpyHostToDevice, stream));
     GLIA_HIP_TRY(hipStreamSynchronize(stream));       // st lives on this stack: the copy must have read it before it changes
     hipLaunchKernelGGL(greedy_bc_kernel, dim3(1 + st.n_helpers), dim3(kBcThreads), 0, stream, (const BcState*)d_st);
