@@ -39,7 +39,10 @@ namespace glia {
 #define GLIA_BC_THREADS 512
 #endif
 constexpr int kBcThreads = GLIA_BC_THREADS;   // 512: 256 VGPRs per thread (1024 spilled into scratch, measured 8% slower); >= 512 needed: the feature blocks of a 96-record chunk take 8 waves
-constexpr int kChunk = 96;              // new edges scored per round (their feature vectors live in LDS)
+#ifndef GLIA_BC_CHUNK
+#define GLIA_BC_CHUNK 96
+#endif
+constexpr int kChunk = GLIA_BC_CHUNK;              // new edges scored per round (their feature vectors live in LDS)
 
 // statistics of one image channel (a distinct volume + histogram among the feature lists); channel 0 = boundary
 // probability: its counts and thresholded counts also serve the shape features
