@@ -91,6 +91,15 @@ def test_random_forest_matches_oracle(ctx, shape, S, G, ntree, depth):
     assert order.shape == o_ref.shape and (order == o_ref).all()
     assert (sal == s_ref).all()              # votes / ntree: exact
     assert _feat_close(feats, f_ref)
+    # the forest is walked by helper workgroups (63 by default); the result may not depend on how many there are:
+    # 0 = the contraction workgroup walks the trees itself, 5 = every helper takes several records of a chunk
+    for nh in ("0", "5"):
+        os.environ["GLIA_HMT_HELPERS"] = nh
+        try:
+            o2, s2 = rm.merge_order_bc(clf)[:2]
+        finally:
+            del os.environ["GLIA_HMT_HELPERS"]
+        assert (o2 == o_ref).all() and (s2 == s_ref).all(), "helpers=" + nh
 
 
 def test_log_and_simple_features(ctx):
