@@ -162,8 +162,15 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
   for (int i = tid; i < kSetSlots; i += blockDim.x) { s.pq.set[0][i] = 0; s.pq.set[1][i] = 0; }
   for (uint32_t i = tid; i < kMarkSlots; i += blockDim.x) { s.mk[i] = 0; s.mv0[i] = 0; s.mv1[i] = 0; }
   const PqTree& pq = st.pq;
+  // mean linkage: the last stored level of the tree (<= 4096 nodes) stays in LDS for the whole launch -- its nodes are
+  // written by one step of the propagation and read by the next, which through global memory is a store round trip plus
+  // a load round trip.  (The median kernel needs the LDS for its merge tiles.)
+  constexpr uint32_t kTopLds = MEDIAN ? 1u : kTopMax;
+  __shared__ Key s_topk[kTopLds];
+  Key* topk = (!MEDIAN && pq.nlevels >= 2 && pq.lv[pq.nlevels - 1].size <= kTopLds) ? s_topk : nullptr;
+  if (topk) pq_top_load<kGreedyThreads>(pq, topk, tid);
   __syncthreads();
-  pq_top<kGreedyThreads>(pq, s.pq, tid);      // the root lives in LDS: rebuilt at every launch
+  pq_top<kGreedyThreads>(pq, s.pq, tid, topk);      // the root lives in LDS: rebuilt at every launch
 
 #ifdef GLIA_HMT_PROFILE
   unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
@@ -222,7 +229,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
     __syncthreads();
     PH(0);
     if (s.stop != ST_RUN) { status = s.stop; break; }
-    if (s.reject) { pq_propagate<kGreedyThreads>(pq, s.pq, tid); continue; }
+    if (s.reject) { pq_propagate<kGreedyThreads>(pq, s.pq, tid, topk); continue; }
     const uint32_t r0 = s.r0, e = s.e, len0 = s.len0, len1 = s.len1, off0 = s.off0, off1 = s.off1;
     const uint32_t r2 = st.R0 + (uint32_t)k;
     const uint32_t total = len0 + len1;
@@ -450,7 +457,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
 
     PH(3);
     // ---- priority structure: propagate dirty nodes level by level ----
-    pq_propagate<kGreedyThreads>(pq, s.pq, tid);
+    pq_propagate<kGreedyThreads>(pq, s.pq, tid, topk);
     PH(4);
 #ifdef GLIA_HMT_PROFILE
     if (tid == 0) {
@@ -462,6 +469,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
     k += 1; ne += newcount; pool_used += total;
   }
   __syncthreads();
+  if (topk) pq_top_store<kGreedyThreads>(pq, topk, tid);      // the next launch (or the host's rebuild) starts from global memory
   if (tid == 0) { st.ctrl[0] = k; st.ctrl[1] = ne; st.ctrl[2] = pool_used; st.ctrl[3] = status; st.ctrl[4] = vals_used; }
 #ifdef GLIA_HMT_PROFILE
   if (tid == 0) printf("[greedy profile] pq propagations by dirty level-0 nodes (<=8, <=16, more): %llu %llu %llu\n", g_pqprof[28], g_pqprof[29], g_pqprof[30]);

@@ -90,7 +90,9 @@ struct PqTree {
 };
 
 // recompute node j of level l with one wave (all 64 lanes must call); returns true when the node's key changed
-__device__ __forceinline__ bool pq_recompute_node(const PqTree& t, int l, uint32_t j, int lane, bool force = false) {
+// topk (optional): the last stored level kept in LDS for the lifetime of a launch (pq_top_load / pq_top_store); nodes of
+// that level are then read and written there
+__device__ __forceinline__ bool pq_recompute_node(const PqTree& t, int l, uint32_t j, int lane, bool force = false, Key* topk = nullptr) {
   Key k;
   k.sal = -__builtin_inf(); k.seq = 0; k.arg = 0;
   // every lane takes kLaneChildren children.  The loads are unconditional (index clamped, validity applied afterwards):
@@ -127,14 +129,20 @@ __device__ __forceinline__ bool pq_recompute_node(const PqTree& t, int l, uint32
 #pragma unroll
   for (int c = 0; c < kLaneChildren; ++c) if (better(kk[c], k)) k = kk[c];
   const PqLevel& d = t.lv[l];
+  const bool in_lds = topk != nullptr && l == t.nlevels - 1;
   // the node's previous key, fetched alongside the children (same round trip)
-  const unsigned long long oseq = d.seq[j];
-  const uint32_t oarg = d.arg[j];
+  unsigned long long oseq;
+  uint32_t oarg;
+  if (in_lds) { oseq = topk[j].seq; oarg = topk[j].arg; }
+  else { oseq = d.seq[j]; oarg = d.arg[j]; }
   k = wave_max(k);
   bool changed = false;
   if (lane == 0) {
     changed = oseq != k.seq || oarg != k.arg;       // (seq, arg) identify the item; its saliency never changes
-    if (changed || force) { d.sal[j] = k.sal; d.seq[j] = k.seq; d.arg[j] = k.arg; }
+    if (changed || force) {
+      if (in_lds) topk[j] = k;
+      else { d.sal[j] = k.sal; d.seq[j] = k.seq; d.arg[j] = k.arg; }
+    }
   }
   return changed;     // meaningful in lane 0
 }
@@ -182,7 +190,7 @@ __device__ unsigned long long g_pqprof[32];     // [l] cycles of level l, [8+l] 
 // the root: one round trip over the last stored level by the whole workgroup (every thread calls; the caller has put a
 // barrier after the last store into that level; ends with a barrier)
 template <int THREADS>
-__device__ __forceinline__ void pq_top(const PqTree& t, PqWork& w, int tid) {
+__device__ __forceinline__ void pq_top(const PqTree& t, PqWork& w, int tid, const Key* topk = nullptr) {
   const PqLevel& cl = t.lv[t.nlevels - 1];
   Key k;
   k.sal = -__builtin_inf(); k.seq = 0; k.arg = 0;
@@ -190,6 +198,9 @@ __device__ __forceinline__ void pq_top(const PqTree& t, PqWork& w, int tid) {
   const unsigned long long tt0 = __builtin_readcyclecounter();
 #endif
   constexpr int kBatch = 4;
+  if (topk) {
+    for (uint32_t ci = tid; ci < cl.size; ci += THREADS) { const Key c = topk[ci]; if (better(c, k)) k = c; }
+  } else
   for (uint32_t base = 0; base < cl.size; base += THREADS * kBatch) {
     Key kk[kBatch];
 #pragma unroll
@@ -226,9 +237,21 @@ __device__ __forceinline__ Key pq_root(const PqWork& w) {
   return b;
 }
 
+// the last stored level <-> LDS (every thread calls; the caller puts the barriers)
+template <int THREADS>
+__device__ __forceinline__ void pq_top_load(const PqTree& t, Key* topk, int tid) {
+  const PqLevel& d = t.lv[t.nlevels - 1];
+  for (uint32_t i = tid; i < d.size; i += THREADS) { Key k; k.sal = d.sal[i]; k.seq = d.seq[i]; k.arg = d.arg[i]; topk[i] = k; }
+}
+template <int THREADS>
+__device__ __forceinline__ void pq_top_store(const PqTree& t, const Key* topk, int tid) {
+  const PqLevel& d = t.lv[t.nlevels - 1];
+  for (uint32_t i = tid; i < d.size; i += THREADS) { const Key k = topk[i]; d.sal[i] = k.sal; d.seq[i] = k.seq; d.arg[i] = k.arg; }
+}
+
 // apply all pending leaf changes level by level; every thread of the workgroup must call (contains barriers)
 template <int THREADS>
-__device__ __forceinline__ void pq_propagate(const PqTree& t, PqWork& w, int tid) {
+__device__ __forceinline__ void pq_propagate(const PqTree& t, PqWork& w, int tid, Key* topk = nullptr) {
   const int lane = tid & 63, wave = tid >> 6;
   constexpr int nwaves = THREADS / 64;
   static_assert(nwaves <= 16, "PqWork::fast");
@@ -248,7 +271,7 @@ __device__ __forceinline__ void pq_propagate(const PqTree& t, PqWork& w, int tid
       const unsigned long long tf0 = __builtin_readcyclecounter();
 #endif
       if (node != kNone) {
-        const bool changed = pq_recompute_node(t, l, node, lane, false);
+        const bool changed = pq_recompute_node(t, l, node, lane, false, topk);
         const bool ch = __shfl((int)changed, 0) != 0;
         if (ch && l + 1 < t.nlevels) parent = node / kFan;
       }
@@ -269,7 +292,7 @@ __device__ __forceinline__ void pq_propagate(const PqTree& t, PqWork& w, int tid
       w.set[0][h] = 0;
     }
     if (tid == 0) w.wln[0] = 0;
-    pq_top<THREADS>(t, w, tid);
+    pq_top<THREADS>(t, w, tid, topk);
     return;
   }
   int cur = 0;
@@ -283,7 +306,7 @@ __device__ __forceinline__ void pq_propagate(const PqTree& t, PqWork& w, int tid
     const uint32_t ng = (ovf || !w.spill) ? 0u : t.gcount[cur];
     for (uint32_t i = wave; i < n; i += nwaves) {
       const uint32_t j = ovf ? i : w.wl[cur][i];
-      const bool changed = pq_recompute_node(t, l, j, lane, ovf);
+      const bool changed = pq_recompute_node(t, l, j, lane, ovf, topk);
       if (lane == 0) {
         // an unchanged node cannot change its ancestors
         if (!ovf && changed && l + 1 < t.nlevels) pq_touch(t, w, l + 1, cur ^ 1, j);
@@ -291,7 +314,7 @@ __device__ __forceinline__ void pq_propagate(const PqTree& t, PqWork& w, int tid
     }
     for (uint32_t i = wave; i < ng; i += nwaves) {
       const uint32_t j = t.glist[cur][i];
-      const bool changed = pq_recompute_node(t, l, j, lane, false);
+      const bool changed = pq_recompute_node(t, l, j, lane, false, topk);
       if (lane == 0) {
         t.lv[l].dirty[j] = 0u;
         if (changed && l + 1 < t.nlevels) pq_touch(t, w, l + 1, cur ^ 1, j);
@@ -318,7 +341,7 @@ __device__ __forceinline__ void pq_propagate(const PqTree& t, PqWork& w, int tid
   }
   __syncthreads();
   if (tid == 0) { w.ovf = 0; w.spill = 0; w.wln[0] = w.wln[1] = 0; }
-  pq_top<THREADS>(t, w, tid);
+  pq_top<THREADS>(t, w, tid, topk);
 }
 
 __global__ void pq_build_level_kernel(PqTree t, int l);

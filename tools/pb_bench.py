@@ -20,4 +20,7 @@ for rep in range(2):
     print("size=%d S=%d type=%d variant=%d R=%d P=%d merges=%d  total %.1f ms (table %.1f loop %.1f) edges %d -> %.0f merges/s; sal[0..3]=%s" % (
         size, S, typ, variant, rm.num_regions, rm.num_pairs, len(order), (t2 - t1) * 1e3, tm["ms_table"], tm["ms_loop"], tm["n_edges_scored"],
         len(order) / (tm["ms_loop"] * 1e-3), sal[:3]), flush=True)
+    if os.environ.get("GLIA_PB_HASH"):     # kernel experiments: the whole result must not change
+        import hashlib
+        print("sha1 order %s sal %s" % (hashlib.sha1(np.ascontiguousarray(order).tobytes()).hexdigest(), hashlib.sha1(np.ascontiguousarray(sal).tobytes()).hexdigest()), flush=True)
     rm.close()
