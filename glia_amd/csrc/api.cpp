@@ -51,6 +51,37 @@ HistSpec make_hist_spec(int bins, double lo, double hi) {
   return h;
 }
 
+
+// Which restatement of glibc's log2 / log reproduces THIS host's libm bit for bit (the reference calls std::log2 in
+// stats::entropy, util/stats.hxx:150, and std::log in slog, glia_base.hxx:80-81; the device must return the same bits).
+// Probe vector: histogram fractions c/n, values around 1 (the near-one branch), and a sweep over exponents.
+// GLIA_HMT_LIBM = device | sse2 | fma overrides the choice (tests).
+static LibmSel probe_host_libm() {
+  std::vector<double> xs;
+  uint64_t s = 0x9E3779B97F4A7C15ull;
+  auto next = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+  for (int i = 0; i < 6000; ++i) { const uint64_t n = 1 + next() % 100000, c = 1 + next() % n; xs.push_back((double)c / (double)n); }
+  for (int i = 0; i < 3000; ++i) xs.push_back(1.0 + ((double)(int64_t)(next() % 2000001) - 1000000.0) * 1e-7);
+  for (int i = 0; i < 3000; ++i) xs.push_back(std::ldexp(1.0 + (double)(next() >> 12) * 0x1p-52, (int)(next() % 120) - 60));
+  for (int e = -1074; e < 1024; e += 37) xs.push_back(std::ldexp(1.0, e));
+  LibmSel sel = {kLibmDevice, kLibmDevice};
+  bool l2 = true, ls = true, lf = true;
+  for (double x : xs) {
+    volatile double vx = x;
+    const double h2 = std::log2(vx), h1 = std::log(vx);
+    l2 = l2 && glibc::as_u64(h2) == glibc::as_u64(glibc::log2_sse2(x));
+    ls = ls && glibc::as_u64(h1) == glibc::as_u64(glibc::log_sse2(x));
+    lf = lf && glibc::as_u64(h1) == glibc::as_u64(glibc::log_fma(x));
+  }
+  if (l2) sel.log2_variant = kLibmSse2;
+  if (lf) sel.log_variant = kLibmFma; else if (ls) sel.log_variant = kLibmSse2;
+  if (const char* e = getenv("GLIA_HMT_LIBM")) {
+    const int v = !strcmp(e, "sse2") ? kLibmSse2 : !strcmp(e, "fma") ? kLibmFma : kLibmDevice;
+    sel.log_variant = v; sel.log2_variant = v == kLibmFma ? kLibmSse2 : v;
+  }
+  return sel;
+}
+
 }  // namespace glia
 
 using namespace glia;
@@ -68,6 +99,7 @@ struct glia_hmt_ctx {
   uint32_t hint_rcap = 0, hint_pcap = 0;
   double transform_ms = 0;
   int tz = kTZ;                  // tile depth of the accumulation pass; halved when the LDS tables of a pass overflowed a lot
+  LibmSel libm = {kLibmDevice, kLibmDevice};   // restatement of the host's log2 / log the kernels use (glibc_math.hpp)
 };
 
 struct glia_hmt_rag {
@@ -143,8 +175,40 @@ int glia_hmt_ctx_create(int device, void* hip_stream, glia_hmt_ctx** out) {
   GLIA_HIP_TRY(hipMemsetAsync(c->flags, 0, 64, c->stream));
   GLIA_HIP_TRY(hipEventCreate(&c->ev0));
   GLIA_HIP_TRY(hipEventCreate(&c->ev1));
+  static const LibmSel sel = probe_host_libm();
+  c->libm = sel;
   *out = c;
   return GLIA_HMT_OK;
+}
+
+int glia_hmt_ctx_libm(const glia_hmt_ctx* c, int* log2_variant, int* log_variant) {
+  if (!c) return GLIA_HMT_ERR_ARG;
+  if (log2_variant) *log2_variant = c->libm.log2_variant;
+  if (log_variant) *log_variant = c->libm.log_variant;
+  return GLIA_HMT_OK;
+}
+
+int glia_hmt_host_libm_probe(int* log2_variant, int* log_variant) {
+  const LibmSel sel = probe_host_libm();
+  if (log2_variant) *log2_variant = sel.log2_variant;
+  if (log_variant) *log_variant = sel.log_variant;
+  return GLIA_HMT_OK;
+}
+
+int glia_hmt_host_libm_eval(int function, int variant, const double* h_in, double* h_out, int64_t n) {
+  if (!h_in || !h_out || n < 0 || function < 0 || function > 1 || (variant != kLibmSse2 && variant != kLibmFma)) {
+    set_error("host_libm_eval: invalid argument");
+    return GLIA_HMT_ERR_ARG;
+  }
+  for (int64_t i = 0; i < n; ++i)
+    h_out[i] = function == 0 ? glibc::log2_sse2(h_in[i]) : variant == kLibmFma ? glibc::log_fma(h_in[i]) : glibc::log_sse2(h_in[i]);
+  return GLIA_HMT_OK;
+}
+
+int glia_hmt_libm_eval(glia_hmt_ctx* c, int function, int variant, const double* d_in, double* d_out, int64_t n) {
+  if (!c || !d_in || !d_out || n < 0 || function < 0 || function > 2) { set_error("libm_eval: invalid argument"); return GLIA_HMT_ERR_ARG; }
+  GLIA_HIP_TRY(hipSetDevice(c->device));
+  return launch_libm_eval(function, variant, d_in, d_out, n, c->stream);
 }
 
 void glia_hmt_ctx_destroy(glia_hmt_ctx* c) {
@@ -676,6 +740,7 @@ static bool make_bc_cfg(const glia_hmt_rag* rag, BcCfg* c) {
   c->use_log = g.use_log_shape; c->use_simple = g.use_simple_features;
   c->norm_area = g.normalizing_area; c->norm_len = g.normalizing_length;
   c->rfdim = bc_rf_dim(*c); c->bfdim = bc_bf_dim(*c); c->fdim = bc_feat_dim(*c);
+  c->libm_log2 = rag->ctx->libm.log2_variant; c->libm_log = rag->ctx->libm.log_variant;
   return true;
 }
 

@@ -15,6 +15,7 @@
 //   selectFeatures                        hmt/bc_feat.hxx:247-279
 #pragma once
 #include "hmt_internal.hpp"
+#include "glibc_math.hpp"
 
 namespace glia {
 
@@ -74,6 +75,7 @@ struct BcCfg {
   int use_log, use_simple;
   double norm_area, norm_len;
   int rfdim, bfdim, fdim;
+  int libm_log2, libm_log;              // which restatement of the host libm the logarithms use (glibc_math.hpp)
 };
 
 __host__ __device__ inline int bc_rf_dim(const BcCfg& c) { return 4 + c.D + 2 * c.T + 5 * c.n_region + c.n_rlabel + 5 * c.n_boundary; }
@@ -86,7 +88,12 @@ __host__ __device__ inline int bc_feat_dim(const BcCfg& c) {
 namespace feat {
 
 __device__ inline double sdiv(double l, double r, double d) { return fabs(r) >= 2.22e-16 ? l / r : d; }
-__device__ inline double slog(double x, double d) { return x > 0.0 ? log(x) : d; }
+// std::log2 / std::log as the HOST libm computes them (glibc_math.hpp); variant 0 = device libm (<= 1 ulp off, unpinned)
+__device__ __forceinline__ double host_log2(double x, int variant) { return variant == kLibmSse2 ? glibc::log2_sse2(x) : log2(x); }
+__device__ __forceinline__ double host_log(double x, int variant) {
+  return variant == kLibmFma ? glibc::log_fma(x) : variant == kLibmSse2 ? glibc::log_sse2(x) : log(x);
+}
+__device__ inline double slog(double x, double d, int variant) { return x > 0.0 ? host_log(x, variant) : d; }
 __device__ inline double ssqrt(double x, double d) { return x >= 0.0 ? sqrt(x) : d; }
 
 // std::pow(perim, D/(D-1)) of type/feat.hxx:78-79 for an integer-valued perim: exponent 2 (2D) is an exact
@@ -107,14 +114,16 @@ __device__ inline double pow_perim(double x, int D) {
 struct ImgFeats { double entropy, mean, stddev, mn, mx; };
 
 __device__ inline void region_log(const BcCfg& c, double* rf) {    // feat.hxx:46-52, 463-467
-  rf[0] = slog(rf[0], 0.0); rf[1] = slog(rf[1], 0.0); rf[3] = slog(rf[3], 0.0);
-  for (int i = 0; i < c.D; ++i) rf[4 + i] = slog(rf[4 + i], 0.0);
-  for (int i = 0; i < c.T; ++i) rf[4 + c.D + i] = slog(rf[4 + c.D + i], 0.0);
+  const int v = c.libm_log;
+  rf[0] = slog(rf[0], 0.0, v); rf[1] = slog(rf[1], 0.0, v); rf[3] = slog(rf[3], 0.0, v);
+  for (int i = 0; i < c.D; ++i) rf[4 + i] = slog(rf[4 + i], 0.0, v);
+  for (int i = 0; i < c.T; ++i) rf[4 + c.D + i] = slog(rf[4 + c.D + i], 0.0, v);
 }
 
 __device__ inline void boundary_log(const BcCfg& c, double* bf) {   // feat.hxx:103-106, 148-155, 531-539
-  bf[0] = slog(bf[0], 0.0); bf[3] = slog(bf[3], 0.0); bf[6] = slog(bf[6], 0.0);
-  for (int i = 0; i < c.T; ++i) bf[11 + i] = slog(bf[11 + i], 0.0);
+  const int v = c.libm_log;
+  bf[0] = slog(bf[0], 0.0, v); bf[3] = slog(bf[3], 0.0, v); bf[6] = slog(bf[6], 0.0, v);
+  for (int i = 0; i < c.T; ++i) bf[11 + i] = slog(bf[11 + i], 0.0, v);
 }
 
 // ---- the vector of hmt/main_merge_order_bc.cxx:54-95, without private arrays --------------------------------------
@@ -128,7 +137,7 @@ struct ImgSrc {               // an image-statistics set: hist = a + b - c (null
   const double* ent;          // entropy computed beforehand (lane-parallel pass of the greedy loop), or null
   __device__ __forceinline__ uint32_t h(int i) const { return (ha ? ha[i] : 0u) + (hb ? hb[i] : 0u) - (hc ? hc[i] : 0u); }
 };
-__device__ __forceinline__ ImgFeats image_feats_src(const ImgSrc& s, int bins) {
+__device__ __forceinline__ ImgFeats image_feats_src(const ImgSrc& s, int bins, int libm_log2) {
   ImgFeats f;
   double ent = 0.0;
   if (s.ent) ent = *s.ent;
@@ -137,7 +146,7 @@ __device__ __forceinline__ ImgFeats image_feats_src(const ImgSrc& s, int bins) {
     for (int i = 0; i < GLIA_HMT_MAX_BINS; ++i) {
       if (i < bins) {
         const double p = s.n ? s.h(i) / (double)s.n : 0.0;
-        if (!(fabs(p - 0.0) < 2.22e-16)) ent -= p * log2(p);
+        if (!(fabs(p - 0.0) < 2.22e-16)) ent -= p * host_log2(p, libm_log2);
       }
     }
   }
@@ -151,9 +160,9 @@ __device__ __forceinline__ ImgFeats image_feats_src(const ImgSrc& s, int bins) {
   return f;
 }
 // one bin's term of an entropy sum / of the two histogram distances (the lane-parallel pass adds them in bin order)
-__device__ __forceinline__ double entropy_term(uint32_t cnt, uint32_t n) {
+__device__ __forceinline__ double entropy_term(uint32_t cnt, uint32_t n, int libm_log2) {
   const double p = n ? cnt / (double)n : 0.0;
-  return (fabs(p - 0.0) < 2.22e-16) ? 0.0 : p * log2(p);
+  return (fabs(p - 0.0) < 2.22e-16) ? 0.0 : p * host_log2(p, libm_log2);
 }
 __device__ __forceinline__ void dist_terms(uint32_t c0, uint32_t n0, uint32_t c1, uint32_t n1, double& tl, double& tx) {
   const double p0 = n0 ? c0 / (double)n0 : 0.0, p1 = n1 ? c1 / (double)n1 : 0.0;
@@ -199,12 +208,12 @@ __device__ __forceinline__ void region_feats_multi(const BcCfg& c, const ShapeIn
   k += 2 * T;
   area_o = area; perim_o = perim;
   for (int i = 0; i < c.n_region; ++i) {
-    const ImgFeats f = image_feats_src(src(0, i), c.cbins[c.rc[i]]);
+    const ImgFeats f = image_feats_src(src(0, i), c.cbins[c.rc[i]], c.libm_log2);
     out[k++] = f.entropy; out[k++] = f.mean; out[k++] = f.stddev; out[k++] = f.mn; out[k++] = f.mx;
   }
-  for (int i = 0; i < c.n_rlabel; ++i) out[k++] = image_feats_src(src(1, i), c.cbins[c.lc[i]]).entropy;
+  for (int i = 0; i < c.n_rlabel; ++i) out[k++] = image_feats_src(src(1, i), c.cbins[c.lc[i]], c.libm_log2).entropy;
   for (int i = 0; i < c.n_boundary; ++i) {
-    const ImgFeats f = image_feats_src(src(2, i), c.cbins[c.bc[i]]);
+    const ImgFeats f = image_feats_src(src(2, i), c.cbins[c.bc[i]], c.libm_log2);
     out[k++] = f.entropy; out[k++] = f.mean; out[k++] = f.stddev; out[k++] = f.mn; out[k++] = f.mx;
   }
 }
@@ -250,7 +259,7 @@ __device__ __forceinline__ void boundary_feats_multi(const BcCfg& c, uint32_t sh
           }
         }
       }
-      const ImgFeats f0 = image_feats_src(s0, bins), f1 = image_feats_src(s1, bins);
+      const ImgFeats f0 = image_feats_src(s0, bins, c.libm_log2), f1 = image_feats_src(s1, bins, c.libm_log2);
       out[k++] = l1; out[k++] = x2; out[k++] = fabs(f0.entropy - f1.entropy);
       if (kind == 0) {
         out[k++] = fabs(f0.mean - f1.mean); out[k++] = fabs(f0.stddev - f1.stddev);
@@ -259,7 +268,7 @@ __device__ __forceinline__ void boundary_feats_multi(const BcCfg& c, uint32_t sh
     }
   }
   for (int i = 0; i < c.n_boundary; ++i) {
-    const ImgFeats f = image_feats_src(srcSh(i), c.cbins[c.bc[i]]);
+    const ImgFeats f = image_feats_src(srcSh(i), c.cbins[c.bc[i]], c.libm_log2);
     out[k++] = f.entropy; out[k++] = f.mean; out[k++] = f.stddev; out[k++] = f.mn; out[k++] = f.mx;
   }
 }

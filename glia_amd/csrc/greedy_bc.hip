@@ -940,8 +940,8 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
               const PStats* P0 = &st.ch[cc].pts[rs]; const PStats* P1 = &st.ch[cc].pts[r2];
               const uint32_t h0 = P0->hist[l16], h1 = P1->hist[l16], pn0 = P0->n, pn1 = P1->n;     // unconditional loads
               if (on && (int)l16 < bins) {
-                t0 = feat::entropy_term(h0, pn0); t1 = feat::entropy_term(h1, pn1);
-                t2 = feat::entropy_term(h0 + h1, pn0 + pn1);
+                t0 = feat::entropy_term(h0, pn0, cf.libm_log2); t1 = feat::entropy_term(h1, pn1, cf.libm_log2);
+                t2 = feat::entropy_term(h0 + h1, pn0 + pn1, cf.libm_log2);
                 feat::dist_terms(h0, pn0, h1, pn1, tl, tx);
               }
               const double e0 = bin_sum(t0, bins, true), e1 = bin_sum(t1, bins, true), e2 = bin_sum(t2, bins, true);
@@ -958,9 +958,9 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
             const EStats* sh = &L.shs[j * K + cc];
             const uint32_t g0 = B0->hist[l16], g1 = B1->hist[l16], ga = A->hist[l16], bn0 = B0->n, bn1 = B1->n, an = A->n;
             if (on && (int)l16 < bins) {
-              t0 = feat::entropy_term(g0, bn0); t1 = feat::entropy_term(g1, bn1);
-              t2 = feat::entropy_term(g0 + g1 - ga, bn0 + bn1 - an);
-              t3 = feat::entropy_term(sh->hist[l16], sh->n);
+              t0 = feat::entropy_term(g0, bn0, cf.libm_log2); t1 = feat::entropy_term(g1, bn1, cf.libm_log2);
+              t2 = feat::entropy_term(g0 + g1 - ga, bn0 + bn1 - an, cf.libm_log2);
+              t3 = feat::entropy_term(sh->hist[l16], sh->n, cf.libm_log2);
             }
             const double e0 = bin_sum(t0, bins, true), e1 = bin_sum(t1, bins, true), e2 = bin_sum(t2, bins, true), e3 = bin_sum(t3, bins, true);
             if ((int)l16 == bins - 1) { double* q = fx + feat::pre_boundary(cf, i); q[0] = e0; q[1] = e1; q[2] = e2; q[3] = e3; }
@@ -997,7 +997,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
           const uint32_t j = i / nlog;
           if (!st.e_table[(uint32_t)ne + c0 + j]) continue;
           double* q = &L.feat[j * fstride + s.logpos[i - j * nlog]];
-          *q = feat::slog(*q, 0.0);
+          *q = feat::slog(*q, 0.0, st.cfg.libm_log);
         }
         __syncthreads();
       }

@@ -130,6 +130,7 @@ int paint_pair_values(const VolumeRef& vol, const uint32_t* d_pa, const uint32_t
 int boundary_confidence_values(int n_trees, const int64_t* n_nodes, const uint32_t* const* node_label, const int32_t* const* parent,
                                const int32_t* const* child0, const double* const* potential, const uint32_t* pa, const uint32_t* pb,
                                int64_t P, std::vector<float>* out);
+int launch_libm_eval(int function, int variant, const double* d_in, double* d_out, int64_t n, hipStream_t stream);
 int merge_rag_arrays(const RagArrays* parts, int n_parts, RagArrays* out, hipStream_t stream);
 
 __host__ __device__ inline uint32_t float_ord(float f) {

@@ -105,6 +105,21 @@ class Context:
     def sync(self):
         _check(lib().glia_hmt_ctx_sync(self.h))
 
+    def libm(self):
+        """(log2 variant, log variant) the kernels use: 1 = glibc non-FMA, 2 = glibc FMA, 0 = device libm (unpinned)."""
+        a, b = C.c_int(0), C.c_int(0)
+        _check(lib().glia_hmt_ctx_libm(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def libm_eval(self, function, variant, x):
+        """Device restatement of the host libm over a CUDA f64 tensor: function 0 = log2, 1 = log, 2 = pow(x, 1.5)."""
+        import torch
+        out = torch.empty_like(x)
+        _check(lib().glia_hmt_libm_eval(self.h, C.c_int(function), C.c_int(variant), C.c_void_p(x.data_ptr()),
+                                        C.c_void_p(out.data_ptr()), C.c_int64(x.numel())))
+        self.sync()
+        return out
+
     def set_table_hint(self, regions, pairs):
         _check(lib().glia_hmt_ctx_set_table_hint(self.h, C.c_int64(regions), C.c_int64(pairs)))
 

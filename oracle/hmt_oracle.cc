@@ -1427,4 +1427,13 @@ int64_t orc_label_transform(const orc_label* node_label, const int32_t* child0, 
   return m;
 }
 
+// The host libm functions the reference's features call: std::log2 (util/stats.hxx:150), std::log (glia_base.hxx:80-81),
+// std::pow(perim, 1.5) (type/feat.hxx:78-79).  function: 0 / 1 / 2.  volatile: no compile-time folding.
+void orc_libm_eval(int function, const double* in, double* out, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) {
+    volatile double x = in[i];
+    out[i] = function == 0 ? std::log2(x) : function == 1 ? std::log(x) : std::pow(x, 1.5);
+  }
+}
+
 }  // extern "C"

@@ -157,6 +157,8 @@ int64_t orc_transform_keys(const orc_label* order, int64_t n_merges, orc_label* 
 void orc_transform_image(orc_label* lab, int64_t n, const orc_label* src, const orc_label* dst, int64_t m,
                          const orc_label* mask, int fill_missing);
 int64_t orc_relabel_image(orc_label* lab, int64_t n, int64_t min_size);
+// host libm as the reference calls it: function 0 = std::log2, 1 = std::log, 2 = std::pow(x, 1.5)
+void orc_libm_eval(int function, const double* in, double* out, int64_t n);
 
 #ifdef __cplusplus
 }

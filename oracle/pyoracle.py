@@ -299,6 +299,14 @@ def relabel_image(labels, min_size=0):
     return out, int(n)
 
 
+def libm_eval(function, x):
+    """std::log2 (0) / std::log (1) / std::pow(x, 1.5) (2) of the host libm, as the reference's features call them."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    lib().orc_libm_eval(C.c_int(function), _p(x), _p(out), C.c_int64(x.size))
+    return out
+
+
 def _tree_potentials(L, prefix, order, merge_probs, region_probs, ptr):
     order = np.ascontiguousarray(order, dtype=np.uint32)
     cap = 3 * len(order) + 1
