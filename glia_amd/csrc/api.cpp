@@ -678,14 +678,14 @@ int glia_hmt_forest_load(glia_hmt_ctx* c, int n_models, const char* const* paths
   f->device = c->device;
   memset(&f->dc, 0, sizeof(f->dc));
   f->dc.kind = 0; f->dc.n_models = n_models;
-  if (dist) { f->dc.dim0 = (int)dist[0]; f->dc.dim1 = (int)dist[1]; f->dc.threshold = dist[2]; }
+  if (dist) {
+    f->dc.dim0 = (int)dist[0]; f->dc.dim1 = (int)dist[1]; f->dc.threshold = dist[2];
+    if (f->dc.dim0 < 0 || f->dc.dim1 < 0) { delete f; set_error("forest_load: negative distributor dimension"); return GLIA_HMT_ERR_ARG; }
+    f->max_var = std::max(f->dc.dim0, f->dc.dim1);
+  }
   for (int i = 0; i < n_models; ++i) {
     HostForest hf;
     int rc = load_forest_file(paths[i], predict_label, &hf);
-    if (rc == GLIA_HMT_OK && i > 0 && hf.ntree != f->dc.f[0].ntree) {
-      set_error("forest_load: ensemble members with different tree counts are not supported");
-      rc = GLIA_HMT_ERR_UNSUPPORTED;
-    }
     if (rc == GLIA_HMT_OK) rc = upload_forest(hf, f, i, c->stream);
     if (rc) { glia_hmt_forest_free(f); return rc; }
   }

@@ -1025,11 +1025,12 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
         PH(5);
         continue;
       } else if (st.clf.kind == 0) {
-        const int ntree = st.clf.f[0].ntree;    // the three ensemble members are required to have equal size
+        int ntree = st.clf.f[0].ntree;          // ensemble members may differ in size: iterate over the largest
+        for (int m = 1; m < st.clf.n_models; ++m) ntree = st.clf.f[m].ntree > ntree ? st.clf.f[m].ntree : ntree;
         for (uint32_t i = tid; i < cn * (uint32_t)ntree; i += kBcThreads) {
           const uint32_t j = i / ntree, t = i % ntree;
           const int m = s.model[cur][j];
-          if (m < 0) continue;
+          if (m < 0 || (int)t >= st.clf.f[m].ntree) continue;
           if (forest_vote(st.clf.f[m], (int)t, &L.feat[j * fstride])) atomicAdd(&s.votes[j], 1);
         }
       }

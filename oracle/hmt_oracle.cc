@@ -1002,6 +1002,11 @@ int orc_feat_dim(int dim, const orc_feat_cfg* c) {
   return bf + 3 * rf;
 }
 
+// alg::EnsembleRandomForest + opt::ThresholdModelDistributor (alg/rf.hxx:63-98, type/function.hxx:71-85): set by
+// orc_merge_order_bc_ensemble for the duration of one call.
+struct EnsembleSel { const orc_forest* const* models; int dim0, dim1; double threshold; };
+static const EnsembleSel* g_ensemble = nullptr;
+
 int64_t orc_merge_order_bc(orc_rag* h, const orc_feat_cfg* c, const orc_forest* forest, int stub_index,
                            orc_label* order_out, double* sal_out, double* feats_out, int64_t cap,
                            int64_t* n_feat_evals) {
@@ -1025,6 +1030,11 @@ int64_t orc_merge_order_bc(orc_rag* h, const orc_feat_cfg* c, const orc_forest* 
     ++nEval;
   };
   auto pred = [&](ItemData const& data) -> double {
+    if (g_ensemble) {   // type/function.hxx:80-84: model 0 if x[dim1] < thr, else 1 if x[dim0] < thr, else 2
+      const EnsembleSel& e = *g_ensemble;
+      const int m = data[e.dim1] < e.threshold ? 0 : data[e.dim0] < e.threshold ? 1 : 2;
+      return forestPredict(e.models[m], data.data(), (int)data.size());   // alg/rf.hxx:97-98
+    }
     if (forest) return forestPredict(forest, data.data(), (int)data.size());
     return 1.0 - data[stub_index];
   };
@@ -1045,6 +1055,16 @@ int64_t orc_merge_order_bc(orc_rag* h, const orc_feat_cfg* c, const orc_forest* 
       for (int k = 0; k < d; ++k) feats_out[i * d + k] = f[k];
     }
   }
+  return n;
+}
+
+// hmt/main_merge_order_bc.cxx:103-109 (--bcm x3 --bcmd dim0 dim1 threshold)
+int64_t orc_merge_order_bc_ensemble(orc_rag* h, const orc_feat_cfg* c, const orc_forest* const* models, int dim0, int dim1,
+                                    double threshold, orc_label* order_out, double* sal_out, double* feats_out, int64_t cap) {
+  EnsembleSel e = {models, dim0, dim1, threshold};
+  g_ensemble = &e;
+  const int64_t n = orc_merge_order_bc(h, c, nullptr, 0, order_out, sal_out, feats_out, cap, nullptr);
+  g_ensemble = nullptr;
   return n;
 }
 
@@ -1425,6 +1445,19 @@ int64_t orc_label_transform(const orc_label* node_label, const int32_t* child0, 
   int64_t m = 0;
   for (auto const& lp : lmap) { src[m] = lp.first; dst[m] = lp.second; ++m; }
   return m;
+}
+
+// The restatements of util/stats.hxx used by the features, exported so that tests can pin them against the reference's own
+// header (oracle/_ref/ref_stats): out = entropy(a), entropy(b), distL1(a,b), distX2(a,b), amedian(a), amedian(b).
+void orc_stats_case(int n, const double* a, const double* b, double* out) {
+  std::vector<double> va(a, a + n), vb(b, b + n);
+  out[0] = entropy(va); out[1] = entropy(vb); out[2] = distL1(va, vb); out[3] = distX2(va, vb);
+  out[4] = amedian(va); out[5] = amedian(vb);
+}
+// util/stats.hxx:264-277 (MLP input scaling, main_merge_order_bc.cxx:130-137)
+void orc_rescale(int n, double* feat, const double* mn, const double* mx, double out_min, double out_max) {
+  const double outputDiff = out_max - out_min;
+  for (int i = 0; i < n; ++i) feat[i] = outputDiff * (feat[i] - mn[i]) / (mx[i] - mn[i] + FEPS) + out_min;
 }
 
 // The host libm functions the reference's features call: std::log2 (util/stats.hxx:150), std::log (glia_base.hxx:80-81),

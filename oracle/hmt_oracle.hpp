@@ -118,6 +118,10 @@ int64_t orc_merge_order_pb(orc_rag*, const float* pb, int type, int update_regio
 int64_t orc_merge_order_bc(orc_rag*, const orc_feat_cfg*, const orc_forest* forest,
                            int stub_index, orc_label* order, double* sal,
                            double* feats_out, int64_t cap, int64_t* n_feat_evals);
+// alg::EnsembleRandomForest with opt::ThresholdModelDistributor(dim0, dim1, threshold) (alg/rf.hxx:63-98,
+// type/function.hxx:71-85; hmt/main_merge_order_bc.cxx:103-109): three models.
+int64_t orc_merge_order_bc_ensemble(orc_rag*, const orc_feat_cfg*, const orc_forest* const* models, int dim0, int dim1,
+                                    double threshold, orc_label* order, double* sal, double* feats_out, int64_t cap);
 int orc_feat_dim(int dim, const orc_feat_cfg*);
 
 // bc_feat pipeline (hmt/main_bc_feat.cxx:27-112): features for a given order.
@@ -158,6 +162,9 @@ void orc_transform_image(orc_label* lab, int64_t n, const orc_label* src, const 
                          const orc_label* mask, int fill_missing);
 int64_t orc_relabel_image(orc_label* lab, int64_t n, int64_t min_size);
 // host libm as the reference calls it: function 0 = std::log2, 1 = std::log, 2 = std::pow(x, 1.5)
+// util/stats.hxx restatements (entropy :145-152, distL1 :155-163, distX2 :177-185, amedian :83-91, rescale :264-277)
+void orc_stats_case(int n, const double* a, const double* b, double* out6);
+void orc_rescale(int n, double* feat, const double* mn, const double* mx, double out_min, double out_max);
 void orc_libm_eval(int function, const double* in, double* out, int64_t n);
 
 #ifdef __cplusplus

@@ -218,6 +218,22 @@ class Rag:
             return order[:n].copy(), sal[:n].copy(), feats[:n].copy()
         return order[:n].copy(), sal[:n].copy()
 
+    def merge_order_bc_ensemble(self, cfg, forests, dim0, dim1, threshold, want_feats=False):
+        """alg::EnsembleRandomForest + ThresholdModelDistributor: forests = three make_forest() results."""
+        cap = max(self.num_regions, 1)
+        order = np.empty((cap, 3), np.uint32); sal = np.empty(cap, np.float64)
+        d = lib().orc_feat_dim(C.c_int(self.dim), C.byref(cfg))
+        feats = np.empty((cap, d), np.float64) if want_feats else None
+        arr = (C.c_void_p * 3)(*[C.addressof(f) for f in forests])
+        lib().orc_merge_order_bc_ensemble.restype = C.c_int64
+        n = lib().orc_merge_order_bc_ensemble(self.h, C.byref(cfg), arr, C.c_int(dim0), C.c_int(dim1), C.c_double(threshold),
+                                              _p(order), _p(sal), _p(feats), C.c_int64(cap))
+        if n < 0:
+            raise RuntimeError("orc_merge_order_bc_ensemble failed: %d" % n)
+        if want_feats:
+            return order[:n].copy(), sal[:n].copy(), feats[:n].copy()
+        return order[:n].copy(), sal[:n].copy()
+
     def bc_feat(self, cfg, order, saliencies=None, init_sal=1.0, sal_bias=1.0):
         order = np.ascontiguousarray(order, dtype=np.uint32)
         d = lib().orc_feat_dim(C.c_int(self.dim), C.byref(cfg))
@@ -297,6 +313,21 @@ def relabel_image(labels, min_size=0):
     out = np.ascontiguousarray(labels, dtype=np.uint32).copy()
     n = lib().orc_relabel_image(_p(out), C.c_int64(out.size), C.c_int64(min_size))
     return out, int(n)
+
+
+def stats_case(a, b):
+    """entropy(a), entropy(b), distL1, distX2, amedian(a), amedian(b) of the util/stats.hxx restatements"""
+    a = np.ascontiguousarray(a, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64)
+    out = np.empty(6)
+    lib().orc_stats_case(C.c_int(a.size), _p(a), _p(b), _p(out))
+    return out
+
+
+def rescale(feat, mn, mx, out_min=-1.0, out_max=1.0):
+    f = np.ascontiguousarray(feat, dtype=np.float64).copy()
+    mn = np.ascontiguousarray(mn, dtype=np.float64); mx = np.ascontiguousarray(mx, dtype=np.float64)
+    lib().orc_rescale(C.c_int(f.size), _p(f), _p(mn), _p(mx), C.c_double(out_min), C.c_double(out_max))
+    return f
 
 
 def libm_eval(function, x):

@@ -86,6 +86,37 @@ def test_merge_order_bc_cli(tools, tmp_path):
     assert np.allclose(got, f_ref, rtol=6e-8, atol=1e-12)            # FLT_PREC = 8 significant digits: half a unit of the 8th
 
 
+def test_merge_order_bc_cli_ensemble(tools, tmp_path):
+    """--bcm m0 --bcm m1 --bcm m2 --bcmd dim0 dim1 threshold (hmt/main_merge_order_bc.cxx:103-109)"""
+    from oracle import pyoracle as O
+    import _rf
+    shape = (32, 32, 32)
+    labels, pb = O.synth(shape, 8, 16)
+    cfg = O.make_cfg(pb, rb=[(pb, 8, 0.0, 1.0)])
+    _, _, f0 = O.Rag(labels).merge_order_bc(cfg, None, stub_index=31, want_feats=True)
+    dim0, dim1 = 35, 35 + 23
+    thr = float(np.median(np.concatenate([f0[:, dim0], f0[:, dim1]]))) + 0.5
+    rng = np.random.default_rng(5)
+    forests = [_rf.random_forest(rng, nt, 6, f0) for nt in (15, 31, 7)]
+    models = []
+    for k, f in enumerate(forests):
+        models.append(str(tmp_path / ("m%d.bin" % k))); _rf.write_model(models[-1], f)
+    seg, pbf, order_f, sal_f = (str(tmp_path / n) for n in ("seg.mha", "pb.mha", "order.txt", "sal.txt"))
+    write_mha(seg, labels)
+    write_mha(pbf, pb)
+    subprocess.check_call([os.path.join(tools, "merge_order_bc"), "--bct", "1", "--bcm", models[0], "--bcm", models[1], "--bcm", models[2],
+                           "--bcmd", str(dim0), "--bcmd", str(dim1), "--bcmd", repr(thr), "-s", seg, "--pb", pbf,
+                           "--rbi", pbf, "--rbb", "8", "--rbl", "0.0", "--rbu", "1.0", "--bt", "0.2", "0.5", "0.8",
+                           "-o", order_f, "--sal", sal_f])
+    o_ref, s_ref = O.Rag(labels).merge_order_bc_ensemble(cfg, [O.make_forest(f, -1) for f in forests], dim0, dim1, thr)
+    assert (np.loadtxt(order_f, dtype=np.int64).reshape(-1, 3) == o_ref).all()
+    assert open(sal_f).read().split("\n")[:-1] == [_g(s) for s in s_ref]
+    # two models, or three without the distributor arguments: the reference's message and exit code
+    r = subprocess.run([os.path.join(tools, "merge_order_bc"), "--bct", "1", "--bcm", models[0], "--bcm", models[1], "--bcm", models[2],
+                        "-s", seg, "--pb", pbf, "-o", order_f], capture_output=True)
+    assert r.returncode == 1 and b"model distributor needs 3 arguments" in r.stderr
+
+
 def read_mha(path):
     raw = open(path, "rb").read()
     i = raw.index(b"ElementDataFile = LOCAL\n") + len(b"ElementDataFile = LOCAL\n")

@@ -58,3 +58,105 @@ def test_constant_pb_tie_torture():
     ro, rs = run_ref(rag, pb, 2, False)
     oo, os_ = rag.merge_order_pb(pb, 2, False)
     assert (ro == oo).all() and (rs == os_).all()
+
+
+# ---- merge tree: genTree / genTreeWithNodePotentials / resolveTreeGreedy (hmt/tree_build.hxx, hmt/tree_greedy.hxx) ----
+REF_TREE = os.path.join(os.path.dirname(REF), "ref_tree")
+REF_STATS = os.path.join(os.path.dirname(REF), "ref_stats")
+
+
+def run_ref_tree(trees):
+    """trees: list of (order, merge_probs | None, region_probs | None) -> per-tree node arrays, single picks, joint picks"""
+    _ensure_ref()
+    if not os.path.exists(REF_TREE):
+        pytest.skip("oracle/_ref/ref_tree not built")
+    lines = ["%d" % len(trees)]
+    for order, mp, rp in trees:
+        lines.append("%d %d %d" % (len(order), mp is not None, rp is not None))
+        lines += ["%d %d %d" % tuple(r) for r in order]
+        if mp is not None:
+            lines += [repr(float(p)) for p in mp]
+        if rp is not None:
+            lines += [repr(float(p)) for p in rp]
+    out = subprocess.run([REF_TREE], input="\n".join(lines) + "\n", capture_output=True, text=True, check=True).stdout.split("\n")
+    k = 0
+    nodes = []
+    for _ in trees:
+        assert out[k].startswith("T ")
+        n = int(out[k].split()[1]); k += 1
+        rows = [out[k + i].split() for i in range(n)]; k += n
+        nodes.append((np.array([int(r[0]) for r in rows], np.uint32), np.array([int(r[1]) for r in rows], np.int32),
+                      np.array([int(r[2]) for r in rows], np.int32), np.array([int(r[3]) for r in rows], np.int32),
+                      np.array([float(r[4]) for r in rows])))
+    n = int(out[k].split()[1]); k += 1
+    single = np.array([int(out[k + i]) for i in range(n)], np.int32); k += n
+    n = int(out[k].split()[1]); k += 1
+    joint = np.array([[int(x) for x in out[k + i].split()] for i in range(n)], np.int32).reshape(-1, 2)
+    return nodes, single, joint
+
+
+def _orders(seed):
+    rng = np.random.default_rng(seed)
+    shape = tuple(int(x) for x in rng.integers(10, 30, size=int(rng.integers(2, 4))))
+    S = int(rng.integers(3, 7))
+    lab, pb = O.synth(shape, S, 2 * S, seed=int(rng.integers(1, 1 << 40)), variant=int(rng.integers(0, 2)))
+    o1, s1 = O.Rag(lab, only_contour=True).merge_order_pb(pb, type=2)
+    o2, s2 = O.Rag(lab, only_contour=True).merge_order_pb(pb, type=1)
+    return rng, (o1, s1), (o2, s2)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_tree_potentials_and_greedy_picks_match_reference(seed):
+    """oracle gen_tree / potentials / greedy picks (one tree and several trees) vs the reference's own headers, incl.
+    equal-potential ties (constant and coarsely quantised merge probabilities) and forests (non-mutual RAGs)"""
+    rng, (o1, s1), (o2, s2) = _orders(seed)
+    mode = seed % 4
+    if mode == 0:   p1, p2 = np.clip(1.0 + 2.5 * s1, 0, 1), np.clip(1.0 + 2.5 * s2, 0, 1)
+    elif mode == 1: p1, p2 = np.full(len(o1), 0.5), np.full(len(o2), 0.5)                               # everything ties
+    elif mode == 2: p1, p2 = np.round(rng.random(len(o1)) * 4) / 4, np.round(rng.random(len(o2)) * 4) / 4   # many ties, 0 and 1
+    else:           p1, p2 = None, None                                                                  # no probabilities: all 1
+    rp = (True, True) if seed % 3 == 0 else (None, None)
+    # region probabilities are one per NODE: size them from the oracle's node count
+    n1 = len(O.gen_tree(o1)[0]); n2 = len(O.gen_tree(o2)[0])
+    r1 = rng.random(n1) if rp[0] is not None else None
+    r2 = rng.random(n2) if rp[1] is not None else None
+    if r1 is not None:
+        r1[::7] = 0.0                                                      # max(p, FEPS) branch
+    nodes, single, joint = run_ref_tree([(o1, p1, r1), (o2, p2, r2)])
+    mine = [O.tree_potentials(o1, p1, r1), O.tree_potentials(o2, p2, r2)]
+    for (lab, par, c0, c1, pot), ref in zip(mine, nodes):
+        assert (lab == ref[0]).all() and (par == ref[1]).all() and (c0 == ref[2]).all() and (c1 == ref[3]).all()
+        assert (pot == ref[4]).all()                                       # %.17g round-trips doubles exactly
+    # genTree alone (labels / parents / children) = the same arrays
+    g = O.gen_tree(o1)
+    assert (g[0] == nodes[0][0]).all() and (g[1] == nodes[0][1]).all()
+    assert (O.resolve_tree_greedy(*mine[0][1:]) == single).all()
+    pt, pn = O.resolve_trees_greedy(mine)
+    assert (pt == joint[:, 0]).all() and (pn == joint[:, 1]).all()
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_stats_match_reference(seed):
+    """entropy / distL1 / distX2 / amedian / rescale restatements vs util/stats.hxx compiled in place"""
+    _ensure_ref()
+    if not os.path.exists(REF_STATS):
+        pytest.skip("oracle/_ref/ref_stats not built")
+    rng = np.random.default_rng(100 + seed)
+    cases = []
+    for _ in range(25):
+        n = int(rng.integers(1, 40))
+        tot = int(rng.integers(1, 5000))
+        a = rng.multinomial(tot, rng.dirichlet(np.ones(n))) / tot          # histograms as the features see them (zeros included)
+        b = rng.multinomial(tot + 3, rng.dirichlet(np.ones(n))) / (tot + 3)
+        if rng.random() < 0.3:
+            a = np.round(rng.random(n) * 4) / 4; b = np.round(rng.random(n) * 4) / 4     # ties for amedian, exact zeros
+        cases.append((a, b))
+    text = "%d\n" % len(cases) + "".join("%d\n%s\n%s\n" % (len(a), " ".join(repr(float(x)) for x in a), " ".join(repr(float(x)) for x in b))
+                                         for a, b in cases)
+    out = subprocess.run([REF_STATS], input=text, capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    for i, (a, b) in enumerate(cases):
+        ref = np.array([float(x) for x in out[2 * i].split()])
+        got = O.stats_case(a, b)
+        assert (got == ref).all(), (i, got, ref)
+        rs = np.array([float(x) for x in out[2 * i + 1].split()])
+        assert (O.rescale(a, np.minimum(a, b), np.maximum(a, b)) == rs).all()
