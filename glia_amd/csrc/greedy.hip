@@ -21,7 +21,9 @@
 // Dense region ids: leaves 0..R-1 ascending by label, merged regions R+k; the map id -> key is monotone,
 // so every key comparison of the reference is an id comparison here.
 #include <cstring>
+#include <limits>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_segmented_radix_sort.hpp>
 
 #include "greedy_common.hpp"
@@ -88,8 +90,31 @@ struct GreedyState {
   uint32_t *mark0, *mark1;        // [2*R0], zero between contractions
   uint32_t* order;                // [R0][3] dense ids
   double* sal_out;
-  unsigned long long* ctrl;       // [0] merges done, [1] edges used, [2] pool used, [3] status, [4] values used
+  unsigned long long* ctrl;       // [0] merges done, [1] edges used, [2] pool used, [3] status, [4] values used, [5] window queue: wlo
   unsigned long long max_iters;
+  // ---- window queue (greedy_window_kernel, see there) ----
+  struct FatEntry* fpool;         // incident-edge lists with the edge's immutable data inlined (replaces pool there)
+  uint32_t wB, E0;                // saliency cells; initial edges
+  uint32_t* whead;                // [wB] newest created edge of the cell's list (kNone = empty); atomics only
+  uint32_t* wcnt;                 // [wB] live queue items of the cell below the threshold (sorted array + list); atomics only
+  uint32_t* wnext;                // [Ecap] list links
+  const double* wrange;           // [0] smallest initial saliency, [1] cells per unit of saliency
+  uint32_t* isort;                // [E0] initial edges by descending (saliency, seq)
+  uint32_t* ige;                  // [wB + 1] initial edges whose cell is >= c
+  uint2 *e_hu, *e_hv;             // [Ecap] (offset, length) of the incident-edge lists of an edge's two regions
+};
+
+// An incident-edge list entry of the window kernel: everything a contraction needs from the edge and from the
+// neighbour, so that one 32-byte load replaces the second dependent round trip (edge record, neighbour's list offset).
+// All of it is immutable for the lifetime of the edge / region.
+struct __attribute__((aligned(16))) FatEntry {
+  uint32_t eid;      // edge slot, kNone = tombstone
+  uint32_t rs;       // the neighbour this entry leads to
+  uint32_t n;        // boundary voxels of the edge
+  uint32_t pos;      // position of the edge's other entry, in rs's list
+  uint32_t off;      // adj_off[rs]
+  uint32_t len;      // adj_len[rs]
+  double mean;       // boundary mean of the edge
 };
 
 
@@ -482,6 +507,576 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
 #endif
 }
 
+// =====================================================================================================================
+// The window queue: the priority queue of the pb-mean loop without a tree.
+//
+// The tournament tree above costs a contraction ~13 k of its ~24 k cycles: every new or dying edge dirties a 256-ary
+// node somewhere in the slot space, each dirty node is a 4 KB gather, and three levels are three dependent round trips
+// (plus two for the pop).  The queue only ever has to answer "largest (saliency, seq)", and popped saliencies fall
+// (almost) monotonically, so the live items are kept in two places instead:
+//   * GLOBAL, below a threshold key tau:
+//       - the INITIAL edges in one array sorted by descending key (rocPRIM, once): consumed front to back by a pointer,
+//         whatever the ties (a 1024^3 Q8 volume has tie groups of thousands of equal means);
+//       - edges CREATED by contractions in singly linked lists, one per saliency CELL (a monotone quantisation of the
+//         saliency, ~E0/4 cells).  Insert = atomicExch on the cell head + one store, nobody waits for it.
+//       A per-cell counter holds the live items of both kinds; a dying edge only decrements it (dead array entries and
+//       list nodes are skipped when their cell is loaded).
+//   * LDS WINDOW, above tau: unordered, <= kWinCap entries carrying (saliency, seq, edge, both regions and their list
+//     headers).  Its maximum is the maximum of the queue; it is found by one scan of the window per contraction, which
+//     also applies the (rare) deaths of window items.  New edges above tau go straight into the window.  When the window
+//     runs empty, tau moves down: whole cells while they fit, then a prefix of the next cell's sorted initial entries
+//     (tau = key of the first entry left behind) plus that cell's list nodes above tau.
+// Exactness: the order is (saliency, seq) with the very seq numbers of the tree kernel, so the result is bit-identical
+// (gate: SHA-1 of the whole 1024^3 order, tools/pb_bench.py); no assumption about the linkage is made (a new edge may
+// well beat the current maximum: it lands in the window).  A cell whose LIST part alone exceeds the window (massive
+// exact ties among created edges) stops the kernel with ST_NEED_TREE and the host continues with the tree kernel from
+// the same state (leaf keys are the ground truth of both queues).
+// With the fat list entries (FatEntry) and the list headers carried in the window a contraction is ONE dependent global
+// round trip -- the two incident-edge lists -- plus LDS work; its stores are fire-and-forget.
+// =====================================================================================================================
+constexpr uint32_t kWinCap = 1536;          // window slots (live items + holes)
+constexpr uint32_t kWinBudget = 768;        // a reload stops before exceeding this many items ...
+constexpr uint32_t kWinMinLoad = 192;       // ... and goes on to the next block of cells below this many
+constexpr uint32_t kWinMinPartial = 96;     // a cell is split only if at least this much room is left
+constexpr uint32_t kKillMax = 8;
+constexpr int kNW = kGreedyThreads / 64;
+struct WinShared {
+  double sal[kWinCap];
+  unsigned long long seq[kWinCap];          // 0 = hole
+  uint32_t e[kWinCap], u[kWinCap], v[kWinCap];
+  uint2 hu[kWinCap], hv[kWinCap];           // (offset, length) of u's and v's incident-edge lists
+  uint32_t n;                               // slots in use
+  // threshold: an item is in the window iff cell(sal) > cthr, or cell(sal) == cthr and (sal, seq) > (tsal, tseq)
+  int cthr; double tsal; unsigned long long tseq;
+  uint32_t iptr;                            // initial entries before this index of the sorted array are consumed
+  uint32_t nk, kovf, kill[kKillMax];        // edges that died in this contraction and sit in the window
+  Key part[kNW];                            // per-wave maxima of the last scan (arg = slot)
+  uint32_t wsum[kNW];                       // block scan scratch
+  uint32_t bcast, maxcell, err, moved, need_tree;
+};
+struct WinWork {                            // the neighbour table of one contraction (small case)
+  uint32_t mk[kMarkSlots], mv0[kMarkSlots], mv1[kMarkSlots];     // neighbour + 1, staged index + 1 of the (r0,rs) / (r1,rs) entry
+  uint32_t items[kMarkMax], newpos[kMarkMax], nitems, newcount, bad;
+  FatEntry stage[kMarkMax];
+};
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }   // global stores stay in flight
+
+__device__ __forceinline__ uint32_t win_cell(double sal, double smin, double scale, uint32_t B) {
+  double t = (sal - smin) * scale;          // monotone in sal (saliencies are never NaN: sdivide guards the division)
+  t = t > 0.0 ? t : 0.0;
+  return t >= (double)(B - 1u) ? B - 1u : (uint32_t)t;
+}
+__device__ __forceinline__ uint32_t ld_l2(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_l2(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool win_above(const WinShared& w, int cell, double sal, unsigned long long seq) {
+  return cell > w.cthr || (cell == w.cthr && (sal > w.tsal || (sal == w.tsal && seq > w.tseq)));
+}
+
+// inclusive block scan of one value per thread (every thread calls; two barriers)
+__device__ __forceinline__ uint32_t block_scan_incl(uint32_t v, uint32_t* wsum, int tid, uint32_t* total) {
+  const int lane = tid & 63, wave = tid >> 6;
+  uint32_t x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, d); if (lane >= d) x += y; }
+  __syncthreads();
+  if (lane == 63) wsum[wave] = x;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < kNW; ++i) { const uint32_t s = wsum[i]; if (i < wave) base += s; tot += s; }
+  *total = tot;
+  return base + x;
+}
+
+__device__ __forceinline__ void win_put(WinShared& w, uint32_t slot, double sal, unsigned long long seq, uint32_t e, uint32_t u, uint32_t v, uint2 hu, uint2 hv) {
+  w.sal[slot] = sal; w.seq[slot] = seq; w.e[slot] = e; w.u[slot] = u; w.v[slot] = v; w.hu[slot] = hu; w.hv[slot] = hv;
+}
+// edge e of the global storage into the window if it is alive
+__device__ __forceinline__ void win_take(const GreedyState& st, WinShared& w, uint32_t e) {
+  const unsigned long long q = st.pq.leaf_seq[e];
+  const double sl = st.pq.leaf_sal[e];
+  const uint32_t u = st.e_u[e], v = st.e_v[e];
+  const uint2 hu = st.e_hu[e], hv = st.e_hv[e];
+  if (q != 0) {
+    const uint32_t slot = atomicAdd(&w.n, 1u);
+    if (slot < kWinCap) win_put(w, slot, sl, q, e, u, v, hu, hv); else w.err = 1;
+  }
+}
+
+// one pass over the window: applies this contraction's deaths, completes the list header of the region just created
+// (its length was not known when its edges were inserted), leaves the per-wave maxima in w.part.
+// Ends with a FULL barrier: every global store of the contraction is done before the next one reads anything.
+__device__ __forceinline__ void win_scan(const GreedyState& st, WinShared& w, int tid, uint32_t r2, uint32_t r2len) {
+  Key k;
+  k.sal = -__builtin_inf(); k.seq = 0; k.arg = 0;
+  const uint32_t n = w.n, nk = w.nk < kKillMax ? w.nk : kKillMax, kovf = w.kovf;
+  for (uint32_t i = tid; i < n; i += kGreedyThreads) {
+    const unsigned long long q = w.seq[i];
+    if (q == 0) continue;
+    const uint32_t e = w.e[i];
+    bool dead = false;
+    for (uint32_t j = 0; j < nk; ++j) dead = dead || w.kill[j] == e;
+    if (kovf) dead = dead || st.pq.leaf_seq[e] == 0;          // more deaths than the list holds (rare): ask the leaf array
+    if (dead) { w.seq[i] = 0; continue; }
+    if (w.v[i] == r2) w.hv[i].y = r2len;
+    Key c; c.sal = w.sal[i]; c.seq = q; c.arg = i;
+    if (better(c, k)) k = c;
+  }
+  k = wave_max(k);
+  if ((tid & 63) == 0) w.part[tid >> 6] = k;
+  __syncthreads();
+  if (tid == 0) { w.nk = 0; w.kovf = 0; }
+}
+__device__ __forceinline__ Key win_root(const WinShared& w) {
+  Key b = w.part[0];
+#pragma unroll
+  for (int j = 1; j < kNW; ++j) { const Key c = w.part[j]; if (better(c, b)) b = c; }
+  return b;
+}
+
+// squeeze the holes out (every thread calls)
+__device__ __forceinline__ void win_compact(WinShared& w, int tid) {
+  constexpr uint32_t per = kWinCap / kGreedyThreads;
+  static_assert(per * kGreedyThreads == kWinCap, "window capacity");
+  double sal[per]; unsigned long long seq[per]; uint32_t e[per], u[per], v[per]; uint2 hu[per], hv[per];
+  uint32_t live = 0;
+  const uint32_t n = w.n;
+#pragma unroll
+  for (uint32_t j = 0; j < per; ++j) {
+    const uint32_t i = (uint32_t)tid * per + j;
+    seq[j] = i < n ? w.seq[i] : 0ull;
+    sal[j] = w.sal[i]; e[j] = w.e[i]; u[j] = w.u[i]; v[j] = w.v[i]; hu[j] = w.hu[i]; hv[j] = w.hv[i];
+    live += seq[j] != 0;
+  }
+  uint32_t total;
+  uint32_t o = block_scan_incl(live, w.wsum, tid, &total) - live;      // barriers inside: every read above is done
+#pragma unroll
+  for (uint32_t j = 0; j < per; ++j) if (seq[j] != 0) { win_put(w, o, sal[j], seq[j], e[j], u[j], v[j], hu[j], hv[j]); ++o; }
+  if (tid == 0) w.n = total;
+  __syncthreads();
+}
+
+__device__ __forceinline__ void win_push_global(const GreedyState& st, uint32_t e, uint32_t cell) {
+  const uint32_t old = atomicExch(&st.whead[cell], e);
+  st.wnext[e] = old;
+  atomicAdd(&st.wcnt[cell], 1u);
+}
+
+// every live window item into its cell's list (initial edges too: their place in the sorted array is gone); afterwards
+// the window is empty and the threshold sits above everything (every thread calls)
+__device__ __forceinline__ void win_flush(const GreedyState& st, WinShared& w, int tid) {
+  const double smin = st.wrange[0], scale = st.wrange[1];
+  if (tid == 0) w.maxcell = 0;
+  __syncthreads();
+  const uint32_t n = w.n;
+  uint32_t mc = 0;
+  for (uint32_t i = tid; i < n; i += kGreedyThreads) {
+    if (w.seq[i] == 0) continue;
+    const uint32_t c = win_cell(w.sal[i], smin, scale, st.wB);
+    win_push_global(st, w.e[i], c);
+    mc = mc > c + 1u ? mc : c + 1u;
+  }
+  if (mc) atomicMax(&w.maxcell, mc);
+  __syncthreads();
+  if (tid == 0) {
+    if (w.maxcell && (int)w.maxcell - 1 >= w.cthr) { w.cthr = (int)w.maxcell - 1; w.tsal = __builtin_inf(); w.tseq = ~0ull; }
+    w.n = 0;
+  }
+  __syncthreads();
+}
+
+// initial entries [a, b) of the sorted array into the window (every thread calls; no barrier)
+__device__ __forceinline__ void win_take_initial(const GreedyState& st, WinShared& w, uint32_t a, uint32_t b, int tid) {
+  for (uint32_t i = a + (uint32_t)tid; i < b; i += kGreedyThreads) win_take(st, w, st.isort[i]);
+}
+
+// The window holds no live item: move the threshold down.  Returns 0 = loaded something (or made progress), 1 = the
+// queue is empty, 2 = a cell's list does not fit the window (every thread calls; contains barriers)
+__device__ __forceinline__ int win_reload(const GreedyState& st, WinShared& w, int tid) {
+  __syncthreads();                       // (vmcnt(0) inside) this workgroup's list pushes and counter updates are done
+  if (tid == 0) { w.n = 0; w.need_tree = 0; }
+  __syncthreads();
+  uint32_t c_hi = (uint32_t)(w.cthr + 1) < st.wB ? (uint32_t)(w.cthr + 1) : st.wB, loaded = 0, iptr = w.iptr;
+  int result = 1;
+  while (c_hi != 0) {
+    const bool valid = (uint32_t)tid < c_hi;
+    const uint32_t c = valid ? c_hi - 1u - (uint32_t)tid : 0u;
+    const uint32_t cn = valid ? ld_l2(&st.wcnt[c]) : 0u;
+    uint32_t total;
+    const uint32_t incl = block_scan_incl(cn, w.wsum, tid, &total);
+    const bool ok = valid && incl <= kWinBudget - loaded;
+    const uint32_t m = (uint32_t)__syncthreads_count(ok ? 1 : 0);       // ok is monotone in tid: the first m cells fit whole
+    const uint32_t nvalid = c_hi < (uint32_t)kGreedyThreads ? c_hi : (uint32_t)kGreedyThreads;
+    if (m != 0) {
+      const uint32_t c_lo = c_hi - m;
+      if ((uint32_t)tid == m - 1u) w.bcast = incl;
+      const uint32_t i_to = st.ige[c_lo];                                // initial entries with cell >= c_lo
+      win_take_initial(st, w, iptr, i_to, tid);
+      iptr = i_to > iptr ? i_to : iptr;
+      if ((uint32_t)tid < m) {
+        uint32_t e = ld_l2(&st.whead[c]);
+        if (e != kNone) {
+          st_l2(&st.whead[c], kNone);
+          if (cn != 0) while (e != kNone) { const uint32_t nx = st.wnext[e]; win_take(st, w, e); e = nx; }
+        }
+        if (cn != 0) st_l2(&st.wcnt[c], 0u);
+      }
+      __syncthreads();
+      loaded += w.bcast;
+      c_hi = c_lo;
+      if (loaded) result = 0;
+    }
+    if (m < nvalid) {
+      // cell c* = c_hi - 1 does not fit whole: a prefix of its sorted initial entries, and its list nodes above the new tau
+      const uint32_t room = kWinBudget - loaded;
+      const uint32_t cs = c_hi - 1u;
+      if (room >= kWinMinPartial || loaded == 0) {
+        const uint32_t seg_end = st.ige[cs];
+        const uint32_t ntake = seg_end > iptr ? (seg_end - iptr < room ? seg_end - iptr : room) : 0u;
+        const uint32_t before = w.n;
+        __syncthreads();                                                     // (everybody has read w.n)
+        win_take_initial(st, w, iptr, iptr + ntake, tid);
+        iptr += ntake;
+        double tsal = -__builtin_inf(); unsigned long long tseq = 0;       // segment exhausted: every list node is above tau
+        if (iptr < seg_end) { const uint32_t et = st.isort[iptr]; tsal = st.pq.leaf_sal[et]; tseq = (unsigned long long)et + 1ull; }
+        __syncthreads();
+        if (tid == 0) {
+          // the list of c*: count the live nodes above tau, move them if they fit and keep the others linked
+          uint32_t head = ld_l2(&st.whead[cs]), cnt_above = 0;
+          for (uint32_t e = head; e != kNone; e = st.wnext[e]) {
+            const unsigned long long q = st.pq.leaf_seq[e];
+            const double sl = st.pq.leaf_sal[e];
+            if (q != 0 && (sl > tsal || (sl == tsal && q > tseq))) ++cnt_above;
+          }
+          if (w.n + cnt_above > kWinCap) w.need_tree = 1;
+          else {
+            uint32_t keep_head = kNone, keep_tail = kNone;
+            for (uint32_t e = head; e != kNone;) {
+              const uint32_t nx = st.wnext[e];
+              const unsigned long long q = st.pq.leaf_seq[e];
+              const double sl = st.pq.leaf_sal[e];
+              if (q != 0) {
+                if (sl > tsal || (sl == tsal && q > tseq)) win_take(st, w, e);
+                else { if (keep_head == kNone) keep_head = e; else st.wnext[keep_tail] = e; keep_tail = e; }
+              }
+              e = nx;
+            }
+            if (keep_tail != kNone) st.wnext[keep_tail] = kNone;
+            st_l2(&st.whead[cs], keep_head);
+          }
+        }
+        __syncthreads();
+        if (w.need_tree) { result = 2; break; }
+        const uint32_t moved = w.n - before;
+        if (tid == 0) { if (moved) atomicSub(&st.wcnt[cs], moved); w.cthr = (int)cs; w.tsal = tsal; w.tseq = tseq; }
+        if (moved || ntake) result = 0;
+        c_hi = cs + 1u;                                                      // (c* stays the threshold cell)
+        __syncthreads();
+        if (tid == 0) w.iptr = iptr;
+        __syncthreads();
+        return result;
+      }
+      break;
+    }
+    if (loaded >= kWinMinLoad) break;      // else: a whole block of (nearly) empty cells, go on below it
+  }
+  __syncthreads();
+  if (tid == 0 && result != 2) { w.cthr = (int)c_hi - 1; w.tsal = __builtin_inf(); w.tseq = ~0ull; w.iptr = iptr; }
+  __syncthreads();
+  return result;
+}
+
+template <bool COND>
+__global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(GreedyState st) {
+  __shared__ WinShared w;
+  __shared__ WinWork s;
+  const int tid = threadIdx.x;
+  unsigned long long k = st.ctrl[0], ne = st.ctrl[1], pool_used = st.ctrl[2];
+  uint32_t status = ST_RUN;
+  if (tid == 0) {
+    w.n = 0; w.nk = 0; w.kovf = 0; w.err = 0; s.nitems = 0; s.newcount = 0; s.bad = 0;
+    w.cthr = (int)(long long)st.ctrl[5]; w.tsal = __longlong_as_double((long long)st.ctrl[6]); w.tseq = st.ctrl[7]; w.iptr = (uint32_t)st.ctrl[8];
+  }
+  for (uint32_t i = tid; i < kMarkSlots; i += kGreedyThreads) { s.mk[i] = 0; s.mv0[i] = 0; s.mv1[i] = 0; }
+  for (int i = tid; i < kNW; i += kGreedyThreads) { w.part[i].sal = -__builtin_inf(); w.part[i].seq = 0; w.part[i].arg = 0; }
+  __syncthreads();
+  const double smin = st.wrange[0], scale = st.wrange[1];
+  const PqTree& pq = st.pq;
+#ifdef GLIA_HMT_PROFILE
+  unsigned long long wph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wlast = __builtin_readcyclecounter(), wtiter = wlast;
+  unsigned long long wtb[5] = {0, 0, 0, 0, 0}, wnb[5] = {0, 0, 0, 0, 0}, wdb[5] = {0, 0, 0, 0, 0}, wreloads = 0, wcompacts = 0, wloaded = 0, winwin = 0;
+#define WPH(i) do { if (tid == 0) { unsigned long long tn = __builtin_readcyclecounter(); wph[i] += tn - wlast; wlast = tn; } } while (0)
+#else
+#define WPH(i) do {} while (0)
+#endif
+
+  for (unsigned long long it = 0; it < st.max_iters; ++it) {
+    const Key root = win_root(w);
+    if (root.seq == 0) {
+      WPH(5);
+      const int r = win_reload(st, w, tid);
+#ifdef GLIA_HMT_PROFILE
+      wreloads += 1; wloaded += w.n;
+#endif
+      WPH(6);
+      if (r == 1) { status = ST_DONE; break; }
+      if (r == 2) { status = ST_NEED_TREE; break; }
+      win_scan(st, w, tid, kNone, 0);
+      continue;
+    }
+    const uint32_t slot = root.arg;
+    const uint32_t e = w.e[slot], r0 = w.u[slot], r1 = w.v[slot];
+    const uint2 h0r = w.hu[slot], h1r = w.hv[slot];
+    const uint32_t off0 = h0r.x, len0 = h0r.y, off1 = h1r.x, len1 = h1r.y;
+    const uint32_t total = len0 + len1;
+    const uint32_t r2 = st.R0 + (uint32_t)k;
+    const uint32_t r2off = (uint32_t)pool_used;
+    WPH(0);
+    if (COND) {
+      // pre_merge condition (gadget/main_pre_merge.cxx:27-76), see the tree kernel: a rejected item leaves the queue for good
+      unsigned long long sz0 = st.rsz[r0], sz1 = st.rsz[r1]; double su0 = st.rsum[r0], su1 = st.rsum[r1];
+      const unsigned long long z2 = sz0 + sz1; const double w2 = su0 + su1;
+      if (sz0 > sz1) { const unsigned long long t = sz0; sz0 = sz1; sz1 = t; const double d = su0; su0 = su1; su1 = d; }
+      bool ok = sz0 < st.cond_t0;
+      if (!ok && st.cond_n > 1) {
+        if (sz0 < st.cond_t1 && sdivide(su0, (double)sz0, 0.0) > st.cond_rpb) ok = true;
+        if (!ok && sz1 < st.cond_t1 && sdivide(su1, (double)sz1, 0.0) > st.cond_rpb) ok = true;
+      }
+      if (!ok) {
+        __syncthreads();                 // every thread has read the slot
+        if (tid == 0) { w.seq[slot] = 0; pq.leaf_seq[e] = 0; }
+        __syncthreads();
+        win_scan(st, w, tid, kNone, 0);
+        continue;
+      }
+      if (tid == 0) { st.rsz[r2] = z2; st.rsum[r2] = w2; }               // TRegionMap::merge (updateRegion)
+    }
+    if (ne + total > st.Ecap) { status = ST_NEED_EDGES; break; }
+    if (pool_used + total > st.pool_cap) { status = ST_NEED_POOL; break; }
+    if (tid == 0) {
+      w.seq[slot] = 0;                                                   // popped (the other threads read the rest of the slot only)
+      st.order[3 * k + 0] = r0; st.order[3 * k + 1] = r1; st.order[3 * k + 2] = r2;
+      st.sal_out[k] = root.sal;
+      pq.leaf_seq[e] = 0;
+    }
+    const bool small = total <= kMarkMax;
+
+    // ---- the one round trip: the two lists; one table entry per distinct neighbour ----
+    for (uint32_t i = tid; i < total; i += kGreedyThreads) {
+      const bool side1 = i >= len0;
+      const FatEntry fe = st.fpool[side1 ? off1 + (i - len0) : off0 + i];
+      if (fe.eid == e || fe.eid == kNone) continue;
+      if (small) {
+        s.stage[i] = fe;
+        uint32_t h = (fe.rs * 2654435761u) >> 21;
+        while (true) {
+          const uint32_t old = atomicCAS(&s.mk[h], 0u, fe.rs + 1u);
+          if (old == 0u) { s.items[atomicAdd(&s.nitems, 1u)] = h; break; }
+          if (old == fe.rs + 1u) break;
+          h = (h + 1u) & (kMarkSlots - 1u);
+        }
+        (side1 ? s.mv1 : s.mv0)[h] = i + 1u;
+      } else (side1 ? st.mark1 : st.mark0)[fe.rs] = i + 1u;
+    }
+    if (small) lds_barrier(); else __syncthreads();
+    WPH(1);
+    // room for every new edge that may land in the window
+    const uint32_t nwork = small ? s.nitems : total;
+    if (w.n + nwork > kWinCap) {
+#ifdef GLIA_HMT_PROFILE
+      wcompacts += 1;
+#endif
+      win_compact(w, tid);
+      if (w.n + nwork > kWinCap) {
+        win_flush(st, w, tid);
+        if (nwork > kWinCap) {             // a contraction wider than the window: nothing of it goes there
+          if (tid == 0) { w.cthr = (int)st.wB; w.tsal = __builtin_inf(); w.tseq = ~0ull; }
+          __syncthreads();
+        }
+      }
+    }
+    WPH(2);
+
+    // ---- one new edge (rs, r2) per distinct neighbour (TBoundaryTable::update) ----
+    bool bad = false;
+    uint32_t pend_e = kNone, pend_old = kNone;          // a list push whose link is stored later (nobody waits for the atomic)
+    for (uint32_t base = 0; base < nwork; base += kGreedyThreads) {
+      const uint32_t i = base + tid;
+      if (i >= nwork) break;
+      FatEntry f0, f1;
+      bool h0, h1;
+      uint32_t rs;
+      if (small) {
+        const uint32_t h = s.items[i];
+        rs = s.mk[h] - 1u;
+        const uint32_t m0 = s.mv0[h], m1 = s.mv1[h];
+        s.mk[h] = 0u; s.mv0[h] = 0u; s.mv1[h] = 0u;
+        h0 = m0 != 0; h1 = m1 != 0;
+        f0 = s.stage[h0 ? m0 - 1u : m1 - 1u]; f1 = s.stage[h1 ? m1 - 1u : m0 - 1u];
+      } else {
+        const bool side1 = i >= len0;
+        const FatEntry fe = st.fpool[side1 ? off1 + (i - len0) : off0 + i];
+        if (fe.eid == e || fe.eid == kNone) continue;
+        rs = fe.rs;
+        if (!side1) {
+          const uint32_t m = st.mark1[rs];
+          h0 = true; h1 = m != 0; f0 = fe;
+          f1 = h1 ? st.fpool[off1 + (m - 1u - len0)] : fe;
+        } else {
+          if (st.mark0[rs] != 0u) continue;               // common neighbour: handled from the r0 side
+          h0 = false; h1 = true; f0 = fe; f1 = fe;
+        }
+      }
+      const uint32_t idx = atomicAdd(&s.newcount, 1u);
+      const uint32_t newE = (uint32_t)ne + idx;
+      // util/struct_merge.hxx:62-76
+      double first = 0.0;
+      int second = 0;
+      if (h0) { first += f0.mean * (int)f0.n; second += (int)f0.n; }
+      if (h1) { first += f1.mean * (int)f1.n; second += (int)f1.n; }
+      first = sdivide(first, (double)second, 0.0);
+      if (first == -1.0) bad = true;                      // DUMMY -> "invalid boundary saliency" (:78-79)
+      const uint32_t offRs = f0.off, posRs = f0.pos, lenRs = f0.len;      // rs's entry of the (r0,rs) edge -- or of (r1,rs) alone -- is reused
+      if (h0 && h1) st.fpool[offRs + f1.pos].eid = kNone; // rs held two entries: the other becomes a tombstone
+      const uint32_t cat = rs < r0 ? 0u : (h0 ? 1u : 2u);
+      const unsigned long long seq = ((k + 1ull) << 32) | ((unsigned long long)cat << 30) | rs;
+      const double sal = -first;
+      st.e_u[newE] = rs; st.e_v[newE] = r2; st.e_posu[newE] = posRs; st.e_posv[newE] = idx;
+      st.e_mean[newE] = first; st.e_n[newE] = second;
+      st.e_hu[newE] = make_uint2(offRs, lenRs); st.e_hv[newE].x = r2off;                       // r2's length: stored below (another word)
+      pq.leaf_sal[newE] = sal; pq.leaf_seq[newE] = seq;
+      FatEntry* pa = &st.fpool[offRs + posRs];          // every field but len (r2's list length: stored below, another word)
+      *reinterpret_cast<uint4*>(pa) = make_uint4(newE, r2, (uint32_t)second, idx);
+      pa->off = r2off; pa->mean = first;
+      FatEntry b; b.eid = newE; b.rs = rs; b.n = (uint32_t)second; b.pos = posRs; b.off = offRs; b.len = lenRs; b.mean = first;
+      st.fpool[r2off + idx] = b;
+      if (small) s.newpos[idx] = offRs + posRs;
+      const uint32_t cell = win_cell(sal, smin, scale, st.wB);
+      if (win_above(w, (int)cell, sal, seq)) {
+        const uint32_t sl = atomicAdd(&w.n, 1u);
+        win_put(w, sl, sal, seq, newE, rs, r2, make_uint2(offRs, lenRs), make_uint2(r2off, 0u));
+      } else {
+        if (pend_e != kNone) st.wnext[pend_e] = pend_old;
+        pend_e = newE; pend_old = atomicExch(&st.whead[cell], newE);
+        atomicAdd(&st.wcnt[cell], 1u);
+      }
+      // the replaced edges leave the queue
+#pragma unroll
+      for (int side = 0; side < 2; ++side) {
+        const bool hs = side ? h1 : h0;
+        if (!hs) continue;
+        const uint32_t de = side ? f1.eid : f0.eid;
+        const double dsal = -(side ? f1.mean : f0.mean);
+        const uint32_t dc = win_cell(dsal, smin, scale, st.wB);
+        unsigned long long dq = 1;
+        const bool tie = (int)dc == w.cthr && dsal == w.tsal;      // tie with tau: the seq decides where the edge lives
+        if (COND || tie) dq = (!COND && de < st.E0) ? (unsigned long long)de + 1ull : pq.leaf_seq[de];   // COND: 0 = rejected earlier, out of the queue
+        pq.leaf_seq[de] = 0;
+        if (dq != 0) {
+          if (win_above(w, (int)dc, dsal, dq)) {
+            const uint32_t j = atomicAdd(&w.nk, 1u); if (j < kKillMax) w.kill[j] = de; else w.kovf = 1;
+          } else atomicSub(&st.wcnt[dc], 1u);
+        }
+      }
+    }
+    if (bad) s.bad = 1;
+    if (small) lds_barrier(); else __syncthreads();         // the stores of this phase stay in flight (the scan's barrier waits for them)
+    if (s.bad) { if (pend_e != kNone) st.wnext[pend_e] = pend_old; status = ST_BAD_SALIENCY; break; }
+    WPH(3);
+    const uint32_t newcount = s.newcount;
+    // r2's list length is known now: complete the headers that point at it
+    for (uint32_t j = tid; j < newcount; j += kGreedyThreads) {
+      const uint32_t p = small ? s.newpos[j] : (st.fpool[r2off + j].off + st.fpool[r2off + j].pos);
+      st.fpool[p].len = newcount;
+      st.e_hv[(uint32_t)ne + j].y = newcount;
+      if (!small) { const uint32_t rs = st.fpool[r2off + j].rs; st.mark0[rs] = 0; st.mark1[rs] = 0; }
+    }
+    if (pend_e != kNone) st.wnext[pend_e] = pend_old;
+    if (tid == 0) { st.adj_off[r2] = r2off; st.adj_len[r2] = newcount; s.nitems = 0; s.newcount = 0; }
+    win_scan(st, w, tid, r2, newcount);
+    WPH(4);
+#ifdef GLIA_HMT_PROFILE
+    if (tid == 0) {
+      const unsigned long long tn = __builtin_readcyclecounter();
+      const int b = total <= 64 ? 0 : total <= 512 ? 1 : total <= kMarkMax ? 2 : total <= 8192 ? 3 : 4;
+      wtb[b] += tn - wtiter; wnb[b] += 1; wdb[b] += total; wtiter = tn; winwin += w.n;
+    }
+#endif
+    k += 1; ne += newcount; pool_used += total;
+  }
+#ifdef GLIA_HMT_PROFILE
+  if (tid == 0) printf("[window profile] merges %llu: pop %llu  lists+table %llu  room %llu  build %llu  finish+scan %llu  loop-top %llu  reload %llu (cycles); reloads %llu (items %llu) compactions %llu; mean window fill %llu\n",
+                       k, wph[0], wph[1], wph[2], wph[3], wph[4], wph[5], wph[6], wreloads, wloaded, wcompacts, k ? winwin / k : 0ull);
+  if (tid == 0) printf("[window profile] by width (<=64, <=512, <=1408, <=8192, more): merges %llu %llu %llu %llu %llu  cycles %llu %llu %llu %llu %llu  entries %llu %llu %llu %llu %llu\n",
+                       wnb[0], wnb[1], wnb[2], wnb[3], wnb[4], wtb[0], wtb[1], wtb[2], wtb[3], wtb[4], wdb[0], wdb[1], wdb[2], wdb[3], wdb[4]);
+#endif
+  // leave through the global lists: the next launch (or the tree kernel) starts from them
+  __syncthreads();
+  win_flush(st, w, tid);
+  if (tid == 0) {
+    st.ctrl[0] = k; st.ctrl[1] = ne; st.ctrl[2] = pool_used; st.ctrl[3] = w.err ? (unsigned long long)ST_INTERNAL : status;
+    st.ctrl[5] = (unsigned long long)(long long)w.cthr; st.ctrl[6] = (unsigned long long)__double_as_longlong(w.tsal); st.ctrl[7] = w.tseq; st.ctrl[8] = w.iptr;
+  }
+}
+
+// order-preserving image of a double: ascending doubles <-> ascending unsigned integers
+__device__ __forceinline__ unsigned long long f64_ord(double d) {
+  unsigned long long b = (unsigned long long)__double_as_longlong(d);
+  return b ^ ((b >> 63) ? ~0ull : 0x8000000000000000ull);
+}
+__global__ void win_range_kernel(const double* sal, uint32_t E0, unsigned long long* mm) {
+  unsigned long long lo = ~0ull, hi = 0ull;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < E0; i += gridDim.x * blockDim.x) {
+    const unsigned long long b = f64_ord(sal[i]);
+    lo = b < lo ? b : lo; hi = b > hi ? b : hi;
+  }
+  atomicMin(&mm[0], lo); atomicMax(&mm[1], hi);
+}
+__global__ void win_params_kernel(const unsigned long long* mm, uint32_t B, double* range) {
+  auto back = [](unsigned long long o) { o ^= (o >> 63) ? 0x8000000000000000ull : ~0ull; return __longlong_as_double((long long)o); };
+  const double smin = back(mm[0]), smax = back(mm[1]);
+  range[0] = smin;
+  range[1] = smax > smin ? (double)B / (smax - smin) : 0.0;
+}
+// sort input: initial edges in DESCENDING slot order with their saliency image; a stable descending sort by saliency
+// then leaves equal saliencies in descending seq (= slot + 1) order
+__global__ void win_sort_input_kernel(GreedyState st, uint32_t E0, unsigned long long* keys, uint32_t* vals) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= E0) return;
+  const uint32_t e = E0 - 1u - i;
+  keys[i] = f64_ord(st.pq.leaf_sal[e]); vals[i] = e;
+  atomicAdd(&st.wcnt[win_cell(st.pq.leaf_sal[e], st.wrange[0], st.wrange[1], st.wB)], 1u);
+}
+// ige[c] = number of initial edges whose cell is >= c (c = 0..B): cell c's segment of the sorted array is [ige[c+1], ige[c])
+__global__ void win_segments_kernel(GreedyState st, uint32_t E0) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > st.wB) return;
+  uint32_t lo = 0, hi = E0;                   // first index whose cell is < c
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (win_cell(st.pq.leaf_sal[st.isort[mid]], st.wrange[0], st.wrange[1], st.wB) >= c) lo = mid + 1; else hi = mid;
+  }
+  st.ige[c] = c == 0 ? E0 : lo;
+}
+__global__ void adj_fill_fat(GreedyState st, uint32_t E0, uint32_t* cursor) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E0) return;
+  const uint32_t u = st.e_u[e], v = st.e_v[e];
+  const uint32_t pu = atomicAdd(&cursor[u], 1u), pv = atomicAdd(&cursor[v], 1u);
+  const uint32_t ou = st.adj_off[u], ov = st.adj_off[v], lu = st.adj_len[u], lv = st.adj_len[v];
+  FatEntry a; a.eid = e; a.rs = v; a.n = (uint32_t)st.e_n[e]; a.pos = pv; a.off = ov; a.len = lv; a.mean = st.e_mean[e];
+  FatEntry b = a; b.rs = u; b.pos = pu; b.off = ou; b.len = lu;
+  st.fpool[ou + pu] = a; st.e_posu[e] = pu;
+  st.fpool[ov + pv] = b; st.e_posv[e] = pv;
+  st.e_hu[e] = make_uint2(ou, lu); st.e_hv[e] = make_uint2(ov, lv);
+}
+// ST_NEED_TREE: the tree kernel continues on thin list entries
+__global__ void fat_to_thin(const FatEntry* f, uint2* out, unsigned long long n) {
+  const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const FatEntry fe = f[i]; out[i] = make_uint2(fe.eid, fe.eid == kNone ? 0u : fe.rs); }
+}
+
 // ---- edge table construction --------------------------------------------------------------------------
 __global__ void edge_flags(const uint32_t* pa, const uint32_t* pb, long long P, uint32_t* flag, long long* partner) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -618,7 +1213,16 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
   st.pool_cap = (unsigned long long)E0 * 16ull + (1u << 16);
   if ((rc = buf.get(&st.adj_off, 2 * (size_t)R, true, stream))) return rc;
   if ((rc = buf.get(&st.adj_len, 2 * (size_t)R + 1, true, stream))) return rc;
-  if ((rc = buf.get(&st.pool, st.pool_cap, false, stream))) return rc;
+  // pb-mean linkage (with or without the pre_merge condition) runs on the window queue; GLIA_HMT_PB_WINDOW=0 keeps the
+  // tournament tree (kernel experiments, parity gate: both must give byte-identical results)
+  const char* wenv = getenv("GLIA_HMT_PB_WINDOW");
+  bool window = !median_of && !size_weight && !(wenv && wenv[0] == '0');
+  if (window) {
+    if ((rc = buf.get(&st.fpool, st.pool_cap, false, stream))) return rc;
+    if ((rc = buf.get(&st.e_hu, st.Ecap, false, stream))) return rc;
+    if ((rc = buf.get(&st.e_hv, st.Ecap, false, stream))) return rc;
+  }
+  else if ((rc = buf.get(&st.pool, st.pool_cap, false, stream))) return rc;
   if ((rc = buf.get(&st.e_u, st.Ecap, false, stream))) return rc;
   if ((rc = buf.get(&st.e_v, st.Ecap, false, stream))) return rc;
   if ((rc = buf.get(&st.e_posu, st.Ecap, false, stream))) return rc;
@@ -637,7 +1241,7 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
   if ((rc = buf.get(&st.mark1, 2 * (size_t)R, true, stream))) return rc;
   if ((rc = buf.get(&st.order, 3 * (size_t)R, false, stream))) return rc;
   if ((rc = buf.get(&st.sal_out, (size_t)R, false, stream))) return rc;
-  if ((rc = buf.get(&st.ctrl, 8, true, stream))) return rc;
+  if ((rc = buf.get(&st.ctrl, 16, true, stream))) return rc;
   uint32_t* cursor;
   if ((rc = buf.get(&cursor, 2 * (size_t)R, true, stream))) return rc;
 
@@ -652,7 +1256,8 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
     if ((rc = buf.get((char**)&d_tmp, tmp ? tmp : 16, false, stream))) return rc;
     GLIA_HIP_TRY(rocprim::exclusive_scan(d_tmp, tmp, st.adj_len, st.adj_off, 0u, (size_t)R, rocprim::plus<uint32_t>(), stream));
   }
-  hipLaunchKernelGGL(adj_fill, dim3((E0 + 255) / 256), dim3(256), 0, stream, st, E0, cursor);
+  if (window) hipLaunchKernelGGL(adj_fill_fat, dim3((E0 + 255) / 256), dim3(256), 0, stream, st, E0, cursor);
+  else hipLaunchKernelGGL(adj_fill, dim3((E0 + 255) / 256), dim3(256), 0, stream, st, E0, cursor);
   GLIA_HIP_TRY(hipGetLastError());
   unsigned long long n_values = 0;
   if (median_of) {
@@ -691,15 +1296,55 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
     hipLaunchKernelGGL(median_init, dim3((E0 + 255) / 256), dim3(256), 0, stream, st, E0);
     GLIA_HIP_TRY(hipGetLastError());
   }
-  if ((rc = pq_setup(buf, st.pq, stream))) return rc;
-  unsigned long long ctrl[5] = {0, E0, 2ull * E0, ST_RUN, n_values};
+  unsigned long long ctrl[9] = {0, E0, 2ull * E0, ST_RUN, n_values, 0, 0, 0, 0};
+  if (window) {
+    // saliency cells: ~4 initial edges per cell on average; the initial edges sorted by descending key; per-cell live counters
+    uint32_t B = 256;
+    while (B < E0 / 4 && B < (1u << 22)) B <<= 1;
+    st.wB = B; st.E0 = E0;
+    const double inf = std::numeric_limits<double>::infinity();
+    ctrl[5] = (unsigned long long)(long long)(B - 1);                       // threshold: everything is below it
+    memcpy(&ctrl[6], &inf, 8); ctrl[7] = ~0ull; ctrl[8] = 0;
+    unsigned long long* mm; double* range;
+    unsigned long long *skeys, *skeys2; uint32_t* svals;
+    if ((rc = buf.get(&st.whead, B, false, stream))) return rc;
+    if ((rc = buf.get(&st.wcnt, B, true, stream))) return rc;
+    if ((rc = buf.get(&st.wnext, st.Ecap, false, stream))) return rc;
+    if ((rc = buf.get(&st.isort, E0, false, stream))) return rc;
+    if ((rc = buf.get(&st.ige, (size_t)B + 1, false, stream))) return rc;
+    if ((rc = buf.get(&mm, 2, false, stream))) return rc;
+    if ((rc = buf.get(&range, 2, false, stream))) return rc;
+    if ((rc = buf.get(&skeys, E0, false, stream))) return rc;
+    if ((rc = buf.get(&skeys2, E0, false, stream))) return rc;
+    if ((rc = buf.get(&svals, E0, false, stream))) return rc;
+    st.wrange = range;
+    GLIA_HIP_TRY(hipMemsetAsync(st.whead, 0xFF, sizeof(uint32_t) * B, stream));
+    const unsigned long long mm0[2] = {~0ull, 0ull};
+    GLIA_HIP_TRY(hipMemcpyAsync(mm, mm0, sizeof(mm0), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(win_range_kernel, dim3(256), dim3(256), 0, stream, st.pq.leaf_sal, E0, mm);
+    hipLaunchKernelGGL(win_params_kernel, dim3(1), dim3(1), 0, stream, mm, B, range);
+    hipLaunchKernelGGL(win_sort_input_kernel, dim3((E0 + 255) / 256), dim3(256), 0, stream, st, E0, skeys, svals);
+    GLIA_HIP_TRY(hipGetLastError());
+    {
+      size_t tmp = 0;
+      GLIA_HIP_TRY(rocprim::radix_sort_pairs_desc(nullptr, tmp, skeys, skeys2, svals, st.isort, (size_t)E0, 0, 64, stream));
+      void* d_tmp;
+      if ((rc = buf.get((char**)&d_tmp, tmp ? tmp : 16, false, stream))) return rc;
+      GLIA_HIP_TRY(rocprim::radix_sort_pairs_desc(d_tmp, tmp, skeys, skeys2, svals, st.isort, (size_t)E0, 0, 64, stream));
+    }
+    hipLaunchKernelGGL(win_segments_kernel, dim3((B + 1 + 255) / 256), dim3(256), 0, stream, st, E0);
+    GLIA_HIP_TRY(hipGetLastError());
+  } else if ((rc = pq_setup(buf, st.pq, stream))) return rc;
   GLIA_HIP_TRY(hipMemcpyAsync(st.ctrl, ctrl, sizeof(ctrl), hipMemcpyHostToDevice, stream));
   GLIA_HIP_TRY(hipEventRecord(ev[1], stream));
 
   // ---- the loop, in bounded launches so a contraction budget can be re-negotiated between them ----
-  st.max_iters = 1ull << 16;
+  st.max_iters = window ? 1ull << 22 : 1ull << 16;
   while (true) {
-    if (median_of) hipLaunchKernelGGL(greedy_pb_kernel<true>, dim3(1), dim3(kGreedyThreads), 0, stream, st);
+    if (window) {
+      if (cond_n > 0) hipLaunchKernelGGL(greedy_window_kernel<true>, dim3(1), dim3(kGreedyThreads), 0, stream, st);
+      else hipLaunchKernelGGL(greedy_window_kernel<false>, dim3(1), dim3(kGreedyThreads), 0, stream, st);
+    } else if (median_of) hipLaunchKernelGGL(greedy_pb_kernel<true>, dim3(1), dim3(kGreedyThreads), 0, stream, st);
     else hipLaunchKernelGGL(greedy_pb_kernel<false>, dim3(1), dim3(kGreedyThreads), 0, stream, st);
     GLIA_HIP_TRY(hipGetLastError());
     GLIA_HIP_TRY(hipMemcpyAsync(ctrl, st.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, stream));
@@ -707,9 +1352,20 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
     if (ctrl[3] == ST_RUN) continue;
     if (ctrl[3] == ST_DONE) break;
     if (ctrl[3] == ST_BAD_SALIENCY) { set_error("Error: invalid boundary saliency..."); return GLIA_HMT_ERR_SALIENCY; }
-    if (ctrl[3] == ST_NEED_POOL) {
+    if (ctrl[3] == ST_INTERNAL) { set_error("greedy: window queue overflow (internal error)"); return GLIA_HMT_ERR_HIP; }
+    if (ctrl[3] == ST_NEED_TREE) {
+      // a saliency cell with more live items than the window holds (massive exact ties): the tournament tree takes over
+      // from the same state -- leaf keys are the ground truth of both queues, the lists get their thin entries
+      if ((rc = buf.get(&st.pool, st.pool_cap, false, stream))) return rc;
+      hipLaunchKernelGGL(fat_to_thin, dim3((unsigned)((ctrl[2] + 255) / 256)), dim3(256), 0, stream, st.fpool, st.pool, ctrl[2]);
+      GLIA_HIP_TRY(hipGetLastError());
+      if ((rc = pq_setup(buf, st.pq, stream))) return rc;
+      window = false;
+      st.max_iters = 1ull << 16;
+    } else if (ctrl[3] == ST_NEED_POOL) {
       unsigned long long ncap = st.pool_cap * 2;
-      if ((rc = buf.grow(&st.pool, (size_t)st.pool_cap, (size_t)ncap, stream))) return rc;
+      if (window) { if ((rc = buf.grow(&st.fpool, (size_t)st.pool_cap, (size_t)ncap, stream))) return rc; }
+      else if ((rc = buf.grow(&st.pool, (size_t)st.pool_cap, (size_t)ncap, stream))) return rc;
       st.pool_cap = ncap;
     } else if (ctrl[3] == ST_NEED_VALUES) {
       unsigned long long ncap = st.vals_cap * 2;
@@ -728,9 +1384,12 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
       if (median_of && (rc = buf.grow(&st.e_off, ocap, ncap, stream))) return rc;
       if ((rc = buf.grow(&st.pq.leaf_sal, ocap, ncap, stream))) return rc;
       if ((rc = buf.grow(&st.pq.leaf_seq, ocap, ncap, stream))) return rc;
+      if (window && (rc = buf.grow(&st.wnext, ocap, ncap, stream))) return rc;
+      if (window && (rc = buf.grow(&st.e_hu, ocap, ncap, stream))) return rc;
+      if (window && (rc = buf.grow(&st.e_hv, ocap, ncap, stream))) return rc;
       st.Ecap = ncap; st.pq.nleaves = ncap;
       hipLaunchKernelGGL(fill_leaves_dead, dim3((ncap - ocap + 255) / 256), dim3(256), 0, stream, st.pq, ocap);
-      if ((rc = pq_setup(buf, st.pq, stream))) return rc;
+      if (!window && (rc = pq_setup(buf, st.pq, stream))) return rc;
     }
     unsigned long long zero = ST_RUN;
     GLIA_HIP_TRY(hipMemcpyAsync(st.ctrl + 3, &zero, sizeof(zero), hipMemcpyHostToDevice, stream));
