@@ -92,16 +92,6 @@ struct GreedyState {
   double* sal_out;
   unsigned long long* ctrl;       // [0] merges done, [1] edges used, [2] pool used, [3] status, [4] values used, [5] window queue: wlo
   unsigned long long max_iters;
-  // ---- window queue (greedy_window_kernel, see there) ----
-  struct FatEntry* fpool;         // incident-edge lists with the edge's immutable data inlined (replaces pool there)
-  uint32_t wB, E0;                // saliency cells; initial edges
-  uint32_t* whead;                // [wB] newest created edge of the cell's list (kNone = empty); atomics only
-  uint32_t* wcnt;                 // [wB] live queue items of the cell below the threshold (sorted array + list); atomics only
-  uint32_t* wnext;                // [Ecap] list links
-  const double* wrange;           // [0] smallest initial saliency, [1] cells per unit of saliency
-  uint32_t* isort;                // [E0] initial edges by descending (saliency, seq)
-  uint32_t* ige;                  // [wB + 1] initial edges whose cell is >= c
-  uint2 *e_hu, *e_hv;             // [Ecap] (offset, length) of the incident-edge lists of an edge's two regions
 };
 
 // An incident-edge list entry of the window kernel: everything a contraction needs from the edge and from the
@@ -530,33 +520,60 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
 // (gate: SHA-1 of the whole 1024^3 order, tools/pb_bench.py); no assumption about the linkage is made (a new edge may
 // well beat the current maximum: it lands in the window).  A cell whose LIST part alone exceeds the window (massive
 // exact ties among created edges) stops the kernel with ST_NEED_TREE and the host continues with the tree kernel from
-// the same state (leaf keys are the ground truth of both queues).
+// the same state (edge records are unpacked into its arrays).
 // With the fat list entries (FatEntry) and the list headers carried in the window a contraction is ONE dependent global
-// round trip -- the two incident-edge lists -- plus LDS work; its stores are fire-and-forget.
+// round trip -- the two incident-edge lists -- plus LDS work; its stores are fire-and-forget: the next contraction only
+// waits for them when it touches a region whose list they rewrite (a bitmap of the touched regions decides).
+// Edge state is one 64-byte record (EdgeRec) instead of twelve arrays: four wide stores per new edge, one base pointer.
 // =====================================================================================================================
+struct __attribute__((aligned(16))) EdgeRec {
+  uint32_t u, v, posu, posv;                // regions (u < v) and the positions of the edge's entries in their lists
+  double mean; int n; uint32_t next;        // linkage data; link of the cell list
+  uint2 hu, hv;                             // (offset, length) of u's and v's incident-edge lists
+  double sal; unsigned long long seq;       // queue key; seq == 0: not in the queue
+};
+static_assert(sizeof(EdgeRec) == 64, "EdgeRec layout");
+struct WinState {
+  EdgeRec* er; FatEntry* fpool;
+  uint32_t* whead;                          // [wB] newest created edge of the cell's list (kNone = empty); atomics only
+  uint32_t* wcnt;                           // [wB] live queue items of the cell below the threshold (sorted array + list); atomics only
+  const uint32_t* isort;                    // [E0] initial edges by descending (saliency, seq)
+  const uint32_t* ige;                      // [wB + 1] initial edges whose cell is >= c
+  const double* wrange;                     // [0] smallest initial saliency, [1] cells per unit of saliency
+  uint32_t* order; double* sal_out; unsigned long long* ctrl;
+  unsigned long long* rsz; double* rsum; uint32_t *mark0, *mark1, *adj_off, *adj_len;
+  unsigned long long pool_cap, max_iters, cond_t0, cond_t1;
+  double cond_rpb;
+  uint32_t R0, Ecap, wB, E0;
+  int cond_n;
+};
 constexpr uint32_t kWinCap = 1536;          // window slots (live items + holes)
 constexpr uint32_t kWinBudget = 768;        // a reload stops before exceeding this many items ...
 constexpr uint32_t kWinMinLoad = 192;       // ... and goes on to the next block of cells below this many
 constexpr uint32_t kWinMinPartial = 96;     // a cell is split only if at least this much room is left
 constexpr uint32_t kKillMax = 8;
 constexpr int kNW = kGreedyThreads / 64;
+constexpr int kWinPer = (int)(kWinCap / kGreedyThreads);
+static_assert(kWinPer * kGreedyThreads == (int)kWinCap, "window capacity");
 struct WinShared {
   double sal[kWinCap];
   unsigned long long seq[kWinCap];          // 0 = hole
   uint32_t e[kWinCap], u[kWinCap], v[kWinCap];
   uint2 hu[kWinCap], hv[kWinCap];           // (offset, length) of u's and v's incident-edge lists
-  uint32_t n;                               // slots in use
   // threshold: an item is in the window iff cell(sal) > cthr, or cell(sal) == cthr and (sal, seq) > (tsal, tseq)
-  int cthr; double tsal; unsigned long long tseq;
-  uint32_t iptr;                            // initial entries before this index of the sorted array are consumed
-  uint32_t nk, kovf, kill[kKillMax];        // edges that died in this contraction and sit in the window
-  Key part[kNW];                            // per-wave maxima of the last scan (arg = slot)
+  int cthr; uint32_t iptr;                  // initial entries before iptr of the sorted array are consumed
+  double tsal; unsigned long long tseq;
+  alignas(16) uint32_t n;                   // slots in use   (n, nk, kovf, pad0: one 16-byte read in the scan)
+  uint32_t nk, kovf, pad0;                  // edges that died in this contraction and sit in the window
+  alignas(16) uint32_t kill[kKillMax];
+  alignas(16) Key part[kNW];                // per-wave maxima of the last scan (arg = slot)
+  uint32_t touched[2][64];                  // regions whose lists the previous / this contraction rewrites (bitmap over id mod 2048)
   uint32_t wsum[kNW];                       // block scan scratch
-  uint32_t bcast, maxcell, err, moved, need_tree;
+  uint32_t bcast, maxcell, err, need_tree;
 };
 struct WinWork {                            // the neighbour table of one contraction (small case)
   uint32_t mk[kMarkSlots], mv0[kMarkSlots], mv1[kMarkSlots];     // neighbour + 1, staged index + 1 of the (r0,rs) / (r1,rs) entry
-  uint32_t items[kMarkMax], newpos[kMarkMax], nitems, newcount, bad;
+  uint32_t items[kMarkMax], newidx[kMarkMax], nitems, newcount, bad;     // items[i]: table slot of neighbour i, then the pool position of its new entry
   FatEntry stage[kMarkMax];
 };
 
@@ -569,8 +586,8 @@ __device__ __forceinline__ uint32_t win_cell(double sal, double smin, double sca
 }
 __device__ __forceinline__ uint32_t ld_l2(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_l2(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ bool win_above(const WinShared& w, int cell, double sal, unsigned long long seq) {
-  return cell > w.cthr || (cell == w.cthr && (sal > w.tsal || (sal == w.tsal && seq > w.tseq)));
+__device__ __forceinline__ bool win_above(int cthr, double tsal, unsigned long long tseq, int cell, double sal, unsigned long long seq) {
+  return cell > cthr || (cell == cthr && (sal > tsal || (sal == tsal && seq > tseq)));
 }
 
 // inclusive block scan of one value per thread (every thread calls; two barriers)
@@ -593,58 +610,73 @@ __device__ __forceinline__ void win_put(WinShared& w, uint32_t slot, double sal,
   w.sal[slot] = sal; w.seq[slot] = seq; w.e[slot] = e; w.u[slot] = u; w.v[slot] = v; w.hu[slot] = hu; w.hv[slot] = hv;
 }
 // edge e of the global storage into the window if it is alive
-__device__ __forceinline__ void win_take(const GreedyState& st, WinShared& w, uint32_t e) {
-  const unsigned long long q = st.pq.leaf_seq[e];
-  const double sl = st.pq.leaf_sal[e];
-  const uint32_t u = st.e_u[e], v = st.e_v[e];
-  const uint2 hu = st.e_hu[e], hv = st.e_hv[e];
-  if (q != 0) {
+__device__ __forceinline__ void win_take(const WinState& st, WinShared& w, uint32_t e, const EdgeRec& r) {
+  if (r.seq != 0) {
     const uint32_t slot = atomicAdd(&w.n, 1u);
-    if (slot < kWinCap) win_put(w, slot, sl, q, e, u, v, hu, hv); else w.err = 1;
+    if (slot < kWinCap) win_put(w, slot, r.sal, r.seq, e, r.u, r.v, r.hu, r.hv); else w.err = 1;
   }
 }
 
-// one pass over the window: applies this contraction's deaths, completes the list header of the region just created
-// (its length was not known when its edges were inserted), leaves the per-wave maxima in w.part.
-// Ends with a FULL barrier: every global store of the contraction is done before the next one reads anything.
-__device__ __forceinline__ void win_scan(const GreedyState& st, WinShared& w, int tid, uint32_t r2, uint32_t r2len) {
+// One pass over the window: applies this contraction's deaths, completes the list header of the region just created
+// (its length was not known when its edges were inserted), leaves the per-wave maxima in w.part.  Every LDS read is
+// issued up front (a load inside a branch is a round trip of its own).  Ends with an LDS-only barrier.
+__device__ __forceinline__ void win_scan(const WinState& st, WinShared& w, int tid, uint32_t r2, uint32_t r2len) {
+  const uint4 hd = *reinterpret_cast<const uint4*>(&w.n);                 // n, nk, kovf
+  const uint4 k0 = *reinterpret_cast<const uint4*>(&w.kill[0]), k1 = *reinterpret_cast<const uint4*>(&w.kill[4]);
+  unsigned long long q[kWinPer]; uint32_t e[kWinPer], v[kWinPer]; double sl[kWinPer];
+#pragma unroll
+  for (int j = 0; j < kWinPer; ++j) { const uint32_t i = (uint32_t)tid + (uint32_t)j * kGreedyThreads; q[j] = w.seq[i]; e[j] = w.e[i]; v[j] = w.v[i]; sl[j] = w.sal[i]; }
+  const uint32_t n = hd.x, nk = hd.y < kKillMax ? hd.y : kKillMax;
+  const uint32_t kl[kKillMax] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
   Key k;
   k.sal = -__builtin_inf(); k.seq = 0; k.arg = 0;
-  const uint32_t n = w.n, nk = w.nk < kKillMax ? w.nk : kKillMax, kovf = w.kovf;
-  for (uint32_t i = tid; i < n; i += kGreedyThreads) {
-    const unsigned long long q = w.seq[i];
-    if (q == 0) continue;
-    const uint32_t e = w.e[i];
+#pragma unroll
+  for (int j = 0; j < kWinPer; ++j) {
+    const uint32_t i = (uint32_t)tid + (uint32_t)j * kGreedyThreads;
+    bool live = i < n && q[j] != 0;
     bool dead = false;
-    for (uint32_t j = 0; j < nk; ++j) dead = dead || w.kill[j] == e;
-    if (kovf) dead = dead || st.pq.leaf_seq[e] == 0;          // more deaths than the list holds (rare): ask the leaf array
-    if (dead) { w.seq[i] = 0; continue; }
-    if (w.v[i] == r2) w.hv[i].y = r2len;
-    Key c; c.sal = w.sal[i]; c.seq = q; c.arg = i;
+    if (nk) {
+#pragma unroll
+      for (uint32_t t = 0; t < kKillMax; ++t) dead = dead || (t < nk && kl[t] == e[j]);
+    }
+    if (live && hd.z) dead = dead || st.er[e[j]].seq == 0;       // more deaths than the list holds (rare): ask the edge record
+    if (live && dead) { w.seq[i] = 0; live = false; }
+    if (live && v[j] == r2) w.hv[i].y = r2len;
+    Key c; c.sal = live ? sl[j] : -__builtin_inf(); c.seq = live ? q[j] : 0ull; c.arg = i;
     if (better(c, k)) k = c;
   }
   k = wave_max(k);
   if ((tid & 63) == 0) w.part[tid >> 6] = k;
-  __syncthreads();
+  lds_barrier();
   if (tid == 0) { w.nk = 0; w.kovf = 0; }
 }
-__device__ __forceinline__ Key win_root(const WinShared& w) {
-  Key b = w.part[0];
-#pragma unroll
-  for (int j = 1; j < kNW; ++j) { const Key c = w.part[j]; if (better(c, b)) b = c; }
-  return b;
+// the maximum of the per-wave maxima, in every lane: lanes 0..7 fetch one each, two quad steps leave the maxima of
+// parts 0..3 / 4..7 in lanes 0 / 4, which are read out and compared as uniform values
+__device__ __forceinline__ Key win_lane_key(const Key& k, int l) {
+  const unsigned long long sb = (unsigned long long)__double_as_longlong(k.sal);
+  Key out;
+  out.sal = __longlong_as_double((long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(sb >> 32), l) << 32) |
+                                              (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)sb, l)));
+  out.seq = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(k.seq >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k.seq, l);
+  out.arg = (uint32_t)__builtin_amdgcn_readlane((int)k.arg, l);
+  return out;
+}
+__device__ __forceinline__ Key win_root(const WinShared& w, int lane) {
+  static_assert(kNW == 8, "win_root");
+  Key k = w.part[lane & (kNW - 1)];
+  key_max_step<0xB1>(k); key_max_step<0x4E>(k);          // quad_perm [1,0,3,2], [2,3,0,1]: every lane holds its quad's maximum
+  const Key a = win_lane_key(k, 0), b = win_lane_key(k, 4);
+  return better(b, a) ? b : a;
 }
 
 // squeeze the holes out (every thread calls)
 __device__ __forceinline__ void win_compact(WinShared& w, int tid) {
-  constexpr uint32_t per = kWinCap / kGreedyThreads;
-  static_assert(per * kGreedyThreads == kWinCap, "window capacity");
-  double sal[per]; unsigned long long seq[per]; uint32_t e[per], u[per], v[per]; uint2 hu[per], hv[per];
+  double sal[kWinPer]; unsigned long long seq[kWinPer]; uint32_t e[kWinPer], u[kWinPer], v[kWinPer]; uint2 hu[kWinPer], hv[kWinPer];
   uint32_t live = 0;
   const uint32_t n = w.n;
 #pragma unroll
-  for (uint32_t j = 0; j < per; ++j) {
-    const uint32_t i = (uint32_t)tid * per + j;
+  for (int j = 0; j < kWinPer; ++j) {
+    const uint32_t i = (uint32_t)tid * kWinPer + j;
     seq[j] = i < n ? w.seq[i] : 0ull;
     sal[j] = w.sal[i]; e[j] = w.e[i]; u[j] = w.u[i]; v[j] = w.v[i]; hu[j] = w.hu[i]; hv[j] = w.hv[i];
     live += seq[j] != 0;
@@ -652,20 +684,20 @@ __device__ __forceinline__ void win_compact(WinShared& w, int tid) {
   uint32_t total;
   uint32_t o = block_scan_incl(live, w.wsum, tid, &total) - live;      // barriers inside: every read above is done
 #pragma unroll
-  for (uint32_t j = 0; j < per; ++j) if (seq[j] != 0) { win_put(w, o, sal[j], seq[j], e[j], u[j], v[j], hu[j], hv[j]); ++o; }
+  for (int j = 0; j < kWinPer; ++j) if (seq[j] != 0) { win_put(w, o, sal[j], seq[j], e[j], u[j], v[j], hu[j], hv[j]); ++o; }
   if (tid == 0) w.n = total;
   __syncthreads();
 }
 
-__device__ __forceinline__ void win_push_global(const GreedyState& st, uint32_t e, uint32_t cell) {
+__device__ __forceinline__ void win_push_global(const WinState& st, uint32_t e, uint32_t cell) {
   const uint32_t old = atomicExch(&st.whead[cell], e);
-  st.wnext[e] = old;
+  st.er[e].next = old;
   atomicAdd(&st.wcnt[cell], 1u);
 }
 
 // every live window item into its cell's list (initial edges too: their place in the sorted array is gone); afterwards
 // the window is empty and the threshold sits above everything (every thread calls)
-__device__ __forceinline__ void win_flush(const GreedyState& st, WinShared& w, int tid) {
+__device__ __forceinline__ void win_flush(const WinState& st, WinShared& w, int tid) {
   const double smin = st.wrange[0], scale = st.wrange[1];
   if (tid == 0) w.maxcell = 0;
   __syncthreads();
@@ -687,13 +719,13 @@ __device__ __forceinline__ void win_flush(const GreedyState& st, WinShared& w, i
 }
 
 // initial entries [a, b) of the sorted array into the window (every thread calls; no barrier)
-__device__ __forceinline__ void win_take_initial(const GreedyState& st, WinShared& w, uint32_t a, uint32_t b, int tid) {
-  for (uint32_t i = a + (uint32_t)tid; i < b; i += kGreedyThreads) win_take(st, w, st.isort[i]);
+__device__ __forceinline__ void win_take_initial(const WinState& st, WinShared& w, uint32_t a, uint32_t b, int tid) {
+  for (uint32_t i = a + (uint32_t)tid; i < b; i += kGreedyThreads) { const uint32_t e = st.isort[i]; const EdgeRec r = st.er[e]; win_take(st, w, e, r); }
 }
 
 // The window holds no live item: move the threshold down.  Returns 0 = loaded something (or made progress), 1 = the
 // queue is empty, 2 = a cell's list does not fit the window (every thread calls; contains barriers)
-__device__ __forceinline__ int win_reload(const GreedyState& st, WinShared& w, int tid) {
+__device__ __forceinline__ int win_reload(const WinState& st, WinShared& w, int tid) {
   __syncthreads();                       // (vmcnt(0) inside) this workgroup's list pushes and counter updates are done
   if (tid == 0) { w.n = 0; w.need_tree = 0; }
   __syncthreads();
@@ -718,7 +750,7 @@ __device__ __forceinline__ int win_reload(const GreedyState& st, WinShared& w, i
         uint32_t e = ld_l2(&st.whead[c]);
         if (e != kNone) {
           st_l2(&st.whead[c], kNone);
-          if (cn != 0) while (e != kNone) { const uint32_t nx = st.wnext[e]; win_take(st, w, e); e = nx; }
+          if (cn != 0) while (e != kNone) { const EdgeRec r = st.er[e]; win_take(st, w, e, r); e = r.next; }
         }
         if (cn != 0) st_l2(&st.wcnt[c], 0u);
       }
@@ -739,41 +771,37 @@ __device__ __forceinline__ int win_reload(const GreedyState& st, WinShared& w, i
         win_take_initial(st, w, iptr, iptr + ntake, tid);
         iptr += ntake;
         double tsal = -__builtin_inf(); unsigned long long tseq = 0;       // segment exhausted: every list node is above tau
-        if (iptr < seg_end) { const uint32_t et = st.isort[iptr]; tsal = st.pq.leaf_sal[et]; tseq = (unsigned long long)et + 1ull; }
+        if (iptr < seg_end) { const uint32_t et = st.isort[iptr]; tsal = st.er[et].sal; tseq = (unsigned long long)et + 1ull; }
         __syncthreads();
         if (tid == 0) {
           // the list of c*: count the live nodes above tau, move them if they fit and keep the others linked
-          uint32_t head = ld_l2(&st.whead[cs]), cnt_above = 0;
-          for (uint32_t e = head; e != kNone; e = st.wnext[e]) {
-            const unsigned long long q = st.pq.leaf_seq[e];
-            const double sl = st.pq.leaf_sal[e];
-            if (q != 0 && (sl > tsal || (sl == tsal && q > tseq))) ++cnt_above;
+          const uint32_t head = ld_l2(&st.whead[cs]);
+          uint32_t cnt_above = 0;
+          for (uint32_t e = head; e != kNone;) {
+            const EdgeRec r = st.er[e];
+            if (r.seq != 0 && (r.sal > tsal || (r.sal == tsal && r.seq > tseq))) ++cnt_above;
+            e = r.next;
           }
           if (w.n + cnt_above > kWinCap) w.need_tree = 1;
           else {
             uint32_t keep_head = kNone, keep_tail = kNone;
             for (uint32_t e = head; e != kNone;) {
-              const uint32_t nx = st.wnext[e];
-              const unsigned long long q = st.pq.leaf_seq[e];
-              const double sl = st.pq.leaf_sal[e];
-              if (q != 0) {
-                if (sl > tsal || (sl == tsal && q > tseq)) win_take(st, w, e);
-                else { if (keep_head == kNone) keep_head = e; else st.wnext[keep_tail] = e; keep_tail = e; }
+              const EdgeRec r = st.er[e];
+              if (r.seq != 0) {
+                if (r.sal > tsal || (r.sal == tsal && r.seq > tseq)) win_take(st, w, e, r);
+                else { if (keep_head == kNone) keep_head = e; else st.er[keep_tail].next = e; keep_tail = e; }
               }
-              e = nx;
+              e = r.next;
             }
-            if (keep_tail != kNone) st.wnext[keep_tail] = kNone;
+            if (keep_tail != kNone) st.er[keep_tail].next = kNone;
             st_l2(&st.whead[cs], keep_head);
           }
         }
         __syncthreads();
         if (w.need_tree) { result = 2; break; }
         const uint32_t moved = w.n - before;
-        if (tid == 0) { if (moved) atomicSub(&st.wcnt[cs], moved); w.cthr = (int)cs; w.tsal = tsal; w.tseq = tseq; }
+        if (tid == 0) { if (moved) atomicSub(&st.wcnt[cs], moved); w.cthr = (int)cs; w.tsal = tsal; w.tseq = tseq; w.iptr = iptr; }
         if (moved || ntake) result = 0;
-        c_hi = cs + 1u;                                                      // (c* stays the threshold cell)
-        __syncthreads();
-        if (tid == 0) w.iptr = iptr;
         __syncthreads();
         return result;
       }
@@ -788,10 +816,10 @@ __device__ __forceinline__ int win_reload(const GreedyState& st, WinShared& w, i
 }
 
 template <bool COND>
-__global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(GreedyState st) {
+__global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(WinState st) {
   __shared__ WinShared w;
   __shared__ WinWork s;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
   unsigned long long k = st.ctrl[0], ne = st.ctrl[1], pool_used = st.ctrl[2];
   uint32_t status = ST_RUN;
   if (tid == 0) {
@@ -799,20 +827,22 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(GreedySta
     w.cthr = (int)(long long)st.ctrl[5]; w.tsal = __longlong_as_double((long long)st.ctrl[6]); w.tseq = st.ctrl[7]; w.iptr = (uint32_t)st.ctrl[8];
   }
   for (uint32_t i = tid; i < kMarkSlots; i += kGreedyThreads) { s.mk[i] = 0; s.mv0[i] = 0; s.mv1[i] = 0; }
-  for (int i = tid; i < kNW; i += kGreedyThreads) { w.part[i].sal = -__builtin_inf(); w.part[i].seq = 0; w.part[i].arg = 0; }
+  for (uint32_t i = tid; i < kWinCap; i += kGreedyThreads) { w.seq[i] = 0; w.e[i] = 0; w.v[i] = 0; w.sal[i] = 0.0; }
+  if (tid < 128) w.touched[tid >> 6][tid & 63] = 0;
+  if (tid < kNW) { w.part[tid].sal = -__builtin_inf(); w.part[tid].seq = 0; w.part[tid].arg = 0; }
   __syncthreads();
   const double smin = st.wrange[0], scale = st.wrange[1];
-  const PqTree& pq = st.pq;
+  uint32_t r2prev = kNone;
 #ifdef GLIA_HMT_PROFILE
   unsigned long long wph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wlast = __builtin_readcyclecounter(), wtiter = wlast;
-  unsigned long long wtb[5] = {0, 0, 0, 0, 0}, wnb[5] = {0, 0, 0, 0, 0}, wdb[5] = {0, 0, 0, 0, 0}, wreloads = 0, wcompacts = 0, wloaded = 0, winwin = 0;
+  unsigned long long wtb[5] = {0, 0, 0, 0, 0}, wnb[5] = {0, 0, 0, 0, 0}, wdb[5] = {0, 0, 0, 0, 0}, wreloads = 0, wcompacts = 0, wloaded = 0, winwin = 0, wdeps = 0;
 #define WPH(i) do { if (tid == 0) { unsigned long long tn = __builtin_readcyclecounter(); wph[i] += tn - wlast; wlast = tn; } } while (0)
 #else
 #define WPH(i) do {} while (0)
 #endif
 
   for (unsigned long long it = 0; it < st.max_iters; ++it) {
-    const Key root = win_root(w);
+    const Key root = win_root(w, lane);
     if (root.seq == 0) {
       WPH(5);
       const int r = win_reload(st, w, tid);
@@ -823,15 +853,28 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(GreedySta
       if (r == 1) { status = ST_DONE; break; }
       if (r == 2) { status = ST_NEED_TREE; break; }
       win_scan(st, w, tid, kNone, 0);
+      r2prev = kNone;                      // (the reload's barriers waited for every store)
       continue;
     }
     const uint32_t slot = root.arg;
     const uint32_t e = w.e[slot], r0 = w.u[slot], r1 = w.v[slot];
     const uint2 h0r = w.hu[slot], h1r = w.hv[slot];
+    const uint32_t wn_now = w.n;
+    const int cthr = w.cthr; const double tsal = w.tsal; const unsigned long long tseq = w.tseq;
     const uint32_t off0 = h0r.x, len0 = h0r.y, off1 = h1r.x, len1 = h1r.y;
     const uint32_t total = len0 + len1;
     const uint32_t r2 = st.R0 + (uint32_t)k;
     const uint32_t r2off = (uint32_t)pool_used;
+    const int par = (int)(k & 1ull);
+    // does this contraction read a list the previous one is still writing?  (r2prev's list and its neighbours' lists)
+    const uint32_t tb0 = w.touched[par ^ 1][(r0 >> 5) & 63u], tb1 = w.touched[par ^ 1][(r1 >> 5) & 63u];
+    const bool dep = r2prev != kNone && (r1 == r2prev || r0 == r2prev || ((tb0 >> (r0 & 31u)) & 1u) || ((tb1 >> (r1 & 31u)) & 1u));
+    if (dep) {
+      __syncthreads();                    // (vmcnt(0) inside) the previous contraction's stores are done
+#ifdef GLIA_HMT_PROFILE
+      wdeps += 1;
+#endif
+    }
     WPH(0);
     if (COND) {
       // pre_merge condition (gadget/main_pre_merge.cxx:27-76), see the tree kernel: a rejected item leaves the queue for good
@@ -845,7 +888,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(GreedySta
       }
       if (!ok) {
         __syncthreads();                 // every thread has read the slot
-        if (tid == 0) { w.seq[slot] = 0; pq.leaf_seq[e] = 0; }
+        if (tid == 0) { w.seq[slot] = 0; st.er[e].seq = 0; }
         __syncthreads();
         win_scan(st, w, tid, kNone, 0);
         continue;
@@ -858,8 +901,9 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(GreedySta
       w.seq[slot] = 0;                                                   // popped (the other threads read the rest of the slot only)
       st.order[3 * k + 0] = r0; st.order[3 * k + 1] = r1; st.order[3 * k + 2] = r2;
       st.sal_out[k] = root.sal;
-      pq.leaf_seq[e] = 0;
+      st.er[e].seq = 0;
     }
+    if (tid >= 64 && tid < 128) w.touched[par][tid & 63] = 0;            // this contraction's bitmap (last read at the pop of the previous one)
     const bool small = total <= kMarkMax;
 
     // ---- the one round trip: the two lists; one table entry per distinct neighbour ----
@@ -879,23 +923,26 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(GreedySta
         (side1 ? s.mv1 : s.mv0)[h] = i + 1u;
       } else (side1 ? st.mark1 : st.mark0)[fe.rs] = i + 1u;
     }
-    if (small) lds_barrier(); else __syncthreads();
+    __syncthreads();     // full: a wave that loaded has waited for its loads anyway, so its older stores are done for free
     WPH(1);
-    // room for every new edge that may land in the window
-    const uint32_t nwork = small ? s.nitems : total;
-    if (w.n + nwork > kWinCap) {
+    // room for every new edge that may land in the window (total bounds their number)
+    if (wn_now + total > kWinCap) {
 #ifdef GLIA_HMT_PROFILE
       wcompacts += 1;
 #endif
       win_compact(w, tid);
-      if (w.n + nwork > kWinCap) {
+      if (w.n + total > kWinCap) {
         win_flush(st, w, tid);
-        if (nwork > kWinCap) {             // a contraction wider than the window: nothing of it goes there
+        if (total > kWinCap) {             // a contraction wider than the window: nothing of it goes there
           if (tid == 0) { w.cthr = (int)st.wB; w.tsal = __builtin_inf(); w.tseq = ~0ull; }
           __syncthreads();
         }
       }
     }
+    const int cthr2 = (wn_now + total > kWinCap) ? w.cthr : cthr;
+    const double tsal2 = (wn_now + total > kWinCap) ? w.tsal : tsal;
+    const unsigned long long tseq2 = (wn_now + total > kWinCap) ? w.tseq : tseq;
+    const uint32_t nwork = small ? s.nitems : total;
     WPH(2);
 
     // ---- one new edge (rs, r2) per distinct neighbour (TBoundaryTable::update) ----
@@ -930,6 +977,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(GreedySta
       }
       const uint32_t idx = atomicAdd(&s.newcount, 1u);
       const uint32_t newE = (uint32_t)ne + idx;
+      atomicOr(&w.touched[par][(rs >> 5) & 63u], 1u << (rs & 31u));
       // util/struct_merge.hxx:62-76
       double first = 0.0;
       int second = 0;
@@ -942,22 +990,26 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(GreedySta
       const uint32_t cat = rs < r0 ? 0u : (h0 ? 1u : 2u);
       const unsigned long long seq = ((k + 1ull) << 32) | ((unsigned long long)cat << 30) | rs;
       const double sal = -first;
-      st.e_u[newE] = rs; st.e_v[newE] = r2; st.e_posu[newE] = posRs; st.e_posv[newE] = idx;
-      st.e_mean[newE] = first; st.e_n[newE] = second;
-      st.e_hu[newE] = make_uint2(offRs, lenRs); st.e_hv[newE].x = r2off;                       // r2's length: stored below (another word)
-      pq.leaf_sal[newE] = sal; pq.leaf_seq[newE] = seq;
-      FatEntry* pa = &st.fpool[offRs + posRs];          // every field but len (r2's list length: stored below, another word)
-      *reinterpret_cast<uint4*>(pa) = make_uint4(newE, r2, (uint32_t)second, idx);
-      pa->off = r2off; pa->mean = first;
+      EdgeRec* pe = &st.er[newE];
+      uint4* pq4 = reinterpret_cast<uint4*>(pe);
+      pq4[0] = make_uint4(rs, r2, posRs, idx);
+      const unsigned long long mb = (unsigned long long)__double_as_longlong(first);
+      pq4[1] = make_uint4((uint32_t)mb, (uint32_t)(mb >> 32), (uint32_t)second, kNone);
+      pq4[2] = make_uint4(offRs, lenRs, r2off, 0u);                        // r2's length: stored below
+      const unsigned long long sbits = (unsigned long long)__double_as_longlong(sal);
+      pq4[3] = make_uint4((uint32_t)sbits, (uint32_t)(sbits >> 32), (uint32_t)seq, (uint32_t)(seq >> 32));
+      FatEntry* pa = &st.fpool[offRs + posRs];
+      FatEntry a; a.eid = newE; a.rs = r2; a.n = (uint32_t)second; a.pos = idx; a.off = r2off; a.len = 0; a.mean = first;   // len: stored below
+      *pa = a;
       FatEntry b; b.eid = newE; b.rs = rs; b.n = (uint32_t)second; b.pos = posRs; b.off = offRs; b.len = lenRs; b.mean = first;
       st.fpool[r2off + idx] = b;
-      if (small) s.newpos[idx] = offRs + posRs;
+      if (small) { s.items[i] = offRs + posRs; s.newidx[i] = idx; }      // (this thread comes back to them below)
       const uint32_t cell = win_cell(sal, smin, scale, st.wB);
-      if (win_above(w, (int)cell, sal, seq)) {
+      if (win_above(cthr2, tsal2, tseq2, (int)cell, sal, seq)) {
         const uint32_t sl = atomicAdd(&w.n, 1u);
         win_put(w, sl, sal, seq, newE, rs, r2, make_uint2(offRs, lenRs), make_uint2(r2off, 0u));
       } else {
-        if (pend_e != kNone) st.wnext[pend_e] = pend_old;
+        if (pend_e != kNone) st.er[pend_e].next = pend_old;
         pend_e = newE; pend_old = atomicExch(&st.whead[cell], newE);
         atomicAdd(&st.wcnt[cell], 1u);
       }
@@ -970,31 +1022,37 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(GreedySta
         const double dsal = -(side ? f1.mean : f0.mean);
         const uint32_t dc = win_cell(dsal, smin, scale, st.wB);
         unsigned long long dq = 1;
-        const bool tie = (int)dc == w.cthr && dsal == w.tsal;      // tie with tau: the seq decides where the edge lives
-        if (COND || tie) dq = (!COND && de < st.E0) ? (unsigned long long)de + 1ull : pq.leaf_seq[de];   // COND: 0 = rejected earlier, out of the queue
-        pq.leaf_seq[de] = 0;
+        const bool tie = (int)dc == cthr2 && dsal == tsal2;       // tie with tau: the seq decides where the edge lives
+        if (COND || tie) dq = (!COND && de < st.E0) ? (unsigned long long)de + 1ull : st.er[de].seq;   // COND: 0 = rejected earlier, out of the queue
+        st.er[de].seq = 0;
         if (dq != 0) {
-          if (win_above(w, (int)dc, dsal, dq)) {
+          if (win_above(cthr2, tsal2, tseq2, (int)dc, dsal, dq)) {
             const uint32_t j = atomicAdd(&w.nk, 1u); if (j < kKillMax) w.kill[j] = de; else w.kovf = 1;
           } else atomicSub(&st.wcnt[dc], 1u);
         }
       }
     }
     if (bad) s.bad = 1;
-    if (small) lds_barrier(); else __syncthreads();         // the stores of this phase stay in flight (the scan's barrier waits for them)
-    if (s.bad) { if (pend_e != kNone) st.wnext[pend_e] = pend_old; status = ST_BAD_SALIENCY; break; }
+    if (small) lds_barrier(); else __syncthreads();         // the stores of this phase stay in flight
+    if (s.bad) { if (pend_e != kNone) st.er[pend_e].next = pend_old; status = ST_BAD_SALIENCY; break; }
     WPH(3);
     const uint32_t newcount = s.newcount;
     // r2's list length is known now: complete the headers that point at it
-    for (uint32_t j = tid; j < newcount; j += kGreedyThreads) {
-      const uint32_t p = small ? s.newpos[j] : (st.fpool[r2off + j].off + st.fpool[r2off + j].pos);
-      st.fpool[p].len = newcount;
-      st.e_hv[(uint32_t)ne + j].y = newcount;
-      if (!small) { const uint32_t rs = st.fpool[r2off + j].rs; st.mark0[rs] = 0; st.mark1[rs] = 0; }
+    if (small) {
+      for (uint32_t i = tid; i < nwork; i += kGreedyThreads) { st.fpool[s.items[i]].len = newcount; st.er[(uint32_t)ne + s.newidx[i]].hv.y = newcount; }
+    } else {
+      for (uint32_t j = tid; j < newcount; j += kGreedyThreads) {
+        const FatEntry fb = st.fpool[r2off + j];
+        st.fpool[fb.off + fb.pos].len = newcount;
+        st.er[(uint32_t)ne + j].hv.y = newcount;
+        st.mark0[fb.rs] = 0; st.mark1[fb.rs] = 0;
+      }
     }
-    if (pend_e != kNone) st.wnext[pend_e] = pend_old;
     if (tid == 0) { st.adj_off[r2] = r2off; st.adj_len[r2] = newcount; s.nitems = 0; s.newcount = 0; }
+    if (w.kovf) __syncthreads();       // the scan will ask the edge records which window items died: those stores must be done
     win_scan(st, w, tid, r2, newcount);
+    if (pend_e != kNone) st.er[pend_e].next = pend_old;     // (the atomic has long returned; only a reload reads the link, behind a full barrier)
+    r2prev = r2;
     WPH(4);
 #ifdef GLIA_HMT_PROFILE
     if (tid == 0) {
@@ -1006,8 +1064,8 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(GreedySta
     k += 1; ne += newcount; pool_used += total;
   }
 #ifdef GLIA_HMT_PROFILE
-  if (tid == 0) printf("[window profile] merges %llu: pop %llu  lists+table %llu  room %llu  build %llu  finish+scan %llu  loop-top %llu  reload %llu (cycles); reloads %llu (items %llu) compactions %llu; mean window fill %llu\n",
-                       k, wph[0], wph[1], wph[2], wph[3], wph[4], wph[5], wph[6], wreloads, wloaded, wcompacts, k ? winwin / k : 0ull);
+  if (tid == 0) printf("[window profile] merges %llu: pop %llu  lists+table %llu  room %llu  build %llu  finish+scan %llu  loop-top %llu  reload %llu (cycles); reloads %llu (items %llu) compactions %llu dependent %llu; mean window fill %llu\n",
+                       k, wph[0], wph[1], wph[2], wph[3], wph[4], wph[5], wph[6], wreloads, wloaded, wcompacts, wdeps, k ? winwin / k : 0ull);
   if (tid == 0) printf("[window profile] by width (<=64, <=512, <=1408, <=8192, more): merges %llu %llu %llu %llu %llu  cycles %llu %llu %llu %llu %llu  entries %llu %llu %llu %llu %llu\n",
                        wnb[0], wnb[1], wnb[2], wnb[3], wnb[4], wtb[0], wtb[1], wtb[2], wtb[3], wtb[4], wdb[0], wdb[1], wdb[2], wdb[3], wdb[4]);
 #endif
@@ -1041,40 +1099,49 @@ __global__ void win_params_kernel(const unsigned long long* mm, uint32_t B, doub
 }
 // sort input: initial edges in DESCENDING slot order with their saliency image; a stable descending sort by saliency
 // then leaves equal saliencies in descending seq (= slot + 1) order
-__global__ void win_sort_input_kernel(GreedyState st, uint32_t E0, unsigned long long* keys, uint32_t* vals) {
+__global__ void win_sort_input_kernel(GreedyState g, WinState st, uint32_t E0, unsigned long long* keys, uint32_t* vals) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= E0) return;
   const uint32_t e = E0 - 1u - i;
-  keys[i] = f64_ord(st.pq.leaf_sal[e]); vals[i] = e;
-  atomicAdd(&st.wcnt[win_cell(st.pq.leaf_sal[e], st.wrange[0], st.wrange[1], st.wB)], 1u);
+  keys[i] = f64_ord(g.pq.leaf_sal[e]); vals[i] = e;
+  atomicAdd(&st.wcnt[win_cell(g.pq.leaf_sal[e], st.wrange[0], st.wrange[1], st.wB)], 1u);
 }
 // ige[c] = number of initial edges whose cell is >= c (c = 0..B): cell c's segment of the sorted array is [ige[c+1], ige[c])
-__global__ void win_segments_kernel(GreedyState st, uint32_t E0) {
+__global__ void win_segments_kernel(GreedyState g, WinState st, uint32_t E0, uint32_t* ige) {
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c > st.wB) return;
   uint32_t lo = 0, hi = E0;                   // first index whose cell is < c
   while (lo < hi) {
     const uint32_t mid = (lo + hi) >> 1;
-    if (win_cell(st.pq.leaf_sal[st.isort[mid]], st.wrange[0], st.wrange[1], st.wB) >= c) lo = mid + 1; else hi = mid;
+    if (win_cell(g.pq.leaf_sal[st.isort[mid]], st.wrange[0], st.wrange[1], st.wB) >= c) lo = mid + 1; else hi = mid;
   }
-  st.ige[c] = c == 0 ? E0 : lo;
+  ige[c] = c == 0 ? E0 : lo;
 }
-__global__ void adj_fill_fat(GreedyState st, uint32_t E0, uint32_t* cursor) {
+__global__ void adj_fill_fat(GreedyState g, WinState st, uint32_t E0, uint32_t* cursor) {
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E0) return;
-  const uint32_t u = st.e_u[e], v = st.e_v[e];
+  const uint32_t u = g.e_u[e], v = g.e_v[e];
   const uint32_t pu = atomicAdd(&cursor[u], 1u), pv = atomicAdd(&cursor[v], 1u);
-  const uint32_t ou = st.adj_off[u], ov = st.adj_off[v], lu = st.adj_len[u], lv = st.adj_len[v];
-  FatEntry a; a.eid = e; a.rs = v; a.n = (uint32_t)st.e_n[e]; a.pos = pv; a.off = ov; a.len = lv; a.mean = st.e_mean[e];
+  const uint32_t ou = g.adj_off[u], ov = g.adj_off[v], lu = g.adj_len[u], lv = g.adj_len[v];
+  FatEntry a; a.eid = e; a.rs = v; a.n = (uint32_t)g.e_n[e]; a.pos = pv; a.off = ov; a.len = lv; a.mean = g.e_mean[e];
   FatEntry b = a; b.rs = u; b.pos = pu; b.off = ou; b.len = lu;
-  st.fpool[ou + pu] = a; st.e_posu[e] = pu;
-  st.fpool[ov + pv] = b; st.e_posv[e] = pv;
-  st.e_hu[e] = make_uint2(ou, lu); st.e_hv[e] = make_uint2(ov, lv);
+  st.fpool[ou + pu] = a; g.e_posu[e] = pu;
+  st.fpool[ov + pv] = b; g.e_posv[e] = pv;
+  EdgeRec r; r.u = u; r.v = v; r.posu = pu; r.posv = pv; r.mean = g.e_mean[e]; r.n = g.e_n[e]; r.next = kNone;
+  r.hu = make_uint2(ou, lu); r.hv = make_uint2(ov, lv); r.sal = g.pq.leaf_sal[e]; r.seq = g.pq.leaf_seq[e];
+  st.er[e] = r;
 }
-// ST_NEED_TREE: the tree kernel continues on thin list entries
+// ST_NEED_TREE: the tree kernel continues on its own arrays -- thin list entries and one array per edge field
 __global__ void fat_to_thin(const FatEntry* f, uint2* out, unsigned long long n) {
   const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { const FatEntry fe = f[i]; out[i] = make_uint2(fe.eid, fe.eid == kNone ? 0u : fe.rs); }
+}
+__global__ void edge_unpack(GreedyState g, const EdgeRec* er, uint32_t n) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const EdgeRec r = er[e];
+  g.e_u[e] = r.u; g.e_v[e] = r.v; g.e_posu[e] = r.posu; g.e_posv[e] = r.posv; g.e_mean[e] = r.mean; g.e_n[e] = r.n;
+  g.pq.leaf_sal[e] = r.sal; g.pq.leaf_seq[e] = r.seq;
 }
 
 // ---- edge table construction --------------------------------------------------------------------------
@@ -1217,10 +1284,11 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
   // tournament tree (kernel experiments, parity gate: both must give byte-identical results)
   const char* wenv = getenv("GLIA_HMT_PB_WINDOW");
   bool window = !median_of && !size_weight && !(wenv && wenv[0] == '0');
+  WinState ws;
+  memset(&ws, 0, sizeof(ws));
   if (window) {
-    if ((rc = buf.get(&st.fpool, st.pool_cap, false, stream))) return rc;
-    if ((rc = buf.get(&st.e_hu, st.Ecap, false, stream))) return rc;
-    if ((rc = buf.get(&st.e_hv, st.Ecap, false, stream))) return rc;
+    if ((rc = buf.get(&ws.fpool, st.pool_cap, false, stream))) return rc;
+    if ((rc = buf.get(&ws.er, st.Ecap, false, stream))) return rc;
   }
   else if ((rc = buf.get(&st.pool, st.pool_cap, false, stream))) return rc;
   if ((rc = buf.get(&st.e_u, st.Ecap, false, stream))) return rc;
@@ -1256,7 +1324,7 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
     if ((rc = buf.get((char**)&d_tmp, tmp ? tmp : 16, false, stream))) return rc;
     GLIA_HIP_TRY(rocprim::exclusive_scan(d_tmp, tmp, st.adj_len, st.adj_off, 0u, (size_t)R, rocprim::plus<uint32_t>(), stream));
   }
-  if (window) hipLaunchKernelGGL(adj_fill_fat, dim3((E0 + 255) / 256), dim3(256), 0, stream, st, E0, cursor);
+  if (window) hipLaunchKernelGGL(adj_fill_fat, dim3((E0 + 255) / 256), dim3(256), 0, stream, st, ws, E0, cursor);
   else hipLaunchKernelGGL(adj_fill, dim3((E0 + 255) / 256), dim3(256), 0, stream, st, E0, cursor);
   GLIA_HIP_TRY(hipGetLastError());
   unsigned long long n_values = 0;
@@ -1301,38 +1369,41 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
     // saliency cells: ~4 initial edges per cell on average; the initial edges sorted by descending key; per-cell live counters
     uint32_t B = 256;
     while (B < E0 / 4 && B < (1u << 22)) B <<= 1;
-    st.wB = B; st.E0 = E0;
+    ws.wB = B; ws.E0 = E0; ws.R0 = R;
     const double inf = std::numeric_limits<double>::infinity();
     ctrl[5] = (unsigned long long)(long long)(B - 1);                       // threshold: everything is below it
     memcpy(&ctrl[6], &inf, 8); ctrl[7] = ~0ull; ctrl[8] = 0;
     unsigned long long* mm; double* range;
-    unsigned long long *skeys, *skeys2; uint32_t* svals;
-    if ((rc = buf.get(&st.whead, B, false, stream))) return rc;
-    if ((rc = buf.get(&st.wcnt, B, true, stream))) return rc;
-    if ((rc = buf.get(&st.wnext, st.Ecap, false, stream))) return rc;
-    if ((rc = buf.get(&st.isort, E0, false, stream))) return rc;
-    if ((rc = buf.get(&st.ige, (size_t)B + 1, false, stream))) return rc;
+    unsigned long long *skeys, *skeys2; uint32_t *svals, *isort, *ige;
+    if ((rc = buf.get(&ws.whead, B, false, stream))) return rc;
+    if ((rc = buf.get(&ws.wcnt, B, true, stream))) return rc;
+    if ((rc = buf.get(&isort, E0, false, stream))) return rc;
+    if ((rc = buf.get(&ige, (size_t)B + 1, false, stream))) return rc;
     if ((rc = buf.get(&mm, 2, false, stream))) return rc;
     if ((rc = buf.get(&range, 2, false, stream))) return rc;
     if ((rc = buf.get(&skeys, E0, false, stream))) return rc;
     if ((rc = buf.get(&skeys2, E0, false, stream))) return rc;
     if ((rc = buf.get(&svals, E0, false, stream))) return rc;
-    st.wrange = range;
-    GLIA_HIP_TRY(hipMemsetAsync(st.whead, 0xFF, sizeof(uint32_t) * B, stream));
+    ws.wrange = range; ws.isort = isort; ws.ige = ige;
+    ws.order = st.order; ws.sal_out = st.sal_out; ws.ctrl = st.ctrl; ws.rsz = st.rsz; ws.rsum = st.rsum;
+    ws.mark0 = st.mark0; ws.mark1 = st.mark1; ws.adj_off = st.adj_off; ws.adj_len = st.adj_len;
+    ws.pool_cap = st.pool_cap; ws.Ecap = st.Ecap;
+    ws.cond_n = st.cond_n; ws.cond_t0 = st.cond_t0; ws.cond_t1 = st.cond_t1; ws.cond_rpb = st.cond_rpb;
+    GLIA_HIP_TRY(hipMemsetAsync(ws.whead, 0xFF, sizeof(uint32_t) * B, stream));
     const unsigned long long mm0[2] = {~0ull, 0ull};
     GLIA_HIP_TRY(hipMemcpyAsync(mm, mm0, sizeof(mm0), hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(win_range_kernel, dim3(256), dim3(256), 0, stream, st.pq.leaf_sal, E0, mm);
     hipLaunchKernelGGL(win_params_kernel, dim3(1), dim3(1), 0, stream, mm, B, range);
-    hipLaunchKernelGGL(win_sort_input_kernel, dim3((E0 + 255) / 256), dim3(256), 0, stream, st, E0, skeys, svals);
+    hipLaunchKernelGGL(win_sort_input_kernel, dim3((E0 + 255) / 256), dim3(256), 0, stream, st, ws, E0, skeys, svals);
     GLIA_HIP_TRY(hipGetLastError());
     {
       size_t tmp = 0;
-      GLIA_HIP_TRY(rocprim::radix_sort_pairs_desc(nullptr, tmp, skeys, skeys2, svals, st.isort, (size_t)E0, 0, 64, stream));
+      GLIA_HIP_TRY(rocprim::radix_sort_pairs_desc(nullptr, tmp, skeys, skeys2, svals, isort, (size_t)E0, 0, 64, stream));
       void* d_tmp;
       if ((rc = buf.get((char**)&d_tmp, tmp ? tmp : 16, false, stream))) return rc;
-      GLIA_HIP_TRY(rocprim::radix_sort_pairs_desc(d_tmp, tmp, skeys, skeys2, svals, st.isort, (size_t)E0, 0, 64, stream));
+      GLIA_HIP_TRY(rocprim::radix_sort_pairs_desc(d_tmp, tmp, skeys, skeys2, svals, isort, (size_t)E0, 0, 64, stream));
     }
-    hipLaunchKernelGGL(win_segments_kernel, dim3((B + 1 + 255) / 256), dim3(256), 0, stream, st, E0);
+    hipLaunchKernelGGL(win_segments_kernel, dim3((B + 1 + 255) / 256), dim3(256), 0, stream, st, ws, E0, ige);
     GLIA_HIP_TRY(hipGetLastError());
   } else if ((rc = pq_setup(buf, st.pq, stream))) return rc;
   GLIA_HIP_TRY(hipMemcpyAsync(st.ctrl, ctrl, sizeof(ctrl), hipMemcpyHostToDevice, stream));
@@ -1342,8 +1413,9 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
   st.max_iters = window ? 1ull << 22 : 1ull << 16;
   while (true) {
     if (window) {
-      if (cond_n > 0) hipLaunchKernelGGL(greedy_window_kernel<true>, dim3(1), dim3(kGreedyThreads), 0, stream, st);
-      else hipLaunchKernelGGL(greedy_window_kernel<false>, dim3(1), dim3(kGreedyThreads), 0, stream, st);
+      ws.max_iters = st.max_iters;
+      if (cond_n > 0) hipLaunchKernelGGL(greedy_window_kernel<true>, dim3(1), dim3(kGreedyThreads), 0, stream, ws);
+      else hipLaunchKernelGGL(greedy_window_kernel<false>, dim3(1), dim3(kGreedyThreads), 0, stream, ws);
     } else if (median_of) hipLaunchKernelGGL(greedy_pb_kernel<true>, dim3(1), dim3(kGreedyThreads), 0, stream, st);
     else hipLaunchKernelGGL(greedy_pb_kernel<false>, dim3(1), dim3(kGreedyThreads), 0, stream, st);
     GLIA_HIP_TRY(hipGetLastError());
@@ -1357,16 +1429,17 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
       // a saliency cell with more live items than the window holds (massive exact ties): the tournament tree takes over
       // from the same state -- leaf keys are the ground truth of both queues, the lists get their thin entries
       if ((rc = buf.get(&st.pool, st.pool_cap, false, stream))) return rc;
-      hipLaunchKernelGGL(fat_to_thin, dim3((unsigned)((ctrl[2] + 255) / 256)), dim3(256), 0, stream, st.fpool, st.pool, ctrl[2]);
+      hipLaunchKernelGGL(fat_to_thin, dim3((unsigned)((ctrl[2] + 255) / 256)), dim3(256), 0, stream, ws.fpool, st.pool, ctrl[2]);
+      hipLaunchKernelGGL(edge_unpack, dim3((unsigned)((ctrl[1] + 255) / 256)), dim3(256), 0, stream, st, ws.er, (uint32_t)ctrl[1]);
       GLIA_HIP_TRY(hipGetLastError());
       if ((rc = pq_setup(buf, st.pq, stream))) return rc;
       window = false;
       st.max_iters = 1ull << 16;
     } else if (ctrl[3] == ST_NEED_POOL) {
       unsigned long long ncap = st.pool_cap * 2;
-      if (window) { if ((rc = buf.grow(&st.fpool, (size_t)st.pool_cap, (size_t)ncap, stream))) return rc; }
+      if (window) { if ((rc = buf.grow(&ws.fpool, (size_t)st.pool_cap, (size_t)ncap, stream))) return rc; }
       else if ((rc = buf.grow(&st.pool, (size_t)st.pool_cap, (size_t)ncap, stream))) return rc;
-      st.pool_cap = ncap;
+      st.pool_cap = ncap; ws.pool_cap = ncap;
     } else if (ctrl[3] == ST_NEED_VALUES) {
       unsigned long long ncap = st.vals_cap * 2;
       if ((rc = buf.grow(&st.vals, (size_t)ctrl[4], (size_t)ncap, stream))) return rc;
@@ -1384,10 +1457,8 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
       if (median_of && (rc = buf.grow(&st.e_off, ocap, ncap, stream))) return rc;
       if ((rc = buf.grow(&st.pq.leaf_sal, ocap, ncap, stream))) return rc;
       if ((rc = buf.grow(&st.pq.leaf_seq, ocap, ncap, stream))) return rc;
-      if (window && (rc = buf.grow(&st.wnext, ocap, ncap, stream))) return rc;
-      if (window && (rc = buf.grow(&st.e_hu, ocap, ncap, stream))) return rc;
-      if (window && (rc = buf.grow(&st.e_hv, ocap, ncap, stream))) return rc;
-      st.Ecap = ncap; st.pq.nleaves = ncap;
+      if (window && (rc = buf.grow(&ws.er, ocap, ncap, stream))) return rc;
+      st.Ecap = ncap; st.pq.nleaves = ncap; ws.Ecap = ncap;
       hipLaunchKernelGGL(fill_leaves_dead, dim3((ncap - ocap + 255) / 256), dim3(256), 0, stream, st.pq, ocap);
       if (!window && (rc = pq_setup(buf, st.pq, stream))) return rc;
     }
