@@ -570,6 +570,7 @@ struct WinShared {
   uint32_t touched[2][64];                  // regions whose lists the previous / this contraction rewrites (bitmap over id mod 2048)
   uint32_t wsum[kNW];                       // block scan scratch
   uint32_t bcast, maxcell, err, need_tree;
+  double psal; unsigned long long pseq;     // split of a cell: the list's contribution to tau
 };
 struct WinWork {                            // the neighbour table of one contraction (small case)
   uint32_t mk[kMarkSlots], mv0[kMarkSlots], mv1[kMarkSlots];     // neighbour + 1, staged index + 1 of the (r0,rs) / (r1,rs) entry
@@ -725,7 +726,8 @@ __device__ __forceinline__ void win_take_initial(const WinState& st, WinShared& 
 
 // The window holds no live item: move the threshold down.  Returns 0 = loaded something (or made progress), 1 = the
 // queue is empty, 2 = a cell's list does not fit the window (every thread calls; contains barriers)
-__device__ __forceinline__ int win_reload(const WinState& st, WinShared& w, int tid) {
+constexpr uint32_t kSelMax = 384;           // list items a split cell hands over at most (bounded min-heap in LDS)
+__device__ __forceinline__ int win_reload(const WinState& st, WinShared& w, int tid, double* sel_sal, unsigned long long* sel_seq) {
   __syncthreads();                       // (vmcnt(0) inside) this workgroup's list pushes and counter updates are done
   if (tid == 0) { w.n = 0; w.need_tree = 0; }
   __syncthreads();
@@ -760,48 +762,84 @@ __device__ __forceinline__ int win_reload(const WinState& st, WinShared& w, int 
       if (loaded) result = 0;
     }
     if (m < nvalid) {
-      // cell c* = c_hi - 1 does not fit whole: a prefix of its sorted initial entries, and its list nodes above the new tau
+      // Cell c* = c_hi - 1 does not fit whole (a tie group of thousands of equal means, typically): the threshold moves
+      // INTO the cell.  Its items are a sorted array segment (initial edges) and an unordered list (created edges); thread 0
+      // finds the list's K largest keys with a bounded min-heap in LDS, the new tau is the larger of the heap's minimum and
+      // the key of the array entry RA places ahead, and everything above tau moves: at most K - 1 + RA items.
       const uint32_t room = kWinBudget - loaded;
       const uint32_t cs = c_hi - 1u;
       if (room >= kWinMinPartial || loaded == 0) {
+        const uint32_t K = room / 2u < kSelMax ? room / 2u : kSelMax, RA = room - K;
         const uint32_t seg_end = st.ige[cs];
-        const uint32_t ntake = seg_end > iptr ? (seg_end - iptr < room ? seg_end - iptr : room) : 0u;
         const uint32_t before = w.n;
-        __syncthreads();                                                     // (everybody has read w.n)
-        win_take_initial(st, w, iptr, iptr + ntake, tid);
-        iptr += ntake;
-        double tsal = -__builtin_inf(); unsigned long long tseq = 0;       // segment exhausted: every list node is above tau
-        if (iptr < seg_end) { const uint32_t et = st.isort[iptr]; tsal = st.er[et].sal; tseq = (unsigned long long)et + 1ull; }
-        __syncthreads();
         if (tid == 0) {
-          // the list of c*: count the live nodes above tau, move them if they fit and keep the others linked
-          const uint32_t head = ld_l2(&st.whead[cs]);
-          uint32_t cnt_above = 0;
-          for (uint32_t e = head; e != kNone;) {
+          uint32_t hn = 0, nlive = 0;
+          for (uint32_t e = ld_l2(&st.whead[cs]); e != kNone;) {
             const EdgeRec r = st.er[e];
-            if (r.seq != 0 && (r.sal > tsal || (r.sal == tsal && r.seq > tseq))) ++cnt_above;
+            if (r.seq != 0) {
+              ++nlive;
+              if (hn < K) {                                                   // push, sift up (min-heap by key)
+                uint32_t i = hn++;
+                while (i > 0) {
+                  const uint32_t p = (i - 1u) >> 1;
+                  if (!(sel_sal[p] > r.sal || (sel_sal[p] == r.sal && sel_seq[p] > r.seq))) break;
+                  sel_sal[i] = sel_sal[p]; sel_seq[i] = sel_seq[p]; i = p;
+                }
+                sel_sal[i] = r.sal; sel_seq[i] = r.seq;
+              } else if (r.sal > sel_sal[0] || (r.sal == sel_sal[0] && r.seq > sel_seq[0])) {   // replace the minimum, sift down
+                uint32_t i = 0;
+                while (true) {
+                  uint32_t c = 2u * i + 1u;
+                  if (c >= hn) break;
+                  if (c + 1u < hn && (sel_sal[c + 1u] < sel_sal[c] || (sel_sal[c + 1u] == sel_sal[c] && sel_seq[c + 1u] < sel_seq[c]))) ++c;
+                  if (!(sel_sal[c] < r.sal || (sel_sal[c] == r.sal && sel_seq[c] < r.seq))) break;
+                  sel_sal[i] = sel_sal[c]; sel_seq[i] = sel_seq[c]; i = c;
+                }
+                sel_sal[i] = r.sal; sel_seq[i] = r.seq;
+              }
+            }
             e = r.next;
           }
-          if (w.n + cnt_above > kWinCap) w.need_tree = 1;
-          else {
-            uint32_t keep_head = kNone, keep_tail = kNone;
-            for (uint32_t e = head; e != kNone;) {
-              const EdgeRec r = st.er[e];
-              if (r.seq != 0) {
-                if (r.sal > tsal || (r.sal == tsal && r.seq > tseq)) win_take(st, w, e, r);
-                else { if (keep_head == kNone) keep_head = e; else st.er[keep_tail].next = e; keep_tail = e; }
-              }
-              e = r.next;
-            }
-            if (keep_tail != kNone) st.er[keep_tail].next = kNone;
-            st_l2(&st.whead[cs], keep_head);
-          }
+          // tau from the list: the heap's minimum if the list holds more than the heap
+          w.psal = nlive > K ? sel_sal[0] : -__builtin_inf(); w.pseq = nlive > K ? sel_seq[0] : 0ull;
         }
         __syncthreads();
-        if (w.need_tree) { result = 2; break; }
+        double tsal = w.psal; unsigned long long tseq = w.pseq;
+        const uint32_t iA = seg_end > iptr ? (seg_end - iptr < RA ? seg_end : iptr + RA) : iptr;
+        if (iA < seg_end) {                                                     // array entries stay behind: their first one bounds tau
+          const uint32_t et = st.isort[iA]; const double as = st.er[et].sal; const unsigned long long aq = (unsigned long long)et + 1ull;
+          if (as > tsal || (as == tsal && aq > tseq)) { tsal = as; tseq = aq; }
+        }
+        if (tid == 0) w.bcast = 0;
+        __syncthreads();
+        // array entries above tau (a prefix of [iptr, iA): the array is sorted)
+        uint32_t mine = 0;
+        for (uint32_t i = iptr + (uint32_t)tid; i < iA; i += kGreedyThreads) {
+          const uint32_t e = st.isort[i]; const EdgeRec r = st.er[e];
+          const unsigned long long q = (unsigned long long)e + 1ull;            // (a dead entry's seq is gone from its record)
+          if (r.sal > tsal || (r.sal == tsal && q > tseq)) { ++mine; win_take(st, w, e, r); }
+        }
+        if (mine) atomicAdd(&w.bcast, mine);
+        __syncthreads();
+        iptr += w.bcast;
+        if (tid == 0) {
+          // list nodes above tau move, the others stay linked
+          uint32_t keep_head = kNone, keep_tail = kNone;
+          for (uint32_t e = ld_l2(&st.whead[cs]); e != kNone;) {
+            const EdgeRec r = st.er[e];
+            if (r.seq != 0) {
+              if (r.sal > tsal || (r.sal == tsal && r.seq > tseq)) win_take(st, w, e, r);
+              else { if (keep_head == kNone) keep_head = e; else st.er[keep_tail].next = e; keep_tail = e; }
+            }
+            e = r.next;
+          }
+          if (keep_tail != kNone) st.er[keep_tail].next = kNone;
+          st_l2(&st.whead[cs], keep_head);
+        }
+        __syncthreads();
         const uint32_t moved = w.n - before;
         if (tid == 0) { if (moved) atomicSub(&st.wcnt[cs], moved); w.cthr = (int)cs; w.tsal = tsal; w.tseq = tseq; w.iptr = iptr; }
-        if (moved || ntake) result = 0;
+        if (moved || w.bcast) result = 0;
         __syncthreads();
         return result;
       }
@@ -845,7 +883,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(WinState 
     const Key root = win_root(w, lane);
     if (root.seq == 0) {
       WPH(5);
-      const int r = win_reload(st, w, tid);
+      const int r = win_reload(st, w, tid, reinterpret_cast<double*>(&s.stage[0]), reinterpret_cast<unsigned long long*>(&s.stage[0]) + kSelMax);
 #ifdef GLIA_HMT_PROFILE
       wreloads += 1; wloaded += w.n;
 #endif
@@ -1069,6 +1107,472 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(WinState 
   if (tid == 0) printf("[window profile] by width (<=64, <=512, <=1408, <=8192, more): merges %llu %llu %llu %llu %llu  cycles %llu %llu %llu %llu %llu  entries %llu %llu %llu %llu %llu\n",
                        wnb[0], wnb[1], wnb[2], wnb[3], wnb[4], wtb[0], wtb[1], wtb[2], wtb[3], wtb[4], wdb[0], wdb[1], wdb[2], wdb[3], wdb[4]);
 #endif
+  // leave through the global lists: the next launch (or the tree kernel) starts from them
+  __syncthreads();
+  win_flush(st, w, tid);
+  if (tid == 0) {
+    st.ctrl[0] = k; st.ctrl[1] = ne; st.ctrl[2] = pool_used; st.ctrl[3] = w.err ? (unsigned long long)ST_INTERNAL : status;
+    st.ctrl[5] = (unsigned long long)(long long)w.cthr; st.ctrl[6] = (unsigned long long)__double_as_longlong(w.tsal); st.ctrl[7] = w.tseq; st.ctrl[8] = w.iptr;
+  }
+}
+
+// =====================================================================================================================
+// Batched contractions on the window queue (pb-mean linkage without a condition).
+//
+// One contraction of two small regions keeps a single wave busy (a few dozen list entries) and costs ~13 k cycles of
+// pure sequence: pop, one global round trip, neighbour matching, a division, a dozen stores, one scan of the window.
+// The other seven waves wait.  The queue's top items, however, are mostly far apart in the volume, and the greedy
+// order of FAR-APART top items is known before any of them is contracted:
+//   let c0 > c1 > ... be the top items of the queue (exact keys).  After contracting c0 the next pop is c1 provided
+//   (a) no edge created by c0 has a saliency >= c1's (a created edge is newer, so it wins a tie), and
+//   (b) c1's two regions are neither c0's regions nor neighbours of them (then c1's lists are untouched by c0);
+//   by induction over the batch, member j is merge number k + j, creates region R0 + k + j and its new edges carry
+//   seq = (k + j + 1) << 32 | ... exactly as in the one-by-one loop.
+// A round: every wave finds the best and the second-best item of its share of the window; the items that beat every
+// second-best are the exact top of the queue, in order.  Wave j COMPUTES member j on its own (lists into registers,
+// neighbour matching in a private LDS table, new means), publishes what it creates (count, largest new saliency, a
+// bitmap of the regions it touches); every wave then evaluates (a) and (b) for the whole batch and the valid prefix
+// COMMITS (stores, queue inserts, deaths) in parallel.  Nothing is speculated on memory: a member that fails the check
+// has only read.  Contractions with more than 64 list entries take the whole workgroup, one at a time.
+// The result is bit-identical to the sequential kernels (same gate: SHA-1 of the whole 1024^3 order).
+// =====================================================================================================================
+constexpr uint32_t kBatchKill = 32;
+struct BatchShared {
+  alignas(16) Key part1[kNW];               // per-wave best / second-best of the last scan
+  alignas(16) Key part2[kNW];
+  uint32_t nkill, kovf; alignas(16) uint32_t kill[kBatchKill];
+  uint32_t byrank[kNW];                     // candidate (wave) index of the batch member of rank r
+  uint32_t bitmap[kNW][64];                 // regions a member touches (id mod 2048): its own two and every neighbour
+  uint32_t m_newcount[kNW], m_total[kNW], m_ok[kNW];
+  double m_maxsal[kNW];
+  uint32_t bad;
+};
+
+// one pass over the window: applies the deaths of the last round, leaves every wave's best and second-best item
+__device__ __forceinline__ void batch_scan(const WinState& st, WinShared& w, BatchShared& b, int tid) {
+  const uint32_t n = w.n, nk = b.nkill < kBatchKill ? b.nkill : kBatchKill, kovf = b.kovf;
+  // Slot ownership is STRIPED over the waves (lane l of wave v scans the l-th slot of chunk (v + l) mod 8 in every block
+  // of 512): a reload fills consecutive slots with consecutive keys, and the exact top of the queue is only as long as
+  // the run of best items that sit with different waves.  (Bank pattern of a wave's reads: that of consecutive slots.)
+  const uint32_t own = 64u * (uint32_t)(((tid >> 6) + (tid & 63)) & 7) + (uint32_t)(tid & 63);
+  unsigned long long q[kWinPer]; uint32_t e[kWinPer]; double sl[kWinPer];
+#pragma unroll
+  for (int j = 0; j < kWinPer; ++j) { const uint32_t i = own + (uint32_t)j * kGreedyThreads; q[j] = w.seq[i]; e[j] = w.e[i]; sl[j] = w.sal[i]; }
+  const uint4 ka = *reinterpret_cast<const uint4*>(&b.kill[0]), kb = *reinterpret_cast<const uint4*>(&b.kill[4]);
+  const uint32_t kl[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
+  Key k1, k2;
+  k1.sal = -__builtin_inf(); k1.seq = 0; k1.arg = 0; k2 = k1;
+#pragma unroll
+  for (int j = 0; j < kWinPer; ++j) {
+    const uint32_t i = own + (uint32_t)j * kGreedyThreads;
+    bool live = i < n && q[j] != 0;
+    bool dead = false;
+#pragma unroll
+    for (uint32_t t = 0; t < 8; ++t) dead = dead || (t < nk && kl[t] == e[j]);
+    if (nk > 8u && live) {
+      for (uint32_t t = 8; t < nk; ++t) dead = dead || b.kill[t] == e[j];
+      if (kovf) dead = dead || st.er[e[j]].seq == 0;        // more deaths than the list holds (rare): ask the edge record
+    }
+    if (live && dead) { w.seq[i] = 0; live = false; }
+    Key c; c.sal = live ? sl[j] : -__builtin_inf(); c.seq = live ? q[j] : 0ull; c.arg = i;
+    if (better(c, k1)) { k2 = k1; k1 = c; } else if (better(c, k2)) k2 = c;
+  }
+  const Key m1 = wave_max(k1);
+  const bool mine = k1.seq == m1.seq && k1.arg == m1.arg && m1.seq != 0;
+  const Key m2 = wave_max(mine ? k2 : k1);
+  if ((tid & 63) == 0) { b.part1[tid >> 6] = m1; b.part2[tid >> 6] = m2; }
+  __syncthreads();
+  if (tid == 0) { b.nkill = 0; b.kovf = 0; }
+}
+
+// The whole workgroup contracts ONE edge (more than 64 list entries): the body of greedy_window_kernel.
+__device__ __forceinline__ uint32_t batch_contract_wide(const WinState& st, WinShared& w, WinWork& s, BatchShared& b, int tid, uint32_t slot, double rootsal,
+                                                      unsigned long long k, unsigned long long ne, unsigned long long pool_used, uint32_t* newcount_out) {
+  const double smin = st.wrange[0], scale = st.wrange[1];
+  const uint32_t e = w.e[slot], r0 = w.u[slot], r1 = w.v[slot];
+  const uint2 h0r = w.hu[slot], h1r = w.hv[slot];
+  const uint32_t wn_now = w.n;
+  const uint32_t off0 = h0r.x, len0 = h0r.y, off1 = h1r.x, len1 = h1r.y;
+  const uint32_t total = len0 + len1;
+  const uint32_t r2 = st.R0 + (uint32_t)k;
+  const uint32_t r2off = (uint32_t)pool_used;
+  __syncthreads();                                                       // every thread has read the slot
+  if (tid == 0) {
+    w.seq[slot] = 0;
+    st.order[3 * k + 0] = r0; st.order[3 * k + 1] = r1; st.order[3 * k + 2] = r2;
+    st.sal_out[k] = rootsal;
+    st.er[e].seq = 0;
+  }
+  const bool small = total <= kMarkMax;
+  for (uint32_t i = tid; i < total; i += kGreedyThreads) {
+    const bool side1 = i >= len0;
+    const FatEntry fe = st.fpool[side1 ? off1 + (i - len0) : off0 + i];
+    if (fe.eid == e || fe.eid == kNone) continue;
+    if (small) {
+      s.stage[i] = fe;
+      uint32_t h = (fe.rs * 2654435761u) >> 21;
+      while (true) {
+        const uint32_t old = atomicCAS(&s.mk[h], 0u, fe.rs + 1u);
+        if (old == 0u) { s.items[atomicAdd(&s.nitems, 1u)] = h; break; }
+        if (old == fe.rs + 1u) break;
+        h = (h + 1u) & (kMarkSlots - 1u);
+      }
+      (side1 ? s.mv1 : s.mv0)[h] = i + 1u;
+    } else (side1 ? st.mark1 : st.mark0)[fe.rs] = i + 1u;
+  }
+  __syncthreads();
+  if (wn_now + total > kWinCap) {
+    win_compact(w, tid);
+    if (w.n + total > kWinCap) {
+      win_flush(st, w, tid);
+      if (total > kWinCap) {               // a contraction wider than the window: nothing of it goes there
+        if (tid == 0) { w.cthr = (int)st.wB; w.tsal = __builtin_inf(); w.tseq = ~0ull; }
+        __syncthreads();
+      }
+    }
+  }
+  const int cthr = w.cthr; const double tsal = w.tsal; const unsigned long long tseq = w.tseq;
+  const uint32_t nwork = small ? s.nitems : total;
+  bool bad = false;
+  uint32_t pend_e = kNone, pend_old = kNone;
+  for (uint32_t base = 0; base < nwork; base += kGreedyThreads) {
+    const uint32_t i = base + tid;
+    if (i >= nwork) break;
+    FatEntry f0, f1;
+    bool h0, h1;
+    uint32_t rs;
+    if (small) {
+      const uint32_t h = s.items[i];
+      rs = s.mk[h] - 1u;
+      const uint32_t m0 = s.mv0[h], m1 = s.mv1[h];
+      s.mk[h] = 0u; s.mv0[h] = 0u; s.mv1[h] = 0u;
+      h0 = m0 != 0; h1 = m1 != 0;
+      f0 = s.stage[h0 ? m0 - 1u : m1 - 1u]; f1 = s.stage[h1 ? m1 - 1u : m0 - 1u];
+    } else {
+      const bool side1 = i >= len0;
+      const FatEntry fe = st.fpool[side1 ? off1 + (i - len0) : off0 + i];
+      if (fe.eid == e || fe.eid == kNone) continue;
+      rs = fe.rs;
+      if (!side1) {
+        const uint32_t m = st.mark1[rs];
+        h0 = true; h1 = m != 0; f0 = fe;
+        f1 = h1 ? st.fpool[off1 + (m - 1u - len0)] : fe;
+      } else {
+        if (st.mark0[rs] != 0u) continue;               // common neighbour: handled from the r0 side
+        h0 = false; h1 = true; f0 = fe; f1 = fe;
+      }
+    }
+    const uint32_t idx = atomicAdd(&s.newcount, 1u);
+    const uint32_t newE = (uint32_t)ne + idx;
+    double first = 0.0;                                  // util/struct_merge.hxx:62-76
+    int second = 0;
+    if (h0) { first += f0.mean * (int)f0.n; second += (int)f0.n; }
+    if (h1) { first += f1.mean * (int)f1.n; second += (int)f1.n; }
+    first = sdivide(first, (double)second, 0.0);
+    if (first == -1.0) bad = true;                      // DUMMY -> "invalid boundary saliency" (:78-79)
+    const uint32_t offRs = f0.off, posRs = f0.pos, lenRs = f0.len;
+    if (h0 && h1) st.fpool[offRs + f1.pos].eid = kNone;
+    const uint32_t cat = rs < r0 ? 0u : (h0 ? 1u : 2u);
+    const unsigned long long seq = ((k + 1ull) << 32) | ((unsigned long long)cat << 30) | rs;
+    const double sal = -first;
+    uint4* pq4 = reinterpret_cast<uint4*>(&st.er[newE]);
+    pq4[0] = make_uint4(rs, r2, posRs, idx);
+    const unsigned long long mb = (unsigned long long)__double_as_longlong(first);
+    pq4[1] = make_uint4((uint32_t)mb, (uint32_t)(mb >> 32), (uint32_t)second, kNone);
+    pq4[2] = make_uint4(offRs, lenRs, r2off, 0u);                        // r2's length: stored below
+    const unsigned long long sbits = (unsigned long long)__double_as_longlong(sal);
+    pq4[3] = make_uint4((uint32_t)sbits, (uint32_t)(sbits >> 32), (uint32_t)seq, (uint32_t)(seq >> 32));
+    FatEntry a; a.eid = newE; a.rs = r2; a.n = (uint32_t)second; a.pos = idx; a.off = r2off; a.len = 0; a.mean = first;   // len: stored below
+    st.fpool[offRs + posRs] = a;
+    FatEntry bb; bb.eid = newE; bb.rs = rs; bb.n = (uint32_t)second; bb.pos = posRs; bb.off = offRs; bb.len = lenRs; bb.mean = first;
+    st.fpool[r2off + idx] = bb;
+    if (small) { s.items[i] = offRs + posRs; s.newidx[i] = idx; }
+    const uint32_t cell = win_cell(sal, smin, scale, st.wB);
+    if (win_above(cthr, tsal, tseq, (int)cell, sal, seq)) {
+      const uint32_t sl = atomicAdd(&w.n, 1u);
+      win_put(w, sl, sal, seq, newE, rs, r2, make_uint2(offRs, lenRs), make_uint2(r2off, 0u));
+    } else {
+      if (pend_e != kNone) st.er[pend_e].next = pend_old;
+      pend_e = newE; pend_old = atomicExch(&st.whead[cell], newE);
+      atomicAdd(&st.wcnt[cell], 1u);
+    }
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      const bool hs = side ? h1 : h0;
+      if (!hs) continue;
+      const uint32_t de = side ? f1.eid : f0.eid;
+      const double dsal = -(side ? f1.mean : f0.mean);
+      const uint32_t dc = win_cell(dsal, smin, scale, st.wB);
+      unsigned long long dq = 1;
+      if ((int)dc == cthr && dsal == tsal) dq = de < st.E0 ? (unsigned long long)de + 1ull : st.er[de].seq;   // tie with tau: the seq decides
+      st.er[de].seq = 0;
+      if (win_above(cthr, tsal, tseq, (int)dc, dsal, dq)) {
+        const uint32_t j = atomicAdd(&b.nkill, 1u); if (j < kBatchKill) b.kill[j] = de; else b.kovf = 1;
+      } else atomicSub(&st.wcnt[dc], 1u);
+    }
+  }
+  if (bad) b.bad = 1;
+  __syncthreads();
+  const uint32_t newcount = s.newcount;
+  if (small) {
+    for (uint32_t i = tid; i < nwork; i += kGreedyThreads) { st.fpool[s.items[i]].len = newcount; st.er[(uint32_t)ne + s.newidx[i]].hv.y = newcount; }
+  } else {
+    for (uint32_t j = tid; j < newcount; j += kGreedyThreads) {
+      const FatEntry fb = st.fpool[r2off + j];
+      st.fpool[fb.off + fb.pos].len = newcount;
+      st.er[(uint32_t)ne + j].hv.y = newcount;
+      st.mark0[fb.rs] = 0; st.mark1[fb.rs] = 0;
+    }
+  }
+  for (uint32_t i = tid; i < w.n; i += kGreedyThreads) if (w.v[i] == r2) w.hv[i].y = newcount;      // window items of r2: its list length
+  if (pend_e != kNone) st.er[pend_e].next = pend_old;
+  if (tid == 0) { st.adj_off[r2] = r2off; st.adj_len[r2] = newcount; }
+  __syncthreads();
+  if (tid == 0) { s.nitems = 0; s.newcount = 0; }
+  *newcount_out = newcount;
+  return total;
+}
+
+__global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState st) {
+  __shared__ WinShared w;
+  __shared__ WinWork s;
+  __shared__ BatchShared b;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned long long k = st.ctrl[0], ne = st.ctrl[1], pool_used = st.ctrl[2];
+  uint32_t status = ST_RUN;
+  if (tid == 0) {
+    w.n = 0; w.nk = 0; w.kovf = 0; w.err = 0; s.nitems = 0; s.newcount = 0; s.bad = 0; b.nkill = 0; b.kovf = 0; b.bad = 0;
+    w.cthr = (int)(long long)st.ctrl[5]; w.tsal = __longlong_as_double((long long)st.ctrl[6]); w.tseq = st.ctrl[7]; w.iptr = (uint32_t)st.ctrl[8];
+  }
+  for (uint32_t i = tid; i < kMarkSlots; i += kGreedyThreads) { s.mk[i] = 0; s.mv0[i] = 0; s.mv1[i] = 0; }
+  for (uint32_t i = tid; i < kWinCap; i += kGreedyThreads) { w.seq[i] = 0; w.e[i] = 0; w.v[i] = 0; w.sal[i] = 0.0; }
+  b.bitmap[wave][lane] = 0;
+  if (tid < kNW) { Key z; z.sal = -__builtin_inf(); z.seq = 0; z.arg = 0; b.part1[tid] = z; b.part2[tid] = z; }
+  __syncthreads();
+  const double smin = st.wrange[0], scale = st.wrange[1];
+  uint32_t pend_e = kNone, pend_old = kNone;          // (per lane) a list push whose link is stored a round later
+  constexpr uint32_t kTab = kMarkSlots / kNW;         // private neighbour table of a wave
+  uint32_t* const tk = &s.mk[wave * kTab]; uint32_t* const t0 = &s.mv0[wave * kTab]; uint32_t* const t1 = &s.mv1[wave * kTab];
+#ifdef GLIA_HMT_PROFILE
+  unsigned long long bph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, blast = __builtin_readcyclecounter(), brounds = 0, bmembers = 0, bvalid = 0, bwide = 0, bcut_sal = 0, bcut_dep = 0;
+#define BPH(i) do { if (tid == 0) { unsigned long long tn = __builtin_readcyclecounter(); bph[i] += tn - blast; blast = tn; } } while (0)
+#else
+#define BPH(i) do {} while (0)
+#endif
+
+  for (unsigned long long it = 0; it < st.max_iters; ++it) {
+    // ---- the exact top of the queue, in order: per-wave bests that beat every per-wave second-best ----
+    const int gi = lane >> 3, gj = lane & 7;                             // an 8 x 8 grid of (i, j) comparisons per wave
+    const Key A = b.part1[gi], B = b.part1[gj], C = b.part2[gi];
+    const unsigned long long beats = __ballot(better(A, B)), under = __ballot(better(C, B));
+    const unsigned long long col = 0x0101010101010101ull << gj;
+    const uint32_t rank = (uint32_t)__popcll(beats & col);               // position of candidate gj in the order
+    const bool cand_ok = B.seq != 0 && (under & col) == 0;               // it beats every second-best: part of the exact top
+    if (gi == 0 && cand_ok) b.byrank[rank] = (uint32_t)gj;               // (every wave writes the same values)
+    const unsigned long long okmask = __ballot(gi == 0 && cand_ok);      // (bit j = candidate j)
+    const uint32_t M = (uint32_t)__popcll(okmask);
+    if (M == 0) {
+      // no live item in the window
+      BPH(5);
+      if (pend_e != kNone) { st.er[pend_e].next = pend_old; pend_e = kNone; }
+      const int r = win_reload(st, w, tid, reinterpret_cast<double*>(&s.stage[0]), reinterpret_cast<unsigned long long*>(&s.stage[0]) + kSelMax);
+      BPH(6);
+      if (r == 1) { status = ST_DONE; break; }
+      if (r == 2) { status = ST_NEED_TREE; break; }
+      batch_scan(st, w, b, tid);
+      continue;
+    }
+    // the candidate this wave is responsible for: the one of rank `wave`
+    const unsigned long long minemask = __ballot(gi == 0 && cand_ok && rank == (uint32_t)wave);
+    const bool member = minemask != 0;                                   // (uniform per wave)
+    const int cj = member ? (int)__builtin_ctzll(minemask) : 0;
+    const Key me = b.part1[cj];
+    const uint32_t slot = me.arg;
+    // member data (every wave reads its own; waves without a member read a harmless slot)
+    const uint32_t e = w.e[slot], r0 = w.u[slot], r1 = w.v[slot];
+    const uint2 h0r = w.hu[slot], h1r = w.hv[slot];
+    const uint32_t off0 = h0r.x, len0 = h0r.y, off1 = h1r.x, len1 = h1r.y;
+    const uint32_t total = len0 + len1;
+    // the best candidate decides: wide -> the whole workgroup takes it alone
+    const unsigned long long firstmask = __ballot(gi == 0 && cand_ok && rank == 0u);
+    const Key top = b.part1[__builtin_ctzll(firstmask)];
+    const uint2 th0 = w.hu[top.arg], th1 = w.hv[top.arg];
+    const uint32_t top_total = th0.y + th1.y;
+    BPH(0);
+    if (top_total > 64u) {
+      if (ne + top_total > st.Ecap) { status = ST_NEED_EDGES; break; }
+      if (pool_used + top_total > st.pool_cap) { status = ST_NEED_POOL; break; }
+      uint32_t newcount = 0;
+      const uint32_t tt = batch_contract_wide(st, w, s, b, tid, top.arg, top.sal, k, ne, pool_used, &newcount);
+      if (b.bad) { status = ST_BAD_SALIENCY; break; }
+      k += 1; ne += newcount; pool_used += tt;
+#ifdef GLIA_HMT_PROFILE
+      bwide += 1;
+#endif
+      batch_scan(st, w, b, tid);
+      BPH(4);
+      continue;
+    }
+    // ---- compute: wave j works out member j (rank order) on its own; wide members end the batch ----
+    const bool narrow = member && total <= 64u;
+    b.bitmap[wave][lane] = 0;
+    FatEntry fe; fe.eid = kNone; fe.rs = 0; fe.n = 0; fe.pos = 0; fe.off = 0; fe.len = 0; fe.mean = 0.0;
+    const bool inlist = narrow && (uint32_t)lane < total;
+    const bool side1 = (uint32_t)lane >= len0;
+    if (inlist) fe = st.fpool[side1 ? off1 + ((uint32_t)lane - len0) : off0 + (uint32_t)lane];
+    if (pend_e != kNone) { st.er[pend_e].next = pend_old; pend_e = kNone; }      // (last round's atomic has returned with these loads)
+    const bool act = inlist && fe.eid != e && fe.eid != kNone;
+    uint32_t h = (fe.rs * 2654435761u) >> 24;
+    if (act) {
+      while (true) {
+        const uint32_t old = atomicCAS(&tk[h], 0u, fe.rs + 1u);
+        if (old == 0u || old == fe.rs + 1u) break;
+        h = (h + 1u) & (kTab - 1u);
+      }
+      (side1 ? t1 : t0)[h] = (uint32_t)lane + 1u;
+      atomicOr(&b.bitmap[wave][(fe.rs >> 5) & 63u], 1u << (fe.rs & 31u));
+    }
+    if (narrow && lane == 0) { atomicOr(&b.bitmap[wave][(r0 >> 5) & 63u], 1u << (r0 & 31u)); atomicOr(&b.bitmap[wave][(r1 >> 5) & 63u], 1u << (r1 & 31u)); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // (a wave's LDS operations execute in order)
+    const uint32_t m0 = act ? t0[h] : 0u, m1 = act ? t1[h] : 0u;
+    const bool owner = act && (!side1 || m0 == 0u);
+    const bool both = owner && !side1 && m1 != 0u;
+    const int plane = both ? (int)(m1 - 1u) : lane;                      // the lane holding the (r1, rs) entry of a common neighbour
+    const uint32_t p_eid = (uint32_t)__shfl((int)fe.eid, plane), p_n = (uint32_t)__shfl((int)fe.n, plane), p_pos = (uint32_t)__shfl((int)fe.pos, plane);
+    const unsigned long long mbits = (unsigned long long)__double_as_longlong(fe.mean);
+    const double p_mean = __longlong_as_double((long long)(((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(mbits >> 32), plane) << 32) | (uint32_t)__shfl((int)(uint32_t)mbits, plane)));
+    if (act) { tk[h] = 0u; t0[h] = 0u; t1[h] = 0u; }                       // the table is clean again
+    const bool h0 = owner && !side1, h1 = owner && (side1 || both);
+    // util/struct_merge.hxx:62-76 (operand order: the (r0,rs) item first)
+    double first = 0.0;
+    int second = 0;
+    if (h0) { first += fe.mean * (int)fe.n; second += (int)fe.n; }
+    if (h1) { const double m = both ? p_mean : fe.mean; const int nn = both ? (int)p_n : (int)fe.n; first += m * nn; second += nn; }
+    first = owner ? sdivide(first, (double)second, 0.0) : 0.0;
+    const bool bad = owner && first == -1.0;             // DUMMY -> "invalid boundary saliency" (:78-79)
+    const double sal = -first;
+    const unsigned long long ownmask = __ballot(owner);
+    const uint32_t newcount = (uint32_t)__popcll(ownmask);
+    const uint32_t idx = (uint32_t)__popcll(ownmask & ((1ull << lane) - 1ull));
+    // the largest saliency this member creates
+    double mx = owner ? sal : -__builtin_inf();
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const double o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
+    if (lane == 0) { b.m_newcount[wave] = narrow ? newcount : 0u; b.m_total[wave] = narrow ? total : 0xFFFFFFFFu; b.m_maxsal[wave] = mx; }
+    if (bad) b.bad = 1;
+    __syncthreads();
+    BPH(1);
+    if (b.bad) { status = ST_BAD_SALIENCY; break; }
+    // ---- validate: the longest prefix of the batch whose order is certain (lane j checks member j) ----
+    uint32_t V, ne_off, pool_off, my_ne, my_pool;
+    {
+      const uint32_t j = (uint32_t)lane & 7u;
+      const Key kj = b.part1[b.byrank[j]];
+      const uint32_t u = w.u[kj.arg], v = w.v[kj.arg];
+      const uint32_t tj = b.m_total[j], nj = b.m_newcount[j];
+      double pm = -__builtin_inf();
+      uint32_t hit = 0, pre_n = 0, pre_t = 0;
+#pragma unroll
+      for (uint32_t i = 0; i < (uint32_t)kNW; ++i) {
+        const double ms = b.m_maxsal[i];
+        const uint32_t bu = b.bitmap[i][(u >> 5) & 63u], bv = b.bitmap[i][(v >> 5) & 63u];
+        const uint32_t ti = b.m_total[i], ni = b.m_newcount[i];
+        if (i < j) { pm = ms > pm ? ms : pm; hit |= ((bu >> (u & 31u)) | (bv >> (v & 31u))) & 1u; pre_n += ni; pre_t += ti; }
+      }
+      const bool okj = j < M && tj != 0xFFFFFFFFu && (j == 0u || (kj.sal > pm && hit == 0u));
+      const uint32_t okbits = (uint32_t)(__ballot(lane < kNW && okj) & 0xFFull);
+      V = (uint32_t)__builtin_ctz(~okbits);                               // members 0 .. V-1 are certain
+#ifdef GLIA_HMT_PROFILE
+      if (V < M) { const uint32_t cutsal = (uint32_t)(__ballot(lane < kNW && j == V && !(kj.sal > pm)) & 0xFFull); if (cutsal) bcut_sal += 1; else bcut_dep += 1; }
+#endif
+      // offsets of this wave's member, totals of the valid prefix
+      my_ne = (uint32_t)__builtin_amdgcn_readlane((int)pre_n, wave); my_pool = (uint32_t)__builtin_amdgcn_readlane((int)pre_t, wave);
+      const uint32_t last = V - 1u;
+      ne_off = (uint32_t)__shfl((int)(pre_n + nj), (int)last); pool_off = (uint32_t)__shfl((int)(pre_t + tj), (int)last);
+    }
+    const uint32_t sum_tot = pool_off;
+    if (ne + sum_tot > st.Ecap) { status = ST_NEED_EDGES; break; }
+    if (pool_used + sum_tot > st.pool_cap) { status = ST_NEED_POOL; break; }
+    // room in the window for everything the batch may insert (the popped items leave first: a flush must not see them)
+    bool popped = false;
+    if (w.n + ne_off > kWinCap) {
+      if ((uint32_t)wave < V && lane == 0) w.seq[slot] = 0;
+      popped = true;                                                     // (slot numbers are void after a compaction)
+      __syncthreads();
+      win_compact(w, tid);
+      if (w.n + ne_off > kWinCap) win_flush(st, w, tid);
+    }
+    const int cthr = w.cthr; const double tsal = w.tsal; const unsigned long long tseq = w.tseq;
+    BPH(2);
+    // ---- commit: the valid members, each by its own wave ----
+    if ((uint32_t)wave < V) {
+      const unsigned long long kk = k + (unsigned long long)wave;
+      const uint32_t r2 = st.R0 + (uint32_t)kk;
+      const uint32_t r2off = (uint32_t)pool_used + my_pool;
+      if (lane == 0) {
+        if (!popped) w.seq[slot] = 0;                                    // popped
+        st.order[3 * kk + 0] = r0; st.order[3 * kk + 1] = r1; st.order[3 * kk + 2] = r2;
+        st.sal_out[kk] = me.sal;
+        st.er[e].seq = 0;
+        st.adj_off[r2] = r2off; st.adj_len[r2] = newcount;
+      }
+      if (owner) {
+        const uint32_t rs = fe.rs;
+        const uint32_t newE = (uint32_t)ne + my_ne + idx;
+        const uint32_t offRs = fe.off, posRs = fe.pos, lenRs = fe.len;   // rs's entry of the (r0,rs) edge -- or of (r1,rs) alone -- is reused
+        if (both) st.fpool[offRs + p_pos].eid = kNone;                   // rs held two entries: the other becomes a tombstone
+        const uint32_t cat = rs < r0 ? 0u : (h0 ? 1u : 2u);
+        const unsigned long long seq = ((kk + 1ull) << 32) | ((unsigned long long)cat << 30) | rs;
+        uint4* pq4 = reinterpret_cast<uint4*>(&st.er[newE]);
+        pq4[0] = make_uint4(rs, r2, posRs, idx);
+        const unsigned long long mb = (unsigned long long)__double_as_longlong(first);
+        pq4[1] = make_uint4((uint32_t)mb, (uint32_t)(mb >> 32), (uint32_t)second, kNone);
+        pq4[2] = make_uint4(offRs, lenRs, r2off, newcount);
+        const unsigned long long sbits = (unsigned long long)__double_as_longlong(sal);
+        pq4[3] = make_uint4((uint32_t)sbits, (uint32_t)(sbits >> 32), (uint32_t)seq, (uint32_t)(seq >> 32));
+        FatEntry a; a.eid = newE; a.rs = r2; a.n = (uint32_t)second; a.pos = idx; a.off = r2off; a.len = newcount; a.mean = first;
+        st.fpool[offRs + posRs] = a;
+        FatEntry bb; bb.eid = newE; bb.rs = rs; bb.n = (uint32_t)second; bb.pos = posRs; bb.off = offRs; bb.len = lenRs; bb.mean = first;
+        st.fpool[r2off + idx] = bb;
+        const uint32_t cell = win_cell(sal, smin, scale, st.wB);
+        if (win_above(cthr, tsal, tseq, (int)cell, sal, seq)) {
+          const uint32_t sl = atomicAdd(&w.n, 1u);
+          win_put(w, sl, sal, seq, newE, rs, r2, make_uint2(offRs, lenRs), make_uint2(r2off, newcount));
+        } else {
+          pend_e = newE; pend_old = atomicExch(&st.whead[cell], newE);
+          atomicAdd(&st.wcnt[cell], 1u);
+        }
+        // the replaced edges leave the queue
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+          const bool hs = side ? h1 : h0;
+          if (!hs) continue;
+          const uint32_t de = (side && both) ? p_eid : fe.eid;
+          const double dsal = -((side && both) ? p_mean : fe.mean);
+          const uint32_t dc = win_cell(dsal, smin, scale, st.wB);
+          unsigned long long dq = 1;
+          if ((int)dc == cthr && dsal == tsal) dq = de < st.E0 ? (unsigned long long)de + 1ull : st.er[de].seq;   // tie with tau: the seq decides
+          st.er[de].seq = 0;
+          if (win_above(cthr, tsal, tseq, (int)dc, dsal, dq)) {
+            const uint32_t j = atomicAdd(&b.nkill, 1u); if (j < kBatchKill) b.kill[j] = de; else b.kovf = 1;
+          } else atomicSub(&st.wcnt[dc], 1u);
+        }
+      }
+    }
+    __syncthreads();
+    BPH(3);
+#ifdef GLIA_HMT_PROFILE
+    brounds += 1; bmembers += M; bvalid += V;
+#endif
+    k += V; ne += ne_off; pool_used += pool_off;
+    batch_scan(st, w, b, tid);
+    BPH(4);
+  }
+#ifdef GLIA_HMT_PROFILE
+  if (tid == 0) printf("[batch profile] merges %llu: select %llu  compute %llu  validate %llu  commit %llu  scan %llu  loop-top %llu  reload %llu (cycles); rounds %llu candidates %llu committed %llu (cut by saliency %llu, by adjacency %llu) wide %llu\n",
+                       k, bph[0], bph[1], bph[2], bph[3], bph[4], bph[5], bph[6], brounds, bmembers, bvalid, bcut_sal, bcut_dep, bwide);
+#endif
+  if (pend_e != kNone) st.er[pend_e].next = pend_old;
   // leave through the global lists: the next launch (or the tree kernel) starts from them
   __syncthreads();
   win_flush(st, w, tid);
@@ -1414,8 +1918,11 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
   while (true) {
     if (window) {
       ws.max_iters = st.max_iters;
+      // GLIA_HMT_PB_BATCH=0: one contraction at a time on the window queue (kernel experiments; same result)
+      const char* benv = getenv("GLIA_HMT_PB_BATCH");
       if (cond_n > 0) hipLaunchKernelGGL(greedy_window_kernel<true>, dim3(1), dim3(kGreedyThreads), 0, stream, ws);
-      else hipLaunchKernelGGL(greedy_window_kernel<false>, dim3(1), dim3(kGreedyThreads), 0, stream, ws);
+      else if (benv && benv[0] == '0') hipLaunchKernelGGL(greedy_window_kernel<false>, dim3(1), dim3(kGreedyThreads), 0, stream, ws);
+      else hipLaunchKernelGGL(greedy_batch_kernel, dim3(1), dim3(kGreedyThreads), 0, stream, ws);
     } else if (median_of) hipLaunchKernelGGL(greedy_pb_kernel<true>, dim3(1), dim3(kGreedyThreads), 0, stream, st);
     else hipLaunchKernelGGL(greedy_pb_kernel<false>, dim3(1), dim3(kGreedyThreads), 0, stream, st);
     GLIA_HIP_TRY(hipGetLastError());

@@ -33,7 +33,7 @@ enum { ST_RUN = 0, ST_DONE = 1, ST_NEED_EDGES = 2, ST_NEED_POOL = 3, ST_BAD_SALI
 struct Key { double sal; unsigned long long seq; uint32_t arg; };
 
 __device__ __forceinline__ bool better(const Key& a, const Key& b) {
-  return a.sal > b.sal || (a.sal == b.sal && a.seq > b.seq);
+  return (a.sal > b.sal) | ((a.sal == b.sal) & (a.seq > b.seq));      // no short-circuit: three compares, no branches
 }
 
 // 64-lane maximum by (saliency, seq), returned to every lane.  Hand-written over DPP: a generic reduction of the 20-byte
@@ -52,7 +52,7 @@ __device__ __forceinline__ void key_max_step(Key& k) {
   const uint32_t a = dpp_u32<CTRL, ROW_MASK>(k.arg);
   const double osal = __longlong_as_double((long long)(((unsigned long long)s_hi << 32) | s_lo));
   const unsigned long long oseq = ((unsigned long long)q_hi << 32) | q_lo;
-  const bool b = osal > k.sal || (osal == k.sal && oseq > k.seq);
+  const bool b = (osal > k.sal) | ((osal == k.sal) & (oseq > k.seq));
   k.sal = b ? osal : k.sal;
   k.seq = b ? oseq : k.seq;
   k.arg = b ? a : k.arg;
