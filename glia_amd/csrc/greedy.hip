@@ -537,14 +537,17 @@ struct WinState {
   EdgeRec* er; FatEntry* fpool;
   uint32_t* whead;                          // [wB] newest created edge of the cell's list (kNone = empty); atomics only
   uint32_t* wcnt;                           // [wB] live queue items of the cell below the threshold (sorted array + list); atomics only
-  const uint32_t* isort;                    // [E0] initial edges by descending (saliency, seq)
-  const uint32_t* ige;                      // [wB + 1] initial edges whose cell is >= c
+  // the BASELINE: every queue item that was alive when it was taken (at the start: the initial edges; later: see
+  // win_rebaseline), sorted by descending (saliency, seq), with its seq (a dead item's record no longer has it)
+  const uint32_t* isort; const unsigned long long* isort_seq;
+  const uint32_t* ige;                      // [wB + 1] baseline items whose cell is >= c
   const double* wrange;                     // [0] smallest initial saliency, [1] cells per unit of saliency
   uint32_t* order; double* sal_out; unsigned long long* ctrl;
   unsigned long long* rsz; double* rsum; uint32_t *mark0, *mark1, *adj_off, *adj_len;
   unsigned long long pool_cap, max_iters, cond_t0, cond_t1;
   double cond_rpb;
-  uint32_t R0, Ecap, wB, E0;
+  uint32_t R0, Ecap, wB, nsort;             // nsort: items of the baseline
+  unsigned long long ne_base, rebase_after; // edges that existed at the baseline; a new one is due after this many more
   int cond_n;
 };
 constexpr uint32_t kWinCap = 1536;          // window slots (live items + holes)
@@ -571,6 +574,7 @@ struct WinShared {
   uint32_t wsum[kNW];                       // block scan scratch
   uint32_t bcast, maxcell, err, need_tree;
   double psal; unsigned long long pseq;     // split of a cell: the list's contribution to tau
+  unsigned long long spill_ord;             // image of the largest saliency that found the window full (0 = none): tau has to rise to it
 };
 struct WinWork {                            // the neighbour table of one contraction (small case)
   uint32_t mk[kMarkSlots], mv0[kMarkSlots], mv1[kMarkSlots];     // neighbour + 1, staged index + 1 of the (r0,rs) / (r1,rs) entry
@@ -578,6 +582,15 @@ struct WinWork {                            // the neighbour table of one contra
   FatEntry stage[kMarkMax];
 };
 
+// order-preserving image of a double: ascending doubles <-> ascending unsigned integers
+__device__ __forceinline__ unsigned long long f64_ord(double d) {
+  unsigned long long b = (unsigned long long)__double_as_longlong(d);
+  return b ^ ((b >> 63) ? ~0ull : 0x8000000000000000ull);
+}
+__device__ __forceinline__ double f64_unord(unsigned long long o) {
+  o ^= (o >> 63) ? 0x8000000000000000ull : ~0ull;
+  return __longlong_as_double((long long)o);
+}
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }   // global stores stay in flight
 
 __device__ __forceinline__ uint32_t win_cell(double sal, double smin, double scale, uint32_t B) {
@@ -674,7 +687,7 @@ __device__ __forceinline__ Key win_root(const WinShared& w, int lane) {
 __device__ __forceinline__ void win_compact(WinShared& w, int tid) {
   double sal[kWinPer]; unsigned long long seq[kWinPer]; uint32_t e[kWinPer], u[kWinPer], v[kWinPer]; uint2 hu[kWinPer], hv[kWinPer];
   uint32_t live = 0;
-  const uint32_t n = w.n;
+  const uint32_t n = w.n < kWinCap ? w.n : kWinCap;
 #pragma unroll
   for (int j = 0; j < kWinPer; ++j) {
     const uint32_t i = (uint32_t)tid * kWinPer + j;
@@ -702,7 +715,7 @@ __device__ __forceinline__ void win_flush(const WinState& st, WinShared& w, int 
   const double smin = st.wrange[0], scale = st.wrange[1];
   if (tid == 0) w.maxcell = 0;
   __syncthreads();
-  const uint32_t n = w.n;
+  const uint32_t n = w.n < kWinCap ? w.n : kWinCap;
   uint32_t mc = 0;
   for (uint32_t i = tid; i < n; i += kGreedyThreads) {
     if (w.seq[i] == 0) continue;
@@ -716,6 +729,23 @@ __device__ __forceinline__ void win_flush(const WinState& st, WinShared& w, int 
     if (w.maxcell && (int)w.maxcell - 1 >= w.cthr) { w.cthr = (int)w.maxcell - 1; w.tsal = __builtin_inf(); w.tseq = ~0ull; }
     w.n = 0;
   }
+  __syncthreads();
+}
+
+// Items above tau found the window full and went to their cells' lists: tau rises to the largest of their saliencies and
+// the window items at or below it follow them (every thread calls, after a scan has applied the pending deaths)
+__device__ __forceinline__ void win_evict(const WinState& st, WinShared& w, int tid) {
+  const double smin = st.wrange[0], scale = st.wrange[1];
+  const double lim = f64_unord(w.spill_ord);
+  const uint32_t n = w.n < kWinCap ? w.n : kWinCap;
+  __syncthreads();
+  for (uint32_t i = tid; i < n; i += kGreedyThreads) {
+    if (w.seq[i] == 0 || w.sal[i] > lim) continue;
+    win_push_global(st, w.e[i], win_cell(w.sal[i], smin, scale, st.wB));
+    w.seq[i] = 0;
+  }
+  __syncthreads();
+  if (tid == 0) { w.n = n; w.cthr = (int)win_cell(lim, smin, scale, st.wB); w.tsal = lim; w.tseq = ~0ull; w.spill_ord = 0; }
   __syncthreads();
 }
 
@@ -807,7 +837,7 @@ __device__ __forceinline__ int win_reload(const WinState& st, WinShared& w, int 
         double tsal = w.psal; unsigned long long tseq = w.pseq;
         const uint32_t iA = seg_end > iptr ? (seg_end - iptr < RA ? seg_end : iptr + RA) : iptr;
         if (iA < seg_end) {                                                     // array entries stay behind: their first one bounds tau
-          const uint32_t et = st.isort[iA]; const double as = st.er[et].sal; const unsigned long long aq = (unsigned long long)et + 1ull;
+          const uint32_t et = st.isort[iA]; const double as = st.er[et].sal; const unsigned long long aq = st.isort_seq[iA];
           if (as > tsal || (as == tsal && aq > tseq)) { tsal = as; tseq = aq; }
         }
         if (tid == 0) w.bcast = 0;
@@ -816,7 +846,7 @@ __device__ __forceinline__ int win_reload(const WinState& st, WinShared& w, int 
         uint32_t mine = 0;
         for (uint32_t i = iptr + (uint32_t)tid; i < iA; i += kGreedyThreads) {
           const uint32_t e = st.isort[i]; const EdgeRec r = st.er[e];
-          const unsigned long long q = (unsigned long long)e + 1ull;            // (a dead entry's seq is gone from its record)
+          const unsigned long long q = st.isort_seq[i];                         // (a dead entry's seq is gone from its record)
           if (r.sal > tsal || (r.sal == tsal && q > tseq)) { ++mine; win_take(st, w, e, r); }
         }
         if (mine) atomicAdd(&w.bcast, mine);
@@ -1061,7 +1091,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(WinState 
         const uint32_t dc = win_cell(dsal, smin, scale, st.wB);
         unsigned long long dq = 1;
         const bool tie = (int)dc == cthr2 && dsal == tsal2;       // tie with tau: the seq decides where the edge lives
-        if (COND || tie) dq = (!COND && de < st.E0) ? (unsigned long long)de + 1ull : st.er[de].seq;   // COND: 0 = rejected earlier, out of the queue
+        if (COND || tie) dq = st.er[de].seq;   // COND: 0 = rejected earlier, out of the queue
         st.er[de].seq = 0;
         if (dq != 0) {
           if (win_above(cthr2, tsal2, tseq2, (int)dc, dsal, dq)) {
@@ -1150,7 +1180,7 @@ struct BatchShared {
 
 // one pass over the window: applies the deaths of the last round, leaves every wave's best and second-best item
 __device__ __forceinline__ void batch_scan(const WinState& st, WinShared& w, BatchShared& b, int tid) {
-  const uint32_t n = w.n, nk = b.nkill < kBatchKill ? b.nkill : kBatchKill, kovf = b.kovf;
+  const uint32_t n = w.n < kWinCap ? w.n : kWinCap, nk = b.nkill < kBatchKill ? b.nkill : kBatchKill, kovf = b.kovf;
   // Slot ownership is STRIPED over the waves (lane l of wave v scans the l-th slot of chunk (v + l) mod 8 in every block
   // of 512): a reload fills consecutive slots with consecutive keys, and the exact top of the queue is only as long as
   // the run of best items that sit with different waves.  (Bank pattern of a wave's reads: that of consecutive slots.)
@@ -1221,16 +1251,7 @@ __device__ __forceinline__ uint32_t batch_contract_wide(const WinState& st, WinS
     } else (side1 ? st.mark1 : st.mark0)[fe.rs] = i + 1u;
   }
   __syncthreads();
-  if (wn_now + total > kWinCap) {
-    win_compact(w, tid);
-    if (w.n + total > kWinCap) {
-      win_flush(st, w, tid);
-      if (total > kWinCap) {               // a contraction wider than the window: nothing of it goes there
-        if (tid == 0) { w.cthr = (int)st.wB; w.tsal = __builtin_inf(); w.tseq = ~0ull; }
-        __syncthreads();
-      }
-    }
-  }
+  if (wn_now + total > kWinCap && wn_now > kWinCap / 2u) win_compact(w, tid);      // (holes out; a full window spills, see win_evict)
   const int cthr = w.cthr; const double tsal = w.tsal; const unsigned long long tseq = w.tseq;
   const uint32_t nwork = small ? s.nitems : total;
   bool bad = false;
@@ -1288,10 +1309,13 @@ __device__ __forceinline__ uint32_t batch_contract_wide(const WinState& st, WinS
     st.fpool[r2off + idx] = bb;
     if (small) { s.items[i] = offRs + posRs; s.newidx[i] = idx; }
     const uint32_t cell = win_cell(sal, smin, scale, st.wB);
+    uint32_t sl = kWinCap;
     if (win_above(cthr, tsal, tseq, (int)cell, sal, seq)) {
-      const uint32_t sl = atomicAdd(&w.n, 1u);
-      win_put(w, sl, sal, seq, newE, rs, r2, make_uint2(offRs, lenRs), make_uint2(r2off, 0u));
-    } else {
+      sl = atomicAdd(&w.n, 1u);
+      if (sl < kWinCap) win_put(w, sl, sal, seq, newE, rs, r2, make_uint2(offRs, lenRs), make_uint2(r2off, 0u));
+      else atomicMax(&w.spill_ord, f64_ord(sal));          // the window is full: tau will rise above this item
+    }
+    if (sl >= kWinCap) {
       if (pend_e != kNone) st.er[pend_e].next = pend_old;
       pend_e = newE; pend_old = atomicExch(&st.whead[cell], newE);
       atomicAdd(&st.wcnt[cell], 1u);
@@ -1304,7 +1328,7 @@ __device__ __forceinline__ uint32_t batch_contract_wide(const WinState& st, WinS
       const double dsal = -(side ? f1.mean : f0.mean);
       const uint32_t dc = win_cell(dsal, smin, scale, st.wB);
       unsigned long long dq = 1;
-      if ((int)dc == cthr && dsal == tsal) dq = de < st.E0 ? (unsigned long long)de + 1ull : st.er[de].seq;   // tie with tau: the seq decides
+      if ((int)dc == cthr && dsal == tsal) dq = st.er[de].seq;   // tie with tau: the seq decides
       st.er[de].seq = 0;
       if (win_above(cthr, tsal, tseq, (int)dc, dsal, dq)) {
         const uint32_t j = atomicAdd(&b.nkill, 1u); if (j < kBatchKill) b.kill[j] = de; else b.kovf = 1;
@@ -1324,7 +1348,7 @@ __device__ __forceinline__ uint32_t batch_contract_wide(const WinState& st, WinS
       st.mark0[fb.rs] = 0; st.mark1[fb.rs] = 0;
     }
   }
-  for (uint32_t i = tid; i < w.n; i += kGreedyThreads) if (w.v[i] == r2) w.hv[i].y = newcount;      // window items of r2: its list length
+  for (uint32_t i = tid; i < (w.n < kWinCap ? w.n : kWinCap); i += kGreedyThreads) if (w.v[i] == r2) w.hv[i].y = newcount;      // window items of r2: its list length
   if (pend_e != kNone) st.er[pend_e].next = pend_old;
   if (tid == 0) { st.adj_off[r2] = r2off; st.adj_len[r2] = newcount; }
   __syncthreads();
@@ -1341,7 +1365,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
   unsigned long long k = st.ctrl[0], ne = st.ctrl[1], pool_used = st.ctrl[2];
   uint32_t status = ST_RUN;
   if (tid == 0) {
-    w.n = 0; w.nk = 0; w.kovf = 0; w.err = 0; s.nitems = 0; s.newcount = 0; s.bad = 0; b.nkill = 0; b.kovf = 0; b.bad = 0;
+    w.n = 0; w.nk = 0; w.kovf = 0; w.err = 0; w.spill_ord = 0; s.nitems = 0; s.newcount = 0; s.bad = 0; b.nkill = 0; b.kovf = 0; b.bad = 0;
     w.cthr = (int)(long long)st.ctrl[5]; w.tsal = __longlong_as_double((long long)st.ctrl[6]); w.tseq = st.ctrl[7]; w.iptr = (uint32_t)st.ctrl[8];
   }
   for (uint32_t i = tid; i < kMarkSlots; i += kGreedyThreads) { s.mk[i] = 0; s.mv0[i] = 0; s.mv1[i] = 0; }
@@ -1361,6 +1385,8 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
 #endif
 
   for (unsigned long long it = 0; it < st.max_iters; ++it) {
+    // lists grow garbage (dead nodes are only dropped when their cell is loaded): time for a new baseline?
+    if (ne - st.ne_base > st.rebase_after) { status = ST_REBASE; break; }
     // ---- the exact top of the queue, in order: per-wave bests that beat every per-wave second-best ----
     const int gi = lane >> 3, gj = lane & 7;                             // an 8 x 8 grid of (i, j) comparisons per wave
     const Key A = b.part1[gi], B = b.part1[gj], C = b.part2[gi];
@@ -1410,6 +1436,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
       bwide += 1;
 #endif
       batch_scan(st, w, b, tid);
+      if (w.spill_ord) { if (pend_e != kNone) { st.er[pend_e].next = pend_old; pend_e = kNone; } win_evict(st, w, tid); batch_scan(st, w, b, tid); }
       BPH(4);
       continue;
     }
@@ -1495,12 +1522,11 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
     if (pool_used + sum_tot > st.pool_cap) { status = ST_NEED_POOL; break; }
     // room in the window for everything the batch may insert (the popped items leave first: a flush must not see them)
     bool popped = false;
-    if (w.n + ne_off > kWinCap) {
+    if (w.n + ne_off > kWinCap && w.n > kWinCap / 2u) {                    // holes out (a full window spills, see win_evict)
       if ((uint32_t)wave < V && lane == 0) w.seq[slot] = 0;
       popped = true;                                                     // (slot numbers are void after a compaction)
       __syncthreads();
       win_compact(w, tid);
-      if (w.n + ne_off > kWinCap) win_flush(st, w, tid);
     }
     const int cthr = w.cthr; const double tsal = w.tsal; const unsigned long long tseq = w.tseq;
     BPH(2);
@@ -1535,10 +1561,13 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
         FatEntry bb; bb.eid = newE; bb.rs = rs; bb.n = (uint32_t)second; bb.pos = posRs; bb.off = offRs; bb.len = lenRs; bb.mean = first;
         st.fpool[r2off + idx] = bb;
         const uint32_t cell = win_cell(sal, smin, scale, st.wB);
+        uint32_t sl = kWinCap;
         if (win_above(cthr, tsal, tseq, (int)cell, sal, seq)) {
-          const uint32_t sl = atomicAdd(&w.n, 1u);
-          win_put(w, sl, sal, seq, newE, rs, r2, make_uint2(offRs, lenRs), make_uint2(r2off, newcount));
-        } else {
+          sl = atomicAdd(&w.n, 1u);
+          if (sl < kWinCap) win_put(w, sl, sal, seq, newE, rs, r2, make_uint2(offRs, lenRs), make_uint2(r2off, newcount));
+          else atomicMax(&w.spill_ord, f64_ord(sal));      // the window is full: tau will rise above this item
+        }
+        if (sl >= kWinCap) {
           pend_e = newE; pend_old = atomicExch(&st.whead[cell], newE);
           atomicAdd(&st.wcnt[cell], 1u);
         }
@@ -1551,7 +1580,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
           const double dsal = -((side && both) ? p_mean : fe.mean);
           const uint32_t dc = win_cell(dsal, smin, scale, st.wB);
           unsigned long long dq = 1;
-          if ((int)dc == cthr && dsal == tsal) dq = de < st.E0 ? (unsigned long long)de + 1ull : st.er[de].seq;   // tie with tau: the seq decides
+          if ((int)dc == cthr && dsal == tsal) dq = st.er[de].seq;   // tie with tau: the seq decides
           st.er[de].seq = 0;
           if (win_above(cthr, tsal, tseq, (int)dc, dsal, dq)) {
             const uint32_t j = atomicAdd(&b.nkill, 1u); if (j < kBatchKill) b.kill[j] = de; else b.kovf = 1;
@@ -1566,6 +1595,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
 #endif
     k += V; ne += ne_off; pool_used += pool_off;
     batch_scan(st, w, b, tid);
+    if (w.spill_ord) { if (pend_e != kNone) { st.er[pend_e].next = pend_old; pend_e = kNone; } win_evict(st, w, tid); batch_scan(st, w, b, tid); }
     BPH(4);
   }
 #ifdef GLIA_HMT_PROFILE
@@ -1582,11 +1612,6 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
   }
 }
 
-// order-preserving image of a double: ascending doubles <-> ascending unsigned integers
-__device__ __forceinline__ unsigned long long f64_ord(double d) {
-  unsigned long long b = (unsigned long long)__double_as_longlong(d);
-  return b ^ ((b >> 63) ? ~0ull : 0x8000000000000000ull);
-}
 __global__ void win_range_kernel(const double* sal, uint32_t E0, unsigned long long* mm) {
   unsigned long long lo = ~0ull, hi = 0ull;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < E0; i += gridDim.x * blockDim.x) {
@@ -1601,25 +1626,36 @@ __global__ void win_params_kernel(const unsigned long long* mm, uint32_t B, doub
   range[0] = smin;
   range[1] = smax > smin ? (double)B / (smax - smin) : 0.0;
 }
-// sort input: initial edges in DESCENDING slot order with their saliency image; a stable descending sort by saliency
-// then leaves equal saliencies in descending seq (= slot + 1) order
-__global__ void win_sort_input_kernel(GreedyState g, WinState st, uint32_t E0, unsigned long long* keys, uint32_t* vals) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= E0) return;
-  const uint32_t e = E0 - 1u - i;
-  keys[i] = f64_ord(g.pq.leaf_sal[e]); vals[i] = e;
-  atomicAdd(&st.wcnt[win_cell(g.pq.leaf_sal[e], st.wrange[0], st.wrange[1], st.wB)], 1u);
+// ---- baseline: every live queue item, sorted by descending (saliency, seq) (whole-GPU kernels between launches) ----
+__global__ void win_collect_kernel(const EdgeRec* er, uint32_t n_edges, unsigned long long* kseq, uint32_t* vals, uint32_t* counter) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_edges) return;
+  const unsigned long long q = er[e].seq;
+  if (q == 0) return;
+  const uint32_t i = atomicAdd(counter, 1u);
+  kseq[i] = q; vals[i] = e;
 }
-// ige[c] = number of initial edges whose cell is >= c (c = 0..B): cell c's segment of the sorted array is [ige[c+1], ige[c])
-__global__ void win_segments_kernel(GreedyState g, WinState st, uint32_t E0, uint32_t* ige) {
+__global__ void win_salkey_kernel(const EdgeRec* er, const uint32_t* vals, uint32_t n, unsigned long long* ksal) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ksal[i] = f64_ord(er[vals[i]].sal);
+}
+__global__ void win_baseline_fill_kernel(WinState st, uint32_t n, uint32_t* isort_w, unsigned long long* isort_seq) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const EdgeRec r = st.er[isort_w[i]];
+  isort_seq[i] = r.seq;
+  atomicAdd(&st.wcnt[win_cell(r.sal, st.wrange[0], st.wrange[1], st.wB)], 1u);
+}
+// ige[c] = number of baseline items whose cell is >= c (c = 0..B): cell c's segment of the sorted array is [ige[c+1], ige[c])
+__global__ void win_segments_kernel(WinState st, const uint32_t* isort, uint32_t n, uint32_t* ige) {
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c > st.wB) return;
-  uint32_t lo = 0, hi = E0;                   // first index whose cell is < c
+  uint32_t lo = 0, hi = n;                    // first index whose cell is < c
   while (lo < hi) {
     const uint32_t mid = (lo + hi) >> 1;
-    if (win_cell(g.pq.leaf_sal[st.isort[mid]], st.wrange[0], st.wrange[1], st.wB) >= c) lo = mid + 1; else hi = mid;
+    if (win_cell(st.er[isort[mid]].sal, st.wrange[0], st.wrange[1], st.wB) >= c) lo = mid + 1; else hi = mid;
   }
-  ige[c] = c == 0 ? E0 : lo;
+  ige[c] = c == 0 ? n : lo;
 }
 __global__ void adj_fill_fat(GreedyState g, WinState st, uint32_t E0, uint32_t* cursor) {
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1869,46 +1905,74 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
     GLIA_HIP_TRY(hipGetLastError());
   }
   unsigned long long ctrl[9] = {0, E0, 2ull * E0, ST_RUN, n_values, 0, 0, 0, 0};
+  // buffers of the window queue's baseline (see win_rebaseline below)
+  unsigned long long *rb_kseq = nullptr, *rb_kseq2 = nullptr, *rb_ksal = nullptr, *rb_ksal2 = nullptr, *rb_iseq = nullptr;
+  uint32_t *rb_vals = nullptr, *rb_vals2 = nullptr, *rb_isort = nullptr, *rb_ige = nullptr, *rb_counter = nullptr;
+  void* rb_tmp = nullptr; size_t rb_tmp_bytes = 0;
+  // A baseline = all live queue items sorted by descending (saliency, seq): two stable radix sorts (by seq, then by the
+  // saliency's order-preserving image), per-cell segments and live counters; the cell lists start empty.  Taken at the start
+  // (the initial edges) and whenever a launch ends before the queue is empty: the lists only shed their dead nodes when
+  // their cell is loaded, so after a few million created edges walking them dominates; a re-sort is ~1 ms of whole-GPU work.
+  auto win_rebaseline = [&](uint32_t n_edges) -> int {
+    GLIA_HIP_TRY(hipMemsetAsync(rb_counter, 0, sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(win_collect_kernel, dim3((n_edges + 255) / 256), dim3(256), 0, stream, ws.er, n_edges, rb_kseq, rb_vals, rb_counter);
+    uint32_t n = 0;
+    GLIA_HIP_TRY(hipMemcpyAsync(&n, rb_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    GLIA_HIP_TRY(hipStreamSynchronize(stream));
+    if (n > E0) { set_error("greedy: more live edges than initial edges (internal error)"); return GLIA_HMT_ERR_HIP; }
+    if (n) {
+      size_t tmp = rb_tmp_bytes;
+      GLIA_HIP_TRY(rocprim::radix_sort_pairs_desc(rb_tmp, tmp, rb_kseq, rb_kseq2, rb_vals, rb_vals2, (size_t)n, 0, 64, stream));
+      hipLaunchKernelGGL(win_salkey_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, ws.er, rb_vals2, n, rb_ksal);
+      tmp = rb_tmp_bytes;
+      GLIA_HIP_TRY(rocprim::radix_sort_pairs_desc(rb_tmp, tmp, rb_ksal, rb_ksal2, rb_vals2, rb_isort, (size_t)n, 0, 64, stream));
+    }
+    GLIA_HIP_TRY(hipMemsetAsync(ws.whead, 0xFF, sizeof(uint32_t) * ws.wB, stream));
+    GLIA_HIP_TRY(hipMemsetAsync(ws.wcnt, 0, sizeof(uint32_t) * ws.wB, stream));
+    if (n) hipLaunchKernelGGL(win_baseline_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, ws, n, rb_isort, rb_iseq);
+    hipLaunchKernelGGL(win_segments_kernel, dim3((ws.wB + 1 + 255) / 256), dim3(256), 0, stream, ws, rb_isort, n, rb_ige);
+    GLIA_HIP_TRY(hipGetLastError());
+    ws.nsort = n; ws.ne_base = n_edges;
+    const char* renv = getenv("GLIA_HMT_REBASE");                          // created edges between baselines (tuning)
+    ws.rebase_after = renv ? strtoull(renv, nullptr, 10) : std::max<unsigned long long>(1ull << 20, 2ull * n);
+    const double inf = std::numeric_limits<double>::infinity();
+    ctrl[5] = (unsigned long long)(long long)(ws.wB - 1);                  // threshold: everything is below it
+    memcpy(&ctrl[6], &inf, 8); ctrl[7] = ~0ull; ctrl[8] = 0;
+    return GLIA_HMT_OK;
+  };
   if (window) {
-    // saliency cells: ~4 initial edges per cell on average; the initial edges sorted by descending key; per-cell live counters
+    // saliency cells: ~4 initial edges per cell on average
     uint32_t B = 256;
     while (B < E0 / 4 && B < (1u << 22)) B <<= 1;
-    ws.wB = B; ws.E0 = E0; ws.R0 = R;
-    const double inf = std::numeric_limits<double>::infinity();
-    ctrl[5] = (unsigned long long)(long long)(B - 1);                       // threshold: everything is below it
-    memcpy(&ctrl[6], &inf, 8); ctrl[7] = ~0ull; ctrl[8] = 0;
+    ws.wB = B; ws.R0 = R;
     unsigned long long* mm; double* range;
-    unsigned long long *skeys, *skeys2; uint32_t *svals, *isort, *ige;
     if ((rc = buf.get(&ws.whead, B, false, stream))) return rc;
     if ((rc = buf.get(&ws.wcnt, B, true, stream))) return rc;
-    if ((rc = buf.get(&isort, E0, false, stream))) return rc;
-    if ((rc = buf.get(&ige, (size_t)B + 1, false, stream))) return rc;
+    if ((rc = buf.get(&rb_isort, E0, false, stream))) return rc;
+    if ((rc = buf.get(&rb_iseq, E0, false, stream))) return rc;
+    if ((rc = buf.get(&rb_ige, (size_t)B + 1, false, stream))) return rc;
     if ((rc = buf.get(&mm, 2, false, stream))) return rc;
     if ((rc = buf.get(&range, 2, false, stream))) return rc;
-    if ((rc = buf.get(&skeys, E0, false, stream))) return rc;
-    if ((rc = buf.get(&skeys2, E0, false, stream))) return rc;
-    if ((rc = buf.get(&svals, E0, false, stream))) return rc;
-    ws.wrange = range; ws.isort = isort; ws.ige = ige;
+    if ((rc = buf.get(&rb_kseq, E0, false, stream))) return rc;
+    if ((rc = buf.get(&rb_kseq2, E0, false, stream))) return rc;
+    if ((rc = buf.get(&rb_ksal, E0, false, stream))) return rc;
+    if ((rc = buf.get(&rb_ksal2, E0, false, stream))) return rc;
+    if ((rc = buf.get(&rb_vals, E0, false, stream))) return rc;
+    if ((rc = buf.get(&rb_vals2, E0, false, stream))) return rc;
+    if ((rc = buf.get(&rb_counter, 1, true, stream))) return rc;
+    GLIA_HIP_TRY(rocprim::radix_sort_pairs_desc(nullptr, rb_tmp_bytes, rb_kseq, rb_kseq2, rb_vals, rb_vals2, (size_t)E0, 0, 64, stream));
+    if ((rc = buf.get((char**)&rb_tmp, rb_tmp_bytes ? rb_tmp_bytes : 16, false, stream))) return rc;
+    ws.wrange = range; ws.isort = rb_isort; ws.isort_seq = rb_iseq; ws.ige = rb_ige;
     ws.order = st.order; ws.sal_out = st.sal_out; ws.ctrl = st.ctrl; ws.rsz = st.rsz; ws.rsum = st.rsum;
     ws.mark0 = st.mark0; ws.mark1 = st.mark1; ws.adj_off = st.adj_off; ws.adj_len = st.adj_len;
     ws.pool_cap = st.pool_cap; ws.Ecap = st.Ecap;
     ws.cond_n = st.cond_n; ws.cond_t0 = st.cond_t0; ws.cond_t1 = st.cond_t1; ws.cond_rpb = st.cond_rpb;
-    GLIA_HIP_TRY(hipMemsetAsync(ws.whead, 0xFF, sizeof(uint32_t) * B, stream));
     const unsigned long long mm0[2] = {~0ull, 0ull};
     GLIA_HIP_TRY(hipMemcpyAsync(mm, mm0, sizeof(mm0), hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(win_range_kernel, dim3(256), dim3(256), 0, stream, st.pq.leaf_sal, E0, mm);
     hipLaunchKernelGGL(win_params_kernel, dim3(1), dim3(1), 0, stream, mm, B, range);
-    hipLaunchKernelGGL(win_sort_input_kernel, dim3((E0 + 255) / 256), dim3(256), 0, stream, st, ws, E0, skeys, svals);
     GLIA_HIP_TRY(hipGetLastError());
-    {
-      size_t tmp = 0;
-      GLIA_HIP_TRY(rocprim::radix_sort_pairs_desc(nullptr, tmp, skeys, skeys2, svals, isort, (size_t)E0, 0, 64, stream));
-      void* d_tmp;
-      if ((rc = buf.get((char**)&d_tmp, tmp ? tmp : 16, false, stream))) return rc;
-      GLIA_HIP_TRY(rocprim::radix_sort_pairs_desc(d_tmp, tmp, skeys, skeys2, svals, isort, (size_t)E0, 0, 64, stream));
-    }
-    hipLaunchKernelGGL(win_segments_kernel, dim3((B + 1 + 255) / 256), dim3(256), 0, stream, st, ws, E0, ige);
-    GLIA_HIP_TRY(hipGetLastError());
+    if ((rc = win_rebaseline(E0))) return rc;
   } else if ((rc = pq_setup(buf, st.pq, stream))) return rc;
   GLIA_HIP_TRY(hipMemcpyAsync(st.ctrl, ctrl, sizeof(ctrl), hipMemcpyHostToDevice, stream));
   GLIA_HIP_TRY(hipEventRecord(ev[1], stream));
@@ -1928,7 +1992,7 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
     GLIA_HIP_TRY(hipGetLastError());
     GLIA_HIP_TRY(hipMemcpyAsync(ctrl, st.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, stream));
     GLIA_HIP_TRY(hipStreamSynchronize(stream));
-    if (ctrl[3] == ST_RUN) continue;
+    if (ctrl[3] == ST_RUN && !window) continue;
     if (ctrl[3] == ST_DONE) break;
     if (ctrl[3] == ST_BAD_SALIENCY) { set_error("Error: invalid boundary saliency..."); return GLIA_HMT_ERR_SALIENCY; }
     if (ctrl[3] == ST_INTERNAL) { set_error("greedy: window queue overflow (internal error)"); return GLIA_HMT_ERR_HIP; }
@@ -1968,6 +2032,11 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
       st.Ecap = ncap; st.pq.nleaves = ncap; ws.Ecap = ncap;
       hipLaunchKernelGGL(fill_leaves_dead, dim3((ncap - ocap + 255) / 256), dim3(256), 0, stream, st.pq, ocap);
       if (!window && (rc = pq_setup(buf, st.pq, stream))) return rc;
+    }
+    if (window) {
+      // the launch left through the lists (everything alive sits there): a fresh baseline, an empty window
+      if ((rc = win_rebaseline((uint32_t)ctrl[1]))) return rc;
+      GLIA_HIP_TRY(hipMemcpyAsync(st.ctrl + 5, ctrl + 5, 4 * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
     }
     unsigned long long zero = ST_RUN;
     GLIA_HIP_TRY(hipMemcpyAsync(st.ctrl + 3, &zero, sizeof(zero), hipMemcpyHostToDevice, stream));

@@ -28,7 +28,7 @@ struct PqLevel {
 };
 
 
-enum { ST_RUN = 0, ST_DONE = 1, ST_NEED_EDGES = 2, ST_NEED_POOL = 3, ST_BAD_SALIENCY = 4, ST_NEED_VALUES = 5, ST_NEED_TREE = 6, ST_INTERNAL = 7 };
+enum { ST_RUN = 0, ST_DONE = 1, ST_NEED_EDGES = 2, ST_NEED_POOL = 3, ST_BAD_SALIENCY = 4, ST_NEED_VALUES = 5, ST_NEED_TREE = 6, ST_INTERNAL = 7, ST_REBASE = 8 };
 
 struct Key { double sal; unsigned long long seq; uint32_t arg; };
 
