@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def cpu_baseline(size, S, bc_size):
+def cpu_baseline(size, S, bc_size, curve_sizes=(), target_regions=0):
     """oracle (reference-faithful port of GLIA's algorithm, 1 thread) on bounded sub-volumes of the same synthetic
     workload: RAG + greedy pb-mean merge tree on size^3, and the classifier-path feature evaluations on bc_size^3."""
     import numpy as np  # noqa: F401
@@ -71,7 +71,42 @@ def cpu_baseline(size, S, bc_size):
     t1 = time.time()
     out["edge_features_per_sec"] = rag.n_feat_evals / (t1 - t0)
     out["bc_merges_per_sec"] = len(order) / (t1 - t0)
+    if curve_sizes and os.path.exists(ref):
+        out["curve"] = reference_curve(curve_sizes, S, ref, target_regions)
     return out
+
+
+def reference_curve(sizes, S, ref, target_regions):
+    """The reference's own merge engine (oracle/_ref/ref_engine) at several region counts of the same synthetic workload:
+    its boundary-table update scans a std::map prefix per merge (type/boundary_table.hxx:127-128), so the rate falls with
+    the region count.  Fits merges/s = a * R^b on the measured points and EXTRAPOLATES to the bench's region count."""
+    import math
+    import subprocess
+    import tempfile
+    from oracle import pyoracle as O
+    pts = []
+    for size in sizes:
+        labels, pb = O.synth((size,) * 3, S, 8 * S)
+        rag = O.Rag(labels, only_contour=True)
+        with tempfile.TemporaryDirectory() as d:
+            dump = os.path.join(d, "dump.txt")
+            rag.dump(pb, 2, False, dump)
+            with open(dump) as f:
+                t0 = time.time()
+                res = subprocess.run([ref], stdin=f, capture_output=True, text=True, check=True, timeout=900)
+                dt = time.time() - t0
+        eng = [l for l in res.stderr.split("\n") if l.startswith("engine_seconds")]
+        if eng:
+            dt = float(eng[-1].split()[1])
+        n = len([l for l in res.stdout.split("\n") if l.strip()])
+        pts.append({"size": size, "regions": n + 1, "merges": n, "engine_seconds": dt, "merges_per_sec": n / dt})
+    xs = [math.log(p["regions"]) for p in pts]; ys = [math.log(p["merges_per_sec"]) for p in pts]
+    mx, my = sum(xs) / len(xs), sum(ys) / len(ys)
+    b = sum((x - mx) * (y - my) for x, y in zip(xs, ys)) / sum((x - mx) ** 2 for x in xs)
+    a = math.exp(my - b * mx)
+    return {"points": pts, "fit": "merges/s = %.4g * regions^%.3f" % (a, b), "exponent": b,
+            "extrapolated": {"regions": target_regions, "merges_per_sec": a * target_regions ** b,
+                             "note": "EXTRAPOLATED from the fit, not measured: the reference needs hours at this size"}}
 
 
 def slab_phase(ctx, hmt, dist, torch, size, S, world, rank, clf):
@@ -135,6 +170,8 @@ def main():
     ap.add_argument("--cpu-size", type=int, default=256)
     ap.add_argument("--cpu-bc-size", type=int, default=40)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-curve", type=str, default="128,256,384", help="volume sizes for the reference engine's scaling curve ('' = none)")
+    ap.add_argument("--no-bc", action="store_true", help="skip the classifier-linkage merge tree (timed once, outside the steps)")
     ap.add_argument("--no-slab", action="store_true", help="N > 1: skip the z-slab split + RCCL exchange phase")
     ap.add_argument("--slab-timeout", type=int, default=240)
     ap.add_argument("--force-slab", action="store_true", help="rehearse the slab phase with a 1-rank RCCL group (N = 1)")
@@ -205,6 +242,20 @@ def main():
         merges = float(sum(i["merges"] for i in infos))
         edges = float(sum(i["n_edges"] for i in infos))
 
+    bc_loop = None
+    if rank == 0 and not args.no_bc:
+        # the north-star linkage: the classifier-driven merge tree (util/struct_merge_bc.hxx:10-58) of the SAME volume, every
+        # new edge featurised (D_f doubles) and scored by the 255-tree forest inside the greedy loop; timed once, outside `value`
+        rm = hmt.RegionMap(ctx, labels, pb=pb, only_contour=False, cfg=cfg)
+        torch.cuda.synchronize(); ctx.sync()
+        t0 = time.time()
+        order, sal = rm.merge_order_bc(clf)
+        t1 = time.time()
+        tm = rm.last_merge_timing()
+        bc_loop = {"linkage": "boundary classifier (random forest, 255 trees, D_f=%d)" % rm.feat_dim(), "merges": len(order),
+                   "seconds": t1 - t0, "merges_per_sec": len(order) / (t1 - t0), "edges_scored": tm["n_edges_scored"],
+                   "edge_features_per_sec": tm["n_edges_scored"] / (t1 - t0), "ms_init": tm["ms_init"], "ms_loop": tm["ms_loop"]}
+        rm.close()
     out = None
     if rank == 0:
         acc_ms = sum(i["acc_ms"] for i in infos) / len(infos)
@@ -242,8 +293,11 @@ def main():
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "algorithmic_bytes_per_launch": infos[0]["acc_bytes"], "avg_launch_ms": acc_ms},
         }
+        if bc_loop is not None:
+            out["bc_loop"] = bc_loop
         if not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_size, args.S, args.cpu_bc_size)
+            curve = tuple(int(x) for x in args.cpu_curve.split(",") if x)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_size, args.S, args.cpu_bc_size, curve, infos[0]["R"])
 
     def emit(slab_info):
         if rank == 0:

@@ -1816,8 +1816,10 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
   GreedyState st;
   memset(&st, 0, sizeof(st));
   st.R0 = R;
-  st.Ecap = (uint32_t)std::min<unsigned long long>(0xFFFFFF00ull, (unsigned long long)E0 * 8ull + (1u << 16));
-  st.pool_cap = (unsigned long long)E0 * 16ull + (1u << 16);
+  // created edges are never reused: a 1024^3 run ends at ~16.4 x E0 edge slots and ~33 x E0 list entries (measured) --
+  // sized so that the usual run never stops to grow (growth = a relaunch plus a copy of gigabytes)
+  st.Ecap = (uint32_t)std::min<unsigned long long>(0xFFFFFF00ull, (unsigned long long)E0 * 18ull + (1u << 16));
+  st.pool_cap = (unsigned long long)E0 * 36ull + (1u << 16);
   if ((rc = buf.get(&st.adj_off, 2 * (size_t)R, true, stream))) return rc;
   if ((rc = buf.get(&st.adj_len, 2 * (size_t)R + 1, true, stream))) return rc;
   // pb-mean linkage (with or without the pre_merge condition) runs on the window queue; GLIA_HMT_PB_WINDOW=0 keeps the

@@ -6,7 +6,8 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-GOLD = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
+GOLD = sorted(p for p in glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz"))
+              if not os.path.basename(p).startswith("fuzz_"))          # fuzz fixtures have their own test (test_gpu_bc.py)
 
 
 @pytest.fixture(scope="module")
