@@ -119,20 +119,52 @@ def slab_phase(ctx, hmt, dist, torch, size, S, world, rank, clf):
     sl, sp = labels[lo:hi], pb[lo:hi]
     cfg = hmt.make_config(sp, rb=[(sp, 8, 0.0, 1.0)], thresholds=(0.2, 0.5, 0.8))
 
+    stats = {}
+
     def once():
         part = hmt.RegionMap(ctx, sl, pb=sp, cfg=cfg, slab=(lo, size, zb, ze))
-        merged = slab.exchange_and_merge(ctx, part)
+        merged, st_ = slab.exchange_and_merge(ctx, part, sl, zb, ze, loop_owner=0)
+        stats.update(st_)
         part.close()
         return merged
 
-    once().close()                                           # warm-up (RCCL channels, allocations)
+    m0 = once()                                              # warm-up (RCCL channels, allocations)
+    if m0 is not None:
+        m0.close()
     dist.barrier(); torch.cuda.synchronize(); ctx.sync()
     t0 = time.time()
     merged = once()
     dist.barrier(); torch.cuda.synchronize(); ctx.sync()
     t = torch.tensor([time.time() - t0], dtype=torch.float64, device="cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    out = {"ms": float(t.item()) * 1e3, "slab_planes_per_rank": ze - zb, "regions": merged.num_regions, "pairs": merged.num_pairs}
+    sent = torch.tensor([float(stats["bytes_sent_cut_exchange"]), float(stats["bytes_sent_to_loop_owner"]), float(stats["records"]),
+                         float(stats["cut_records"])], dtype=torch.float64, device="cuda")
+    smax = sent.clone(); dist.all_reduce(smax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(sent, op=dist.ReduceOp.SUM)
+    out = {"ms": float(t.item()) * 1e3, "slab_planes_per_rank": ze - zb,
+           "exchange": "cut records (label on a plane next to a cut) -> keyed owner (hash(label) mod N), point-to-point, unpadded; "
+                       "reduced cut + interior records once to the loop owner (rank 0)",
+           "records_all_ranks": int(sent[2].item()), "cut_records_all_ranks": int(sent[3].item()),
+           "bytes_sent_cut_exchange_max_rank": int(smax[0].item()), "bytes_sent_to_loop_owner_max_rank": int(smax[1].item()),
+           "bytes_sent_all_ranks": int(sent[0].item() + sent[1].item())}
+    if rank == 0:
+        out["regions"] = merged.num_regions; out["pairs"] = merged.num_pairs
+    # the merged map lives on the loop owner only: the others receive its compact records for the sharded scoring below
+    rec = merged.to_tensors() if rank == 0 else None
+    shapes = torch.tensor([rec["rlabel"].numel(), rec["pa"].numel()] if rank == 0 else [0, 0], dtype=torch.int64, device="cuda")
+    dist.broadcast(shapes, 0)
+    if rank != 0:
+        like = hmt.RegionMap(ctx, sl, pb=sp, cfg=cfg, slab=(lo, size, zb, ze))
+        lt = like.to_tensors()
+        R_, P_ = int(shapes[0].item()), int(shapes[1].item())
+        rec = dict(rlabel=torch.empty(R_, dtype=torch.int32, device="cuda"), rrec=torch.empty((R_, lt["rrec"].shape[1]), dtype=torch.int32, device="cuda"),
+                   pa=torch.empty(P_, dtype=torch.int32, device="cuda"), pb=torch.empty(P_, dtype=torch.int32, device="cuda"),
+                   prec=torch.empty((P_, lt["prec"].shape[1]), dtype=torch.int32, device="cuda"))
+    for k_ in slab.KEYS:
+        dist.broadcast(rec[k_], 0)
+    if rank != 0:
+        merged = hmt.RegionMap.from_tensors(ctx, like, rec)
+        like.close()
     # K7 on the merged map, sharded by record (independent per edge): every rank scores 1/world of the initial edges,
     # one all_gather of the scores, element-wise max
     dist.barrier(); torch.cuda.synchronize(); ctx.sync()

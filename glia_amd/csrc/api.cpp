@@ -468,6 +468,16 @@ int glia_hmt_rag_merge(glia_hmt_ctx* c, glia_hmt_rag* const* parts, int n_parts,
   return GLIA_HMT_OK;
 }
 
+int glia_hmt_rag_cut_flags(glia_hmt_ctx* c, const glia_hmt_rag* rag, const int64_t dims_local[3], int64_t z_begin, int64_t z_end,
+                           const uint32_t* d_labels, uint8_t* d_region_cut, uint8_t* d_pair_cut) {
+  if (!c || !rag || !dims_local || !d_labels || !d_region_cut || !d_pair_cut || rag->ctx != c || z_begin < 0 || z_end > dims_local[2] || z_begin >= z_end) {
+    set_error("rag_cut_flags: invalid argument");
+    return GLIA_HMT_ERR_ARG;
+  }
+  GLIA_HIP_TRY(hipSetDevice(c->device));
+  return rag_cut_flags(rag->arr, d_labels, dims_local[0], dims_local[1], dims_local[2], z_begin, z_end, d_region_cut, d_pair_cut, c->stream);
+}
+
 int glia_hmt_rag_device_arrays(const glia_hmt_rag* r, const uint32_t** d_region_label, const uint32_t** d_region_rec,
                                const uint32_t** d_pair_a, const uint32_t** d_pair_b, const uint32_t** d_pair_rec,
                                int* region_words, int* pair_words) {

@@ -132,6 +132,8 @@ int boundary_confidence_values(int n_trees, const int64_t* n_nodes, const uint32
                                int64_t P, std::vector<float>* out);
 int launch_libm_eval(int function, int variant, const double* d_in, double* d_out, int64_t n, hipStream_t stream);
 int merge_rag_arrays(const RagArrays* parts, int n_parts, RagArrays* out, hipStream_t stream);
+int rag_cut_flags(const RagArrays& rag, const uint32_t* d_lab, int64_t nx, int64_t ny, int64_t nzl, int64_t zb, int64_t ze,
+                  uint8_t* d_rflag, uint8_t* d_pflag, hipStream_t stream);
 
 __host__ __device__ inline uint32_t float_ord(float f) {
   uint32_t u = __builtin_bit_cast(uint32_t, f);

@@ -135,6 +135,62 @@ int merge_kind(const RagArrays* parts, int n_parts, RagArrays* out, hipStream_t 
 
 }  // namespace
 
+namespace {
+__global__ void gather_plane_labels(const uint32_t* lab, long long plane_voxels, const long long* plane_z, int n_planes, uint32_t* out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= plane_voxels * n_planes) return;
+  const int pl = (int)(i / plane_voxels);
+  out[i] = lab[plane_z[pl] * plane_voxels + (i - (long long)pl * plane_voxels)];
+}
+__device__ __forceinline__ bool in_sorted(const uint32_t* a, uint32_t n, uint32_t key) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; }
+  return lo < n && a[lo] == key;
+}
+__global__ void cut_flags_kernel(const uint32_t* cutlab, uint32_t ncut, const uint32_t* rlabel, uint32_t R, const uint32_t* pa, const uint32_t* pb,
+                                 uint32_t P, uint8_t* rflag, uint8_t* pflag) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < R) rflag[i] = in_sorted(cutlab, ncut, rlabel[i]) ? 1 : 0;
+  if (i < P) pflag[i] = (in_sorted(cutlab, ncut, pa[i]) || in_sorted(cutlab, ncut, pb[i])) ? 1 : 0;
+}
+}  // namespace
+
+// Which records of a slab's partial map can have a counterpart in another slab: those whose label (either label of a
+// pair) occurs on a plane next to a cut -- the slab's first / last owned plane or the halo plane beyond it.  (A connected
+// region that crosses a cut has voxels there; records this test misses are still combined by the final merge, the flags
+// only decide which records take the keyed owner exchange.)
+int rag_cut_flags(const RagArrays& rag, const uint32_t* d_lab, int64_t nx, int64_t ny, int64_t nzl, int64_t zb, int64_t ze,
+                  uint8_t* d_rflag, uint8_t* d_pflag, hipStream_t stream) {
+  long long planes[4]; int np = 0;
+  if (zb > 0) { planes[np++] = zb - 1; planes[np++] = zb; }
+  if (ze < nzl) { planes[np++] = ze - 1; planes[np++] = ze; }
+  const uint32_t R = (uint32_t)rag.R, P = (uint32_t)rag.P;
+  if (np == 0) {
+    if (R) GLIA_HIP_TRY(hipMemsetAsync(d_rflag, 0, R, stream));
+    if (P) GLIA_HIP_TRY(hipMemsetAsync(d_pflag, 0, P, stream));
+    return GLIA_HMT_OK;
+  }
+  const long long pv = (long long)nx * ny, n = pv * np;
+  DeviceBuffers buf;
+  int rc;
+  long long* d_planes; uint32_t *l0, *l1;
+  if ((rc = buf.get(&d_planes, 4, false, stream))) return rc;
+  if ((rc = buf.get(&l0, (size_t)n, false, stream))) return rc;
+  if ((rc = buf.get(&l1, (size_t)n, false, stream))) return rc;
+  GLIA_HIP_TRY(hipMemcpyAsync(d_planes, planes, sizeof(long long) * np, hipMemcpyHostToDevice, stream));
+  hipLaunchKernelGGL(gather_plane_labels, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_lab, pv, d_planes, np, l0);
+  size_t tmp = 0;
+  GLIA_HIP_TRY(rocprim::radix_sort_keys(nullptr, tmp, l0, l1, (size_t)n, 0, 32, stream));
+  char* d_tmp;
+  if ((rc = buf.get(&d_tmp, tmp ? tmp : 16, false, stream))) return rc;
+  GLIA_HIP_TRY(rocprim::radix_sort_keys((void*)d_tmp, tmp, l0, l1, (size_t)n, 0, 32, stream));
+  const uint32_t m = R > P ? R : P;
+  if (m) hipLaunchKernelGGL(cut_flags_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, l1, (uint32_t)n, rag.d_rlabel, R, rag.d_pa, rag.d_pb, P, d_rflag, d_pflag);
+  GLIA_HIP_TRY(hipGetLastError());
+  GLIA_HIP_TRY(hipStreamSynchronize(stream));
+  return GLIA_HMT_OK;
+}
+
 int merge_rag_arrays(const RagArrays* parts, int n_parts, RagArrays* out, hipStream_t stream) {
   int rc = merge_kind<true>(parts, n_parts, out, stream);
   if (rc) return rc;

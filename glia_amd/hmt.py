@@ -386,6 +386,18 @@ class RegionMap:
         _check(lib().glia_hmt_rag_copy_arrays(self.h, *[C.c_void_p(t[k].data_ptr()) for k in ("rlabel", "rrec", "pa", "pb", "prec")]))
         return t
 
+    def cut_flags(self, labels_slab, z_begin, z_end):
+        """glia_hmt_rag_cut_flags: boolean CUDA tensors (regions, pairs) -- records whose label occurs next to a cut of the slab."""
+        import torch
+        dev = torch.device("cuda", self.ctx.device)
+        _, d = _dims(tuple(labels_slab.shape))
+        rcut = torch.zeros(max(self.num_regions, 1), dtype=torch.uint8, device=dev)
+        pcut = torch.zeros(max(self.num_pairs, 1), dtype=torch.uint8, device=dev)
+        _fence(labels_slab)
+        _check(lib().glia_hmt_rag_cut_flags(self.ctx.h, self.h, d, C.c_int64(z_begin), C.c_int64(z_end), C.c_void_p(labels_slab.data_ptr()),
+                                            C.c_void_p(rcut.data_ptr()), C.c_void_p(pcut.data_ptr())))
+        return rcut[:self.num_regions].bool(), pcut[:self.num_pairs].bool()
+
     @staticmethod
     def from_tensors(ctx, like, t):
         h = C.c_void_p()

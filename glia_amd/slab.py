@@ -1,12 +1,27 @@
-"""z-slab partition of one volume across ranks: geometry and the keyed exchange of partial records.
+"""z-slab partition of one volume across ranks: geometry and the exchange of partial records.
 
-The accumulation pass shards by z with one halo plane per cut; every statistic is a commutative monoid, so the only
-communication is ONE exchange of the compact partial records (regions keyed by label, directed pairs by (a,b)) followed
-by glia_hmt_rag_merge.  The greedy loop does not shard: the merged map lives on the gathering rank(s).
-Communication is torch.distributed only (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests); the
-functions below are device-agnostic so the N>1 plumbing is testable without GPUs."""
+The accumulation pass shards by z with one halo plane per cut; every statistic is a commutative monoid, so partial records
+with the same key (region: label; directed pair: (a, b)) are simply reduced.  BASELINE.json's north star asks for "RCCL over
+xGMI exchanging only the cross-slab boundary regions", and that is the shape of the exchange here:
+
+  1. every rank flags the records that can have a counterpart elsewhere -- their label occurs on a plane next to a cut
+     (glia_hmt_rag_cut_flags);
+  2. only the flagged records take a KEYED OWNER EXCHANGE: owner = hash(label) mod N (a pair goes with its first label), one
+     unpadded point-to-point message per (source, destination) -- xGMI is point-to-point, all seven links carry traffic at once;
+     the owner reduces what it receives (glia_hmt_rag_merge);
+  3. the reduced cut records and the untouched interior records travel ONCE to the rank that runs the merge loop (the loop
+     does not shard), which reduces everything by key a last time -- so a record the flags missed (a label that occurs in two
+     slabs without touching a cut plane: a disconnected "region") is still combined: the flags decide the route, never the result.
+
+At 1024^3 / S=16 / 8 slabs a rank holds ~33 k region and ~470 k pair records (~64 MB) of which ~15 % are flagged; the previous
+exchange (all_gather of everything, padded to the largest rank) moved 8 x 64 MB to every rank.
+
+Communication is torch.distributed only (backend "nccl" = RCCL on the GPU box, "gloo" in the CPU tests); everything below but
+`exchange_cut_records` is device-agnostic, so the N > 1 plumbing runs under gloo on CPU tensors."""
 import torch
 import torch.distributed as dist
+
+KEYS = ("rlabel", "rrec", "pa", "pb", "prec")
 
 
 def slab_bounds(nz, world, rank):
@@ -25,31 +40,107 @@ def slab_with_halo(nz, world, rank):
     return lo, hi, z0 - lo, z1 - lo
 
 
-def all_gather_variable(t, group=None):
-    """all_gather of tensors whose first dimension differs between ranks: returns the list of every rank's tensor.
-    Two collectives: the sizes (one int64 per rank) and the payload padded to the largest size."""
-    world = dist.get_world_size(group)
-    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n, group=group)
-    sizes = [int(s.item()) for s in sizes]
-    m = max(max(sizes), 1)
-    pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    pad[: t.shape[0]] = t
-    out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad, group=group)
-    return [o[:s].contiguous() for o, s in zip(out, sizes)]
+def owner_of(label, world):
+    """The rank that reduces the records of a label (uint32 payload in an int32 tensor): a multiplicative hash, mod world."""
+    h = (label.to(torch.int64) & 0xFFFFFFFF) * 2654435761
+    return ((h >> 11) & 0x7FFFFFFF) % world
 
 
-def exchange_and_merge(ctx, partial, group=None):
-    """Every rank contributes its partial hmt.RegionMap; every rank returns the merged map of the whole volume
-    (the loop owner uses it, the others may drop it).  Records cross the wire once."""
+def select_records(t, rmask, pmask):
+    """The sub-dictionary of a record dictionary picked by two boolean masks (regions, pairs)."""
+    return dict(rlabel=t["rlabel"][rmask], rrec=t["rrec"][rmask], pa=t["pa"][pmask], pb=t["pb"][pmask], prec=t["prec"][pmask])
+
+
+def concat_records(parts, like):
+    if not parts:
+        return {k: like[k][:0] for k in KEYS}
+    return {k: torch.cat([p[k] for p in parts]) for k in KEYS}
+
+
+def pack_records(t):
+    """One flat int32 message: [R, P, rlabel, rrec, pa, pb, prec]."""
+    head = torch.tensor([t["rlabel"].numel(), t["pa"].numel()], dtype=torch.int32, device=t["rlabel"].device)
+    return torch.cat([head] + [t[k].reshape(-1).to(torch.int32) for k in KEYS])
+
+
+def unpack_records(buf, like):
+    R, P = int(buf[0].item()), int(buf[1].item())
+    rw, pw = like["rrec"].shape[1], like["prec"].shape[1]
+    o = 2
+    out = {}
+    for k, n, shape in (("rlabel", R, (R,)), ("rrec", R * rw, (R, rw)), ("pa", P, (P,)), ("pb", P, (P,)), ("prec", P * pw, (P, pw))):
+        out[k] = buf[o:o + n].reshape(shape).contiguous()
+        o += n
+    return out
+
+
+def exchange_variable(send, group=None):
+    """send[d] = 1-D tensor for rank d (any length, may be empty).  Returns (recv list, bytes sent to other ranks).
+    One all_gather of the length matrix, then one unpadded point-to-point message per non-empty (source, destination)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev, dt = send[0].device, send[0].dtype
+    lens = torch.tensor([s.numel() for s in send], dtype=torch.int64, device=dev)
+    allv = [torch.zeros_like(lens) for _ in range(world)]
+    dist.all_gather(allv, lens, group=group)
+    n_from = [int(allv[s][rank].item()) for s in range(world)]
+    recv = [torch.empty(n_from[s], dtype=dt, device=dev) for s in range(world)]
+    recv[rank] = send[rank]
+    ops = []
+    for d in range(world):
+        if d != rank and send[d].numel():
+            ops.append(dist.P2POp(dist.isend, send[d].contiguous(), d, group))
+    for s in range(world):
+        if s != rank and n_from[s]:
+            ops.append(dist.P2POp(dist.irecv, recv[s], s, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    sent = sum(send[d].numel() * send[d].element_size() for d in range(world) if d != rank)
+    return recv, sent
+
+
+def exchange_cut_records(t, rcut, pcut, reduce_fn, loop_owner=0, group=None):
+    """Steps 2 and 3 of the module docstring on a record dictionary `t` (tensors of this rank's partial map) with boolean
+    cut masks.  reduce_fn(list of record dictionaries) -> record dictionary reduced by key (glia_hmt_rag_merge on the GPU).
+    Returns (whole-volume records on the loop owner | None, statistics)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    interior = select_records(t, ~rcut, ~pcut)
+    cut = select_records(t, rcut, pcut)
+    # 2. keyed owner exchange of the cut records
+    r_owner, p_owner = owner_of(cut["rlabel"], world), owner_of(cut["pa"], world)
+    send = [pack_records(select_records(cut, r_owner == d, p_owner == d)) for d in range(world)]
+    recv, sent_cut = exchange_variable(send, group)
+    mine = reduce_fn([unpack_records(b, t) for b in recv])
+    # 3. everything once to the loop owner
+    outgoing = pack_records(concat_records([interior, mine], t))
+    send = [outgoing if d == loop_owner else outgoing[:0] for d in range(world)]
+    recv, sent_final = exchange_variable(send, group)
+    stats = dict(records=int(t["rlabel"].numel() + t["pa"].numel()), cut_records=int(cut["rlabel"].numel() + cut["pa"].numel()),
+                 bytes_sent_cut_exchange=int(sent_cut), bytes_sent_to_loop_owner=int(sent_final))
+    if rank != loop_owner:
+        return None, stats
+    return reduce_fn([unpack_records(b, t) for b in recv if b.numel()]), stats
+
+
+def exchange_and_merge(ctx, partial, labels_slab=None, z_begin=None, z_end=None, loop_owner=0, group=None):
+    """The slab exchange on the GPU: `partial` = this rank's hmt.RegionMap built with slab=...; labels_slab / z_begin / z_end =
+    the label planes it was built from.  Returns (hmt.RegionMap of the whole volume on the loop owner | None, statistics)."""
     from . import hmt
-    mine = partial.to_tensors()
-    parts = {k: all_gather_variable(v, group) for k, v in mine.items()}
-    world = dist.get_world_size(group)
-    maps = [hmt.RegionMap.from_tensors(ctx, partial, {k: parts[k][r] for k in parts}) for r in range(world)]
-    merged = hmt.RegionMap.merge(ctx, maps)
-    for m in maps:
-        m.close()
-    return merged
+    t = partial.to_tensors()
+    rcut, pcut = partial.cut_flags(labels_slab, z_begin, z_end)
+
+    def reduce_fn(parts):
+        maps = [hmt.RegionMap.from_tensors(ctx, partial, p) for p in parts if p["rlabel"].numel() or p["pa"].numel()]
+        if not maps:
+            return {k: t[k][:0] for k in KEYS}
+        merged = hmt.RegionMap.merge(ctx, maps)
+        out = merged.to_tensors()
+        for m in maps:
+            m.close()
+        merged.close()
+        return out
+
+    whole, stats = exchange_cut_records(t, rcut, pcut, reduce_fn, loop_owner, group)
+    if whole is None:
+        return None, stats
+    return hmt.RegionMap.from_tensors(ctx, partial, whole), stats

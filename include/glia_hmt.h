@@ -112,6 +112,13 @@ int glia_hmt_rag_build_slab(glia_hmt_ctx* ctx, const int64_t dims_local[3], int6
                             int64_t nz_global, int64_t z_begin, int64_t z_end, const uint32_t* d_labels,
                             int only_contour, const float* d_pb, const glia_hmt_feat_config* cfg, glia_hmt_rag** out);
 int glia_hmt_rag_merge(glia_hmt_ctx* ctx, glia_hmt_rag* const* parts, int n_parts, glia_hmt_rag** out);
+/* Which records of a slab's partial map may have a counterpart in another slab ("exchanging only the cross-slab boundary
+ * regions"): d_region_cut[i] / d_pair_cut[i] (device, one byte per record, in the order of glia_hmt_rag_device_arrays) = 1 iff
+ * the region's label / one of the pair's labels occurs on a plane next to a cut (first / last owned plane, halo plane).  Only
+ * flagged records take the keyed owner exchange (glia_amd/slab.py); the others go once to the rank that runs the merge loop.
+ * dims_local / z_begin / z_end / d_labels: as handed to glia_hmt_rag_build_slab. */
+int glia_hmt_rag_cut_flags(glia_hmt_ctx* ctx, const glia_hmt_rag* rag, const int64_t dims_local[3], int64_t z_begin, int64_t z_end,
+                           const uint32_t* d_labels, uint8_t* d_region_cut, uint8_t* d_pair_cut);
 int glia_hmt_rag_device_arrays(const glia_hmt_rag* rag, const uint32_t** d_region_label, const uint32_t** d_region_rec,
                                const uint32_t** d_pair_a, const uint32_t** d_pair_b, const uint32_t** d_pair_rec,
                                int* region_words, int* pair_words);

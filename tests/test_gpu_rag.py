@@ -141,6 +141,77 @@ def test_slab_partials_merge_to_the_whole(ctx, shape, S, G, variant, nslab):
     assert (o1 == o2).all() and (variant == 1 or (s1 == s2).all())
 
 
+@pytest.mark.parametrize("shape,S,G,variant,nslab", [((64, 40, 64), 8, 16, 0, 2), ((96, 36, 28), 6, 12, 0, 3), ((128, 48, 64), 8, 32, 0, 4)])
+def test_cut_record_exchange_reproduces_the_whole_map(ctx, shape, S, G, variant, nslab):
+    """The north-star exchange ("only the cross-slab boundary regions"), N ranks emulated on one GPU with the routing code of
+    glia_amd/slab.py: glia_hmt_rag_cut_flags marks the records next to a cut, those go to their keyed owner (hash(label) mod N)
+    and are reduced there, reduced cut + interior records go once to the loop owner, whose final reduction is bit-identical to
+    the single-pass map.  The cut set stays within its analytic bound: no more regions than distinct labels on the planes
+    next to the cuts, and a minority of all records."""
+    torch = _torch()
+    from glia_amd import hmt, slab
+    from oracle import pyoracle as O
+    labels, pb = O.synth(shape, S, G, variant=variant)
+    d_lab = torch.from_numpy(labels.view(np.int32)).cuda()
+    d_pb = torch.from_numpy(pb).cuda()
+    mk = lambda img: hmt.make_config(img, rb=[(img, 8, 0.0, 1.0)])
+    whole = hmt.RegionMap(ctx, d_lab, pb=d_pb, cfg=mk(d_pb))
+    nz = shape[0]
+    parts, recs, cuts = [], [], []
+    n_cut = n_all = 0
+    for r in range(nslab):
+        lo, hi, zb, ze = slab.slab_with_halo(nz, nslab, r)
+        sl, sp = d_lab[lo:hi].contiguous(), d_pb[lo:hi].contiguous()
+        part = hmt.RegionMap(ctx, sl, pb=sp, cfg=mk(sp), slab=(lo, nz, zb, ze))
+        rcut, pcut = part.cut_flags(sl, zb, ze)
+        t = part.to_tensors()
+        # analytic bound: a flagged region's label is on a plane next to a cut
+        planes = [z for z in ((zb - 1, zb) if zb > 0 else ()) + ((ze - 1, ze) if ze < hi - lo else ())]
+        on_cut = np.unique(labels[lo:hi][planes]) if planes else np.zeros(0, np.uint32)
+        got = t["rlabel"][rcut].cpu().numpy().view(np.uint32)
+        assert set(got.tolist()) <= set(on_cut.tolist()) and len(got) <= len(on_cut)
+        own = np.unique(labels[lo + zb:lo + ze])
+        assert set(got.tolist()) == set(on_cut.tolist()) & set(own.tolist())          # exactly the owned labels seen next to a cut
+        pa, pb_ = t["pa"].cpu().numpy().view(np.uint32), t["pb"].cpu().numpy().view(np.uint32)
+        assert (pcut.cpu().numpy() == (np.isin(pa, on_cut) | np.isin(pb_, on_cut))).all()
+        n_cut += int(rcut.sum() + pcut.sum()); n_all += t["rlabel"].numel() + t["pa"].numel()
+        parts.append(part); recs.append(t); cuts.append((rcut, pcut))
+    assert 0 < n_cut < n_all                                                    # only part of the records is exchanged
+
+    def reduce_fn(ps):
+        maps = [hmt.RegionMap.from_tensors(ctx, parts[0], p) for p in ps if p["rlabel"].numel() or p["pa"].numel()]
+        if not maps:
+            return {k: recs[0][k][:0] for k in slab.KEYS}
+        m = hmt.RegionMap.merge(ctx, maps)
+        out = m.to_tensors()
+        for x in maps:
+            x.close()
+        m.close()
+        return out
+
+    # step 2, emulated: what every rank packs for every owner, through pack / unpack
+    inbox = [[] for _ in range(nslab)]
+    for r in range(nslab):
+        cut = slab.select_records(recs[r], *cuts[r])
+        ro, po = slab.owner_of(cut["rlabel"], nslab), slab.owner_of(cut["pa"], nslab)
+        for d in range(nslab):
+            inbox[d].append(slab.unpack_records(slab.pack_records(slab.select_records(cut, ro == d, po == d)), recs[r]))
+    reduced = [reduce_fn(inbox[d]) for d in range(nslab)]
+    # step 3: interior + reduced cut records of every rank at the loop owner
+    final = []
+    for r in range(nslab):
+        interior = slab.select_records(recs[r], ~cuts[r][0], ~cuts[r][1])
+        final.append(slab.unpack_records(slab.pack_records(slab.concat_records([interior, reduced[r]], recs[r])), recs[r]))
+    merged = hmt.RegionMap.from_tensors(ctx, parts[0], reduce_fn(final))
+    for get in ("regions", "pairs"):
+        a, b = getattr(whole, get)(), getattr(merged, get)()
+        for k in a:
+            assert (a[k] == b[k]).all(), (get, k)
+    o1, s1 = whole.merge_order_pb(type=2)
+    o2, s2 = merged.merge_order_pb(type=2)
+    assert (o1 == o2).all() and (s1 == s2).all()
+
+
 def _mask_for(shape, seed=3):
     """a mask with holes, a masked face and a few fully masked supervoxels-worth of space"""
     rng = np.random.default_rng(seed)
