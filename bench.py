@@ -160,7 +160,7 @@ def slab_phase(ctx, hmt, dist, torch, size, S, world, rank, clf):
         rec = dict(rlabel=torch.empty(R_, dtype=torch.int32, device="cuda"), rrec=torch.empty((R_, lt["rrec"].shape[1]), dtype=torch.int32, device="cuda"),
                    pa=torch.empty(P_, dtype=torch.int32, device="cuda"), pb=torch.empty(P_, dtype=torch.int32, device="cuda"),
                    prec=torch.empty((P_, lt["prec"].shape[1]), dtype=torch.int32, device="cuda"))
-    for k_ in slab.KEYS:
+    for k_ in sorted(rec.keys()):
         dist.broadcast(rec[k_], 0)
     if rank != 0:
         merged = hmt.RegionMap.from_tensors(ctx, like, rec)

@@ -317,10 +317,6 @@ static int rag_build_impl(glia_hmt_ctx* c, int dim, const int64_t dims[3], int64
       set_error("rag_build: histogram bins must be 1..16 and hi > lo");
       return GLIA_HMT_ERR_ARG;
     }
-  if (chans.size() > 1 && !(zb == 0 && ze == nz && gz0 == 0 && gnz == nz)) {
-    set_error("rag_build_slab: slab builds take a single image channel");
-    return GLIA_HMT_ERR_UNSUPPORTED;
-  }
   const float* img = chans[0].img;
   const int bins = chans[0].bins;
 
@@ -449,7 +445,7 @@ int glia_hmt_rag_merge(glia_hmt_ctx* c, glia_hmt_rag* const* parts, int n_parts,
   GLIA_HIP_TRY(hipSetDevice(c->device));
   std::vector<RagArrays> arrs;
   for (int i = 0; i < n_parts; ++i) {
-    if (!parts[i] || parts[i]->ctx != c || parts[i]->bins != parts[0]->bins || parts[i]->nthr != parts[0]->nthr ||
+    if (!parts[i] || parts[i]->ctx != c || parts[i]->bins != parts[0]->bins || parts[i]->nthr != parts[0]->nthr || parts[i]->arr.K != parts[0]->arr.K ||
         parts[i]->dims[0] != parts[0]->dims[0] || parts[i]->dims[1] != parts[0]->dims[1] || parts[i]->dims[2] != parts[0]->dims[2]) {
       set_error("rag_merge: parts do not belong together");
       return GLIA_HMT_ERR_ARG;
@@ -461,10 +457,35 @@ int glia_hmt_rag_merge(glia_hmt_ctx* c, glia_hmt_rag* const* parts, int n_parts,
   rag->pass_ms = 0; rag->alg_bytes = 0;
   for (int i = 0; i < n_parts; ++i) { rag->pass_ms += parts[i]->pass_ms; rag->alg_bytes += parts[i]->alg_bytes; }
   int rc = merge_rag_arrays(arrs.data(), n_parts, &rag->arr, c->stream);
-  rag->arr.K = 1; rag->arr.c_rrec[0] = rag->arr.d_rrec; rag->arr.c_prec[0] = rag->arr.d_prec; rag->arr.c_bins[0] = rag->bins;
   rag->d_folded = nullptr; rag->vol = VolumeRef();
   if (rc) { delete rag; return rc; }
   *out = rag;
+  return GLIA_HMT_OK;
+}
+
+int glia_hmt_rag_num_channels(const glia_hmt_rag* r) { return r ? r->arr.K : -1; }
+
+int glia_hmt_rag_copy_channel(const glia_hmt_rag* r, int channel, uint32_t* d_region_rec, uint32_t* d_pair_rec) {
+  if (!r || channel < 0 || channel >= r->arr.K || !d_region_rec || !d_pair_rec) { set_error("rag_copy_channel: invalid argument"); return GLIA_HMT_ERR_ARG; }
+  GLIA_HIP_TRY(hipSetDevice(r->ctx->device));
+  hipStream_t s = r->ctx->stream;
+  if (r->arr.R) GLIA_HIP_TRY(hipMemcpyAsync(d_region_rec, r->arr.c_rrec[channel], sizeof(uint32_t) * (size_t)r->arr.R * kRegionWords, hipMemcpyDeviceToDevice, s));
+  if (r->arr.P) GLIA_HIP_TRY(hipMemcpyAsync(d_pair_rec, r->arr.c_prec[channel], sizeof(uint32_t) * (size_t)r->arr.P * kPairWords, hipMemcpyDeviceToDevice, s));
+  GLIA_HIP_TRY(hipStreamSynchronize(s));
+  return GLIA_HMT_OK;
+}
+
+int glia_hmt_rag_add_channel(glia_hmt_ctx* c, glia_hmt_rag* r, const uint32_t* d_region_rec, const uint32_t* d_pair_rec) {
+  if (!c || !r || r->ctx != c || !d_region_rec || !d_pair_rec || r->arr.K < 1 || r->arr.K >= kMaxChannels) { set_error("rag_add_channel: invalid argument"); return GLIA_HMT_ERR_ARG; }
+  GLIA_HIP_TRY(hipSetDevice(c->device));
+  const int k = r->arr.K;
+  uint32_t *rr, *pr;
+  GLIA_HIP_TRY(hipMalloc(&rr, sizeof(uint32_t) * kRegionWords * (size_t)(r->arr.R ? r->arr.R : 1)));
+  GLIA_HIP_TRY(hipMalloc(&pr, sizeof(uint32_t) * kPairWords * (size_t)(r->arr.P ? r->arr.P : 1)));
+  if (r->arr.R) GLIA_HIP_TRY(hipMemcpyAsync(rr, d_region_rec, sizeof(uint32_t) * (size_t)r->arr.R * kRegionWords, hipMemcpyDeviceToDevice, c->stream));
+  if (r->arr.P) GLIA_HIP_TRY(hipMemcpyAsync(pr, d_pair_rec, sizeof(uint32_t) * (size_t)r->arr.P * kPairWords, hipMemcpyDeviceToDevice, c->stream));
+  GLIA_HIP_TRY(hipStreamSynchronize(c->stream));
+  r->arr.c_rrec[k] = rr; r->arr.c_prec[k] = pr; r->arr.K = k + 1;
   return GLIA_HMT_OK;
 }
 
@@ -526,7 +547,9 @@ int glia_hmt_rag_from_arrays(glia_hmt_ctx* c, const glia_hmt_rag* like, int64_t 
   if ((rc = dup(&rag->arr.d_rlabel, d_region_label, (size_t)n_regions)) || (rc = dup(&rag->arr.d_rrec, d_region_rec, (size_t)n_regions * kRegionWords)) ||
       (rc = dup(&rag->arr.d_pa, d_pair_a, (size_t)n_pairs)) || (rc = dup(&rag->arr.d_pb, d_pair_b, (size_t)n_pairs)) ||
       (rc = dup(&rag->arr.d_prec, d_pair_rec, (size_t)n_pairs * kPairWords))) { glia_hmt_rag_free(rag); return rc; }
-  rag->arr.K = 1; rag->arr.c_rrec[0] = rag->arr.d_rrec; rag->arr.c_prec[0] = rag->arr.d_prec; rag->arr.c_bins[0] = rag->bins;
+  rag->arr.K = 1; rag->arr.c_rrec[0] = rag->arr.d_rrec; rag->arr.c_prec[0] = rag->arr.d_prec;
+  for (int k = 0; k < kMaxChannels; ++k) rag->arr.c_bins[k] = like->arr.c_bins[k];      // (further channels: glia_hmt_rag_add_channel)
+  rag->arr.c_bins[0] = rag->bins;
   GLIA_HIP_TRY(hipStreamSynchronize(c->stream));
   *out = rag;
   return GLIA_HMT_OK;

@@ -90,14 +90,13 @@ int merge_kind(const RagArrays* parts, int n_parts, RagArrays* out, hipStream_t 
   if ((rc = buf.get(&flag, (size_t)n + 1, true, stream))) return rc;
   if ((rc = buf.get(&oidx, (size_t)n + 1, false, stream))) return rc;
   if ((rc = buf.get(&src, (size_t)n * W, false, stream))) return rc;
+  const int K = parts[0].K > 0 ? parts[0].K : 1;
   uint32_t base = 0;
   for (int p = 0; p < n_parts; ++p) {
     const uint32_t m = (uint32_t)(REGION ? parts[p].R : parts[p].P);
     if (!m) continue;
     if (REGION) hipLaunchKernelGGL(make_region_keys, dim3((m + 255) / 256), dim3(256), 0, stream, parts[p].d_rlabel, k0, i0, m, base, (uint32_t)p);
     else hipLaunchKernelGGL(make_pair_keys, dim3((m + 255) / 256), dim3(256), 0, stream, parts[p].d_pa, parts[p].d_pb, k0, i0, m, base);
-    GLIA_HIP_TRY(hipMemcpyAsync(src + (size_t)base * W, REGION ? parts[p].d_rrec : parts[p].d_prec, sizeof(uint32_t) * (size_t)m * W,
-                                hipMemcpyDeviceToDevice, stream));
     base += m;
   }
   const int shift = REGION ? 8 : 0;
@@ -117,19 +116,35 @@ int merge_kind(const RagArrays* parts, int n_parts, RagArrays* out, hipStream_t 
     GLIA_HIP_TRY(hipMemcpyAsync(&nout, oidx + n, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     GLIA_HIP_TRY(hipStreamSynchronize(stream));
   }
-  uint32_t *dst, *oa, *ob = nullptr;
-  GLIA_HIP_TRY(hipMalloc(&dst, sizeof(uint32_t) * W * (size_t)(nout ? nout : 1)));
+  uint32_t *oa, *ob = nullptr;
   GLIA_HIP_TRY(hipMalloc(&oa, sizeof(uint32_t) * (size_t)(nout ? nout : 1)));
   if (!REGION) GLIA_HIP_TRY(hipMalloc(&ob, sizeof(uint32_t) * (size_t)(nout ? nout : 1)));
-  if (n) {
-    const unsigned long long threads = (unsigned long long)n * W;
-    hipLaunchKernelGGL(combine_records<REGION>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, k1, i1, flag, oidx, src, n,
-                       shift, dst, oa, ob);
-    GLIA_HIP_TRY(hipGetLastError());
-    GLIA_HIP_TRY(hipStreamSynchronize(stream));
+  // the keys are shared by all image channels; every channel's records are reduced in the same sorted order
+  for (int ch = 0; ch < K; ++ch) {
+    uint32_t* dst;
+    GLIA_HIP_TRY(hipMalloc(&dst, sizeof(uint32_t) * W * (size_t)(nout ? nout : 1)));
+    uint32_t b2 = 0;
+    for (int p = 0; p < n_parts; ++p) {
+      const uint32_t m = (uint32_t)(REGION ? parts[p].R : parts[p].P);
+      if (!m) continue;
+      const uint32_t* rec = REGION ? (ch == 0 ? parts[p].d_rrec : parts[p].c_rrec[ch]) : (ch == 0 ? parts[p].d_prec : parts[p].c_prec[ch]);
+      GLIA_HIP_TRY(hipMemcpyAsync(src + (size_t)b2 * W, rec, sizeof(uint32_t) * (size_t)m * W, hipMemcpyDeviceToDevice, stream));
+      b2 += m;
+    }
+    if (n) {
+      const unsigned long long threads = (unsigned long long)n * W;
+      hipLaunchKernelGGL(combine_records<REGION>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, k1, i1, flag, oidx, src, n,
+                         shift, dst, oa, ob);
+      GLIA_HIP_TRY(hipGetLastError());
+      GLIA_HIP_TRY(hipStreamSynchronize(stream));
+    }
+    if (REGION) { out->c_rrec[ch] = dst; if (ch == 0) out->d_rrec = dst; }
+    else { out->c_prec[ch] = dst; if (ch == 0) out->d_prec = dst; }
   }
-  if (REGION) { out->R = nout; out->d_rlabel = oa; out->d_rrec = dst; }
-  else { out->P = nout; out->d_pa = oa; out->d_pb = ob; out->d_prec = dst; }
+  if (REGION) { out->R = nout; out->d_rlabel = oa; }
+  else { out->P = nout; out->d_pa = oa; out->d_pb = ob; }
+  out->K = K;
+  for (int ch = 0; ch < K; ++ch) out->c_bins[ch] = parts[0].c_bins[ch];
   return GLIA_HMT_OK;
 }
 

@@ -384,6 +384,11 @@ class RegionMap:
                  pa=torch.empty(P, dtype=torch.int32, device=dev), pb=torch.empty(P, dtype=torch.int32, device=dev),
                  prec=torch.empty((P, pw.value), dtype=torch.int32, device=dev))
         _check(lib().glia_hmt_rag_copy_arrays(self.h, *[C.c_void_p(t[k].data_ptr()) for k in ("rlabel", "rrec", "pa", "pb", "prec")]))
+        # further image channels (feature lists with several volumes): same keys, one more record set each
+        for k in range(1, lib().glia_hmt_rag_num_channels(self.h)):
+            t["rrec%d" % k] = torch.empty((R, rw.value), dtype=torch.int32, device=dev)
+            t["prec%d" % k] = torch.empty((P, pw.value), dtype=torch.int32, device=dev)
+            _check(lib().glia_hmt_rag_copy_channel(self.h, C.c_int(k), C.c_void_p(t["rrec%d" % k].data_ptr()), C.c_void_p(t["prec%d" % k].data_ptr())))
         return t
 
     def cut_flags(self, labels_slab, z_begin, z_end):
@@ -408,6 +413,10 @@ class RegionMap:
                                               C.c_void_p(t["rrec"].data_ptr()), C.c_int64(t["pa"].numel()),
                                               C.c_void_p(t["pa"].data_ptr()), C.c_void_p(t["pb"].data_ptr()),
                                               C.c_void_p(t["prec"].data_ptr()), C.byref(h)))
+        k = 1
+        while "rrec%d" % k in t:
+            _check(lib().glia_hmt_rag_add_channel(ctx.h, h, C.c_void_p(t["rrec%d" % k].data_ptr()), C.c_void_p(t["prec%d" % k].data_ptr())))
+            k += 1
         return RegionMap(ctx, None, cfg=like.cfg, _handle=h)
 
     def last_pass(self):

@@ -21,7 +21,16 @@ Communication is torch.distributed only (backend "nccl" = RCCL on the GPU box, "
 import torch
 import torch.distributed as dist
 
-KEYS = ("rlabel", "rrec", "pa", "pb", "prec")
+KEYS = ("rlabel", "rrec", "pa", "pb", "prec")      # channel 0; maps with several image channels add "rrec1", "prec1", ...
+
+
+def _keys(t):
+    """keys of a record dictionary in a fixed order: region-shaped first (they start with "r"), then pair-shaped"""
+    return sorted(t.keys(), key=lambda k: (0 if k.startswith("r") else 1, len(k), k))
+
+
+def _is_region(k):
+    return k.startswith("r")
 
 
 def slab_bounds(nz, world, rank):
@@ -48,27 +57,29 @@ def owner_of(label, world):
 
 def select_records(t, rmask, pmask):
     """The sub-dictionary of a record dictionary picked by two boolean masks (regions, pairs)."""
-    return dict(rlabel=t["rlabel"][rmask], rrec=t["rrec"][rmask], pa=t["pa"][pmask], pb=t["pb"][pmask], prec=t["prec"][pmask])
+    return {k: t[k][rmask if _is_region(k) else pmask] for k in _keys(t)}
 
 
 def concat_records(parts, like):
     if not parts:
-        return {k: like[k][:0] for k in KEYS}
-    return {k: torch.cat([p[k] for p in parts]) for k in KEYS}
+        return {k: like[k][:0] for k in _keys(like)}
+    return {k: torch.cat([p[k] for p in parts]) for k in _keys(like)}
 
 
 def pack_records(t):
-    """One flat int32 message: [R, P, rlabel, rrec, pa, pb, prec]."""
+    """One flat int32 message: [R, P, region-shaped arrays ..., pair-shaped arrays ...]."""
     head = torch.tensor([t["rlabel"].numel(), t["pa"].numel()], dtype=torch.int32, device=t["rlabel"].device)
-    return torch.cat([head] + [t[k].reshape(-1).to(torch.int32) for k in KEYS])
+    return torch.cat([head] + [t[k].reshape(-1).to(torch.int32) for k in _keys(t)])
 
 
 def unpack_records(buf, like):
     R, P = int(buf[0].item()), int(buf[1].item())
-    rw, pw = like["rrec"].shape[1], like["prec"].shape[1]
     o = 2
     out = {}
-    for k, n, shape in (("rlabel", R, (R,)), ("rrec", R * rw, (R, rw)), ("pa", P, (P,)), ("pb", P, (P,)), ("prec", P * pw, (P, pw))):
+    for k in _keys(like):
+        rows = R if _is_region(k) else P
+        shape = (rows,) + tuple(like[k].shape[1:])
+        n = rows * (like[k].shape[1] if like[k].dim() > 1 else 1)
         out[k] = buf[o:o + n].reshape(shape).contiguous()
         o += n
     return out
@@ -132,7 +143,7 @@ def exchange_and_merge(ctx, partial, labels_slab=None, z_begin=None, z_end=None,
     def reduce_fn(parts):
         maps = [hmt.RegionMap.from_tensors(ctx, partial, p) for p in parts if p["rlabel"].numel() or p["pa"].numel()]
         if not maps:
-            return {k: t[k][:0] for k in KEYS}
+            return {k: t[k][:0] for k in _keys(t)}
         merged = hmt.RegionMap.merge(ctx, maps)
         out = merged.to_tensors()
         for m in maps:

@@ -129,6 +129,13 @@ int glia_hmt_rag_from_arrays(glia_hmt_ctx* ctx, const glia_hmt_rag* like, int64_
                              const uint32_t* d_region_label, const uint32_t* d_region_rec, int64_t n_pairs,
                              const uint32_t* d_pair_a, const uint32_t* d_pair_b, const uint32_t* d_pair_rec,
                              glia_hmt_rag** out);
+/* Feature lists with several image volumes give a map one record set per CHANNEL (distinct volume + histogram); the keys are
+ * common.  glia_hmt_rag_device_arrays / _copy_arrays / _from_arrays handle channel 0; the further channels of a partial map
+ * are copied out with glia_hmt_rag_copy_channel and attached, in order, to a map made by glia_hmt_rag_from_arrays with
+ * glia_hmt_rag_add_channel (`like` supplied the histogram layout of every channel). */
+int glia_hmt_rag_num_channels(const glia_hmt_rag* rag);
+int glia_hmt_rag_copy_channel(const glia_hmt_rag* rag, int channel, uint32_t* d_region_rec, uint32_t* d_pair_rec);
+int glia_hmt_rag_add_channel(glia_hmt_ctx* ctx, glia_hmt_rag* rag, const uint32_t* d_region_rec, const uint32_t* d_pair_rec);
 void glia_hmt_rag_free(glia_hmt_rag* rag);
 int64_t glia_hmt_rag_num_regions(const glia_hmt_rag* rag);
 int64_t glia_hmt_rag_num_pairs(const glia_hmt_rag* rag);     /* directed label pairs */

@@ -212,6 +212,39 @@ def test_cut_record_exchange_reproduces_the_whole_map(ctx, shape, S, G, variant,
     assert (o1 == o2).all() and (s1 == s2).all()
 
 
+def test_slab_partials_with_two_image_channels(ctx):
+    """feature lists with two volumes (--rbi raw --rbi pb): every channel's records travel and merge with the common keys; the
+    classifier-path merge order of the merged map equals the single-pass one"""
+    torch = _torch()
+    from glia_amd import hmt, slab
+    from oracle import pyoracle as O
+    shape, nslab = (48, 40, 36), 3
+    labels, pb = O.synth(shape, 6, 12)
+    rng = np.random.default_rng(9)
+    raw = (np.round(rng.random(shape) * 255) / 256.0).astype(np.float32)
+    d_lab = torch.from_numpy(labels.view(np.int32)).cuda()
+    d_pb, d_raw = torch.from_numpy(pb).cuda(), torch.from_numpy(raw).cuda()
+    mk = lambda p_, r_: hmt.make_config(p_, rb=[(r_, 8, 0.0, 1.0), (p_, 8, 0.0, 1.0)])
+    whole = hmt.RegionMap(ctx, d_lab, pb=d_pb, cfg=mk(d_pb, d_raw))
+    parts = []
+    for r in range(nslab):
+        lo, hi, zb, ze = slab.slab_with_halo(shape[0], nslab, r)
+        sl, sp, sr = d_lab[lo:hi].contiguous(), d_pb[lo:hi].contiguous(), d_raw[lo:hi].contiguous()
+        parts.append(hmt.RegionMap(ctx, sl, pb=sp, cfg=mk(sp, sr), slab=(lo, shape[0], zb, ze)))
+    tens = [p.to_tensors() for p in parts]
+    assert "rrec1" in tens[0] and "prec1" in tens[0]
+    # through pack / unpack (what crosses the wire) and from_tensors
+    rebuilt = [hmt.RegionMap.from_tensors(ctx, parts[0], slab.unpack_records(slab.pack_records(t), t)) for t in tens]
+    merged = hmt.RegionMap.merge(ctx, rebuilt)
+    mt, wt = merged.to_tensors(), whole.to_tensors()
+    for k in wt:
+        assert torch.equal(mt[k], wt[k]), k
+    clf = hmt.FeatureStubClassifier(ctx, 40)
+    o1, s1 = whole.merge_order_bc(clf)
+    o2, s2 = merged.merge_order_bc(clf)
+    assert (o1 == o2).all() and (s1 == s2).all()
+
+
 def _mask_for(shape, seed=3):
     """a mask with holes, a masked face and a few fully masked supervoxels-worth of space"""
     rng = np.random.default_rng(seed)
