@@ -312,6 +312,10 @@ static int rag_build_impl(glia_hmt_ctx* c, int dim, const int64_t dims[3], int64
     for (int i = 0; i < nthr; ++i) thr[i] = cfg->thresholds[i];
   } else if (d_pb) chans.push_back(Chan{d_pb, 8, 0.0, 1.0});
   if (chans.empty()) { set_error("rag_build: no image volume given"); return GLIA_HMT_ERR_ARG; }
+  if (cfg && cfg->use_median_features) {
+    set_error("rag_build: the GLIA_USE_MEDIAN_AS_FEATS layout (type/feat.hxx:677-722) is not implemented: it needs every region's value multiset");
+    return GLIA_HMT_ERR_UNSUPPORTED;
+  }
   for (const Chan& ch : chans)
     if (ch.bins < 1 || ch.bins > GLIA_HMT_MAX_BINS || !(ch.hi > ch.lo)) {
       set_error("rag_build: histogram bins must be 1..16 and hi > lo");
@@ -770,7 +774,7 @@ static bool make_bc_cfg(const glia_hmt_rag* rag, BcCfg* c) {
   for (int k = 0; k < kMaxChannels; ++k) c->cbins[k] = k < rag->arr.K ? rag->arr.c_bins[k] : 0;
   c->n_region = g.n_region; c->n_rlabel = g.n_rlabel; c->n_boundary = g.n_boundary;
   for (int i = 0; i < kMaxListed; ++i) { c->rc[i] = rag->map_region[i]; c->lc[i] = rag->map_rlabel[i]; c->bc[i] = rag->map_boundary[i]; }
-  c->use_log = g.use_log_shape; c->use_simple = g.use_simple_features;
+  c->use_log = g.use_log_shape; c->use_simple = g.use_simple_features; c->use_hist = g.use_histogram_features;
   c->norm_area = g.normalizing_area; c->norm_len = g.normalizing_length;
   c->rfdim = bc_rf_dim(*c); c->bfdim = bc_bf_dim(*c); c->fdim = bc_feat_dim(*c);
   c->libm_log2 = rag->ctx->libm.log2_variant; c->libm_log = rag->ctx->libm.log_variant;

@@ -19,7 +19,7 @@
 
 namespace glia {
 
-constexpr int kMaxFeat = 272;   // 11+4T+7r+3l+5b + 3*(4+D+2T+5r+l+5b) with D=3, T=4 and four images per list
+constexpr int kMaxFeat = 384;   // longest vector a kernel can hold (per-thread array of the initial-edge kernel); e.g. two 16-bin + two 8-bin image blocks with histogram columns = 314
 
 // statistics of a set of boundary voxels (a commutative monoid under combine)
 struct EStats {
@@ -73,13 +73,24 @@ struct BcCfg {
   int n_region, n_rlabel, n_boundary;   // lengths of the three image lists (prepareImages, hmt/hmt_util.hxx:17-56)
   int rc[kMaxListed], lc[kMaxListed], bc[kMaxListed];   // list entry -> channel
   int use_log, use_simple;
+  int use_hist;                         // GLIA_USE_HISTOGRAM_AS_FEATS: every image block carries its histogram ahead of the entropy
   double norm_area, norm_len;
   int rfdim, bfdim, fdim;
   int libm_log2, libm_log;              // which restatement of the host libm the logarithms use (glibc_math.hpp)
 };
 
-__host__ __device__ inline int bc_rf_dim(const BcCfg& c) { return 4 + c.D + 2 * c.T + 5 * c.n_region + c.n_rlabel + 5 * c.n_boundary; }
-__host__ __device__ inline int bc_bf_dim(const BcCfg& c) { return 11 + 4 * c.T + 7 * c.n_region + 3 * c.n_rlabel + 5 * c.n_boundary; }
+// histogram columns of the image lists (0 unless use_hist): ImageLabelFeats::dim = histBin + 1 (type/feat.hxx:608-612)
+__host__ __device__ inline int bc_hist_cols(const BcCfg& c, int kind) {
+  if (!c.use_hist) return 0;
+  int n = 0;
+  const int cnt = kind == 0 ? c.n_region : kind == 1 ? c.n_rlabel : c.n_boundary;
+  for (int i = 0; i < cnt; ++i) n += c.cbins[kind == 0 ? c.rc[i] : kind == 1 ? c.lc[i] : c.bc[i]];
+  return n;
+}
+__host__ __device__ inline int bc_rf_dim(const BcCfg& c) {
+  return 4 + c.D + 2 * c.T + 5 * c.n_region + c.n_rlabel + 5 * c.n_boundary + bc_hist_cols(c, 0) + bc_hist_cols(c, 1) + bc_hist_cols(c, 2);
+}
+__host__ __device__ inline int bc_bf_dim(const BcCfg& c) { return 11 + 4 * c.T + 7 * c.n_region + 3 * c.n_rlabel + 5 * c.n_boundary + bc_hist_cols(c, 2); }
 __host__ __device__ inline int bc_full_dim(const BcCfg& c) { return bc_bf_dim(c) + 3 * bc_rf_dim(c); }
 __host__ __device__ inline int bc_feat_dim(const BcCfg& c) {
   return c.use_simple ? 5 + c.n_boundary + 4 * c.n_region + 2 * c.n_rlabel : bc_bf_dim(c) + 3 * bc_rf_dim(c);
@@ -171,6 +182,13 @@ __device__ __forceinline__ void dist_terms(uint32_t c0, uint32_t n0, uint32_t c1
   tx = (d * d) / (p0 + p1 + 2.22e-16);
 }
 
+// the normalised histogram of a voxel set (util/image_stats.hxx:45-52) as feature columns; returns their number
+__device__ __forceinline__ int put_hist(const ImgSrc& s, int bins, double* out) {
+#pragma unroll
+  for (int i = 0; i < GLIA_HMT_MAX_BINS; ++i) if (i < bins) out[i] = s.n ? s.h(i) / (double)s.n : 0.0;
+  return bins;
+}
+
 // Image lists: a source functor hands out the statistics of one list entry -- src(kind, i) with kind 0 = the voxel set on
 // region-list image i, 1 = the voxel set on label-list image i, 2 = the boundary set on boundary-list image i.
 struct ShapeIn { uint32_t n, border; int lo[3], hi[3]; uint32_t bn; uint32_t thr[GLIA_HMT_MAX_THRESH]; };
@@ -208,12 +226,20 @@ __device__ __forceinline__ void region_feats_multi(const BcCfg& c, const ShapeIn
   k += 2 * T;
   area_o = area; perim_o = perim;
   for (int i = 0; i < c.n_region; ++i) {
-    const ImgFeats f = image_feats_src(src(0, i), c.cbins[c.rc[i]], c.libm_log2);
+    const ImgSrc s = src(0, i);
+    const ImgFeats f = image_feats_src(s, c.cbins[c.rc[i]], c.libm_log2);
+    if (c.use_hist) k += put_hist(s, c.cbins[c.rc[i]], out + k);
     out[k++] = f.entropy; out[k++] = f.mean; out[k++] = f.stddev; out[k++] = f.mn; out[k++] = f.mx;
   }
-  for (int i = 0; i < c.n_rlabel; ++i) out[k++] = image_feats_src(src(1, i), c.cbins[c.lc[i]], c.libm_log2).entropy;
+  for (int i = 0; i < c.n_rlabel; ++i) {
+    const ImgSrc s = src(1, i);
+    if (c.use_hist) k += put_hist(s, c.cbins[c.lc[i]], out + k);
+    out[k++] = image_feats_src(s, c.cbins[c.lc[i]], c.libm_log2).entropy;
+  }
   for (int i = 0; i < c.n_boundary; ++i) {
-    const ImgFeats f = image_feats_src(src(2, i), c.cbins[c.bc[i]], c.libm_log2);
+    const ImgSrc s = src(2, i);
+    const ImgFeats f = image_feats_src(s, c.cbins[c.bc[i]], c.libm_log2);
+    if (c.use_hist) k += put_hist(s, c.cbins[c.bc[i]], out + k);
     out[k++] = f.entropy; out[k++] = f.mean; out[k++] = f.stddev; out[k++] = f.mn; out[k++] = f.mx;
   }
 }
@@ -268,7 +294,9 @@ __device__ __forceinline__ void boundary_feats_multi(const BcCfg& c, uint32_t sh
     }
   }
   for (int i = 0; i < c.n_boundary; ++i) {
-    const ImgFeats f = image_feats_src(srcSh(i), c.cbins[c.bc[i]], c.libm_log2);
+    const ImgSrc s = srcSh(i);
+    const ImgFeats f = image_feats_src(s, c.cbins[c.bc[i]], c.libm_log2);
+    if (c.use_hist) k += put_hist(s, c.cbins[c.bc[i]], out + k);
     out[k++] = f.entropy; out[k++] = f.mean; out[k++] = f.stddev; out[k++] = f.mn; out[k++] = f.mx;
   }
 }
@@ -303,7 +331,11 @@ __device__ __forceinline__ void simple_selection(const BcCfg& c, double* out) {
     const int r = 11 + 4 * c.T, rl = r + 7 * c.n_region, bimg = rl + 3 * c.n_rlabel;
     int k = 0;
     out[k++] = v0; out[k++] = v1; out[k++] = v2; out[k++] = v3; out[k++] = v4;     // slots 0..4 < every source below (>= 11)
-    for (int i = 0; i < c.n_boundary; ++i) out[k++] = bf[bimg + 5 * i + 1];
+    for (int i = 0, o = bimg; i < c.n_boundary; ++i) {            // the mean of the shared boundary on boundary image i
+      const int hb = c.use_hist ? c.cbins[c.bc[i]] : 0;
+      out[k++] = bf[o + hb + 1];
+      o += hb + 5;
+    }
     for (int i = 0; i < c.n_region; ++i) {
       const double m = bf[r + 7 * i + 3], l1 = bf[r + 7 * i + 0], xx = bf[r + 7 * i + 1], en = bf[r + 7 * i + 2];
       out[k++] = m; out[k++] = l1; out[k++] = xx; out[k++] = en;

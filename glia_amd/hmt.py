@@ -33,6 +33,7 @@ class FeatConfig(C.Structure):
         ("d_pb", C.c_void_p), ("n_thresholds", C.c_int), ("thresholds", C.c_double * MAX_THRESH),
         ("normalizing_area", C.c_double), ("normalizing_length", C.c_double),
         ("use_log_shape", C.c_int), ("use_simple_features", C.c_int),
+        ("use_histogram_features", C.c_int), ("use_median_features", C.c_int),
     ]
 
 
@@ -136,7 +137,8 @@ class Context:
 
 
 def make_config(pb, rb=(), r=(), rl=(), b=(), thresholds=(0.2, 0.5, 0.8), normalizing_area=1.0,
-                normalizing_length=1.0, use_log_shape=False, use_simple_features=False):
+                normalizing_length=1.0, use_log_shape=False, use_simple_features=False, use_histogram_features=False,
+                use_median_features=False):
     """Builds the image lists the way prepareImages does (hmt/hmt_util.hxx:17-56).
     rb/r/rl/b: sequences of (device tensor, bins, lo, hi)."""
     cfg = FeatConfig()
@@ -158,6 +160,7 @@ def make_config(pb, rb=(), r=(), rl=(), b=(), thresholds=(0.2, 0.5, 0.8), normal
         cfg.thresholds[i] = t
     cfg.normalizing_area, cfg.normalizing_length = normalizing_area, normalizing_length
     cfg.use_log_shape, cfg.use_simple_features = int(use_log_shape), int(use_simple_features)
+    cfg.use_histogram_features, cfg.use_median_features = int(use_histogram_features), int(use_median_features)
     cfg._keep = keep
     return cfg
 

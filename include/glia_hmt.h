@@ -84,6 +84,12 @@ typedef struct {
   double normalizing_length;
   int use_log_shape;                 /* --logs */
   int use_simple_features;           /* --simpf */
+  /* Build options of the reference that change the vector layout (CMakeLists.txt:54-64, type/feat.hxx:608-621, 677-722):
+   * GLIA_HMT_HIST_FEAT -> GLIA_USE_HISTOGRAM_AS_FEATS: every image-feature block carries its normalised histogram ahead of
+   * the entropy (bins more columns per block).  GLIA_HMT_MEDIAN_FEAT -> GLIA_USE_MEDIAN_AS_FEATS is not implemented
+   * (GLIA_HMT_ERR_UNSUPPORTED): it needs the value multiset of every region. */
+  int use_histogram_features;
+  int use_median_features;
 } glia_hmt_feat_config;
 
 /* ---- region adjacency structure -------------------------------------------------------

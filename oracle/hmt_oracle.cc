@@ -427,8 +427,9 @@ struct ImageFeats {
   std::vector<double> histogram;
   double entropy = 0.0, mean = 0.0, stddev = 0.0, min = 0.0, max = 0.0;
   bool hasReal = true;
-  template <typename M> void generate(M const& points, const float* img, HistSpec const& hs, bool real) {
-    hasReal = real;
+  bool histAsFeats = false;     // GLIA_USE_HISTOGRAM_AS_FEATS (CMakeLists.txt:54-58): the histogram itself precedes its entropy (feat.hxx:608-621)
+  template <typename M> void generate(M const& points, const float* img, HistSpec const& hs, bool real, bool histFeats = false) {
+    hasReal = real; histAsFeats = histFeats;
     histOver(histogram, points, img, hs);
     entropy = ::entropy(histogram);
     if (!real) return;
@@ -446,6 +447,7 @@ struct ImageFeats {
     stddev = ssqrt(stddev / n - mean * mean, 0.0);
   }
   void serialize(std::vector<double>& f) const {
+    if (histAsFeats) for (double x : histogram) f.push_back(x);
     f.push_back(entropy);
     if (hasReal) { f.push_back(mean); f.push_back(stddev); f.push_back(min); f.push_back(max); }
   }
@@ -509,11 +511,11 @@ struct RegionFeats {
     }
     // bc_feat.hxx:100-124
     region.resize(cfg.c.n_rimg);
-    for (int i = 0; i < cfg.c.n_rimg; ++i) region[i].generate(reg.pts, cfg.c.rimg[i], cfg.rh[i], true);
+    for (int i = 0; i < cfg.c.n_rimg; ++i) region[i].generate(reg.pts, cfg.c.rimg[i], cfg.rh[i], true, cfg.c.hist_as_feats != 0);
     labelRegion.resize(cfg.c.n_rlimg);
-    for (int i = 0; i < cfg.c.n_rlimg; ++i) labelRegion[i].generate(reg.pts, cfg.c.rlimg[i], cfg.rlh[i], false);
+    for (int i = 0; i < cfg.c.n_rlimg; ++i) labelRegion[i].generate(reg.pts, cfg.c.rlimg[i], cfg.rlh[i], false, cfg.c.hist_as_feats != 0);
     boundary.resize(cfg.c.n_bimg);
-    for (int i = 0; i < cfg.c.n_bimg; ++i) boundary[i].generate(reg.boundary, cfg.c.bimg[i], cfg.bh[i], true);
+    for (int i = 0; i < cfg.c.n_bimg; ++i) boundary[i].generate(reg.boundary, cfg.c.bimg[i], cfg.bh[i], true, cfg.c.hist_as_feats != 0);
   }
   void log() {  // feat.hxx:46-52, 463-467
     area = slog(area, 0.0); perim = slog(perim, 0.0); bboxArea = slog(bboxArea, 0.0);
@@ -595,7 +597,7 @@ struct BoundaryFeats {
       labelRegion.push_back(d);
     }
     boundary.resize(cfg.c.n_bimg);
-    for (int i = 0; i < cfg.c.n_bimg; ++i) boundary[i].generate(b, cfg.c.bimg[i], cfg.bh[i], true);
+    for (int i = 0; i < cfg.c.n_bimg; ++i) boundary[i].generate(b, cfg.c.bimg[i], cfg.bh[i], true, cfg.c.hist_as_feats != 0);
   }
   void log() {  // feat.hxx:103-106, 148-155, 531-539
     areaDiff = slog(areaDiff, 0.0); perimDiff = slog(perimDiff, 0.0);
@@ -999,6 +1001,14 @@ int orc_feat_dim(int dim, const orc_feat_cfg* c) {
   int T = c->n_thr;
   int rf = 4 + dim + 2 * T + 5 * c->n_rimg + c->n_rlimg + 5 * c->n_bimg;
   int bf = 11 + 4 * T + 7 * c->n_rimg + 3 * c->n_rlimg + 5 * c->n_bimg;
+  if (c->hist_as_feats) {        // every ImageLabelFeats block carries its histogram (feat.hxx:608-621); the diff blocks do not
+    int hb = 0;
+    for (int i = 0; i < c->n_bimg; ++i) hb += c->bbins[i];
+    bf += hb;
+    for (int i = 0; i < c->n_rimg; ++i) rf += c->rbins[i];
+    for (int i = 0; i < c->n_rlimg; ++i) rf += c->rlbins[i];
+    rf += hb;
+  }
   return bf + 3 * rf;
 }
 

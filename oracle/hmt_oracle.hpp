@@ -62,6 +62,7 @@ typedef struct {
   double norm_area, norm_len;          // 1.0 unless --ns
   int use_log;                         // --logs
   int use_simple;                      // --simpf
+  int hist_as_feats;                   // build option GLIA_HMT_HIST_FEAT -> GLIA_USE_HISTOGRAM_AS_FEATS (CMakeLists.txt:54-58, feat.hxx:608-621)
 } orc_feat_cfg;
 
 // Random forest in the layout produced by rf_old::readModelFromBinaryFile after

@@ -190,6 +190,46 @@ def test_log_and_simple_features(ctx):
         assert (order == o_ref).all() and _feat_close(feats, f_ref)
 
 
+@pytest.mark.parametrize("shape,S,G,layout", [((32, 32, 32), 8, 16, 0), ((40, 36, 28), 6, 12, 1), ((64, 64), 4, 16, 2), ((32, 32, 32), 8, 16, 3)])
+def test_histogram_as_features_layout(ctx, shape, S, G, layout):
+    """GLIA_HMT_HIST_FEAT / GLIA_USE_HISTOGRAM_AS_FEATS (CMakeLists.txt:54-58, type/feat.hxx:608-621): every image block carries
+    its normalised histogram ahead of the entropy -- D_f grows by the bins of every block; order, saliencies and rows vs the oracle,
+    also with --simpf (whose boundary-image means move) and --logs, and for a given order (bc_feat)."""
+    import torch
+    from glia_amd import hmt
+    from oracle import pyoracle as O
+    labels, pb = O.synth(shape, S, G)
+    rng = np.random.default_rng(21)
+    raw = (np.round(rng.random(shape) * 255) / 256.0).astype(np.float32)
+    d_lab = torch.from_numpy(labels.view(np.int32)).cuda()
+    d_pb, d_raw = torch.from_numpy(pb).cuda(), torch.from_numpy(raw).cuda()
+    if layout == 0: okw, dkw, flags = dict(rb=[(pb, 8, 0.0, 1.0)]), dict(rb=[(d_pb, 8, 0.0, 1.0)]), {}
+    elif layout == 1: okw, dkw, flags = dict(rb=[(raw, 16, 0.0, 1.0), (pb, 8, 0.0, 1.0)]), dict(rb=[(d_raw, 16, 0.0, 1.0), (d_pb, 8, 0.0, 1.0)]), dict(use_log=True)
+    elif layout == 2: okw, dkw, flags = dict(r=[(raw, 4, 0.0, 1.0)], b=[(pb, 8, 0.0, 1.0)], rl=[(raw, 4, 0.0, 1.0)]), dict(r=[(d_raw, 4, 0.0, 1.0)], b=[(d_pb, 8, 0.0, 1.0)], rl=[(d_raw, 4, 0.0, 1.0)]), {}
+    else: okw, dkw, flags = dict(rb=[(pb, 8, 0.0, 1.0)], b=[(raw, 4, 0.0, 1.0)]), dict(rb=[(d_pb, 8, 0.0, 1.0)], b=[(d_raw, 4, 0.0, 1.0)]), dict(use_simple=True)
+    ocfg = O.make_cfg(pb, hist_as_feats=True, **okw, **flags)
+    plain = O.make_cfg(pb, **okw, **flags)
+    cfg = hmt.make_config(d_pb, use_histogram_features=True, use_log_shape=flags.get("use_log", False),
+                          use_simple_features=flags.get("use_simple", False), **dkw)
+    rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, cfg=cfg)
+    fd = rm.feat_dim()
+    assert fd == O.feat_dim(len(shape), ocfg)
+    if not flags.get("use_simple"):
+        assert fd > O.feat_dim(len(shape), plain)                 # the layout really is wider
+    stub = fd - 3
+    order, sal, feats = rm.merge_order_bc(hmt.FeatureStubClassifier(ctx, stub), want_feats=True)
+    o_ref, s_ref, f_ref = O.Rag(labels).merge_order_bc(ocfg, None, stub_index=stub, want_feats=True)
+    assert feats.shape == f_ref.shape and (order == o_ref).all() and (sal == s_ref).all()
+    assert _feat_close(feats, f_ref)
+    # bc_feat for a given order
+    po, _ = O.Rag(labels, only_contour=True).merge_order_pb(pb, type=2)
+    assert _feat_close(rm.bc_feat(po), O.Rag(labels).bc_feat(ocfg, po))
+    rm.close()
+    # the median layout is refused, not silently ignored
+    with pytest.raises(hmt.HmtError):
+        hmt.RegionMap(ctx, d_lab, pb=d_pb, cfg=hmt.make_config(d_pb, use_median_features=True, **dkw))
+
+
 @pytest.mark.parametrize("shape,S,G", [((32, 32, 32), 8, 16), ((40, 36, 28), 6, 12), ((64, 64), 4, 16)])
 def test_bc_feat_for_a_given_order(ctx, shape, S, G):
     """hmt/main_bc_feat.cxx path: features of every merge of a GIVEN order (here: the pb-mean order)."""
