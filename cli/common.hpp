@@ -245,6 +245,8 @@ inline void loadFeatInputs(const Args& a, FeatInputs& f) {
   f.cfg.normalizing_length = flagOf(a, "ns") ? std::sqrt(diag) : 1.0;
   f.cfg.use_log_shape = flagOf(a, "logs");
   f.cfg.use_simple_features = flagOf(a, "simpf");
+  // the reference fixes this layout at build time (cmake -DGLIA_HMT_HIST_FEAT=ON -> GLIA_USE_HISTOGRAM_AS_FEATS); here it is a flag
+  f.cfg.use_histogram_features = a.has("histf") ? flagOf(a, "histf") : 0;
 }
 
 }  // namespace cli
