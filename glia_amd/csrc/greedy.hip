@@ -1167,6 +1167,8 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(WinState 
 // The result is bit-identical to the sequential kernels (same gate: SHA-1 of the whole 1024^3 order).
 // =====================================================================================================================
 constexpr uint32_t kBatchKill = 32;
+constexpr int kMemP = 3;                   // list entries per lane of a batch member ...
+constexpr uint32_t kMemMax = 160;          // ... and their limit (the wave's 256-slot neighbour table stays under 2/3 full)
 struct BatchShared {
   alignas(16) Key part1[kNW];               // per-wave best / second-best of the last scan
   alignas(16) Key part2[kNW];
@@ -1254,6 +1256,7 @@ __device__ __forceinline__ uint32_t batch_contract_wide(const WinState& st, WinS
   if (wn_now + total > kWinCap && wn_now > kWinCap / 2u) win_compact(w, tid);      // (holes out; a full window spills, see win_evict)
   const int cthr = w.cthr; const double tsal = w.tsal; const unsigned long long tseq = w.tseq;
   const uint32_t nwork = small ? s.nitems : total;
+  const uint32_t lenR2 = small ? nwork : 0u;        // small case: every table item becomes exactly one new edge, so r2's list length is known here
   bool bad = false;
   uint32_t pend_e = kNone, pend_old = kNone;
   for (uint32_t base = 0; base < nwork; base += kGreedyThreads) {
@@ -1300,19 +1303,18 @@ __device__ __forceinline__ uint32_t batch_contract_wide(const WinState& st, WinS
     pq4[0] = make_uint4(rs, r2, posRs, idx);
     const unsigned long long mb = (unsigned long long)__double_as_longlong(first);
     pq4[1] = make_uint4((uint32_t)mb, (uint32_t)(mb >> 32), (uint32_t)second, kNone);
-    pq4[2] = make_uint4(offRs, lenRs, r2off, 0u);                        // r2's length: stored below
+    pq4[2] = make_uint4(offRs, lenRs, r2off, lenR2);                     // (wide case: r2's length is stored below)
     const unsigned long long sbits = (unsigned long long)__double_as_longlong(sal);
     pq4[3] = make_uint4((uint32_t)sbits, (uint32_t)(sbits >> 32), (uint32_t)seq, (uint32_t)(seq >> 32));
-    FatEntry a; a.eid = newE; a.rs = r2; a.n = (uint32_t)second; a.pos = idx; a.off = r2off; a.len = 0; a.mean = first;   // len: stored below
+    FatEntry a; a.eid = newE; a.rs = r2; a.n = (uint32_t)second; a.pos = idx; a.off = r2off; a.len = lenR2; a.mean = first;
     st.fpool[offRs + posRs] = a;
     FatEntry bb; bb.eid = newE; bb.rs = rs; bb.n = (uint32_t)second; bb.pos = posRs; bb.off = offRs; bb.len = lenRs; bb.mean = first;
     st.fpool[r2off + idx] = bb;
-    if (small) { s.items[i] = offRs + posRs; s.newidx[i] = idx; }
     const uint32_t cell = win_cell(sal, smin, scale, st.wB);
     uint32_t sl = kWinCap;
     if (win_above(cthr, tsal, tseq, (int)cell, sal, seq)) {
       sl = atomicAdd(&w.n, 1u);
-      if (sl < kWinCap) win_put(w, sl, sal, seq, newE, rs, r2, make_uint2(offRs, lenRs), make_uint2(r2off, 0u));
+      if (sl < kWinCap) win_put(w, sl, sal, seq, newE, rs, r2, make_uint2(offRs, lenRs), make_uint2(r2off, lenR2));
       else atomicMax(&w.spill_ord, f64_ord(sal));          // the window is full: tau will rise above this item
     }
     if (sl >= kWinCap) {
@@ -1338,9 +1340,7 @@ __device__ __forceinline__ uint32_t batch_contract_wide(const WinState& st, WinS
   if (bad) b.bad = 1;
   __syncthreads();
   const uint32_t newcount = s.newcount;
-  if (small) {
-    for (uint32_t i = tid; i < nwork; i += kGreedyThreads) { st.fpool[s.items[i]].len = newcount; st.er[(uint32_t)ne + s.newidx[i]].hv.y = newcount; }
-  } else {
+  if (!small) {
     for (uint32_t j = tid; j < newcount; j += kGreedyThreads) {
       const FatEntry fb = st.fpool[r2off + j];
       st.fpool[fb.off + fb.pos].len = newcount;
@@ -1348,7 +1348,7 @@ __device__ __forceinline__ uint32_t batch_contract_wide(const WinState& st, WinS
       st.mark0[fb.rs] = 0; st.mark1[fb.rs] = 0;
     }
   }
-  for (uint32_t i = tid; i < (w.n < kWinCap ? w.n : kWinCap); i += kGreedyThreads) if (w.v[i] == r2) w.hv[i].y = newcount;      // window items of r2: its list length
+  if (!small) for (uint32_t i = tid; i < (w.n < kWinCap ? w.n : kWinCap); i += kGreedyThreads) if (w.v[i] == r2) w.hv[i].y = newcount;      // window items of r2: its list length
   if (pend_e != kNone) st.er[pend_e].next = pend_old;
   if (tid == 0) { st.adj_off[r2] = r2off; st.adj_len[r2] = newcount; }
   __syncthreads();
@@ -1377,6 +1377,13 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
   uint32_t pend_e = kNone, pend_old = kNone;          // (per lane) a list push whose link is stored a round later
   constexpr uint32_t kTab = kMarkSlots / kNW;         // private neighbour table of a wave
   uint32_t* const tk = &s.mk[wave * kTab]; uint32_t* const t0 = &s.mv0[wave * kTab]; uint32_t* const t1 = &s.mv1[wave * kTab];
+  // ... and what a slot's (r1, rs) entry carries for the lane that owns the (r0, rs) entry; lives in the staging area of
+  // the whole-workgroup path (never active at the same time)
+  static_assert(sizeof(s.stage) >= (size_t)kNW * kTab * 20, "per-wave staging");
+  uint32_t* const sg_eid = reinterpret_cast<uint32_t*>(&s.stage[0]) + wave * kTab;
+  uint32_t* const sg_n = reinterpret_cast<uint32_t*>(&s.stage[0]) + (kNW + wave) * kTab;
+  uint32_t* const sg_pos = reinterpret_cast<uint32_t*>(&s.stage[0]) + (2 * kNW + wave) * kTab;
+  double* const sg_mean = reinterpret_cast<double*>(reinterpret_cast<uint32_t*>(&s.stage[0]) + 3 * kNW * kTab) + wave * kTab;
 #ifdef GLIA_HMT_PROFILE
   unsigned long long bph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, blast = __builtin_readcyclecounter(), brounds = 0, bmembers = 0, bvalid = 0, bwide = 0, bcut_sal = 0, bcut_dep = 0;
 #define BPH(i) do { if (tid == 0) { unsigned long long tn = __builtin_readcyclecounter(); bph[i] += tn - blast; blast = tn; } } while (0)
@@ -1425,7 +1432,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
     const uint2 th0 = w.hu[top.arg], th1 = w.hv[top.arg];
     const uint32_t top_total = th0.y + th1.y;
     BPH(0);
-    if (top_total > 64u) {
+    if (top_total > kMemMax) {
       if (ne + top_total > st.Ecap) { status = ST_NEED_EDGES; break; }
       if (pool_used + top_total > st.pool_cap) { status = ST_NEED_POOL; break; }
       uint32_t newcount = 0;
@@ -1440,49 +1447,73 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
       BPH(4);
       continue;
     }
-    // ---- compute: wave j works out member j (rank order) on its own; wide members end the batch ----
-    const bool narrow = member && total <= 64u;
+    // ---- compute: wave j works out member j (rank order) on its own, up to kMemP list entries per lane; wider members end the batch ----
+    const bool narrow = member && total <= kMemMax;
     b.bitmap[wave][lane] = 0;
-    FatEntry fe; fe.eid = kNone; fe.rs = 0; fe.n = 0; fe.pos = 0; fe.off = 0; fe.len = 0; fe.mean = 0.0;
-    const bool inlist = narrow && (uint32_t)lane < total;
-    const bool side1 = (uint32_t)lane >= len0;
-    if (inlist) fe = st.fpool[side1 ? off1 + ((uint32_t)lane - len0) : off0 + (uint32_t)lane];
+    FatEntry fe[kMemP];
+    bool act[kMemP], side1[kMemP];
+    uint32_t h[kMemP];
+#pragma unroll
+    for (int p = 0; p < kMemP; ++p) {
+      const uint32_t i = (uint32_t)lane + 64u * (uint32_t)p;
+      const bool inlist = narrow && i < total;
+      side1[p] = i >= len0;
+      fe[p].eid = kNone; fe[p].rs = 0; fe[p].n = 0; fe[p].pos = 0; fe[p].off = 0; fe[p].len = 0; fe[p].mean = 0.0;
+      if (inlist) fe[p] = st.fpool[side1[p] ? off1 + (i - len0) : off0 + i];
+      act[p] = inlist;
+    }
     if (pend_e != kNone) { st.er[pend_e].next = pend_old; pend_e = kNone; }      // (last round's atomic has returned with these loads)
-    const bool act = inlist && fe.eid != e && fe.eid != kNone;
-    uint32_t h = (fe.rs * 2654435761u) >> 24;
-    if (act) {
-      while (true) {
-        const uint32_t old = atomicCAS(&tk[h], 0u, fe.rs + 1u);
-        if (old == 0u || old == fe.rs + 1u) break;
-        h = (h + 1u) & (kTab - 1u);
+#pragma unroll
+    for (int p = 0; p < kMemP; ++p) {
+      act[p] = act[p] && fe[p].eid != e && fe[p].eid != kNone;
+      h[p] = (fe[p].rs * 2654435761u) >> 24;
+      if (act[p]) {
+        while (true) {
+          const uint32_t old = atomicCAS(&tk[h[p]], 0u, fe[p].rs + 1u);
+          if (old == 0u || old == fe[p].rs + 1u) break;
+          h[p] = (h[p] + 1u) & (kTab - 1u);
+        }
+        if (side1[p]) {                                  // the (r1, rs) entry: its data waits in the table for the (r0, rs) entry's lane
+          t1[h[p]] = 1u;
+          sg_eid[h[p]] = fe[p].eid; sg_n[h[p]] = fe[p].n; sg_pos[h[p]] = fe[p].pos; sg_mean[h[p]] = fe[p].mean;
+        } else t0[h[p]] = 1u;
+        atomicOr(&b.bitmap[wave][(fe[p].rs >> 5) & 63u], 1u << (fe[p].rs & 31u));
       }
-      (side1 ? t1 : t0)[h] = (uint32_t)lane + 1u;
-      atomicOr(&b.bitmap[wave][(fe.rs >> 5) & 63u], 1u << (fe.rs & 31u));
     }
     if (narrow && lane == 0) { atomicOr(&b.bitmap[wave][(r0 >> 5) & 63u], 1u << (r0 & 31u)); atomicOr(&b.bitmap[wave][(r1 >> 5) & 63u], 1u << (r1 & 31u)); }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // (a wave's LDS operations execute in order)
-    const uint32_t m0 = act ? t0[h] : 0u, m1 = act ? t1[h] : 0u;
-    const bool owner = act && (!side1 || m0 == 0u);
-    const bool both = owner && !side1 && m1 != 0u;
-    const int plane = both ? (int)(m1 - 1u) : lane;                      // the lane holding the (r1, rs) entry of a common neighbour
-    const uint32_t p_eid = (uint32_t)__shfl((int)fe.eid, plane), p_n = (uint32_t)__shfl((int)fe.n, plane), p_pos = (uint32_t)__shfl((int)fe.pos, plane);
-    const unsigned long long mbits = (unsigned long long)__double_as_longlong(fe.mean);
-    const double p_mean = __longlong_as_double((long long)(((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(mbits >> 32), plane) << 32) | (uint32_t)__shfl((int)(uint32_t)mbits, plane)));
-    if (act) { tk[h] = 0u; t0[h] = 0u; t1[h] = 0u; }                       // the table is clean again
-    const bool h0 = owner && !side1, h1 = owner && (side1 || both);
-    // util/struct_merge.hxx:62-76 (operand order: the (r0,rs) item first)
-    double first = 0.0;
-    int second = 0;
-    if (h0) { first += fe.mean * (int)fe.n; second += (int)fe.n; }
-    if (h1) { const double m = both ? p_mean : fe.mean; const int nn = both ? (int)p_n : (int)fe.n; first += m * nn; second += nn; }
-    first = owner ? sdivide(first, (double)second, 0.0) : 0.0;
-    const bool bad = owner && first == -1.0;             // DUMMY -> "invalid boundary saliency" (:78-79)
-    const double sal = -first;
-    const unsigned long long ownmask = __ballot(owner);
-    const uint32_t newcount = (uint32_t)__popcll(ownmask);
-    const uint32_t idx = (uint32_t)__popcll(ownmask & ((1ull << lane) - 1ull));
-    // the largest saliency this member creates
-    double mx = owner ? sal : -__builtin_inf();
+    bool owner[kMemP], both[kMemP];
+    uint32_t p_eid[kMemP], p_n[kMemP], p_pos[kMemP];
+    double p_mean[kMemP];
+#pragma unroll
+    for (int p = 0; p < kMemP; ++p) {
+      const uint32_t m0 = act[p] ? t0[h[p]] : 0u, m1 = act[p] ? t1[h[p]] : 0u;
+      owner[p] = act[p] && (!side1[p] || m0 == 0u);
+      both[p] = owner[p] && !side1[p] && m1 != 0u;
+      p_eid[p] = sg_eid[h[p]]; p_n[p] = sg_n[h[p]]; p_pos[p] = sg_pos[h[p]]; p_mean[p] = sg_mean[h[p]];
+    }
+#pragma unroll
+    for (int p = 0; p < kMemP; ++p) if (act[p]) { tk[h[p]] = 0u; t0[h[p]] = 0u; t1[h[p]] = 0u; }      // the table is clean again
+    double first[kMemP]; int second[kMemP]; uint32_t idx[kMemP];
+    bool bad = false;
+    uint32_t newcount = 0;
+    double mx = -__builtin_inf();
+#pragma unroll
+    for (int p = 0; p < kMemP; ++p) {
+      const bool h0 = owner[p] && !side1[p], h1 = owner[p] && (side1[p] || both[p]);
+      // util/struct_merge.hxx:62-76 (operand order: the (r0,rs) item first)
+      double f = 0.0;
+      int sc = 0;
+      if (h0) { f += fe[p].mean * (int)fe[p].n; sc += (int)fe[p].n; }
+      if (h1) { const double m = both[p] ? p_mean[p] : fe[p].mean; const int nn = both[p] ? (int)p_n[p] : (int)fe[p].n; f += m * nn; sc += nn; }
+      f = owner[p] ? sdivide(f, (double)sc, 0.0) : 0.0;
+      bad = bad || (owner[p] && f == -1.0);               // DUMMY -> "invalid boundary saliency" (:78-79)
+      first[p] = f; second[p] = sc;
+      const unsigned long long ownmask = __ballot(owner[p]);
+      idx[p] = newcount + (uint32_t)__popcll(ownmask & ((1ull << lane) - 1ull));
+      newcount += (uint32_t)__popcll(ownmask);
+      mx = (owner[p] && -f > mx) ? -f : mx;              // the largest saliency this member creates
+    }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { const double o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
     if (lane == 0) { b.m_newcount[wave] = narrow ? newcount : 0u; b.m_total[wave] = narrow ? total : 0xFFFFFFFFu; b.m_maxsal[wave] = mx; }
@@ -1542,24 +1573,28 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
         st.er[e].seq = 0;
         st.adj_off[r2] = r2off; st.adj_len[r2] = newcount;
       }
-      if (owner) {
-        const uint32_t rs = fe.rs;
-        const uint32_t newE = (uint32_t)ne + my_ne + idx;
-        const uint32_t offRs = fe.off, posRs = fe.pos, lenRs = fe.len;   // rs's entry of the (r0,rs) edge -- or of (r1,rs) alone -- is reused
-        if (both) st.fpool[offRs + p_pos].eid = kNone;                   // rs held two entries: the other becomes a tombstone
+#pragma unroll
+      for (int p = 0; p < kMemP; ++p) {
+        if (!owner[p]) continue;
+        const bool h0 = !side1[p];
+        const uint32_t rs = fe[p].rs;
+        const uint32_t newE = (uint32_t)ne + my_ne + idx[p];
+        const uint32_t offRs = fe[p].off, posRs = fe[p].pos, lenRs = fe[p].len;   // rs's entry of the (r0,rs) edge -- or of (r1,rs) alone -- is reused
+        if (both[p]) st.fpool[offRs + p_pos[p]].eid = kNone;             // rs held two entries: the other becomes a tombstone
         const uint32_t cat = rs < r0 ? 0u : (h0 ? 1u : 2u);
         const unsigned long long seq = ((kk + 1ull) << 32) | ((unsigned long long)cat << 30) | rs;
+        const double sal = -first[p];
         uint4* pq4 = reinterpret_cast<uint4*>(&st.er[newE]);
-        pq4[0] = make_uint4(rs, r2, posRs, idx);
-        const unsigned long long mb = (unsigned long long)__double_as_longlong(first);
-        pq4[1] = make_uint4((uint32_t)mb, (uint32_t)(mb >> 32), (uint32_t)second, kNone);
+        pq4[0] = make_uint4(rs, r2, posRs, idx[p]);
+        const unsigned long long mb = (unsigned long long)__double_as_longlong(first[p]);
+        pq4[1] = make_uint4((uint32_t)mb, (uint32_t)(mb >> 32), (uint32_t)second[p], kNone);
         pq4[2] = make_uint4(offRs, lenRs, r2off, newcount);
         const unsigned long long sbits = (unsigned long long)__double_as_longlong(sal);
         pq4[3] = make_uint4((uint32_t)sbits, (uint32_t)(sbits >> 32), (uint32_t)seq, (uint32_t)(seq >> 32));
-        FatEntry a; a.eid = newE; a.rs = r2; a.n = (uint32_t)second; a.pos = idx; a.off = r2off; a.len = newcount; a.mean = first;
+        FatEntry a; a.eid = newE; a.rs = r2; a.n = (uint32_t)second[p]; a.pos = idx[p]; a.off = r2off; a.len = newcount; a.mean = first[p];
         st.fpool[offRs + posRs] = a;
-        FatEntry bb; bb.eid = newE; bb.rs = rs; bb.n = (uint32_t)second; bb.pos = posRs; bb.off = offRs; bb.len = lenRs; bb.mean = first;
-        st.fpool[r2off + idx] = bb;
+        FatEntry bb; bb.eid = newE; bb.rs = rs; bb.n = (uint32_t)second[p]; bb.pos = posRs; bb.off = offRs; bb.len = lenRs; bb.mean = first[p];
+        st.fpool[r2off + idx[p]] = bb;
         const uint32_t cell = win_cell(sal, smin, scale, st.wB);
         uint32_t sl = kWinCap;
         if (win_above(cthr, tsal, tseq, (int)cell, sal, seq)) {
@@ -1568,19 +1603,20 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
           else atomicMax(&w.spill_ord, f64_ord(sal));      // the window is full: tau will rise above this item
         }
         if (sl >= kWinCap) {
+          if (pend_e != kNone) st.er[pend_e].next = pend_old;
           pend_e = newE; pend_old = atomicExch(&st.whead[cell], newE);
           atomicAdd(&st.wcnt[cell], 1u);
         }
         // the replaced edges leave the queue
 #pragma unroll
         for (int side = 0; side < 2; ++side) {
-          const bool hs = side ? h1 : h0;
+          const bool hs = side ? (side1[p] || both[p]) : h0;
           if (!hs) continue;
-          const uint32_t de = (side && both) ? p_eid : fe.eid;
-          const double dsal = -((side && both) ? p_mean : fe.mean);
+          const uint32_t de = (side && both[p]) ? p_eid[p] : fe[p].eid;
+          const double dsal = -((side && both[p]) ? p_mean[p] : fe[p].mean);
           const uint32_t dc = win_cell(dsal, smin, scale, st.wB);
           unsigned long long dq = 1;
-          if ((int)dc == cthr && dsal == tsal) dq = st.er[de].seq;   // tie with tau: the seq decides
+          if ((int)dc == cthr && dsal == tsal) dq = st.er[de].seq;         // tie with tau: the seq decides
           st.er[de].seq = 0;
           if (win_above(cthr, tsal, tseq, (int)dc, dsal, dq)) {
             const uint32_t j = atomicAdd(&b.nkill, 1u); if (j < kBatchKill) b.kill[j] = de; else b.kovf = 1;
