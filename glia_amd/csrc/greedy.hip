@@ -548,6 +548,7 @@ struct WinState {
   double cond_rpb;
   uint32_t R0, Ecap, wB, nsort;             // nsort: items of the baseline
   unsigned long long ne_base, rebase_after; // edges that existed at the baseline; a new one is due after this many more
+  uint32_t wcap, wbudget;                   // window slots in use (<= kWinCap) and the items a reload brings at most (tests shrink them: GLIA_HMT_WINCAP)
   int cond_n;
 };
 constexpr uint32_t kWinCap = 1536;          // window slots (live items + holes)
@@ -684,10 +685,10 @@ __device__ __forceinline__ Key win_root(const WinShared& w, int lane) {
 }
 
 // squeeze the holes out (every thread calls)
-__device__ __forceinline__ void win_compact(WinShared& w, int tid) {
+__device__ __forceinline__ void win_compact(WinShared& w, int tid, uint32_t cap = kWinCap) {
   double sal[kWinPer]; unsigned long long seq[kWinPer]; uint32_t e[kWinPer], u[kWinPer], v[kWinPer]; uint2 hu[kWinPer], hv[kWinPer];
   uint32_t live = 0;
-  const uint32_t n = w.n < kWinCap ? w.n : kWinCap;
+  const uint32_t n = w.n < cap ? w.n : cap;
 #pragma unroll
   for (int j = 0; j < kWinPer; ++j) {
     const uint32_t i = (uint32_t)tid * kWinPer + j;
@@ -715,7 +716,7 @@ __device__ __forceinline__ void win_flush(const WinState& st, WinShared& w, int 
   const double smin = st.wrange[0], scale = st.wrange[1];
   if (tid == 0) w.maxcell = 0;
   __syncthreads();
-  const uint32_t n = w.n < kWinCap ? w.n : kWinCap;
+  const uint32_t n = w.n < st.wcap ? w.n : st.wcap;
   uint32_t mc = 0;
   for (uint32_t i = tid; i < n; i += kGreedyThreads) {
     if (w.seq[i] == 0) continue;
@@ -737,7 +738,7 @@ __device__ __forceinline__ void win_flush(const WinState& st, WinShared& w, int 
 __device__ __forceinline__ void win_evict(const WinState& st, WinShared& w, int tid) {
   const double smin = st.wrange[0], scale = st.wrange[1];
   const double lim = f64_unord(w.spill_ord);
-  const uint32_t n = w.n < kWinCap ? w.n : kWinCap;
+  const uint32_t n = w.n < st.wcap ? w.n : st.wcap;
   __syncthreads();
   for (uint32_t i = tid; i < n; i += kGreedyThreads) {
     if (w.seq[i] == 0 || w.sal[i] > lim) continue;
@@ -769,7 +770,7 @@ __device__ __forceinline__ int win_reload(const WinState& st, WinShared& w, int 
     const uint32_t cn = valid ? ld_l2(&st.wcnt[c]) : 0u;
     uint32_t total;
     const uint32_t incl = block_scan_incl(cn, w.wsum, tid, &total);
-    const bool ok = valid && incl <= kWinBudget - loaded;
+    const bool ok = valid && incl <= st.wbudget - loaded;
     const uint32_t m = (uint32_t)__syncthreads_count(ok ? 1 : 0);       // ok is monotone in tid: the first m cells fit whole
     const uint32_t nvalid = c_hi < (uint32_t)kGreedyThreads ? c_hi : (uint32_t)kGreedyThreads;
     if (m != 0) {
@@ -796,10 +797,10 @@ __device__ __forceinline__ int win_reload(const WinState& st, WinShared& w, int 
       // INTO the cell.  Its items are a sorted array segment (initial edges) and an unordered list (created edges); thread 0
       // finds the list's K largest keys with a bounded min-heap in LDS, the new tau is the larger of the heap's minimum and
       // the key of the array entry RA places ahead, and everything above tau moves: at most K - 1 + RA items.
-      const uint32_t room = kWinBudget - loaded;
+      const uint32_t room = st.wbudget - loaded;
       const uint32_t cs = c_hi - 1u;
-      if (room >= kWinMinPartial || loaded == 0) {
-        const uint32_t K = room / 2u < kSelMax ? room / 2u : kSelMax, RA = room - K;
+      if (room >= (kWinMinPartial < st.wbudget / 8u ? kWinMinPartial : st.wbudget / 8u) || loaded == 0) {
+        const uint32_t K = (room / 2u < kSelMax ? room / 2u : kSelMax) > 1u ? (room / 2u < kSelMax ? room / 2u : kSelMax) : 2u, RA = room > K ? room - K : 1u;
         const uint32_t seg_end = st.ige[cs];
         const uint32_t before = w.n;
         if (tid == 0) {
@@ -875,7 +876,7 @@ __device__ __forceinline__ int win_reload(const WinState& st, WinShared& w, int 
       }
       break;
     }
-    if (loaded >= kWinMinLoad) break;      // else: a whole block of (nearly) empty cells, go on below it
+    if (loaded >= (kWinMinLoad < st.wbudget / 4u ? kWinMinLoad : st.wbudget / 4u)) break;      // else: a whole block of (nearly) empty cells, go on below it
   }
   __syncthreads();
   if (tid == 0 && result != 2) { w.cthr = (int)c_hi - 1; w.tsal = __builtin_inf(); w.tseq = ~0ull; w.iptr = iptr; }
@@ -1182,7 +1183,7 @@ struct BatchShared {
 
 // one pass over the window: applies the deaths of the last round, leaves every wave's best and second-best item
 __device__ __forceinline__ void batch_scan(const WinState& st, WinShared& w, BatchShared& b, int tid) {
-  const uint32_t n = w.n < kWinCap ? w.n : kWinCap, nk = b.nkill < kBatchKill ? b.nkill : kBatchKill, kovf = b.kovf;
+  const uint32_t n = w.n < st.wcap ? w.n : st.wcap, nk = b.nkill < kBatchKill ? b.nkill : kBatchKill, kovf = b.kovf;
   // Slot ownership is STRIPED over the waves (lane l of wave v scans the l-th slot of chunk (v + l) mod 8 in every block
   // of 512): a reload fills consecutive slots with consecutive keys, and the exact top of the queue is only as long as
   // the run of best items that sit with different waves.  (Bank pattern of a wave's reads: that of consecutive slots.)
@@ -1253,7 +1254,7 @@ __device__ __forceinline__ uint32_t batch_contract_wide(const WinState& st, WinS
     } else (side1 ? st.mark1 : st.mark0)[fe.rs] = i + 1u;
   }
   __syncthreads();
-  if (wn_now + total > kWinCap && wn_now > kWinCap / 2u) win_compact(w, tid);      // (holes out; a full window spills, see win_evict)
+  if (wn_now + total > st.wcap && wn_now > st.wcap / 2u) win_compact(w, tid, st.wcap);      // (holes out; a full window spills, see win_evict)
   const int cthr = w.cthr; const double tsal = w.tsal; const unsigned long long tseq = w.tseq;
   const uint32_t nwork = small ? s.nitems : total;
   const uint32_t lenR2 = small ? nwork : 0u;        // small case: every table item becomes exactly one new edge, so r2's list length is known here
@@ -1314,10 +1315,10 @@ __device__ __forceinline__ uint32_t batch_contract_wide(const WinState& st, WinS
     uint32_t sl = kWinCap;
     if (win_above(cthr, tsal, tseq, (int)cell, sal, seq)) {
       sl = atomicAdd(&w.n, 1u);
-      if (sl < kWinCap) win_put(w, sl, sal, seq, newE, rs, r2, make_uint2(offRs, lenRs), make_uint2(r2off, lenR2));
+      if (sl < st.wcap) win_put(w, sl, sal, seq, newE, rs, r2, make_uint2(offRs, lenRs), make_uint2(r2off, lenR2));
       else atomicMax(&w.spill_ord, f64_ord(sal));          // the window is full: tau will rise above this item
     }
-    if (sl >= kWinCap) {
+    if (sl >= st.wcap) {
       if (pend_e != kNone) st.er[pend_e].next = pend_old;
       pend_e = newE; pend_old = atomicExch(&st.whead[cell], newE);
       atomicAdd(&st.wcnt[cell], 1u);
@@ -1348,7 +1349,7 @@ __device__ __forceinline__ uint32_t batch_contract_wide(const WinState& st, WinS
       st.mark0[fb.rs] = 0; st.mark1[fb.rs] = 0;
     }
   }
-  if (!small) for (uint32_t i = tid; i < (w.n < kWinCap ? w.n : kWinCap); i += kGreedyThreads) if (w.v[i] == r2) w.hv[i].y = newcount;      // window items of r2: its list length
+  if (!small) for (uint32_t i = tid; i < (w.n < st.wcap ? w.n : st.wcap); i += kGreedyThreads) if (w.v[i] == r2) w.hv[i].y = newcount;      // window items of r2: its list length
   if (pend_e != kNone) st.er[pend_e].next = pend_old;
   if (tid == 0) { st.adj_off[r2] = r2off; st.adj_len[r2] = newcount; }
   __syncthreads();
@@ -1553,11 +1554,11 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
     if (pool_used + sum_tot > st.pool_cap) { status = ST_NEED_POOL; break; }
     // room in the window for everything the batch may insert (the popped items leave first: a flush must not see them)
     bool popped = false;
-    if (w.n + ne_off > kWinCap && w.n > kWinCap / 2u) {                    // holes out (a full window spills, see win_evict)
+    if (w.n + ne_off > st.wcap && w.n > st.wcap / 2u) {                    // holes out (a full window spills, see win_evict)
       if ((uint32_t)wave < V && lane == 0) w.seq[slot] = 0;
       popped = true;                                                     // (slot numbers are void after a compaction)
       __syncthreads();
-      win_compact(w, tid);
+      win_compact(w, tid, st.wcap);
     }
     const int cthr = w.cthr; const double tsal = w.tsal; const unsigned long long tseq = w.tseq;
     BPH(2);
@@ -1599,10 +1600,10 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
         uint32_t sl = kWinCap;
         if (win_above(cthr, tsal, tseq, (int)cell, sal, seq)) {
           sl = atomicAdd(&w.n, 1u);
-          if (sl < kWinCap) win_put(w, sl, sal, seq, newE, rs, r2, make_uint2(offRs, lenRs), make_uint2(r2off, newcount));
+          if (sl < st.wcap) win_put(w, sl, sal, seq, newE, rs, r2, make_uint2(offRs, lenRs), make_uint2(r2off, newcount));
           else atomicMax(&w.spill_ord, f64_ord(sal));      // the window is full: tau will rise above this item
         }
-        if (sl >= kWinCap) {
+        if (sl >= st.wcap) {
           if (pend_e != kNone) st.er[pend_e].next = pend_old;
           pend_e = newE; pend_old = atomicExch(&st.whead[cell], newE);
           atomicAdd(&st.wcnt[cell], 1u);
@@ -1983,6 +1984,11 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
     uint32_t B = 256;
     while (B < E0 / 4 && B < (1u << 22)) B <<= 1;
     ws.wB = B; ws.R0 = R;
+    ws.wcap = kWinCap; ws.wbudget = kWinBudget;
+    if (const char* cenv = getenv("GLIA_HMT_WINCAP")) {                  // tests: a tiny window makes spills, evictions and cell splits routine
+      const uint32_t c = (uint32_t)strtoul(cenv, nullptr, 10);
+      if (c >= 16 && c <= kWinCap) { ws.wcap = c; ws.wbudget = c / 2; }
+    }
     unsigned long long* mm; double* range;
     if ((rc = buf.get(&ws.whead, B, false, stream))) return rc;
     if ((rc = buf.get(&ws.wcnt, B, true, stream))) return rc;

@@ -1,0 +1,110 @@
+"""-m gpu: the three priority-queue implementations of the pb-mean merge loop give byte-identical merge orders.
+
+  tournament tree (greedy_pb_kernel, round 1)  ==  window queue, one contraction at a time (greedy_window_kernel)
+                                               ==  window queue, batched contractions (greedy_batch_kernel, the default)
+under conditions that force every rare path of the window queue: a tiny window (spills, evictions, cells split by the bounded
+heap), frequent re-baselines, massive exact ties, launches that end early.  The switches are environment variables read per call
+(glia_amd/csrc/greedy.hip): GLIA_HMT_PB_WINDOW=0 (tree), GLIA_HMT_PB_BATCH=0 (sequential window), GLIA_HMT_WINCAP, GLIA_HMT_REBASE."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    assert torch.cuda.is_available(), "GPU test run without a GPU"
+    from glia_amd import hmt
+    c = hmt.Context(0)
+    yield c
+    c.close()
+
+
+def _order(ctx, d_lab, d_pb, **env):
+    from glia_amd import hmt
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, only_contour=True)
+        o, s = rm.merge_order_pb(type=2)
+        rm.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+    return o, s
+
+
+def _volume(ctx, shape, S, variant, levels=None):
+    import torch
+    labels, pb = ctx.synth(shape, S, 4 * S, variant=variant)
+    if levels:
+        pb = torch.floor(pb * levels) / levels
+    return labels, pb.contiguous()
+
+
+CASES = [((96, 96, 96), 8, 0, None), ((128, 128, 128), 8, 1, None), ((96, 80, 64), 6, 0, 4), ((160, 160), 4, 0, None)]
+
+
+@pytest.mark.parametrize("shape,S,variant,levels", CASES)
+def test_three_queues_agree(ctx, shape, S, variant, levels):
+    d_lab, d_pb = _volume(ctx, shape, S, variant, levels)
+    tree = _order(ctx, d_lab, d_pb, GLIA_HMT_PB_WINDOW=0)
+    assert len(tree[0]) > 500
+    for env in (dict(), dict(GLIA_HMT_PB_BATCH=0)):
+        o, s = _order(ctx, d_lab, d_pb, **env)
+        assert o.shape == tree[0].shape and (o == tree[0]).all() and (s == tree[1]).all(), env
+
+
+@pytest.mark.parametrize("shape,S,variant,levels", CASES)
+@pytest.mark.parametrize("env", [dict(GLIA_HMT_WINCAP=32), dict(GLIA_HMT_WINCAP=16, GLIA_HMT_REBASE=300), dict(GLIA_HMT_REBASE=100),
+                                 dict(GLIA_HMT_WINCAP=64, GLIA_HMT_PB_BATCH=0)])
+def test_window_queue_rare_paths(ctx, shape, S, variant, levels, env):
+    """tiny windows: nearly every insertion spills and raises tau, every reload splits a cell; tiny re-baseline intervals: the
+    launch ends every few hundred created edges and the live items are re-sorted"""
+    d_lab, d_pb = _volume(ctx, shape, S, variant, levels)
+    tree = _order(ctx, d_lab, d_pb, GLIA_HMT_PB_WINDOW=0)
+    o, s = _order(ctx, d_lab, d_pb, **env)
+    assert o.shape == tree[0].shape and (o == tree[0]).all() and (s == tree[1]).all()
+
+
+def test_constant_pb_on_every_queue(ctx):
+    """every saliency equal: one saliency cell holds the whole queue, the order is the tie rule alone"""
+    import torch
+    from oracle import pyoracle as O
+    labels, _ = O.synth((40, 40, 40), 5, 10)
+    pb = np.full(labels.shape, 0.25, np.float32)
+    d_lab, d_pb = torch.from_numpy(labels.view(np.int32)).cuda(), torch.from_numpy(pb).cuda()
+    o_ref, s_ref = O.Rag(labels, only_contour=True).merge_order_pb(pb, type=2)
+    for env in (dict(), dict(GLIA_HMT_PB_BATCH=0), dict(GLIA_HMT_PB_WINDOW=0), dict(GLIA_HMT_WINCAP=32), dict(GLIA_HMT_WINCAP=48, GLIA_HMT_REBASE=200)):
+        o, s = _order(ctx, d_lab, d_pb, **env)
+        assert (o == o_ref).all() and (s == s_ref).all(), env
+
+
+def test_pre_merge_on_a_tiny_window(ctx):
+    """the condition kernel (greedy_window_kernel<true>) with a tiny reload budget vs the oracle"""
+    import torch
+    from glia_amd import hmt
+    from oracle import pyoracle as O
+    labels, pb = O.synth((48, 48, 48), 6, 12)
+    d_lab, d_pb = torch.from_numpy(labels.view(np.int32)).cuda(), torch.from_numpy(pb).cuda()
+    ro, rs = O.Rag(labels).pre_merge(pb, [150, 400], 0.3)
+    for env in (dict(), dict(GLIA_HMT_WINCAP=32), dict(GLIA_HMT_REBASE=200)):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update({k: str(v) for k, v in env.items()})
+        try:
+            rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, only_contour=False)
+            o, s = rm.pre_merge([150, 400], 0.3)
+            rm.close()
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+        assert o.shape == ro.shape and (o == ro).all() and (s == rs).all(), env
