@@ -1973,7 +1973,7 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
     GLIA_HIP_TRY(hipGetLastError());
     ws.nsort = n; ws.ne_base = n_edges;
     const char* renv = getenv("GLIA_HMT_REBASE");                          // created edges between baselines (tuning)
-    ws.rebase_after = renv ? strtoull(renv, nullptr, 10) : std::max<unsigned long long>(1ull << 20, 2ull * n);
+    ws.rebase_after = renv ? strtoull(renv, nullptr, 10) : std::max<unsigned long long>(800000ull, (unsigned long long)n / 2ull);
     const double inf = std::numeric_limits<double>::infinity();
     ctrl[5] = (unsigned long long)(long long)(ws.wB - 1);                  // threshold: everything is below it
     memcpy(&ctrl[6], &inf, 8); ctrl[7] = ~0ull; ctrl[8] = 0;
