@@ -467,6 +467,13 @@ int glia_hmt_rag_merge(glia_hmt_ctx* c, glia_hmt_rag* const* parts, int n_parts,
   return GLIA_HMT_OK;
 }
 
+int glia_hmt_watershed(glia_hmt_ctx* c, int dim, const int64_t dims[3], const float* d_image, double level, uint32_t* d_labels, uint32_t* n_labels,
+                       int* sweeps) {
+  if (!c || !dims || !d_image || !d_labels || (dim != 2 && dim != 3) || !(level >= 0.0)) { set_error("watershed: invalid argument"); return GLIA_HMT_ERR_ARG; }
+  GLIA_HIP_TRY(hipSetDevice(c->device));
+  return watershed_labels(dim, dims, d_image, level, d_labels, n_labels, sweeps, c->stream);
+}
+
 int glia_hmt_rag_num_channels(const glia_hmt_rag* r) { return r ? r->arr.K : -1; }
 
 int glia_hmt_rag_copy_channel(const glia_hmt_rag* r, int channel, uint32_t* d_region_rec, uint32_t* d_pair_rec) {

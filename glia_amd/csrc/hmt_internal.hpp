@@ -130,6 +130,8 @@ int paint_pair_values(const VolumeRef& vol, const uint32_t* d_pa, const uint32_t
 int boundary_confidence_values(int n_trees, const int64_t* n_nodes, const uint32_t* const* node_label, const int32_t* const* parent,
                                const int32_t* const* child0, const double* const* potential, const uint32_t* pa, const uint32_t* pb,
                                int64_t P, std::vector<float>* out);
+int watershed_labels(int dim, const int64_t dims[3], const float* d_img, double level, uint32_t* d_out, uint32_t* n_labels, int* sweeps,
+                     hipStream_t stream);
 int launch_libm_eval(int function, int variant, const double* d_in, double* d_out, int64_t n, hipStream_t stream);
 int merge_rag_arrays(const RagArrays* parts, int n_parts, RagArrays* out, hipStream_t stream);
 int rag_cut_flags(const RagArrays& rag, const uint32_t* d_lab, int64_t nx, int64_t ny, int64_t nzl, int64_t zb, int64_t ze,

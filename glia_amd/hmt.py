@@ -121,6 +121,18 @@ class Context:
         self.sync()
         return out
 
+    def watershed(self, image, level):
+        """glia::watershed (util/image_alg.hxx:9-21) of a CUDA float32 tensor -> (labels int32 tensor holding uint32 1..n, n, sweeps)."""
+        import torch
+        assert image.is_cuda and image.dtype == torch.float32 and image.is_contiguous()
+        dim, d = _dims(tuple(image.shape))
+        out = torch.empty(image.shape, dtype=torch.int32, device=image.device)
+        n, sw = C.c_uint32(0), C.c_int(0)
+        _fence(image)
+        _check(lib().glia_hmt_watershed(self.h, C.c_int(dim), d, C.c_void_p(image.data_ptr()), C.c_double(level), C.c_void_p(out.data_ptr()),
+                                        C.byref(n), C.byref(sw)))
+        return out, n.value, sw.value
+
     def set_table_hint(self, regions, pairs):
         _check(lib().glia_hmt_ctx_set_table_hint(self.h, C.c_int64(regions), C.c_int64(pairs)))
 

@@ -291,6 +291,16 @@ int glia_hmt_score_initial_edges_shard(glia_hmt_ctx* ctx, glia_hmt_rag* rag, con
 int glia_hmt_last_merge_timing(const glia_hmt_rag* rag, double* ms_table, double* ms_init, double* ms_loop,
                                int64_t* n_edges_scored);
 
+/* ---- the step before the path: watershed over-segmentation (gadget/main_watershed.cxx, util/image_alg.hxx:9-21) ----------
+ * glia::watershed = itk::MorphologicalWatershedImageFilter(level, MarkWatershedLineOff, face connectivity): h-minima transform
+ * of the image (minima shallower than `level` vanish), regional minima as markers numbered in raster order, flooding without
+ * watershed lines.  ITK decides flooding ties by the arrival order of a sequential hierarchical queue; here every tie has an
+ * order-free rule (lowest flood level, then shortest way on the plateau, then smaller label), so labels are reproducible but
+ * NOT pinned against ITK (absent from this image).  d_labels: uint32 volume, labels 1..*n_labels; *sweeps (optional): whole-volume
+ * passes it took. */
+int glia_hmt_watershed(glia_hmt_ctx* ctx, int dim, const int64_t dims[3], const float* d_image, double level, uint32_t* d_labels,
+                       uint32_t* n_labels, int* sweeps);
+
 /* ---- synthetic inputs for tests / bench, generated on the device -------------- */
 int glia_hmt_synth(glia_hmt_ctx* ctx, int dim, const int64_t dims[3], int S, int G, uint64_t seed,
                    int variant, uint32_t* d_labels, float* d_pb);

@@ -13,6 +13,8 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <deque>
+#include <limits>
 #include <queue>
 #include <unordered_map>
 #include <unordered_set>
@@ -1455,6 +1457,90 @@ int64_t orc_label_transform(const orc_label* node_label, const int32_t* child0, 
   int64_t m = 0;
   for (auto const& lp : lmap) { src[m] = lp.first; dst[m] = lp.second; ++m; }
   return m;
+}
+
+// ---- morphological watershed (util/image_alg.hxx:9-21 = itk::MorphologicalWatershedImageFilter, level, no watershed line,
+// face connectivity).  PARITY WITH ITK IS UNPINNED (ITK is not in this image, the reference holds no fixture): this restates the
+// documented pipeline -- h-minima transform, regional minima as markers numbered in raster order, flooding -- with the same
+// order-free tie rules as the device code (lowest flood level, then fewest steps since the level last rose, then the smaller
+// label), by sequential algorithms of its own: a worklist reconstruction, breadth-first plateaus, Dijkstra flooding.
+int64_t orc_watershed(int dim, const int64_t* dims, const float* img, double level, orc_label* out) {
+  const int64_t nx = dims[0], ny = dims[1], nz = dim == 3 ? dims[2] : 1, n = nx * ny * nz;
+  auto nbrs = [&](int64_t p, int64_t* q) {
+    int k = 0;
+    const int64_t x = p % nx, y = (p / nx) % ny, z = p / (nx * ny);
+    if (x > 0) q[k++] = p - 1;
+    if (x + 1 < nx) q[k++] = p + 1;
+    if (y > 0) q[k++] = p - nx;
+    if (y + 1 < ny) q[k++] = p + nx;
+    if (dim == 3) { if (z > 0) q[k++] = p - nx * ny; if (z + 1 < nz) q[k++] = p + nx * ny; }
+    return k;
+  };
+  // 1. reconstruction by erosion of (float)(f + level) above f: lower a voxel to max(f, a neighbour's value) until stable
+  std::vector<float> g(n);
+  for (int64_t p = 0; p < n; ++p) g[p] = (float)((double)img[p] + level);
+  {
+    std::deque<int64_t> work;
+    std::vector<char> queued(n, 1);
+    for (int64_t p = 0; p < n; ++p) work.push_back(p);
+    int64_t q[6];
+    while (!work.empty()) {
+      const int64_t p = work.front(); work.pop_front(); queued[p] = 0;
+      const int k = nbrs(p, q);
+      for (int i = 0; i < k; ++i) {
+        const float cand = std::max(img[q[i]], g[p]);
+        if (cand < g[q[i]]) { g[q[i]] = cand; if (!queued[q[i]]) { queued[q[i]] = 1; work.push_back(q[i]); } }
+      }
+    }
+  }
+  // 2. plateaus in raster order; a plateau without a lower neighbour is a marker
+  std::vector<orc_label> lab(n, 0);
+  std::vector<char> seen(n, 0);
+  orc_label nlab = 0;
+  {
+    std::vector<int64_t> plateau;
+    int64_t q[6];
+    for (int64_t s0 = 0; s0 < n; ++s0) {
+      if (seen[s0]) continue;
+      plateau.clear(); plateau.push_back(s0); seen[s0] = 1;
+      bool lower = false;
+      for (size_t h = 0; h < plateau.size(); ++h) {
+        const int64_t p = plateau[h];
+        const int k = nbrs(p, q);
+        for (int i = 0; i < k; ++i) {
+          if (g[q[i]] < g[p]) lower = true;
+          else if (g[q[i]] == g[p] && !seen[q[i]]) { seen[q[i]] = 1; plateau.push_back(q[i]); }
+        }
+      }
+      if (!lower) { ++nlab; for (int64_t p : plateau) lab[p] = nlab; }
+    }
+  }
+  // 3. flooding: Dijkstra on the cost (flood level, steps since it last rose, label)
+  struct St { float L; uint32_t d; orc_label l; int64_t p; };
+  auto worse = [](St const& a, St const& b) { return a.L > b.L || (a.L == b.L && (a.d > b.d || (a.d == b.d && a.l > b.l))); };
+  std::priority_queue<St, std::vector<St>, decltype(worse)> pq(worse);
+  std::vector<float> L(n, std::numeric_limits<float>::infinity());
+  std::vector<uint32_t> D(n, 0xFFFFFFFFu);
+  std::vector<char> marker(n, 0), done(n, 0);
+  for (int64_t p = 0; p < n; ++p) if (lab[p]) { marker[p] = 1; L[p] = g[p]; D[p] = 0; pq.push(St{g[p], 0u, lab[p], p}); }
+  int64_t q[6];
+  while (!pq.empty()) {
+    const St s1 = pq.top(); pq.pop();
+    if (done[s1.p] || s1.L != L[s1.p] || s1.d != D[s1.p] || s1.l != lab[s1.p]) continue;
+    done[s1.p] = 1;
+    const int k = nbrs(s1.p, q);
+    for (int i = 0; i < k; ++i) {
+      const int64_t t = q[i];
+      if (marker[t] || done[t]) continue;
+      const float Lc = std::max(s1.L, g[t]);
+      const uint32_t dc = Lc == s1.L ? s1.d + 1u : 0u;
+      if (lab[t] == 0 || Lc < L[t] || (Lc == L[t] && (dc < D[t] || (dc == D[t] && s1.l < lab[t])))) {
+        L[t] = Lc; D[t] = dc; lab[t] = s1.l; pq.push(St{Lc, dc, s1.l, t});
+      }
+    }
+  }
+  for (int64_t p = 0; p < n; ++p) out[p] = lab[p];
+  return (int64_t)nlab;
 }
 
 // The restatements of util/stats.hxx used by the features, exported so that tests can pin them against the reference's own

@@ -163,6 +163,8 @@ void orc_transform_image(orc_label* lab, int64_t n, const orc_label* src, const 
                          const orc_label* mask, int fill_missing);
 int64_t orc_relabel_image(orc_label* lab, int64_t n, int64_t min_size);
 // host libm as the reference calls it: function 0 = std::log2, 1 = std::log, 2 = std::pow(x, 1.5)
+// morphological watershed (util/image_alg.hxx:9-21; ITK absent: parity unpinned, tie rules as in glia_amd/csrc/watershed.hip)
+int64_t orc_watershed(int dim, const int64_t* dims, const float* img, double level, orc_label* out);
 // util/stats.hxx restatements (entropy :145-152, distL1 :155-163, distX2 :177-185, amedian :83-91, rescale :264-277)
 void orc_stats_case(int n, const double* a, const double* b, double* out6);
 void orc_rescale(int n, double* feat, const double* mn, const double* mx, double out_min, double out_max);

@@ -316,6 +316,16 @@ def relabel_image(labels, min_size=0):
     return out, int(n)
 
 
+def watershed(img, level):
+    """morphological watershed labels (1..n) of a float32 image, see orc_watershed"""
+    img = np.ascontiguousarray(img, dtype=np.float32)
+    dim, d = _dims(img.shape)
+    out = np.empty(img.shape, np.uint32)
+    lib().orc_watershed.restype = C.c_int64
+    n = lib().orc_watershed(C.c_int(dim), _p(d), _p(img), C.c_double(level), _p(out))
+    return out, int(n)
+
+
 def stats_case(a, b):
     """entropy(a), entropy(b), distL1, distX2, amedian(a), amedian(b) of the util/stats.hxx restatements"""
     a = np.ascontiguousarray(a, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64)
