@@ -64,8 +64,8 @@ static LibmSel probe_host_libm() {
   for (int i = 0; i < 3000; ++i) xs.push_back(1.0 + ((double)(int64_t)(next() % 2000001) - 1000000.0) * 1e-7);
   for (int i = 0; i < 3000; ++i) xs.push_back(std::ldexp(1.0 + (double)(next() >> 12) * 0x1p-52, (int)(next() % 120) - 60));
   for (int e = -1074; e < 1024; e += 37) xs.push_back(std::ldexp(1.0, e));
-  LibmSel sel = {kLibmDevice, kLibmDevice};
-  bool l2 = true, ls = true, lf = true;
+  LibmSel sel = {kLibmDevice, kLibmDevice, kLibmDevice};
+  bool l2 = true, ls = true, lf = true, ps = true, pf = true;
   for (double x : xs) {
     volatile double vx = x;
     const double h2 = std::log2(vx), h1 = std::log(vx);
@@ -73,11 +73,20 @@ static LibmSel probe_host_libm() {
     ls = ls && glibc::as_u64(h1) == glibc::as_u64(glibc::log_sse2(x));
     lf = lf && glibc::as_u64(h1) == glibc::as_u64(glibc::log_fma(x));
   }
+  // std::pow(perim, 1.5) of the compactness feature (type/feat.hxx:78-79): integer perimeters, small and large
+  for (int i = 0; i < 12000; ++i) {
+    const double x = i < 4000 ? (double)(i + 1) : (double)(1 + next() % (i < 8000 ? (1ull << 24) : (1ull << 40)));
+    volatile double vx = x, vy = 1.5;
+    const uint64_t h = glibc::as_u64(std::pow(vx, vy));
+    ps = ps && h == glibc::as_u64(glibc::pow_sse2(x, 1.5));
+    pf = pf && h == glibc::as_u64(glibc::pow_fma(x, 1.5));
+  }
   if (l2) sel.log2_variant = kLibmSse2;
   if (lf) sel.log_variant = kLibmFma; else if (ls) sel.log_variant = kLibmSse2;
+  if (pf) sel.pow_variant = kLibmFma; else if (ps) sel.pow_variant = kLibmSse2;
   if (const char* e = getenv("GLIA_HMT_LIBM")) {
     const int v = !strcmp(e, "sse2") ? kLibmSse2 : !strcmp(e, "fma") ? kLibmFma : kLibmDevice;
-    sel.log_variant = v; sel.log2_variant = v == kLibmFma ? kLibmSse2 : v;
+    sel.log_variant = v; sel.log2_variant = v == kLibmFma ? kLibmSse2 : v; sel.pow_variant = v;
   }
   return sel;
 }
@@ -99,7 +108,7 @@ struct glia_hmt_ctx {
   uint32_t hint_rcap = 0, hint_pcap = 0;
   double transform_ms = 0;
   int tz = kTZ;                  // tile depth of the accumulation pass; halved when the LDS tables of a pass overflowed a lot
-  LibmSel libm = {kLibmDevice, kLibmDevice};   // restatement of the host's log2 / log the kernels use (glibc_math.hpp)
+  LibmSel libm = {kLibmDevice, kLibmDevice, kLibmDevice};   // restatement of the host's log2 / log the kernels use (glibc_math.hpp)
 };
 
 struct glia_hmt_rag {
@@ -188,6 +197,18 @@ int glia_hmt_ctx_libm(const glia_hmt_ctx* c, int* log2_variant, int* log_variant
   return GLIA_HMT_OK;
 }
 
+int glia_hmt_ctx_libm_pow(const glia_hmt_ctx* c, int* pow_variant) {
+  if (!c || !pow_variant) return GLIA_HMT_ERR_ARG;
+  *pow_variant = c->libm.pow_variant;
+  return GLIA_HMT_OK;
+}
+
+int glia_hmt_host_libm_probe_pow(int* pow_variant) {
+  if (!pow_variant) return GLIA_HMT_ERR_ARG;
+  *pow_variant = probe_host_libm().pow_variant;
+  return GLIA_HMT_OK;
+}
+
 int glia_hmt_host_libm_probe(int* log2_variant, int* log_variant) {
   const LibmSel sel = probe_host_libm();
   if (log2_variant) *log2_variant = sel.log2_variant;
@@ -196,12 +217,15 @@ int glia_hmt_host_libm_probe(int* log2_variant, int* log_variant) {
 }
 
 int glia_hmt_host_libm_eval(int function, int variant, const double* h_in, double* h_out, int64_t n) {
-  if (!h_in || !h_out || n < 0 || function < 0 || function > 1 || (variant != kLibmSse2 && variant != kLibmFma)) {
+  if (!h_in || !h_out || n < 0 || function < 0 || function > 2 || (variant != kLibmSse2 && variant != kLibmFma)) {
     set_error("host_libm_eval: invalid argument");
     return GLIA_HMT_ERR_ARG;
   }
-  for (int64_t i = 0; i < n; ++i)
-    h_out[i] = function == 0 ? glibc::log2_sse2(h_in[i]) : variant == kLibmFma ? glibc::log_fma(h_in[i]) : glibc::log_sse2(h_in[i]);
+  for (int64_t i = 0; i < n; ++i) {
+    const double x = h_in[i];
+    if (function == 2) h_out[i] = !glibc::pow_in_domain(x, 1.5) ? std::pow(x, 1.5) : variant == kLibmFma ? glibc::pow_fma(x, 1.5) : glibc::pow_sse2(x, 1.5);
+    else h_out[i] = function == 0 ? glibc::log2_sse2(x) : variant == kLibmFma ? glibc::log_fma(x) : glibc::log_sse2(x);
+  }
   return GLIA_HMT_OK;
 }
 
@@ -784,7 +808,7 @@ static bool make_bc_cfg(const glia_hmt_rag* rag, BcCfg* c) {
   c->use_log = g.use_log_shape; c->use_simple = g.use_simple_features; c->use_hist = g.use_histogram_features;
   c->norm_area = g.normalizing_area; c->norm_len = g.normalizing_length;
   c->rfdim = bc_rf_dim(*c); c->bfdim = bc_bf_dim(*c); c->fdim = bc_feat_dim(*c);
-  c->libm_log2 = rag->ctx->libm.log2_variant; c->libm_log = rag->ctx->libm.log_variant;
+  c->libm_log2 = rag->ctx->libm.log2_variant; c->libm_log = rag->ctx->libm.log_variant; c->libm_pow = rag->ctx->libm.pow_variant;
   return true;
 }
 

@@ -76,7 +76,7 @@ struct BcCfg {
   int use_hist;                         // GLIA_USE_HISTOGRAM_AS_FEATS: every image block carries its histogram ahead of the entropy
   double norm_area, norm_len;
   int rfdim, bfdim, fdim;
-  int libm_log2, libm_log;              // which restatement of the host libm the logarithms use (glibc_math.hpp)
+  int libm_log2, libm_log, libm_pow;    // which restatement of the host libm log2 / log / pow use (glibc_math.hpp)
 };
 
 // histogram columns of the image lists (0 unless use_hist): ImageLabelFeats::dim = histBin + 1 (type/feat.hxx:608-612)
@@ -107,12 +107,16 @@ __device__ __forceinline__ double host_log(double x, int variant) {
 __device__ inline double slog(double x, double d, int variant) { return x > 0.0 ? host_log(x, variant) : d; }
 __device__ inline double ssqrt(double x, double d) { return x >= 0.0 ? sqrt(x) : d; }
 
-// std::pow(perim, D/(D-1)) of type/feat.hxx:78-79 for an integer-valued perim: exponent 2 (2D) is an exact
-// square; exponent 1.5 (3D) is perim*sqrt(perim) evaluated in double-double and rounded once, i.e. the correctly
-// rounded value, which is what glibc's pow returns except in vanishingly rare near-tie cases.
-__device__ inline double pow_perim(double x, int D) {
+// std::pow(perim, D/(D-1)) of type/feat.hxx:78-79 for an integer-valued perim: exponent 2 (2D) is an exact square (glibc's
+// pow returns it: the exact value is representable and pow's error is far below half an ulp of it); exponent 1.5 (3D) is the
+// restatement of the host's pow (glibc_math.hpp) the context probed.  Variant 0 (no restatement matched the host: UNPINNED)
+// is perim*sqrt(perim) evaluated in double-double and rounded once, i.e. the correctly rounded value, which glibc's pow
+// misses by one ulp on ~0.1 % of integer arguments.
+__device__ inline double pow_perim(double x, int D, int variant) {
   if (D == 2) return x * x;
   if (!(x > 0.0)) return 0.0;
+  if (variant == kLibmFma) return glibc::pow_fma(x, 1.5);
+  if (variant == kLibmSse2) return glibc::pow_sse2(x, 1.5);
   const double s = sqrt(x);                       // correctly rounded
   const double r = __builtin_fma(-s, s, x);       // x - s*s, exact
   const double sl = r / (2.0 * s);                // sqrt(x) = s + sl (+ O(ulp^2))
@@ -205,7 +209,7 @@ __device__ __forceinline__ void region_feats_multi(const BcCfg& c, const ShapeIn
   const int D = c.D, T = c.T;
   double area = (double)r.n;
   double perim = (double)((unsigned long long)r.bn + (unsigned long long)r.border);
-  const double compactness = sdiv(pow_perim(perim, D), area, 0.0);
+  const double compactness = sdiv(pow_perim(perim, D, c.libm_pow), area, 0.0);
   area = sdiv(area, c.norm_area, 0.0);
   perim = sdiv(perim, c.norm_len, 0.0);
   double bboxArea = 1.0;

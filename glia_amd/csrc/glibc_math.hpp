@@ -189,10 +189,110 @@ __host__ __device__ inline double log_fma(double x) {
 #undef LA_
 #undef LB_
 
+// ---- pow(x, y) for x > 0 normal, 2^-65 < |y log x| < 1024 (e_pow.c; the callers: std::pow(perim, 1.5), type/feat.hxx:78-79) -----
+// log_inline gives log(x) = hi + lo in double-double from the {invc, logc, logctail} table, pow multiplies by y, exp_inline
+// evaluates exp(ehi + elo) = 2^(k/128) * (1 + tail + polynomial(r)).  The IFUNC __pow_finite picks __pow_fma
+// (libm.so.6 + 0x768b0: the __FP_FAST_FMA source paths plus the contractions gcc made, transcribed from the code) or
+// __pow_sse2 (the non-FMA source paths: Dekker splits, no contraction possible).
+constexpr uint64_t kPowOff = 0x3fe6955500000000ull;
+#define PA_(i) as_f64(kPowLogHead[2 + (i)])
+#define EC_(i) as_f64(kExpHead[4 + (i)])     /* C2..C5 */
+__host__ __device__ inline double pow_exp_fma_tail(double ehi, double elo, bool fma) {
+  const double invln2n = as_f64(kExpHead[0]), shift = as_f64(kExpHead[1]), nhi = as_f64(kExpHead[2]), nlo = as_f64(kExpHead[3]);
+  double kd = fma ? __builtin_fma(ehi, invln2n, shift) : invln2n * ehi + shift;
+  const uint64_t ki = as_u64(kd);
+  kd = kd - shift;
+  double r = fma ? __builtin_fma(kd, nlo, __builtin_fma(kd, nhi, ehi)) : (ehi + kd * nhi) + kd * nlo;
+  r = r + elo;
+  const uint64_t idx = 2 * (ki & 127);
+  const double tail = as_f64(kExpTab[idx]);
+  const double scale = as_f64(kExpTab[idx + 1] + (ki << 45));
+  const double r2 = r * r;
+  if (fma) {
+    const double a = __builtin_fma(r, EC_(1), EC_(0));          // C2 + r C3
+    const double b = __builtin_fma(r, EC_(3), EC_(2));          // C4 + r C5
+    const double t = __builtin_fma(a, r2, tail + r);
+    const double tmp = __builtin_fma(b, r2 * r2, t);
+    return __builtin_fma(tmp, scale, scale);
+  }
+  const double tmp = ((tail + r) + r2 * (EC_(0) + r * EC_(1))) + (r2 * r2) * (EC_(2) + r * EC_(3));
+  return scale + scale * tmp;
+}
+// domain check shared by both variants: everything else (zero, negative, subnormal, inf/nan, over/underflow) is not a perimeter
+__host__ __device__ inline bool pow_in_domain(double x, double y) {
+  const uint64_t ix = as_u64(x), iy = as_u64(y);
+  const uint32_t tx = (uint32_t)(ix >> 52), ty = (uint32_t)(iy >> 52) & 0x7ff;
+  return tx - 1u < 0x7feu && ty - 0x3beu < 0x43eu - 0x3beu;
+}
+__host__ __device__ inline double pow_fma(double x, double y) {
+  const uint64_t ix = as_u64(x);
+  const uint64_t tmp = ix - kPowOff;
+  const int i = (int)((tmp >> (52 - 7)) & 127);
+  const double kd = (double)(int)((int64_t)tmp >> 52);
+  const double z = as_f64(ix - (tmp & (0xfffull << 52)));
+  const double invc = as_f64(kPowLogTab[4 * i]), logc = as_f64(kPowLogTab[4 * i + 2]), logctail = as_f64(kPowLogTab[4 * i + 3]);
+  const double ln2hi = as_f64(kPowLogHead[0]), ln2lo = as_f64(kPowLogHead[1]);
+  const double r = __builtin_fma(z, invc, -1.0);
+  const double t1 = __builtin_fma(kd, ln2hi, logc);
+  const double t2 = t1 + r;
+  const double lo1 = __builtin_fma(kd, ln2lo, logctail);
+  const double lo2 = (t1 - t2) + r;
+  const double ar = PA_(0) * r, ar2 = r * ar, ar3 = r * ar2;
+  const double hi = t2 + ar2;
+  const double lo3 = __builtin_fma(ar, r, -ar2);
+  const double lo4 = (t2 - hi) + ar2;
+  const double q = __builtin_fma(ar2, __builtin_fma(__builtin_fma(r, PA_(6), PA_(5)), ar2, __builtin_fma(r, PA_(4), PA_(3))),
+                                 __builtin_fma(r, PA_(2), PA_(1)));
+  const double lo = __builtin_fma(ar3, q, ((lo1 + lo2) + lo3) + lo4);
+  const double lh = hi + lo;
+  const double ll = (hi - lh) + lo;
+  const double ehi = y * lh;
+  const double elo = __builtin_fma(y, ll, __builtin_fma(y, lh, -ehi));
+  if (((as_u64(ehi) >> 52) & 0x7ff) - 0x3c9u >= 0x3fu) return ehi == 0.0 || ((as_u64(ehi) >> 52) & 0x7ff) < 0x3c9u ? 1.0 : __builtin_nan("");
+  return pow_exp_fma_tail(ehi, elo, true);
+}
+__host__ __device__ inline double pow_sse2(double x, double y) {
+  const uint64_t ix = as_u64(x), iy = as_u64(y);
+  const uint64_t tmp = ix - kPowOff;
+  const int i = (int)((tmp >> (52 - 7)) & 127);
+  const double kd = (double)(int)((int64_t)tmp >> 52);
+  const uint64_t iz = ix - (tmp & (0xfffull << 52));
+  const double z = as_f64(iz);
+  const double invc = as_f64(kPowLogTab[4 * i]), logc = as_f64(kPowLogTab[4 * i + 2]), logctail = as_f64(kPowLogTab[4 * i + 3]);
+  const double ln2hi = as_f64(kPowLogHead[0]), ln2lo = as_f64(kPowLogHead[1]);
+  const double zhi = as_f64((iz + (1ull << 31)) & (~0ull << 32));
+  const double zlo = z - zhi;
+  const double rhi = zhi * invc - 1.0;
+  const double rlo = zlo * invc;
+  const double r = rhi + rlo;
+  const double t1 = kd * ln2hi + logc;
+  const double t2 = t1 + r;
+  const double lo1 = kd * ln2lo + logctail;
+  const double lo2 = (t1 - t2) + r;
+  const double ar = PA_(0) * r, ar2 = r * ar, ar3 = r * ar2;
+  const double arhi = PA_(0) * rhi, arhi2 = rhi * arhi;
+  const double hi = t2 + arhi2;
+  const double lo3 = rlo * (ar + arhi);
+  const double lo4 = (t2 - hi) + arhi2;
+  const double p = ar3 * ((PA_(1) + r * PA_(2)) + ar2 * ((PA_(3) + r * PA_(4)) + ar2 * (PA_(5) + r * PA_(6))));
+  const double lo = (((lo1 + lo2) + lo3) + lo4) + p;
+  const double lh = hi + lo;
+  const double ll = (hi - lh) + lo;
+  const double yhi = as_f64(iy & (~0ull << 27)), ylo = y - yhi;
+  const double lhi = as_f64(as_u64(lh) & (~0ull << 27));
+  const double llo = (lh - lhi) + ll;
+  const double ehi = yhi * lhi;
+  const double elo = ylo * lhi + y * llo;
+  if (((as_u64(ehi) >> 52) & 0x7ff) - 0x3c9u >= 0x3fu) return ehi == 0.0 || ((as_u64(ehi) >> 52) & 0x7ff) < 0x3c9u ? 1.0 : __builtin_nan("");
+  return pow_exp_fma_tail(ehi, elo, false);
+}
+#undef PA_
+#undef EC_
+
 }  // namespace glibc
 
 // Variant selection (glia_hmt_ctx_create -> kernels): which restatement reproduces the host's libm.
 enum : int { kLibmDevice = 0 /* unpinned: device libm */, kLibmSse2 = 1, kLibmFma = 2 };
-struct LibmSel { int log2_variant, log_variant; };
+struct LibmSel { int log2_variant, log_variant, pow_variant; };
 
 }  // namespace glia

@@ -6,7 +6,7 @@ namespace glia {
 
 __global__ void libm_eval_kernel(int function, int variant, const double* __restrict__ in, double* __restrict__ out, long long n) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = function == 0 ? feat::host_log2(in[i], variant) : function == 1 ? feat::host_log(in[i], variant) : feat::pow_perim(in[i], 3);
+  if (i < n) out[i] = function == 0 ? feat::host_log2(in[i], variant) : function == 1 ? feat::host_log(in[i], variant) : feat::pow_perim(in[i], 3, variant);
 }
 
 int launch_libm_eval(int function, int variant, const double* d_in, double* d_out, int64_t n, hipStream_t stream) {

@@ -112,6 +112,12 @@ class Context:
         _check(lib().glia_hmt_ctx_libm(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def libm_pow(self):
+        """variant of std::pow(perim, 1.5) the kernels use (same codes as libm())"""
+        a = C.c_int(0)
+        _check(lib().glia_hmt_ctx_libm_pow(self.h, C.byref(a)))
+        return a.value
+
     def libm_eval(self, function, variant, x):
         """Device restatement of the host libm over a CUDA f64 tensor: function 0 = log2, 1 = log, 2 = pow(x, 1.5)."""
         import torch

@@ -48,14 +48,17 @@ int glia_hmt_ctx_create(int device, void* hip_stream, glia_hmt_ctx** out);
 void glia_hmt_ctx_destroy(glia_hmt_ctx* ctx);
 int glia_hmt_ctx_sync(glia_hmt_ctx* ctx);
 /* Logarithms of the feature vector.  The reference computes histogram entropies with std::log2 (util/stats.hxx:145-152)
- * and the --logs features with std::log (glia_base.hxx:80-81), i.e. with the host's glibc, which is not correctly
+ * and the --logs features with std::log (glia_base.hxx:80-81), the compactness with std::pow (type/feat.hxx:78-79), i.e.
+ * with the host's glibc, which is not correctly
  * rounded; the kernels carry restatements of glibc's algorithms (glia_amd/csrc/glibc_math.hpp) and the context selects,
  * by probing the host's libm when it is created, the one that reproduces it bit for bit: 1 = non-FMA build ("sse2"),
  * 2 = FMA build, 0 = no restatement matches this host (device libm, within 1 ulp: entropy features then UNPINNED).
  * glia_hmt_host_libm_probe runs the same probe without a GPU; glia_hmt_libm_eval evaluates function (0 = log2, 1 = log,
  * 2 = the pow(perim, 1.5) of type/feat.hxx:78-79) in the given variant over a device array (parity tests). */
 int glia_hmt_ctx_libm(const glia_hmt_ctx* ctx, int* log2_variant, int* log_variant);
+int glia_hmt_ctx_libm_pow(const glia_hmt_ctx* ctx, int* pow_variant);        /* same, for std::pow(perim, 1.5) (type/feat.hxx:78-79) */
 int glia_hmt_host_libm_probe(int* log2_variant, int* log_variant);
+int glia_hmt_host_libm_probe_pow(int* pow_variant);
 int glia_hmt_host_libm_eval(int function, int variant, const double* h_in, double* h_out, int64_t n);  /* host code of the same restatement, no GPU */
 int glia_hmt_libm_eval(glia_hmt_ctx* ctx, int function, int variant, const double* d_in, double* d_out, int64_t n);
 /* Optional sizing hint for the accumulation hash tables (0 = derive from the volume size; they grow and

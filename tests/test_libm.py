@@ -1,5 +1,6 @@
-"""The logarithms of the feature vector must carry the HOST libm's bits (the reference calls std::log2 in
-stats::entropy, util/stats.hxx:145-152, and std::log in slog, glia_base.hxx:80-81): the library restates glibc's
+"""The logarithms and the power of the feature vector must carry the HOST libm's bits (the reference calls std::log2 in
+stats::entropy, util/stats.hxx:145-152, std::log in slog, glia_base.hxx:80-81, and std::pow(perim, 1.5) in
+type/feat.hxx:78-79): the library restates glibc's
 table-driven algorithms (glia_amd/csrc/glibc_math.hpp) and selects the variant that reproduces this host's libm.
 CPU part: the host code of the restatement against the libm, bit for bit.  GPU part: the device code against both."""
 import ctypes as C
@@ -38,6 +39,29 @@ def test_host_libm_is_pinned_by_a_restatement():
     a, b = C.c_int(-1), C.c_int(-1)
     assert lib.glia_hmt_host_libm_probe(C.byref(a), C.byref(b)) == 0
     assert a.value in (1, 2) and b.value in (1, 2), "no restatement reproduces this host's libm: entropy features unpinned"
+    p = C.c_int(-1)
+    assert lib.glia_hmt_host_libm_probe_pow(C.byref(p)) == 0
+    assert p.value in (1, 2), "no restatement reproduces this host's pow: compactness unpinned"
+
+
+def _perimeters(seed=3, dense=1 << 23):
+    rng = np.random.default_rng(seed)
+    return np.concatenate([np.arange(1, dense + 1, dtype=np.float64), rng.integers(1 << 23, 1 << 40, size=1 << 20).astype(np.float64)])
+
+
+def test_pow_restatement_equals_host_pow_bit_for_bit():
+    """pow(perim, 1.5) over every integer up to 2^23 (a 1024^3 volume's largest perimeters are ~1e6) and a sample up to 2^40"""
+    from oracle import pyoracle as O
+    lib = C.CDLL(SO)
+    p = C.c_int(-1)
+    lib.glia_hmt_host_libm_probe_pow(C.byref(p))
+    x = _perimeters()
+    got = _host_eval(2, p.value, x)
+    ref = O.libm_eval(2, x)
+    bad = got.view(np.uint64) != ref.view(np.uint64)
+    assert not bad.any(), "pow variant %d: %d of %d differ, first x=%r" % (p.value, bad.sum(), x.size, x[bad][:3])
+    other = _host_eval(2, 3 - p.value, x)      # the other build of pow really is a different function
+    assert (other.view(np.uint64) != ref.view(np.uint64)).any()
 
 
 def test_restatement_equals_host_libm_bit_for_bit():
@@ -73,20 +97,23 @@ def test_device_logarithms_equal_host_libm_bit_for_bit():
 
 
 @pytest.mark.gpu
-def test_device_pow_of_perimeters_vs_host_pow():
-    """compactness = pow(perim, 1.5) (type/feat.hxx:78-79): perim is a voxel count, so the domain is the integers.
-    The device returns the CORRECTLY ROUNDED perim*sqrt(perim) (double-double); glibc's pow is within 0.52 ulp but not
-    correctly rounded, so about 0.09 % of the integers differ by exactly one ulp (measured on the host: 72 956 of 2^26 + 2^24).
-    Tolerance of this feature: 1 ulp (north_star: per-edge float features within 1e-5)."""
+def test_device_pow_of_perimeters_equals_host_pow_bit_for_bit():
+    """compactness = pow(perim, 1.5) (type/feat.hxx:78-79): perim is a voxel count, so the domain is the integers.  glibc's
+    pow is within 0.52 ulp but not correctly rounded (about 0.09 % of the integers are one ulp off the rounded true value), so
+    the device evaluates the restatement of the host's pow the context probed -- bit for bit.  Variant 0 (the correctly rounded
+    double-double value a context falls back to on an unknown libm) stays within one ulp."""
     import torch
     from glia_amd import hmt
     from oracle import pyoracle as O
     ctx = hmt.Context(0)
-    rng = np.random.default_rng(3)
-    x = np.concatenate([np.arange(1, (1 << 24) + 1, dtype=np.float64), rng.integers(1 << 24, 1 << 40, size=1 << 20).astype(np.float64)])
-    got = ctx.libm_eval(2, 0, torch.from_numpy(x).cuda()).cpu().numpy()
+    vp = ctx.libm_pow()
+    assert vp != 0, "host pow not pinned"
+    x = _perimeters(dense=1 << 24)
+    d_x = torch.from_numpy(x).cuda()
     ref = O.libm_eval(2, x)
-    ulps = np.abs(got.view(np.int64) - ref.view(np.int64))
-    assert ulps.max() <= 1
-    assert (ulps != 0).mean() < 2e-3
+    got = ctx.libm_eval(2, vp, d_x).cpu().numpy()
+    bad = got.view(np.uint64) != ref.view(np.uint64)
+    assert not bad.any(), "%d of %d differ, first x=%r" % (bad.sum(), x.size, x[bad][:3])
+    ulps = np.abs(ctx.libm_eval(2, 0, d_x).cpu().numpy().view(np.int64) - ref.view(np.int64))
+    assert ulps.max() <= 1 and (ulps != 0).mean() < 2e-3
     ctx.close()
