@@ -1185,6 +1185,17 @@ int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& cl
     int nh = env ? atoi(env) : 63;
     if (nh < 0) nh = 0;
     if (nh > 200) nh = 200;
+    // the loop's workgroup and its helpers talk through polled flags, so they must all be resident at once: never ask for
+    // more workgroups than the device can hold of this kernel (a helper that still does not answer -- the device is shared --
+    // is noticed by the spin limit and reported as a failed run)
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    GLIA_HIP_TRY(hipGetDevice(&dev));
+    GLIA_HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    GLIA_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, greedy_bc_kernel, (int)kBcThreads, 0));
+    const int resident = per_cu * prop.multiProcessorCount;
+    if (resident < 1) { set_error("merge_order_bc: the loop kernel does not fit this device"); return GLIA_HMT_ERR_HIP; }
+    if (nh > resident - 1) nh = resident - 1;
     st.n_helpers = (clf.kind == 0 && !h_forced && !init_only) ? (uint32_t)nh : 0u;
   }
   if ((rc = buf.get(&st.ctrl, 8, true, stream))) return rc;

@@ -1,14 +1,17 @@
+# the GPU measurements a round's profiles/ are built from: bash tools/closing_set.sh <tag>   (on the GPU box, via gpurun)
 set -e
-mkdir -p gpurun_out/r01k
+TAG=${1:-r02a}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 400 python bench.py --steps 3 --warmup 1 > gpurun_out/r01k/bench1024.json 2> gpurun_out/r01k/bench1024.err
+timeout -k 10 500 python bench.py --steps 3 --warmup 1 > $OUT/bench1024.json 2> $OUT/bench1024.err
 echo bench done
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r01k/prof -o bench -- python3 bench.py --steps 2 --warmup 1 --no-cpu > gpurun_out/r01k/prof_bench.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-bc > $OUT/prof_bench.log 2>&1
 echo stats done
-timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/r01k/pmc_fetch -o acc -- python3 tools/acc_bench.py 1024 16 1 > gpurun_out/r01k/pmc_fetch.log 2>&1
-timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/r01k/pmc_write -o acc -- python3 tools/acc_bench.py 1024 16 1 > gpurun_out/r01k/pmc_write.log 2>&1
+timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o acc -- python3 tools/acc_bench.py 1024 16 1 > $OUT/pmc_fetch.log 2>&1
+timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o acc -- python3 tools/acc_bench.py 1024 16 1 > $OUT/pmc_write.log 2>&1
 echo pmc done
-timeout -k 10 200 python tools/bc_bench.py 512 16 > gpurun_out/r01k/bc512_final.txt 2>&1
-timeout -k 10 200 python tools/bc_bench.py 256 16 > gpurun_out/r01k/bc256_final.txt 2>&1
-timeout -k 10 300 python tools/pb_bench.py 512 16 1 > gpurun_out/r01k/pbmed512_final.txt 2>&1
-echo bc done
+GLIA_PB_HASH=1 timeout -k 10 200 python tools/pb_bench.py 1024 16 2 > $OUT/pb1024_hash.txt 2>&1
+GLIA_PB_HASH=1 timeout -k 10 200 python tools/pb_bench.py 512 16 2 > $OUT/pb512_hash.txt 2>&1
+timeout -k 10 200 python tools/bc_bench.py 512 16 > $OUT/bc512.txt 2>&1
+echo loops done
