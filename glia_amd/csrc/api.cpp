@@ -11,6 +11,7 @@
 
 #include "bc_features.hpp"
 #include "forest.hpp"
+#include "rmap_order.hpp"
 #include "hmt_internal.hpp"
 
 namespace glia {
@@ -206,6 +207,16 @@ int glia_hmt_ctx_libm_pow(const glia_hmt_ctx* c, int* pow_variant) {
 int glia_hmt_host_libm_probe_pow(int* pow_variant) {
   if (!pow_variant) return GLIA_HMT_ERR_ARG;
   *pow_variant = probe_host_libm().pow_variant;
+  return GLIA_HMT_OK;
+}
+
+int glia_hmt_host_rmap_ranks(const uint32_t* labels, const int64_t* first_voxel, int64_t n, int mode, uint32_t* rank) {
+  if (!labels || !first_voxel || !rank || n < 0 || mode < 0 || mode > 2) { set_error("host_rmap_ranks: invalid argument"); return GLIA_HMT_ERR_ARG; }
+  std::vector<uint32_t> lab(labels, labels + n), out;
+  std::vector<long long> first(first_voxel, first_voxel + n);
+  for (int64_t i = 1; i < n; ++i) if (lab[i] <= lab[i - 1]) { set_error("host_rmap_ranks: labels must be ascending"); return GLIA_HMT_ERR_ARG; }
+  rmap_ranks(lab, first, &out, mode);
+  std::copy(out.begin(), out.end(), rank);
   return GLIA_HMT_OK;
 }
 

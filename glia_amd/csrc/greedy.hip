@@ -1387,6 +1387,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
   double* const sg_mean = reinterpret_cast<double*>(reinterpret_cast<uint32_t*>(&s.stage[0]) + 3 * kNW * kTab) + wave * kTab;
 #ifdef GLIA_HMT_PROFILE
   unsigned long long bph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, blast = __builtin_readcyclecounter(), brounds = 0, bmembers = 0, bvalid = 0, bwide = 0, bcut_sal = 0, bcut_dep = 0;
+  unsigned long long bw_n[4] = {0, 0, 0, 0}, bw_cyc[4] = {0, 0, 0, 0}, bw_ent[4] = {0, 0, 0, 0}, bw_new[4] = {0, 0, 0, 0};
 #define BPH(i) do { if (tid == 0) { unsigned long long tn = __builtin_readcyclecounter(); bph[i] += tn - blast; blast = tn; } } while (0)
 #else
 #define BPH(i) do {} while (0)
@@ -1437,11 +1438,15 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
       if (ne + top_total > st.Ecap) { status = ST_NEED_EDGES; break; }
       if (pool_used + top_total > st.pool_cap) { status = ST_NEED_POOL; break; }
       uint32_t newcount = 0;
+#ifdef GLIA_HMT_PROFILE
+      const unsigned long long tw0 = __builtin_readcyclecounter();
+#endif
       const uint32_t tt = batch_contract_wide(st, w, s, b, tid, top.arg, top.sal, k, ne, pool_used, &newcount);
       if (b.bad) { status = ST_BAD_SALIENCY; break; }
       k += 1; ne += newcount; pool_used += tt;
 #ifdef GLIA_HMT_PROFILE
       bwide += 1;
+      { const int cls = tt <= 512u ? 0 : tt <= kMarkMax ? 1 : tt <= 8192u ? 2 : 3; bw_n[cls] += 1; bw_cyc[cls] += __builtin_readcyclecounter() - tw0; bw_ent[cls] += tt; bw_new[cls] += newcount; }
 #endif
       batch_scan(st, w, b, tid);
       if (w.spill_ord) { if (pend_e != kNone) { st.er[pend_e].next = pend_old; pend_e = kNone; } win_evict(st, w, tid); batch_scan(st, w, b, tid); }
@@ -1638,6 +1643,8 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
 #ifdef GLIA_HMT_PROFILE
   if (tid == 0) printf("[batch profile] merges %llu: select %llu  compute %llu  validate %llu  commit %llu  scan %llu  loop-top %llu  reload %llu (cycles); rounds %llu candidates %llu committed %llu (cut by saliency %llu, by adjacency %llu) wide %llu\n",
                        k, bph[0], bph[1], bph[2], bph[3], bph[4], bph[5], bph[6], brounds, bmembers, bvalid, bcut_sal, bcut_dep, bwide);
+  if (tid == 0) printf("[batch profile] wide by entries (<=512, <=1408, <=8192, more): n %llu %llu %llu %llu  cycles %llu %llu %llu %llu  entries %llu %llu %llu %llu  new edges %llu %llu %llu %llu\n",
+                       bw_n[0], bw_n[1], bw_n[2], bw_n[3], bw_cyc[0], bw_cyc[1], bw_cyc[2], bw_cyc[3], bw_ent[0], bw_ent[1], bw_ent[2], bw_ent[3], bw_new[0], bw_new[1], bw_new[2], bw_new[3]);
 #endif
   if (pend_e != kNone) st.er[pend_e].next = pend_old;
   // leave through the global lists: the next launch (or the tree kernel) starts from them

@@ -19,19 +19,20 @@
 //   * feature vector and orientation: bc_features.hpp; initial edges are passed to fBcFeat in the orientation
 //     in which TBoundaryTable::init meets them, i.e. the region that comes first in the unordered_map
 //     iteration order of the region map (rank[] is computed on the host by replaying the reference's insertion
-//     sequences through the same libstdc++ container); updated edges are passed as (rs, r2).
+//     sequences through libstdc++'s hashtable rules, rmap_order.cpp); updated edges are passed as (rs, r2).
 //
 // MI355X mapping: one persistent workgroup (the contraction chain is sequential); per contraction the new
 // records are built data-parallel, features are computed one thread per new edge into a workspace, and the
 // forest is evaluated with (edge, tree) pairs spread over the whole workgroup.
 #include <algorithm>
 #include <cstring>
-#include <unordered_map>
+#include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
 #include "bc_features.hpp"
 #include "forest.hpp"
 #include "greedy_common.hpp"
+#include "rmap_order.hpp"
 
 namespace glia {
 
@@ -1059,25 +1060,13 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
 
 }  // namespace
 
-// iteration order of the reference's region map, as ranks per leaf: replay of genPointMap (util/struct.hxx:77-92:
-// cmap in first-raster-occurrence order, pmap in cmap iteration order) and TRegionMap::init
-// (type/region_map.hxx:79-95: emplace in pmap iteration order) through the same libstdc++ container.
-static void rmap_ranks(const std::vector<uint32_t>& labels, const std::vector<long long>& first, std::vector<uint32_t>* rank) {
-  const size_t R = labels.size();
-  std::vector<uint32_t> byFirst(R);
-  for (size_t i = 0; i < R; ++i) byFirst[i] = (uint32_t)i;
-  std::sort(byFirst.begin(), byFirst.end(), [&](uint32_t a, uint32_t b) { return first[a] < first[b]; });
-  std::unordered_map<uint32_t, size_t> cmap;
-  for (uint32_t i : byFirst) cmap[labels[i]] = 1;
-  std::unordered_map<uint32_t, int> pmap;
-  for (auto const& cp : cmap) pmap[cp.first] = 0;
-  std::unordered_map<uint32_t, int> rmap;
-  for (auto const& pp : pmap) rmap.emplace(pp.first, 0);
-  std::unordered_map<uint32_t, uint32_t> pos;
-  uint32_t n = 0;
-  for (auto const& rp : rmap) pos[rp.first] = n++;
-  rank->resize(R);
-  for (size_t i = 0; i < R; ++i) (*rank)[i] = pos[labels[i]];
+// first voxel index of every leaf (the accumulation pass records its complement, R_FIRST) as a sort key
+__global__ void bc_first_keys(const uint32_t* rrec, uint32_t R, unsigned long long* keys, uint32_t* leaf) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R) return;
+  const uint2 f = *reinterpret_cast<const uint2*>(&rrec[(size_t)i * kRegionWords + R_FIRST]);
+  keys[i] = ~(((unsigned long long)f.y << 32) | f.x);
+  leaf[i] = i;
 }
 
 int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& clf, hipStream_t stream,
@@ -1099,13 +1088,25 @@ int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& cl
   st.R0 = R; st.P = P; st.cfg = cfg; st.clf = clf;
   st.shard = (uint32_t)shard; st.n_shards = (uint32_t)(n_shards > 0 ? n_shards : 1);
 
-  // host side: reference region-map iteration order
-  std::vector<uint32_t> lab(R), rrec((size_t)R * kRegionWords), rank;
-  GLIA_HIP_TRY(hipMemcpy(lab.data(), rag.d_rlabel, sizeof(uint32_t) * R, hipMemcpyDeviceToHost));
-  GLIA_HIP_TRY(hipMemcpy(rrec.data(), rag.d_rrec, sizeof(uint32_t) * kRegionWords * R, hipMemcpyDeviceToHost));
-  std::vector<long long> first(R);
-  for (uint32_t i = 0; i < R; ++i) { unsigned long long f; memcpy(&f, &rrec[(size_t)i * kRegionWords + R_FIRST], 8); first[i] = (long long)~f; }
-  rmap_ranks(lab, first, &rank);
+  // reference region-map iteration order (rmap_order.cpp): leaves sorted by first voxel on the device, the hashtable replay on the host
+  std::vector<uint32_t> lab(R), by_first(R), rank;
+  {
+    unsigned long long* k0; unsigned long long* k1; uint32_t* v0; uint32_t* v1;
+    if ((rc = buf.get(&k0, R, false, stream))) return rc;
+    if ((rc = buf.get(&k1, R, false, stream))) return rc;
+    if ((rc = buf.get(&v0, R, false, stream))) return rc;
+    if ((rc = buf.get(&v1, R, false, stream))) return rc;
+    hipLaunchKernelGGL(bc_first_keys, dim3((R + 255) / 256), dim3(256), 0, stream, rag.d_rrec, R, k0, v0);
+    size_t tmp = 0;
+    GLIA_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, k0, k1, v0, v1, (size_t)R, 0, 64, stream));
+    char* d_tmp;
+    if ((rc = buf.get(&d_tmp, tmp ? tmp : 16, false, stream))) return rc;
+    GLIA_HIP_TRY(rocprim::radix_sort_pairs((void*)d_tmp, tmp, k0, k1, v0, v1, (size_t)R, 0, 64, stream));
+    GLIA_HIP_TRY(hipMemcpyAsync(by_first.data(), v1, sizeof(uint32_t) * R, hipMemcpyDeviceToHost, stream));
+    GLIA_HIP_TRY(hipMemcpyAsync(lab.data(), rag.d_rlabel, sizeof(uint32_t) * R, hipMemcpyDeviceToHost, stream));
+    GLIA_HIP_TRY(hipStreamSynchronize(stream));
+  }
+  rmap_ranks_ordered(lab, by_first, &rank);
   uint32_t* d_rank;
   if ((rc = buf.get(&d_rank, R, false, stream))) return rc;
   GLIA_HIP_TRY(hipMemcpyAsync(d_rank, rank.data(), sizeof(uint32_t) * R, hipMemcpyHostToDevice, stream));

@@ -61,6 +61,13 @@ int glia_hmt_host_libm_probe(int* log2_variant, int* log_variant);
 int glia_hmt_host_libm_probe_pow(int* pow_variant);
 int glia_hmt_host_libm_eval(int function, int variant, const double* h_in, double* h_out, int64_t n);  /* host code of the same restatement, no GPU */
 int glia_hmt_libm_eval(glia_hmt_ctx* ctx, int function, int variant, const double* d_in, double* d_out, int64_t n);
+/* Which region is "region 0" of an initial edge, everything else being equal, follows the iteration order of the reference's
+ * std::unordered_map region map (type/region_map.hxx:79-95 filled from genPointMap, util/struct.hxx:77-92).  The library
+ * reproduces it by replaying the insertions under libstdc++'s hashtable rules (glia_amd/csrc/rmap_order.cpp).  This host-only
+ * entry evaluates the replay for n leaves (labels ascending, first_voxel = raster index of a label's first voxel): rank[i] =
+ * position of leaf i in that order.  mode 0 = as the library does, 1 = through the real container, 2 = the array emulation
+ * (tests compare them). */
+int glia_hmt_host_rmap_ranks(const uint32_t* labels, const int64_t* first_voxel, int64_t n, int mode, uint32_t* rank);
 /* Optional sizing hint for the accumulation hash tables (0 = derive from the volume size; they grow and
  * the pass is redone if they fill up). */
 int glia_hmt_ctx_set_table_hint(glia_hmt_ctx* ctx, int64_t expected_regions, int64_t expected_pairs);

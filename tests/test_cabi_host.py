@@ -134,3 +134,25 @@ def test_reference_reader_reads_files_written_by_our_test_writer():
     assert (xb == forest["xbestsplit"].reshape(-1)).all()
     assert (tm == forest["treemap"].reshape(-1)).all()
     assert (ns == forest["nodestatus"].reshape(-1)).all()
+
+
+def test_region_map_order_emulation_equals_the_libstdcxx_container():
+    """The orientation of initial edges follows the iteration order of the reference's std::unordered_map region map; the
+    library replays the insertions on arrays under libstdc++'s hashtable rules (rmap_order.cpp) -- it must give what the
+    real container gives, for dense and sparse label sets, across many growth steps."""
+    import ctypes as C
+    import numpy as np
+    lib = C.CDLL(SO)
+    rng = np.random.default_rng(7)
+    for n, sparse in ((1, 0), (2, 0), (12, 1), (13, 0), (14, 1), (1000, 1), (4099, 0), (70001, 1), (300000, 0)):
+        step = rng.integers(1, 5000, size=n) if sparse else np.ones(n, dtype=np.int64)
+        labels = np.cumsum(step).astype(np.uint32)
+        first = rng.permutation(n * 7)[:n].astype(np.int64)
+        out = []
+        for mode in (1, 2, 0):
+            r = np.empty(n, dtype=np.uint32)
+            assert lib.glia_hmt_host_rmap_ranks(labels.ctypes.data_as(C.c_void_p), first.ctypes.data_as(C.c_void_p), C.c_int64(n), C.c_int(mode),
+                                                r.ctypes.data_as(C.c_void_p)) == 0
+            out.append(r)
+        assert sorted(out[0].tolist()) == list(range(n))
+        assert (out[0] == out[1]).all() and (out[0] == out[2]).all(), n
