@@ -550,6 +550,11 @@ struct WinState {
   unsigned long long ne_base, rebase_after; // edges that existed at the baseline; a new one is due after this many more
   uint32_t wcap, wbudget;                   // window slots in use (<= kWinCap) and the items a reload brings at most (tests shrink them: GLIA_HMT_WINCAP)
   int cond_n;
+  // HORIZON (batch kernel): cells below wch are out of the queue's reach until the next baseline.  An edge created there is
+  // neither linked into its cell's list nor counted, an edge dying there is not counted either: its record and its two list
+  // entries are all that is written (the baseline is rebuilt from the records).  A reload that would have to go below the
+  // horizon ends the launch with ST_REBASE instead.  0 = no horizon.
+  uint32_t wch;
 };
 constexpr uint32_t kWinCap = 1536;          // window slots (live items + holes)
 constexpr uint32_t kWinBudget = 768;        // a reload stops before exceeding this many items ...
@@ -588,13 +593,13 @@ __device__ __forceinline__ unsigned long long f64_ord(double d) {
   unsigned long long b = (unsigned long long)__double_as_longlong(d);
   return b ^ ((b >> 63) ? ~0ull : 0x8000000000000000ull);
 }
-__device__ __forceinline__ double f64_unord(unsigned long long o) {
+__host__ __device__ __forceinline__ double f64_unord(unsigned long long o) {
   o ^= (o >> 63) ? 0x8000000000000000ull : ~0ull;
-  return __longlong_as_double((long long)o);
+  return __builtin_bit_cast(double, o);
 }
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }   // global stores stay in flight
 
-__device__ __forceinline__ uint32_t win_cell(double sal, double smin, double scale, uint32_t B) {
+__host__ __device__ __forceinline__ uint32_t win_cell(double sal, double smin, double scale, uint32_t B) {
   double t = (sal - smin) * scale;          // monotone in sal (saliencies are never NaN: sdivide guards the division)
   t = t > 0.0 ? t : 0.0;
   return t >= (double)(B - 1u) ? B - 1u : (uint32_t)t;
@@ -756,7 +761,8 @@ __device__ __forceinline__ void win_take_initial(const WinState& st, WinShared& 
 }
 
 // The window holds no live item: move the threshold down.  Returns 0 = loaded something (or made progress), 1 = the
-// queue is empty, 2 = a cell's list does not fit the window (every thread calls; contains barriers)
+// queue is empty, 2 = a cell's list does not fit the window, 3 = nothing left above the horizon (every thread calls;
+// contains barriers)
 constexpr uint32_t kSelMax = 384;           // list items a split cell hands over at most (bounded min-heap in LDS)
 __device__ __forceinline__ int win_reload(const WinState& st, WinShared& w, int tid, double* sel_sal, unsigned long long* sel_seq) {
   __syncthreads();                       // (vmcnt(0) inside) this workgroup's list pushes and counter updates are done
@@ -764,15 +770,16 @@ __device__ __forceinline__ int win_reload(const WinState& st, WinShared& w, int 
   __syncthreads();
   uint32_t c_hi = (uint32_t)(w.cthr + 1) < st.wB ? (uint32_t)(w.cthr + 1) : st.wB, loaded = 0, iptr = w.iptr;
   int result = 1;
-  while (c_hi != 0) {
-    const bool valid = (uint32_t)tid < c_hi;
+  const uint32_t c_floor = st.wch < st.wB ? st.wch : 0u;      // the horizon: cells below it are not loaded
+  while (c_hi > c_floor) {
+    const bool valid = (uint32_t)tid < c_hi - c_floor;
     const uint32_t c = valid ? c_hi - 1u - (uint32_t)tid : 0u;
     const uint32_t cn = valid ? ld_l2(&st.wcnt[c]) : 0u;
     uint32_t total;
     const uint32_t incl = block_scan_incl(cn, w.wsum, tid, &total);
     const bool ok = valid && incl <= st.wbudget - loaded;
     const uint32_t m = (uint32_t)__syncthreads_count(ok ? 1 : 0);       // ok is monotone in tid: the first m cells fit whole
-    const uint32_t nvalid = c_hi < (uint32_t)kGreedyThreads ? c_hi : (uint32_t)kGreedyThreads;
+    const uint32_t nvalid = c_hi - c_floor < (uint32_t)kGreedyThreads ? c_hi - c_floor : (uint32_t)kGreedyThreads;
     if (m != 0) {
       const uint32_t c_lo = c_hi - m;
       if ((uint32_t)tid == m - 1u) w.bcast = incl;
@@ -881,6 +888,7 @@ __device__ __forceinline__ int win_reload(const WinState& st, WinShared& w, int 
   __syncthreads();
   if (tid == 0 && result != 2) { w.cthr = (int)c_hi - 1; w.tsal = __builtin_inf(); w.tseq = ~0ull; w.iptr = iptr; }
   __syncthreads();
+  if (result == 1 && c_floor != 0u) result = 3;
   return result;
 }
 
@@ -921,6 +929,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(WinState 
       WPH(6);
       if (r == 1) { status = ST_DONE; break; }
       if (r == 2) { status = ST_NEED_TREE; break; }
+      if (r == 3) { status = ST_REBASE; break; }
       win_scan(st, w, tid, kNone, 0);
       r2prev = kNone;                      // (the reload's barriers waited for every store)
       continue;
@@ -1218,6 +1227,12 @@ __device__ __forceinline__ void batch_scan(const WinState& st, WinShared& w, Bat
   if (tid == 0) { b.nkill = 0; b.kovf = 0; }
 }
 
+#ifdef GLIA_HMT_PROFILE
+__device__ unsigned long long g_wideprof[8];
+#define WIDE_T(i) do { if (tid == 0) { const unsigned long long tn_ = __builtin_readcyclecounter(); g_wideprof[i] += tn_ - wt_; wt_ = tn_; } } while (0)
+#else
+#define WIDE_T(i) do {} while (0)
+#endif
 // The whole workgroup contracts ONE edge (more than 64 list entries): the body of greedy_window_kernel.
 __device__ __forceinline__ uint32_t batch_contract_wide(const WinState& st, WinShared& w, WinWork& s, BatchShared& b, int tid, uint32_t slot, double rootsal,
                                                       unsigned long long k, unsigned long long ne, unsigned long long pool_used, uint32_t* newcount_out) {
@@ -1229,7 +1244,11 @@ __device__ __forceinline__ uint32_t batch_contract_wide(const WinState& st, WinS
   const uint32_t total = len0 + len1;
   const uint32_t r2 = st.R0 + (uint32_t)k;
   const uint32_t r2off = (uint32_t)pool_used;
+#ifdef GLIA_HMT_PROFILE
+  unsigned long long wt_ = __builtin_readcyclecounter();
+#endif
   __syncthreads();                                                       // every thread has read the slot
+  WIDE_T(0);
   if (tid == 0) {
     w.seq[slot] = 0;
     st.order[3 * k + 0] = r0; st.order[3 * k + 1] = r1; st.order[3 * k + 2] = r2;
@@ -1254,7 +1273,9 @@ __device__ __forceinline__ uint32_t batch_contract_wide(const WinState& st, WinS
     } else (side1 ? st.mark1 : st.mark0)[fe.rs] = i + 1u;
   }
   __syncthreads();
+  WIDE_T(1);
   if (wn_now + total > st.wcap && wn_now > st.wcap / 2u) win_compact(w, tid, st.wcap);      // (holes out; a full window spills, see win_evict)
+  WIDE_T(2);
   const int cthr = w.cthr; const double tsal = w.tsal; const unsigned long long tseq = w.tseq;
   const uint32_t nwork = small ? s.nitems : total;
   const uint32_t lenR2 = small ? nwork : 0u;        // small case: every table item becomes exactly one new edge, so r2's list length is known here
@@ -1313,12 +1334,13 @@ __device__ __forceinline__ uint32_t batch_contract_wide(const WinState& st, WinS
     st.fpool[r2off + idx] = bb;
     const uint32_t cell = win_cell(sal, smin, scale, st.wB);
     uint32_t sl = kWinCap;
-    if (win_above(cthr, tsal, tseq, (int)cell, sal, seq)) {
+    const bool above = win_above(cthr, tsal, tseq, (int)cell, sal, seq);
+    if (above) {
       sl = atomicAdd(&w.n, 1u);
       if (sl < st.wcap) win_put(w, sl, sal, seq, newE, rs, r2, make_uint2(offRs, lenRs), make_uint2(r2off, lenR2));
       else atomicMax(&w.spill_ord, f64_ord(sal));          // the window is full: tau will rise above this item
     }
-    if (sl >= st.wcap) {
+    if (sl >= st.wcap && (above || cell >= st.wch)) {                   // (an item below the horizon is not queued at all)
       if (pend_e != kNone) st.er[pend_e].next = pend_old;
       pend_e = newE; pend_old = atomicExch(&st.whead[cell], newE);
       atomicAdd(&st.wcnt[cell], 1u);
@@ -1335,11 +1357,13 @@ __device__ __forceinline__ uint32_t batch_contract_wide(const WinState& st, WinS
       st.er[de].seq = 0;
       if (win_above(cthr, tsal, tseq, (int)dc, dsal, dq)) {
         const uint32_t j = atomicAdd(&b.nkill, 1u); if (j < kBatchKill) b.kill[j] = de; else b.kovf = 1;
-      } else atomicSub(&st.wcnt[dc], 1u);
+      } else if (dc >= st.wch) atomicSub(&st.wcnt[dc], 1u);
     }
   }
   if (bad) b.bad = 1;
+  WIDE_T(3);
   __syncthreads();
+  WIDE_T(4);
   const uint32_t newcount = s.newcount;
   if (!small) {
     for (uint32_t j = tid; j < newcount; j += kGreedyThreads) {
@@ -1353,6 +1377,7 @@ __device__ __forceinline__ uint32_t batch_contract_wide(const WinState& st, WinS
   if (pend_e != kNone) st.er[pend_e].next = pend_old;
   if (tid == 0) { st.adj_off[r2] = r2off; st.adj_len[r2] = newcount; }
   __syncthreads();
+  WIDE_T(5);
   if (tid == 0) { s.nitems = 0; s.newcount = 0; }
   *newcount_out = newcount;
   return total;
@@ -1414,6 +1439,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
       BPH(6);
       if (r == 1) { status = ST_DONE; break; }
       if (r == 2) { status = ST_NEED_TREE; break; }
+      if (r == 3) { status = ST_REBASE; break; }                          // the queue continues below the horizon: new baseline
       batch_scan(st, w, b, tid);
       continue;
     }
@@ -1603,12 +1629,13 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
         st.fpool[r2off + idx[p]] = bb;
         const uint32_t cell = win_cell(sal, smin, scale, st.wB);
         uint32_t sl = kWinCap;
-        if (win_above(cthr, tsal, tseq, (int)cell, sal, seq)) {
+        const bool above = win_above(cthr, tsal, tseq, (int)cell, sal, seq);
+        if (above) {
           sl = atomicAdd(&w.n, 1u);
           if (sl < st.wcap) win_put(w, sl, sal, seq, newE, rs, r2, make_uint2(offRs, lenRs), make_uint2(r2off, newcount));
           else atomicMax(&w.spill_ord, f64_ord(sal));      // the window is full: tau will rise above this item
         }
-        if (sl >= st.wcap) {
+        if (sl >= st.wcap && (above || cell >= st.wch)) {               // (an item below the horizon is not queued at all)
           if (pend_e != kNone) st.er[pend_e].next = pend_old;
           pend_e = newE; pend_old = atomicExch(&st.whead[cell], newE);
           atomicAdd(&st.wcnt[cell], 1u);
@@ -1626,7 +1653,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
           st.er[de].seq = 0;
           if (win_above(cthr, tsal, tseq, (int)dc, dsal, dq)) {
             const uint32_t j = atomicAdd(&b.nkill, 1u); if (j < kBatchKill) b.kill[j] = de; else b.kovf = 1;
-          } else atomicSub(&st.wcnt[dc], 1u);
+          } else if (dc >= st.wch) atomicSub(&st.wcnt[dc], 1u);
         }
       }
     }
@@ -1643,6 +1670,8 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
 #ifdef GLIA_HMT_PROFILE
   if (tid == 0) printf("[batch profile] merges %llu: select %llu  compute %llu  validate %llu  commit %llu  scan %llu  loop-top %llu  reload %llu (cycles); rounds %llu candidates %llu committed %llu (cut by saliency %llu, by adjacency %llu) wide %llu\n",
                        k, bph[0], bph[1], bph[2], bph[3], bph[4], bph[5], bph[6], brounds, bmembers, bvalid, bcut_sal, bcut_dep, bwide);
+  if (tid == 0) printf("[batch profile] wide phases (cumulative cycles): entry-barrier %llu  lists+table %llu  compact %llu  main loop (wave 0) %llu  loop barrier %llu  tail %llu\n",
+                       g_wideprof[0], g_wideprof[1], g_wideprof[2], g_wideprof[3], g_wideprof[4], g_wideprof[5]);
   if (tid == 0) printf("[batch profile] wide by entries (<=512, <=1408, <=8192, more): n %llu %llu %llu %llu  cycles %llu %llu %llu %llu  entries %llu %llu %llu %llu  new edges %llu %llu %llu %llu\n",
                        bw_n[0], bw_n[1], bw_n[2], bw_n[3], bw_cyc[0], bw_cyc[1], bw_cyc[2], bw_cyc[3], bw_ent[0], bw_ent[1], bw_ent[2], bw_ent[3], bw_new[0], bw_new[1], bw_new[2], bw_new[3]);
 #endif
@@ -1959,6 +1988,10 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
   // saliency's order-preserving image), per-cell segments and live counters; the cell lists start empty.  Taken at the start
   // (the initial edges) and whenever a launch ends before the queue is empty: the lists only shed their dead nodes when
   // their cell is loaded, so after a few million created edges walking them dominates; a re-sort is ~1 ms of whole-GPU work.
+  double h_range[2] = {0.0, 0.0};
+  long long prev_top_cell = -1;
+  unsigned long long prev_ne = 0;
+  double horizon_factor = 0.0;                                           // 0 = no horizon (set below for the batch kernel)
   auto win_rebaseline = [&](uint32_t n_edges) -> int {
     GLIA_HIP_TRY(hipMemsetAsync(rb_counter, 0, sizeof(uint32_t), stream));
     hipLaunchKernelGGL(win_collect_kernel, dim3((n_edges + 255) / 256), dim3(256), 0, stream, ws.er, n_edges, rb_kseq, rb_vals, rb_counter);
@@ -1978,9 +2011,25 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
     if (n) hipLaunchKernelGGL(win_baseline_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, ws, n, rb_isort, rb_iseq);
     hipLaunchKernelGGL(win_segments_kernel, dim3((ws.wB + 1 + 255) / 256), dim3(256), 0, stream, ws, rb_isort, n, rb_ige);
     GLIA_HIP_TRY(hipGetLastError());
-    ws.nsort = n; ws.ne_base = n_edges;
+    ws.nsort = n;
     const char* renv = getenv("GLIA_HMT_REBASE");                          // created edges between baselines (tuning)
     ws.rebase_after = renv ? strtoull(renv, nullptr, 10) : std::max<unsigned long long>(800000ull, (unsigned long long)n / 2ull);
+    // the horizon (WinState::wch): the top of the queue sank by d cells while the last interval's edges were created; the next
+    // interval is given twice that (scaled to its planned length) before a reload would run into the horizon
+    ws.wch = 0;
+    if (horizon_factor > 0.0 && n > 4096) {
+      unsigned long long topkey = 0;
+      GLIA_HIP_TRY(hipMemcpyAsync(&topkey, rb_ksal2, sizeof(topkey), hipMemcpyDeviceToHost, stream));
+      GLIA_HIP_TRY(hipStreamSynchronize(stream));
+      const long long top_cell = (long long)win_cell(f64_unord(topkey), h_range[0], h_range[1], ws.wB);
+      if (prev_top_cell >= 0 && n_edges > prev_ne) {
+        const double d = (double)std::max<long long>(0, prev_top_cell - top_cell);
+        const double delta = std::max(horizon_factor * d * (double)ws.rebase_after / (double)(n_edges - prev_ne), (double)ws.wB / 512.0);
+        ws.wch = (double)top_cell > delta ? (uint32_t)((double)top_cell - delta) : 0u;
+      }
+      prev_top_cell = top_cell; prev_ne = n_edges;
+    }
+    ws.ne_base = n_edges;
     const double inf = std::numeric_limits<double>::infinity();
     ctrl[5] = (unsigned long long)(long long)(ws.wB - 1);                  // threshold: everything is below it
     memcpy(&ctrl[6], &inf, 8); ctrl[7] = ~0ull; ctrl[8] = 0;
@@ -2023,6 +2072,13 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
     hipLaunchKernelGGL(win_range_kernel, dim3(256), dim3(256), 0, stream, st.pq.leaf_sal, E0, mm);
     hipLaunchKernelGGL(win_params_kernel, dim3(1), dim3(1), 0, stream, mm, B, range);
     GLIA_HIP_TRY(hipGetLastError());
+    GLIA_HIP_TRY(hipMemcpyAsync(h_range, range, sizeof(h_range), hipMemcpyDeviceToHost, stream));
+    GLIA_HIP_TRY(hipStreamSynchronize(stream));
+    {
+      const char* benv = getenv("GLIA_HMT_PB_BATCH");
+      const char* henv = getenv("GLIA_HMT_HORIZON");                     // 0 = off; else the factor on the measured descent (default 2)
+      if (cond_n <= 0 && !(benv && benv[0] == '0')) horizon_factor = henv ? atof(henv) : 2.0;
+    }
     if ((rc = win_rebaseline(E0))) return rc;
   } else if ((rc = pq_setup(buf, st.pq, stream))) return rc;
   GLIA_HIP_TRY(hipMemcpyAsync(st.ctrl, ctrl, sizeof(ctrl), hipMemcpyHostToDevice, stream));
