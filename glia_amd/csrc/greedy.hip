@@ -876,6 +876,14 @@ __device__ __forceinline__ int win_reload(const WinState& st, WinShared& w, int 
         }
         __syncthreads();
         const uint32_t moved = w.n - before;
+        if (moved == 0u && w.bcast == 0u) {
+          // nothing above the new tau and no array entry passed: the cell is empty, its count was too high (counts are upper
+          // bounds: the batch kernel does not discount an edge that dies with exactly tau's key) -- on to the cells below
+          __syncthreads();
+          if (tid == 0) st_l2(&st.wcnt[cs], 0u);
+          c_hi = cs;
+          continue;
+        }
         if (tid == 0) { if (moved) atomicSub(&st.wcnt[cs], moved); w.cthr = (int)cs; w.tsal = tsal; w.tseq = tseq; w.iptr = iptr; }
         if (moved || w.bcast) result = 0;
         __syncthreads();
@@ -1281,85 +1289,94 @@ __device__ __forceinline__ uint32_t batch_contract_wide(const WinState& st, WinS
   const uint32_t lenR2 = small ? nwork : 0u;        // small case: every table item becomes exactly one new edge, so r2's list length is known here
   bool bad = false;
   uint32_t pend_e = kNone, pend_old = kNone;
-  for (uint32_t base = 0; base < nwork; base += kGreedyThreads) {
-    const uint32_t i = base + tid;
-    if (i >= nwork) break;
-    FatEntry f0, f1;
-    bool h0, h1;
-    uint32_t rs;
-    if (small) {
-      const uint32_t h = s.items[i];
-      rs = s.mk[h] - 1u;
-      const uint32_t m0 = s.mv0[h], m1 = s.mv1[h];
-      s.mk[h] = 0u; s.mv0[h] = 0u; s.mv1[h] = 0u;
-      h0 = m0 != 0; h1 = m1 != 0;
-      f0 = s.stage[h0 ? m0 - 1u : m1 - 1u]; f1 = s.stage[h1 ? m1 - 1u : m0 - 1u];
-    } else {
-      const bool side1 = i >= len0;
-      const FatEntry fe = st.fpool[side1 ? off1 + (i - len0) : off0 + i];
-      if (fe.eid == e || fe.eid == kNone) continue;
-      rs = fe.rs;
-      if (!side1) {
-        const uint32_t m = st.mark1[rs];
-        h0 = true; h1 = m != 0; f0 = fe;
-        f1 = h1 ? st.fpool[off1 + (m - 1u - len0)] : fe;
+  // Two instances of the loop: the LDS-table case must not share code with the one that loads from global memory -- where
+  // the two meet the compiler waits for "every memory operation", and that counter includes the stores of earlier rounds.
+  auto rounds = [&](auto small_tag) {
+    constexpr bool SMALL = decltype(small_tag)::value;
+    for (uint32_t base = 0; base < nwork; base += kGreedyThreads) {
+      const uint32_t i = base + tid;
+      if (i >= nwork) break;
+      FatEntry f0, f1;
+      bool h0, h1;
+      uint32_t rs;
+      if constexpr (SMALL) {
+        const uint32_t h = s.items[i];
+        rs = s.mk[h] - 1u;
+        const uint32_t m0 = s.mv0[h], m1 = s.mv1[h];
+        s.mk[h] = 0u; s.mv0[h] = 0u; s.mv1[h] = 0u;
+        h0 = m0 != 0; h1 = m1 != 0;
+        f0 = s.stage[h0 ? m0 - 1u : m1 - 1u]; f1 = s.stage[h1 ? m1 - 1u : m0 - 1u];
       } else {
-        if (st.mark0[rs] != 0u) continue;               // common neighbour: handled from the r0 side
-        h0 = false; h1 = true; f0 = fe; f1 = fe;
+        const bool side1 = i >= len0;
+        const FatEntry fe = st.fpool[side1 ? off1 + (i - len0) : off0 + i];
+        if (fe.eid == e || fe.eid == kNone) continue;
+        rs = fe.rs;
+        if (!side1) {
+          const uint32_t m = st.mark1[rs];
+          h0 = true; h1 = m != 0; f0 = fe;
+          f1 = h1 ? st.fpool[off1 + (m - 1u - len0)] : fe;
+        } else {
+          if (st.mark0[rs] != 0u) continue;               // common neighbour: handled from the r0 side
+          h0 = false; h1 = true; f0 = fe; f1 = fe;
+        }
+      }
+      const uint32_t idx = atomicAdd(&s.newcount, 1u);
+      const uint32_t newE = (uint32_t)ne + idx;
+      double first = 0.0;                                  // util/struct_merge.hxx:62-76
+      int second = 0;
+      if (h0) { first += f0.mean * (int)f0.n; second += (int)f0.n; }
+      if (h1) { first += f1.mean * (int)f1.n; second += (int)f1.n; }
+      first = sdivide(first, (double)second, 0.0);
+      if (first == -1.0) bad = true;                      // DUMMY -> "invalid boundary saliency" (:78-79)
+      const uint32_t offRs = f0.off, posRs = f0.pos, lenRs = f0.len;
+      if (h0 && h1) st.fpool[offRs + f1.pos].eid = kNone;
+      const uint32_t cat = rs < r0 ? 0u : (h0 ? 1u : 2u);
+      const unsigned long long seq = ((k + 1ull) << 32) | ((unsigned long long)cat << 30) | rs;
+      const double sal = -first;
+      uint4* pq4 = reinterpret_cast<uint4*>(&st.er[newE]);
+      pq4[0] = make_uint4(rs, r2, posRs, idx);
+      const unsigned long long mb = (unsigned long long)__double_as_longlong(first);
+      pq4[1] = make_uint4((uint32_t)mb, (uint32_t)(mb >> 32), (uint32_t)second, kNone);
+      pq4[2] = make_uint4(offRs, lenRs, r2off, lenR2);                     // (wide case: r2's length is stored below)
+      const unsigned long long sbits = (unsigned long long)__double_as_longlong(sal);
+      pq4[3] = make_uint4((uint32_t)sbits, (uint32_t)(sbits >> 32), (uint32_t)seq, (uint32_t)(seq >> 32));
+      FatEntry a; a.eid = newE; a.rs = r2; a.n = (uint32_t)second; a.pos = idx; a.off = r2off; a.len = lenR2; a.mean = first;
+      st.fpool[offRs + posRs] = a;
+      FatEntry bb; bb.eid = newE; bb.rs = rs; bb.n = (uint32_t)second; bb.pos = posRs; bb.off = offRs; bb.len = lenRs; bb.mean = first;
+      st.fpool[r2off + idx] = bb;
+      const uint32_t cell = win_cell(sal, smin, scale, st.wB);
+      uint32_t sl = kWinCap;
+      const bool above = win_above(cthr, tsal, tseq, (int)cell, sal, seq);
+      if (above) {
+        sl = atomicAdd(&w.n, 1u);
+        if (sl < st.wcap) win_put(w, sl, sal, seq, newE, rs, r2, make_uint2(offRs, lenRs), make_uint2(r2off, lenR2));
+        else atomicMax(&w.spill_ord, f64_ord(sal));          // the window is full: tau will rise above this item
+      }
+      if (sl >= st.wcap && (above || cell >= st.wch)) {                   // (an item below the horizon is not queued at all)
+        if (pend_e != kNone) st.er[pend_e].next = pend_old;
+        pend_e = newE; pend_old = atomicExch(&st.whead[cell], newE);
+        atomicAdd(&st.wcnt[cell], 1u);
+      }
+  #pragma unroll
+      for (int side = 0; side < 2; ++side) {
+        const bool hs = side ? h1 : h0;
+        if (!hs) continue;
+        const uint32_t de = side ? f1.eid : f0.eid;
+        const double dsal = -(side ? f1.mean : f0.mean);
+        const uint32_t dc = win_cell(dsal, smin, scale, st.wB);
+        // A key equal to tau's in tau's cell: the seq would decide, and it sits in the edge record -- a load in the middle of
+        // the store stream, which on this hardware makes the wave wait for every store before it (one counter for both).  Such
+        // an edge is treated as a window item instead: a kill that matches nothing is harmless, and its cell's count stays one
+        // too high until the next baseline (counts are upper bounds: a reload walks a list whenever its count is not zero).
+        const bool tie = (int)dc == cthr && dsal == tsal;
+        st.er[de].seq = 0;
+        if (tie || win_above(cthr, tsal, tseq, (int)dc, dsal, 0ull)) {
+          const uint32_t j = atomicAdd(&b.nkill, 1u); if (j < kBatchKill) b.kill[j] = de; else b.kovf = 1;
+        } else if (dc >= st.wch) atomicSub(&st.wcnt[dc], 1u);
       }
     }
-    const uint32_t idx = atomicAdd(&s.newcount, 1u);
-    const uint32_t newE = (uint32_t)ne + idx;
-    double first = 0.0;                                  // util/struct_merge.hxx:62-76
-    int second = 0;
-    if (h0) { first += f0.mean * (int)f0.n; second += (int)f0.n; }
-    if (h1) { first += f1.mean * (int)f1.n; second += (int)f1.n; }
-    first = sdivide(first, (double)second, 0.0);
-    if (first == -1.0) bad = true;                      // DUMMY -> "invalid boundary saliency" (:78-79)
-    const uint32_t offRs = f0.off, posRs = f0.pos, lenRs = f0.len;
-    if (h0 && h1) st.fpool[offRs + f1.pos].eid = kNone;
-    const uint32_t cat = rs < r0 ? 0u : (h0 ? 1u : 2u);
-    const unsigned long long seq = ((k + 1ull) << 32) | ((unsigned long long)cat << 30) | rs;
-    const double sal = -first;
-    uint4* pq4 = reinterpret_cast<uint4*>(&st.er[newE]);
-    pq4[0] = make_uint4(rs, r2, posRs, idx);
-    const unsigned long long mb = (unsigned long long)__double_as_longlong(first);
-    pq4[1] = make_uint4((uint32_t)mb, (uint32_t)(mb >> 32), (uint32_t)second, kNone);
-    pq4[2] = make_uint4(offRs, lenRs, r2off, lenR2);                     // (wide case: r2's length is stored below)
-    const unsigned long long sbits = (unsigned long long)__double_as_longlong(sal);
-    pq4[3] = make_uint4((uint32_t)sbits, (uint32_t)(sbits >> 32), (uint32_t)seq, (uint32_t)(seq >> 32));
-    FatEntry a; a.eid = newE; a.rs = r2; a.n = (uint32_t)second; a.pos = idx; a.off = r2off; a.len = lenR2; a.mean = first;
-    st.fpool[offRs + posRs] = a;
-    FatEntry bb; bb.eid = newE; bb.rs = rs; bb.n = (uint32_t)second; bb.pos = posRs; bb.off = offRs; bb.len = lenRs; bb.mean = first;
-    st.fpool[r2off + idx] = bb;
-    const uint32_t cell = win_cell(sal, smin, scale, st.wB);
-    uint32_t sl = kWinCap;
-    const bool above = win_above(cthr, tsal, tseq, (int)cell, sal, seq);
-    if (above) {
-      sl = atomicAdd(&w.n, 1u);
-      if (sl < st.wcap) win_put(w, sl, sal, seq, newE, rs, r2, make_uint2(offRs, lenRs), make_uint2(r2off, lenR2));
-      else atomicMax(&w.spill_ord, f64_ord(sal));          // the window is full: tau will rise above this item
-    }
-    if (sl >= st.wcap && (above || cell >= st.wch)) {                   // (an item below the horizon is not queued at all)
-      if (pend_e != kNone) st.er[pend_e].next = pend_old;
-      pend_e = newE; pend_old = atomicExch(&st.whead[cell], newE);
-      atomicAdd(&st.wcnt[cell], 1u);
-    }
-#pragma unroll
-    for (int side = 0; side < 2; ++side) {
-      const bool hs = side ? h1 : h0;
-      if (!hs) continue;
-      const uint32_t de = side ? f1.eid : f0.eid;
-      const double dsal = -(side ? f1.mean : f0.mean);
-      const uint32_t dc = win_cell(dsal, smin, scale, st.wB);
-      unsigned long long dq = 1;
-      if ((int)dc == cthr && dsal == tsal) dq = st.er[de].seq;   // tie with tau: the seq decides
-      st.er[de].seq = 0;
-      if (win_above(cthr, tsal, tseq, (int)dc, dsal, dq)) {
-        const uint32_t j = atomicAdd(&b.nkill, 1u); if (j < kBatchKill) b.kill[j] = de; else b.kovf = 1;
-      } else if (dc >= st.wch) atomicSub(&st.wcnt[dc], 1u);
-    }
-  }
+  };
+  if (small) rounds(std::true_type{}); else rounds(std::false_type{});
   if (bad) b.bad = 1;
   WIDE_T(3);
   __syncthreads();
@@ -1648,10 +1665,9 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
           const uint32_t de = (side && both[p]) ? p_eid[p] : fe[p].eid;
           const double dsal = -((side && both[p]) ? p_mean[p] : fe[p].mean);
           const uint32_t dc = win_cell(dsal, smin, scale, st.wB);
-          unsigned long long dq = 1;
-          if ((int)dc == cthr && dsal == tsal) dq = st.er[de].seq;         // tie with tau: the seq decides
+          const bool tie = (int)dc == cthr && dsal == tsal;                // (no look at the record's seq: see batch_contract_wide)
           st.er[de].seq = 0;
-          if (win_above(cthr, tsal, tseq, (int)dc, dsal, dq)) {
+          if (tie || win_above(cthr, tsal, tseq, (int)dc, dsal, 0ull)) {
             const uint32_t j = atomicAdd(&b.nkill, 1u); if (j < kBatchKill) b.kill[j] = de; else b.kovf = 1;
           } else if (dc >= st.wch) atomicSub(&st.wcnt[dc], 1u);
         }
