@@ -1199,7 +1199,17 @@ struct BatchShared {
 };
 
 // one pass over the window: applies the deaths of the last round, leaves every wave's best and second-best item
+#ifdef GLIA_HMT_PROFILE
+__device__ unsigned long long g_scanprof[8];
+#define SCAN_T(i) do { if (tid == 0) { const unsigned long long tn_ = __builtin_readcyclecounter(); g_scanprof[i] += tn_ - st_; st_ = tn_; } } while (0)
+#else
+#define SCAN_T(i) do {} while (0)
+#endif
 __device__ __forceinline__ void batch_scan(const WinState& st, WinShared& w, BatchShared& b, int tid) {
+#ifdef GLIA_HMT_PROFILE
+  unsigned long long st_ = __builtin_readcyclecounter();
+  if (tid == 0) g_scanprof[7] += 1;
+#endif
   const uint32_t n = w.n < st.wcap ? w.n : st.wcap, nk = b.nkill < kBatchKill ? b.nkill : kBatchKill, kovf = b.kovf;
   // Slot ownership is STRIPED over the waves (lane l of wave v scans the l-th slot of chunk (v + l) mod 8 in every block
   // of 512): a reload fills consecutive slots with consecutive keys, and the exact top of the queue is only as long as
@@ -1212,26 +1222,53 @@ __device__ __forceinline__ void batch_scan(const WinState& st, WinShared& w, Bat
   const uint32_t kl[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
   Key k1, k2;
   k1.sal = -__builtin_inf(); k1.seq = 0; k1.arg = 0; k2 = k1;
+  SCAN_T(0);
+  // deaths: branch-free for the first eight (a short-circuit || / && chain compiles to one branch per term), a uniform
+  // loop over the rest of the list, and -- only when the list overflowed -- a look at the edge records
+  uint32_t deadm[kWinPer];
+#pragma unroll
+  for (int j = 0; j < kWinPer; ++j) {
+    uint32_t d = 0;
+#pragma unroll
+    for (uint32_t t = 0; t < 8; ++t) d |= (uint32_t)(t < nk) & (uint32_t)(kl[t] == e[j]);
+    deadm[j] = d;
+  }
+  if (nk > 8u) {                                                         // (uniform)
+    for (uint32_t t = 8; t < nk; ++t) {
+      const uint32_t kt = b.kill[t];
+#pragma unroll
+      for (int j = 0; j < kWinPer; ++j) deadm[j] |= (uint32_t)(kt == e[j]);
+    }
+    if (kovf) {                                                          // more deaths than the list holds (rare): ask the edge records
+#pragma unroll
+      for (int j = 0; j < kWinPer; ++j) {
+        const uint32_t i = own + (uint32_t)j * kGreedyThreads;
+        if (i < n && q[j] != 0) deadm[j] |= (uint32_t)(st.er[e[j]].seq == 0);
+      }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < kWinPer; ++j) {
     const uint32_t i = own + (uint32_t)j * kGreedyThreads;
-    bool live = i < n && q[j] != 0;
-    bool dead = false;
-#pragma unroll
-    for (uint32_t t = 0; t < 8; ++t) dead = dead || (t < nk && kl[t] == e[j]);
-    if (nk > 8u && live) {
-      for (uint32_t t = 8; t < nk; ++t) dead = dead || b.kill[t] == e[j];
-      if (kovf) dead = dead || st.er[e[j]].seq == 0;        // more deaths than the list holds (rare): ask the edge record
-    }
-    if (live && dead) { w.seq[i] = 0; live = false; }
+    const bool was = (i < n) & (q[j] != 0);
+    const bool live = was & (deadm[j] == 0u);
+    if (was & !live) w.seq[i] = 0;
     Key c; c.sal = live ? sl[j] : -__builtin_inf(); c.seq = live ? q[j] : 0ull; c.arg = i;
-    if (better(c, k1)) { k2 = k1; k1 = c; } else if (better(c, k2)) k2 = c;
+    const bool b1 = better(c, k1), b2 = better(c, k2);
+    // new best: the old best becomes second; else new second if it beats the old second (field by field: selecting whole
+    // structs goes through private memory)
+    k2.sal = b1 ? k1.sal : (b2 ? c.sal : k2.sal); k2.seq = b1 ? k1.seq : (b2 ? c.seq : k2.seq); k2.arg = b1 ? k1.arg : (b2 ? c.arg : k2.arg);
+    k1.sal = b1 ? c.sal : k1.sal; k1.seq = b1 ? c.seq : k1.seq; k1.arg = b1 ? c.arg : k1.arg;
   }
+  SCAN_T(1);
   const Key m1 = wave_max(k1);
+  SCAN_T(2);
   const bool mine = k1.seq == m1.seq && k1.arg == m1.arg && m1.seq != 0;
   const Key m2 = wave_max(mine ? k2 : k1);
+  SCAN_T(3);
   if ((tid & 63) == 0) { b.part1[tid >> 6] = m1; b.part2[tid >> 6] = m2; }
   __syncthreads();
+  SCAN_T(4);
   if (tid == 0) { b.nkill = 0; b.kovf = 0; }
 }
 
@@ -1686,6 +1723,8 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
 #ifdef GLIA_HMT_PROFILE
   if (tid == 0) printf("[batch profile] merges %llu: select %llu  compute %llu  validate %llu  commit %llu  scan %llu  loop-top %llu  reload %llu (cycles); rounds %llu candidates %llu committed %llu (cut by saliency %llu, by adjacency %llu) wide %llu\n",
                        k, bph[0], bph[1], bph[2], bph[3], bph[4], bph[5], bph[6], brounds, bmembers, bvalid, bcut_sal, bcut_dep, bwide);
+  if (tid == 0) printf("[batch profile] scan phases (cumulative cycles, wave 0): loads %llu  compare %llu  max1 %llu  max2 %llu  barrier %llu  calls %llu\n",
+                       g_scanprof[0], g_scanprof[1], g_scanprof[2], g_scanprof[3], g_scanprof[4], g_scanprof[7]);
   if (tid == 0) printf("[batch profile] wide phases (cumulative cycles): entry-barrier %llu  lists+table %llu  compact %llu  main loop (wave 0) %llu  loop barrier %llu  tail %llu\n",
                        g_wideprof[0], g_wideprof[1], g_wideprof[2], g_wideprof[3], g_wideprof[4], g_wideprof[5]);
   if (tid == 0) printf("[batch profile] wide by entries (<=512, <=1408, <=8192, more): n %llu %llu %llu %llu  cycles %llu %llu %llu %llu  entries %llu %llu %llu %llu  new edges %llu %llu %llu %llu\n",
