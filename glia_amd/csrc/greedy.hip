@@ -1261,10 +1261,11 @@ __device__ __forceinline__ void batch_scan(const WinState& st, WinShared& w, Bat
     k1.sal = b1 ? c.sal : k1.sal; k1.seq = b1 ? c.seq : k1.seq; k1.arg = b1 ? c.arg : k1.arg;
   }
   SCAN_T(1);
-  const Key m1 = wave_max(k1);
+  const Key m1 = wave_max_sal_first(k1);
   SCAN_T(2);
-  const bool mine = k1.seq == m1.seq && k1.arg == m1.arg && m1.seq != 0;
-  const Key m2 = wave_max(mine ? k2 : k1);
+  const bool mine = (k1.seq == m1.seq) & (k1.arg == m1.arg) & (m1.seq != 0);
+  Key kk; kk.sal = mine ? k2.sal : k1.sal; kk.seq = mine ? k2.seq : k1.seq; kk.arg = mine ? k2.arg : k1.arg;
+  const Key m2 = wave_max_sal_first(kk);
   SCAN_T(3);
   if ((tid & 63) == 0) { b.part1[tid >> 6] = m1; b.part2[tid >> 6] = m2; }
   __syncthreads();

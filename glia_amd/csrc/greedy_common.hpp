@@ -76,6 +76,46 @@ __device__ __forceinline__ Key wave_max(Key k) {
   return out;
 }
 
+// The same maximum, cheaper when saliency ties inside a wave are uncommon: reduce the order-preserving integer image of the
+// saliency alone (two DPP moves, one 64-bit compare and two selects per step instead of five moves, three compares and five
+// selects), then fetch the winner's seq and arg with v_readlane; only if several lanes share the largest saliency a
+// second reduction over their seq decides.  Same result as wave_max for keys whose (sal, seq) pairs are distinct or empty.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ void u64_max_step(unsigned long long& v) {
+  const uint32_t lo = dpp_u32<CTRL, ROW_MASK>((uint32_t)v), hi = dpp_u32<CTRL, ROW_MASK>((uint32_t)(v >> 32));
+  const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+  v = o > v ? o : v;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+  u64_max_step<0xB1>(v);
+  u64_max_step<0x4E>(v);
+  u64_max_step<0x124>(v);
+  u64_max_step<0x128>(v);
+  u64_max_step<0x142, 0xa>(v);
+  u64_max_step<0x143, 0xc>(v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ Key wave_max_sal_first(const Key& k) {
+  unsigned long long ord = (unsigned long long)__double_as_longlong(k.sal);
+  ord ^= (ord >> 63) ? ~0ull : 0x8000000000000000ull;                   // ascending doubles <-> ascending integers
+  const unsigned long long m = wave_max_u64(ord);
+  unsigned long long tied = __ballot(ord == m);
+  if (__popcll(tied) > 1) {                                              // (uniform) equal saliencies: the largest seq among them
+    const unsigned long long ms = wave_max_u64(ord == m ? k.seq : 0ull);
+    tied = __ballot((ord == m) & (k.seq == ms));
+  }
+  const int src = (int)__builtin_ctzll(tied);                            // (at least one lane holds the maximum)
+  const unsigned long long sb = (unsigned long long)__double_as_longlong(k.sal);
+  Key out;
+  const uint32_t s_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)sb, src), s_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(sb >> 32), src);
+  const uint32_t q_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k.seq, src), q_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(k.seq >> 32), src);
+  out.sal = __longlong_as_double((long long)(((unsigned long long)s_hi << 32) | s_lo));
+  out.seq = ((unsigned long long)q_hi << 32) | q_lo;
+  out.arg = (uint32_t)__builtin_amdgcn_readlane((int)k.arg, src);
+  return out;
+}
+
 
 // The tree: level 0 nodes are the parents of the leaves (edge slots); the last stored level (<= kTopMax nodes) has no
 // stored parent -- pq_top() reduces it with the whole workgroup into PqWork::part (LDS), from where pop reads the root.
