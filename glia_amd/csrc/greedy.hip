@@ -1186,7 +1186,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(WinState 
 // =====================================================================================================================
 constexpr uint32_t kBatchKill = 32;
 constexpr int kMemP = 3;                   // list entries per lane of a batch member ...
-constexpr uint32_t kMemMax = 160;          // ... and their limit (the wave's 256-slot neighbour table stays under 2/3 full)
+constexpr uint32_t kMemMax = 192;          // ... and their limit (the wave's 256-slot neighbour table stays under 3/4 full)
 struct BatchShared {
   alignas(16) Key part1[kNW];               // per-wave best / second-best of the last scan
   alignas(16) Key part2[kNW];

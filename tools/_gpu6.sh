@@ -1,4 +1,8 @@
-cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r02r
-timeout -k 10 1100 python -m pytest tests -x -q -m gpu > gpurun_out/r02r/pytest.log 2>&1; tail -4 gpurun_out/r02r/pytest.log
-timeout -k 10 500 python bench.py --steps 5 --warmup 1 > gpurun_out/r02r/bench.json 2> gpurun_out/r02r/bench.err; tail -c 1500 gpurun_out/r02r/bench.json
+set -e
+OUT=gpurun_out/r02f
+mkdir -p $OUT
+timeout -k 10 300 python tools/step_breakdown.py 1024 16 > $OUT/step_breakdown.txt 2>&1
+grep -v amdgpu $OUT/step_breakdown.txt
+timeout -k 10 500 python bench.py --steps 3 --warmup 1 --no-bc --cpu-curve '' > $OUT/bench_nobc.json 2> $OUT/bench.err
+python -c "
+import json; d=json.load(open('$OUT/bench_nobc.json')); print(d['value'], d['ms_per_step'], d['phases_ms'])"
