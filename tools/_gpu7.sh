@@ -1,4 +1,5 @@
-cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r02n
-timeout -k 10 600 python -m pytest tests/test_gpu_rag.py -x -q -m gpu > gpurun_out/r02n/pytest.log 2>&1; tail -12 gpurun_out/r02n/pytest.log
-timeout -k 10 400 python bench.py --steps 1 --warmup 0 --no-cpu --no-bc --force-slab --size 512 > gpurun_out/r02n/bench_slab.json 2> gpurun_out/r02n/bench_slab.err; tail -c 1200 gpurun_out/r02n/bench_slab.json; tail -5 gpurun_out/r02n/bench_slab.err
+set -e
+OUT=gpurun_out/r02g
+mkdir -p $OUT
+GLIA_HMT_LIB=$GRAFT_REPO_ROOT/glia_amd/libglia_hmt_prof.so timeout -k 10 300 python tools/bc_bench.py 512 16 > $OUT/bc512_prof.txt 2>&1
+grep "bc profile\|merges/s" $OUT/bc512_prof.txt | tail -8

@@ -4,7 +4,7 @@ TAG=${1:-r02a}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 500 python bench.py --steps 3 --warmup 1 > $OUT/bench1024.json 2> $OUT/bench1024.err
+timeout -k 10 500 python bench.py --steps 5 --warmup 1 > $OUT/bench1024.json 2> $OUT/bench1024.err
 echo bench done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-bc > $OUT/prof_bench.log 2>&1
 echo stats done
@@ -15,3 +15,5 @@ GLIA_PB_HASH=1 timeout -k 10 200 python tools/pb_bench.py 1024 16 2 > $OUT/pb102
 GLIA_PB_HASH=1 timeout -k 10 200 python tools/pb_bench.py 512 16 2 > $OUT/pb512_hash.txt 2>&1
 timeout -k 10 200 python tools/bc_bench.py 512 16 > $OUT/bc512.txt 2>&1
 echo loops done
+timeout -k 10 300 python tools/e2e_bench.py > $OUT/e2e_2048x2048x512.txt 2>&1
+echo e2e done
