@@ -94,6 +94,20 @@ static LibmSel probe_host_libm() {
 
 }  // namespace glia
 
+namespace glia {
+int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& clf, hipStream_t stream, uint32_t* h_order,
+              double* h_sal, double* h_feats, int64_t capacity, int64_t* n_merges, double* ms_table, double* ms_init,
+              double* ms_loop, int64_t* n_scored, bool init_only, const uint32_t* h_forced, int64_t n_forced, int shard,
+              int n_shards, double* h_scores) {
+  auto* fn = &greedy_bc_generic;
+  if (cfg.libm_log2 == kLibmSse2 && cfg.libm_log == kLibmFma && cfg.libm_pow == kLibmFma) fn = &greedy_bc_fma;
+  else if (cfg.libm_log2 == kLibmSse2 && cfg.libm_log == kLibmSse2 && cfg.libm_pow == kLibmSse2) fn = &greedy_bc_sse2;
+  if (getenv("GLIA_HMT_BC_GENERIC")) fn = &greedy_bc_generic;       // tests: the run-time-dispatch instance
+  return fn(rag, cfg, clf, stream, h_order, h_sal, h_feats, capacity, n_merges, ms_table, ms_init, ms_loop, n_scored, init_only,
+            h_forced, n_forced, shard, n_shards, h_scores);
+}
+}  // namespace glia
+
 using namespace glia;
 
 struct glia_hmt_ctx {

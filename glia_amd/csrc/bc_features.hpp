@@ -99,10 +99,21 @@ __host__ __device__ inline int bc_feat_dim(const BcCfg& c) {
 namespace feat {
 
 __device__ inline double sdiv(double l, double r, double d) { return fabs(r) >= 2.22e-16 ? l / r : d; }
-// std::log2 / std::log as the HOST libm computes them (glibc_math.hpp); variant 0 = device libm (<= 1 ulp off, unpinned)
-__device__ __forceinline__ double host_log2(double x, int variant) { return variant == kLibmSse2 ? glibc::log2_sse2(x) : log2(x); }
+// std::log2 / std::log as the HOST libm computes them (glibc_math.hpp); variant 0 = device libm (<= 1 ulp off, unpinned).
+// GLIA_LIBM_FIXED = log2 | log << 4 | pow << 8 fixes the variants at compile time (hmt_internal.hpp: greedy_bc instances).
+#ifdef GLIA_LIBM_FIXED
+#define GLIA_LIBM_SEL(run_time, shift) (((GLIA_LIBM_FIXED) >> (shift)) & 15)
+#else
+#define GLIA_LIBM_SEL(run_time, shift) (run_time)
+#endif
+__device__ __forceinline__ double host_log2(double x, int variant) { return GLIA_LIBM_SEL(variant, 0) == kLibmSse2 ? glibc::log2_sse2(x) : log2(x); }
+// the same with the glibc tables taken from `tab` (a kernel's LDS copy: kLog2Head | kLog2Tab | kLog2Tab2)
+__device__ __forceinline__ double host_log2(double x, int variant, const uint64_t* tab) {
+  return GLIA_LIBM_SEL(variant, 0) == kLibmSse2 ? glibc::log2_sse2_tab(x, tab, tab + 18, tab + 18 + 128) : log2(x);
+}
 __device__ __forceinline__ double host_log(double x, int variant) {
-  return variant == kLibmFma ? glibc::log_fma(x) : variant == kLibmSse2 ? glibc::log_sse2(x) : log(x);
+  const int v = GLIA_LIBM_SEL(variant, 4);
+  return v == kLibmFma ? glibc::log_fma(x) : v == kLibmSse2 ? glibc::log_sse2(x) : log(x);
 }
 __device__ inline double slog(double x, double d, int variant) { return x > 0.0 ? host_log(x, variant) : d; }
 __device__ inline double ssqrt(double x, double d) { return x >= 0.0 ? sqrt(x) : d; }
@@ -115,8 +126,9 @@ __device__ inline double ssqrt(double x, double d) { return x >= 0.0 ? sqrt(x) :
 __device__ inline double pow_perim(double x, int D, int variant) {
   if (D == 2) return x * x;
   if (!(x > 0.0)) return 0.0;
-  if (variant == kLibmFma) return glibc::pow_fma(x, 1.5);
-  if (variant == kLibmSse2) return glibc::pow_sse2(x, 1.5);
+  const int v = GLIA_LIBM_SEL(variant, 8);
+  if (v == kLibmFma) return glibc::pow_fma(x, 1.5);
+  if (v == kLibmSse2) return glibc::pow_sse2(x, 1.5);
   const double s = sqrt(x);                       // correctly rounded
   const double r = __builtin_fma(-s, s, x);       // x - s*s, exact
   const double sl = r / (2.0 * s);                // sqrt(x) = s + sl (+ O(ulp^2))
@@ -178,6 +190,12 @@ __device__ __forceinline__ ImgFeats image_feats_src(const ImgSrc& s, int bins, i
 __device__ __forceinline__ double entropy_term(uint32_t cnt, uint32_t n, int libm_log2) {
   const double p = n ? cnt / (double)n : 0.0;
   return (fabs(p - 0.0) < 2.22e-16) ? 0.0 : p * host_log2(p, libm_log2);
+}
+// ... for the greedy loop: tables from LDS, and a full bin (p == 1: log2 is +0, the term 0.0) answered without the call -- one
+// lane with p near 1 sends its whole wave through the near-one polynomial AND the table path of the restatement
+__device__ __forceinline__ double entropy_term(uint32_t cnt, uint32_t n, int libm_log2, const uint64_t* tab) {
+  const double p = n ? cnt / (double)n : 0.0;
+  return ((fabs(p - 0.0) < 2.22e-16) | (cnt == n)) ? 0.0 : p * host_log2(p, libm_log2, tab);
 }
 __device__ __forceinline__ void dist_terms(uint32_t c0, uint32_t n0, uint32_t c1, uint32_t n1, double& tl, double& tx) {
   const double p0 = n0 ? c0 / (double)n0 : 0.0, p1 = n1 ? c1 / (double)n1 : 0.0;

@@ -29,6 +29,13 @@ namespace glibc {
 #include "glibc_tables.inc"
 #undef GLIBC_TABLE_QUALIFIER
 
+// On the device the restatements are real functions (one copy each): inlined at every call site of a large kernel they cost
+// more in code size and registers than the calls do (greedy_bc.hip: -8 % loop time with ~40 inlined copies).
+#ifdef __HIP_DEVICE_COMPILE__
+#define GLIBC_FN __host__ __device__ __noinline__
+#else
+#define GLIBC_FN __host__ __device__ inline
+#endif
 __host__ __device__ __forceinline__ double as_f64(uint64_t u) { return __builtin_bit_cast(double, u); }
 __host__ __device__ __forceinline__ uint64_t as_u64(double d) { return __builtin_bit_cast(uint64_t, d); }
 
@@ -42,8 +49,8 @@ __host__ __device__ inline double special(double x) {
 }
 
 // ---- log2, glibc 2.35 x86-64 (function at libm.so.6 + 0x2f6b0) --------------------------------------------------
-__host__ __device__ inline double log2_sse2(double x) {
-  const uint64_t* H = kLog2Head;      // invln2hi, invln2lo, A[0..5], B[0..9]
+// (the tables are parameters so that a kernel can keep a copy in LDS: H = kLog2Head, T = kLog2Tab, T2 = kLog2Tab2)
+GLIBC_FN double log2_sse2_tab(double x, const uint64_t* H, const uint64_t* T, const uint64_t* T2) {
   uint64_t ix = as_u64(x);
   const uint32_t top = (uint32_t)(ix >> 48);
   const uint64_t LO = 0x3feea4af00000000ull /* 1 - 0x1.5b51p-5 */, HI = 0x3ff0b55900000000ull /* 1 + 0x1.6ab2p-5 */;
@@ -75,8 +82,8 @@ __host__ __device__ inline double log2_sse2(double x) {
   const int i = (int)((tmp >> (52 - 6)) & 63);
   const int k = (int)((int64_t)tmp >> 52);
   const uint64_t iz = ix - (tmp & (0xfffull << 52));
-  const double invc = as_f64(kLog2Tab[2 * i]), logc = as_f64(kLog2Tab[2 * i + 1]);
-  const double chi = as_f64(kLog2Tab2[2 * i]), clo = as_f64(kLog2Tab2[2 * i + 1]);
+  const double invc = as_f64(T[2 * i]), logc = as_f64(T[2 * i + 1]);
+  const double chi = as_f64(T2[2 * i]), clo = as_f64(T2[2 * i + 1]);
   const double z = as_f64(iz), kd = (double)k;
   const double r = ((z - chi) - clo) * invc;
   const double rhi = as_f64(as_u64(r) & 0xffffffff00000000ull);
@@ -92,6 +99,8 @@ __host__ __device__ inline double log2_sse2(double x) {
 #undef A_
   return (lo + r2 * p) + hi;
 }
+__host__ __device__ inline double log2_sse2(double x) { return log2_sse2_tab(x, kLog2Head, kLog2Tab, kLog2Tab2); }
+constexpr int kLog2TabWords = 18 + 128 + 128;       // H | T | T2 in one array (LDS copy)
 
 // ---- log, glibc 2.35 x86-64: common range reduction ---------------------------------------------------------------
 struct LogArgs { double z, kd, invc, logc, chi, clo; };
@@ -115,7 +124,7 @@ __host__ __device__ inline bool log_reduce(double x, uint64_t ix, LogArgs& a, do
 constexpr uint64_t kLogLo = 0x3fee000000000000ull /* 1 - 0x1p-4 */, kLogHi = 0x3ff1090000000000ull /* 1 + 0x1.09p-4 */;
 
 // __log_sse2 (libm.so.6 + 0x29200; __log_avx is the same sequence VEX-encoded)
-__host__ __device__ inline double log_sse2(double x) {
+GLIBC_FN double log_sse2(double x) {
   const uint64_t ix = as_u64(x);
   if (ix - kLogLo < kLogHi - kLogLo) {
     if (ix == 0x3ff0000000000000ull) return 0.0;
@@ -148,7 +157,7 @@ __host__ __device__ inline double log_sse2(double x) {
 }
 
 // __log_fma (libm.so.6 + 0x76660): the __FP_FAST_FMA source path, with the contractions gcc made
-__host__ __device__ inline double log_fma(double x) {
+GLIBC_FN double log_fma(double x) {
   const uint64_t ix = as_u64(x);
   if (ix - kLogLo < kLogHi - kLogLo) {
     if (ix == 0x3ff0000000000000ull) return 0.0;
@@ -224,7 +233,7 @@ __host__ __device__ inline bool pow_in_domain(double x, double y) {
   const uint32_t tx = (uint32_t)(ix >> 52), ty = (uint32_t)(iy >> 52) & 0x7ff;
   return tx - 1u < 0x7feu && ty - 0x3beu < 0x43eu - 0x3beu;
 }
-__host__ __device__ inline double pow_fma(double x, double y) {
+GLIBC_FN double pow_fma(double x, double y) {
   const uint64_t ix = as_u64(x);
   const uint64_t tmp = ix - kPowOff;
   const int i = (int)((tmp >> (52 - 7)) & 127);
@@ -251,7 +260,7 @@ __host__ __device__ inline double pow_fma(double x, double y) {
   if (((as_u64(ehi) >> 52) & 0x7ff) - 0x3c9u >= 0x3fu) return ehi == 0.0 || ((as_u64(ehi) >> 52) & 0x7ff) < 0x3c9u ? 1.0 : __builtin_nan("");
   return pow_exp_fma_tail(ehi, elo, true);
 }
-__host__ __device__ inline double pow_sse2(double x, double y) {
+GLIBC_FN double pow_sse2(double x, double y) {
   const uint64_t ix = as_u64(x), iy = as_u64(y);
   const uint64_t tmp = ix - kPowOff;
   const int i = (int)((tmp >> (52 - 7)) & 127);

@@ -419,6 +419,7 @@ struct BcShared {
   int model[2][kChunk];          // [job parity]: a job's models are needed again when its votes come back
   uint32_t nlog;                 // slots of the full vector that take a logarithm
   uint32_t lost;                 // a helper did not answer in time
+  alignas(16) uint64_t log2tab[glibc::kLog2TabWords];   // glibc's log2 tables (glibc_math.hpp): head | tab | tab2
   uint16_t logpos[feat::kMaxLogSlots];
   PqWork pq;
   __attribute__((aligned(16))) unsigned char pool[kPoolBytes];
@@ -526,6 +527,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
   const int K = st.cfg.K;
   const BcLayout L = bc_layout(st.cfg, s.pool);
   if (tid == 0) { s.pq.wln[0] = s.pq.wln[1] = 0; s.pq.ovf = 0; s.pq.spill = 0; s.lost = 0; s.nlog = (uint32_t)feat::log_slots(st.cfg, s.logpos); }
+  for (int i = tid; i < glibc::kLog2TabWords; i += blockDim.x) s.log2tab[i] = i < 18 ? glibc::kLog2Head[i] : i < 18 + 128 ? glibc::kLog2Tab[i - 18] : glibc::kLog2Tab2[i - 18 - 128];
   for (int i = tid; i < kSetSlots; i += blockDim.x) { s.pq.set[0][i] = 0; s.pq.set[1][i] = 0; }
   __syncthreads();
   pq_top<kBcThreads>(st.pq, s.pq, tid);      // the root lives in LDS: rebuilt at every launch
@@ -941,8 +943,14 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
               const PStats* P0 = &st.ch[cc].pts[rs]; const PStats* P1 = &st.ch[cc].pts[r2];
               const uint32_t h0 = P0->hist[l16], h1 = P1->hist[l16], pn0 = P0->n, pn1 = P1->n;     // unconditional loads
               if (on && (int)l16 < bins) {
-                t0 = feat::entropy_term(h0, pn0, cf.libm_log2); t1 = feat::entropy_term(h1, pn1, cf.libm_log2);
-                t2 = feat::entropy_term(h0 + h1, pn0 + pn1, cf.libm_log2);
+                // (one inlined copy of the logarithm per loop, not one per term: seven copies of the glibc restatement cost
+                // the loop 8 % through register pressure alone)
+#pragma unroll 1
+                for (int q = 0; q < 3; ++q) {
+                  const uint32_t cq = q == 0 ? h0 : q == 1 ? h1 : h0 + h1, nq = q == 0 ? pn0 : q == 1 ? pn1 : pn0 + pn1;
+                  const double t = feat::entropy_term(cq, nq, cf.libm_log2, s.log2tab);
+                  t0 = q == 0 ? t : t0; t1 = q == 1 ? t : t1; t2 = q == 2 ? t : t2;
+                }
                 feat::dist_terms(h0, pn0, h1, pn1, tl, tx);
               }
               const double e0 = bin_sum(t0, bins, true), e1 = bin_sum(t1, bins, true), e2 = bin_sum(t2, bins, true);
@@ -959,9 +967,14 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
             const EStats* sh = &L.shs[j * K + cc];
             const uint32_t g0 = B0->hist[l16], g1 = B1->hist[l16], ga = A->hist[l16], bn0 = B0->n, bn1 = B1->n, an = A->n;
             if (on && (int)l16 < bins) {
-              t0 = feat::entropy_term(g0, bn0, cf.libm_log2); t1 = feat::entropy_term(g1, bn1, cf.libm_log2);
-              t2 = feat::entropy_term(g0 + g1 - ga, bn0 + bn1 - an, cf.libm_log2);
-              t3 = feat::entropy_term(sh->hist[l16], sh->n, cf.libm_log2);
+              const uint32_t gs = sh->hist[l16], sn = sh->n;
+#pragma unroll 1
+              for (int q = 0; q < 4; ++q) {
+                const uint32_t cq = q == 0 ? g0 : q == 1 ? g1 : q == 2 ? g0 + g1 - ga : gs;
+                const uint32_t nq = q == 0 ? bn0 : q == 1 ? bn1 : q == 2 ? bn0 + bn1 - an : sn;
+                const double t = feat::entropy_term(cq, nq, cf.libm_log2, s.log2tab);
+                t0 = q == 0 ? t : t0; t1 = q == 1 ? t : t1; t2 = q == 2 ? t : t2; t3 = q == 3 ? t : t3;
+              }
             }
             const double e0 = bin_sum(t0, bins, true), e1 = bin_sum(t1, bins, true), e2 = bin_sum(t2, bins, true), e3 = bin_sum(t3, bins, true);
             if ((int)l16 == bins - 1) { double* q = fx + feat::pre_boundary(cf, i); q[0] = e0; q[1] = e1; q[2] = e2; q[3] = e3; }
@@ -1061,6 +1074,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
 }  // namespace
 
 // first voxel index of every leaf (the accumulation pass records its complement, R_FIRST) as a sort key
+namespace {
 __global__ void bc_first_keys(const uint32_t* rrec, uint32_t R, unsigned long long* keys, uint32_t* leaf) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= R) return;
@@ -1068,8 +1082,12 @@ __global__ void bc_first_keys(const uint32_t* rrec, uint32_t R, unsigned long lo
   keys[i] = ~(((unsigned long long)f.y << 32) | f.x);
   leaf[i] = i;
 }
+}  // namespace
 
-int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& clf, hipStream_t stream,
+#ifndef GLIA_BC_ENTRY
+#define GLIA_BC_ENTRY greedy_bc_generic        // (see hmt_internal.hpp: the Makefile builds two more instances with GLIA_LIBM_FIXED)
+#endif
+int GLIA_BC_ENTRY(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& clf, hipStream_t stream,
               uint32_t* h_order, double* h_sal, double* h_feats, int64_t capacity, int64_t* n_merges,
               double* ms_table, double* ms_init, double* ms_loop, int64_t* n_scored, bool init_only,
               const uint32_t* h_forced, int64_t n_forced, int shard, int n_shards, double* h_scores) {

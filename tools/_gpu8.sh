@@ -1,3 +1,9 @@
-cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r02o
-timeout -k 10 900 python -m pytest tests/test_gpu_bc.py tests/test_gpu_cli.py tests/test_gpu_golden.py -x -q -m gpu > gpurun_out/r02o/pytest.log 2>&1; tail -12 gpurun_out/r02o/pytest.log
+set -e
+OUT=gpurun_out/r02i
+mkdir -p $OUT
+timeout -k 10 300 python -m cProfile -o $OUT/bench.prof bench.py --steps 4 --warmup 1 --no-bc --no-cpu --cpu-curve '' > $OUT/bench.json 2> $OUT/bench.err
+python - <<'P' > $OUT/prof.txt
+import pstats
+p=pstats.Stats('gpurun_out/r02i/bench.prof'); p.sort_stats('cumulative').print_stats(35)
+P
+grep -v "^$" $OUT/prof.txt | head -60
