@@ -243,16 +243,24 @@ def main():
 
     def step():
         # K1-K3 accumulation (regions + directed pairs, all statistics) -> K4 compaction
+        t_a = time.time()
         rm = hmt.RegionMap(ctx, labels, pb=pb, only_contour=False, cfg=cfg)
         ms, by = rm.last_pass()
+        if os.environ.get("GLIA_BENCH_SYNC"):
+            torch.cuda.synchronize(); ctx.sync()
+        t_b = time.time()
         # K6 + K7: feature vector + forest score of every initial edge (TBoundaryTable::init, classifier linkage)
         n_edges, ms_score = rm.score_initial_edges(clf)
+        t_c = time.time()
         # K4b + K5: edge table + greedy merge loop (pb-mean linkage), R-1 contractions
         order, sal = rm.merge_order_pb(type=2)
+        t_d = time.time()
         tm = rm.last_merge_timing()
         info = dict(R=rm.num_regions, P=rm.num_pairs, merges=len(order), acc_ms=ms, acc_bytes=by, n_edges=n_edges,
                     ms_score=ms_score, feat_dim=rm.feat_dim(), **tm)
         rm.close()
+        t_e = time.time()
+        info["host_ms"] = dict(build=(t_b - t_a) * 1e3, score=(t_c - t_b) * 1e3, merge_order=(t_d - t_c) * 1e3, close=(t_e - t_d) * 1e3)
         return info
 
     for _ in range(args.warmup):
@@ -319,6 +327,7 @@ def main():
             "edge_features_per_sec": edges / dt,
             "phases_ms": {"accumulate": acc_ms, "edge_features_and_scores": score_ms,
                           "edge_table": sum(i["ms_table"] for i in infos) / len(infos), "merge_loop": loop_ms},
+            "host_call_ms": {k: sum(i["host_ms"][k] for i in infos) / len(infos) for k in infos[0]["host_ms"]},
             "merge_loop_merges_per_sec": infos[0]["merges"] / (loop_ms * 1e-3) if loop_ms else None,
             "edge_feature_kernel_per_sec": infos[0]["n_edges"] / (score_ms * 1e-3) if score_ms else None,
             "roofline": {"bound": "hbm", "kernel": "rag_accumulate_kernel", "achieved": achieved, "peak": 8000.0,

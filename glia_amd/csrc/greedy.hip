@@ -2215,8 +2215,8 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
   *n_scored = (int64_t)ctrl[1];
   if (n > capacity) { set_error("merge_order: output capacity too small"); return GLIA_HMT_ERR_CAPACITY; }
   if (n) {
-    GLIA_HIP_TRY(hipMemcpy(h_order, st.order, sizeof(uint32_t) * 3 * n, hipMemcpyDeviceToHost));
-    GLIA_HIP_TRY(hipMemcpy(h_sal, st.sal_out, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if ((rc = copy_to_host_staged(h_order, st.order, sizeof(uint32_t) * 3 * n))) return rc;
+    if ((rc = copy_to_host_staged(h_sal, st.sal_out, sizeof(double) * n))) return rc;
   }
   *n_merges = n;
   return GLIA_HMT_OK;

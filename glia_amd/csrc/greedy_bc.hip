@@ -25,6 +25,8 @@
 // records are built data-parallel, features are computed one thread per new edge into a workspace, and the
 // forest is evaluated with (edge, tree) pairs spread over the whole workgroup.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -1108,6 +1110,7 @@ int GLIA_BC_ENTRY(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier
 
   // reference region-map iteration order (rmap_order.cpp): leaves sorted by first voxel on the device, the hashtable replay on the host
   std::vector<uint32_t> lab(R), by_first(R), rank;
+  uint32_t* h_stage = nullptr;                // page-locked: [by_first | labels | rank]
   {
     unsigned long long* k0; unsigned long long* k1; uint32_t* v0; uint32_t* v1;
     if ((rc = buf.get(&k0, R, false, stream))) return rc;
@@ -1120,14 +1123,23 @@ int GLIA_BC_ENTRY(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier
     char* d_tmp;
     if ((rc = buf.get(&d_tmp, tmp ? tmp : 16, false, stream))) return rc;
     GLIA_HIP_TRY(rocprim::radix_sort_pairs((void*)d_tmp, tmp, k0, k1, v0, v1, (size_t)R, 0, 64, stream));
-    GLIA_HIP_TRY(hipMemcpyAsync(by_first.data(), v1, sizeof(uint32_t) * R, hipMemcpyDeviceToHost, stream));
-    GLIA_HIP_TRY(hipMemcpyAsync(lab.data(), rag.d_rlabel, sizeof(uint32_t) * R, hipMemcpyDeviceToHost, stream));
+    if ((rc = PinnedHost::mine().get((void**)&h_stage, sizeof(uint32_t) * 3 * (size_t)R))) return rc;
+    GLIA_HIP_TRY(hipMemcpyAsync(h_stage, v1, sizeof(uint32_t) * R, hipMemcpyDeviceToHost, stream));
+    GLIA_HIP_TRY(hipMemcpyAsync(h_stage + R, rag.d_rlabel, sizeof(uint32_t) * R, hipMemcpyDeviceToHost, stream));
     GLIA_HIP_TRY(hipStreamSynchronize(stream));
+    std::copy(h_stage, h_stage + R, by_first.begin());
+    std::copy(h_stage + R, h_stage + 2 * (size_t)R, lab.begin());
   }
+  const bool trace = getenv("GLIA_HMT_TRACE") != nullptr;
+  const auto tr0 = std::chrono::steady_clock::now();
+  auto tr_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count(); };
   rmap_ranks_ordered(lab, by_first, &rank);
+  if (trace) fprintf(stderr, "[trace] greedy_bc: region-map order replay %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count());
   uint32_t* d_rank;
   if ((rc = buf.get(&d_rank, R, false, stream))) return rc;
-  GLIA_HIP_TRY(hipMemcpyAsync(d_rank, rank.data(), sizeof(uint32_t) * R, hipMemcpyHostToDevice, stream));
+  std::copy(rank.begin(), rank.end(), h_stage + 2 * (size_t)R);
+  GLIA_HIP_TRY(hipMemcpyAsync(d_rank, h_stage + 2 * (size_t)R, sizeof(uint32_t) * R, hipMemcpyHostToDevice, stream));
+  if (trace) { fprintf(stderr, "[trace] greedy_bc: rank upload queued at %.2f ms\n", tr_ms()); (void)hipStreamSynchronize(stream); fprintf(stderr, "[trace] greedy_bc: rank upload done at %.2f ms\n", tr_ms()); }
 
   if ((rc = buf.get(&st.le_src, P, false, stream))) return rc;
   if ((rc = buf.get(&st.le_dst, P, false, stream))) return rc;
@@ -1140,6 +1152,7 @@ int GLIA_BC_ENTRY(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier
   if ((rc = buf.get(&partner, P, false, stream))) return rc;
   if ((rc = buf.get(&flag, P + 1, true, stream))) return rc;
   if ((rc = buf.get(&eidx, P + 1, false, stream))) return rc;
+  if (trace) { (void)hipStreamSynchronize(stream); fprintf(stderr, "[trace] greedy_bc: leaf buffers taken (and zeroed) at %.2f ms\n", tr_ms()); }
   const unsigned gP = (unsigned)((P + 255) / 256);
   for (int c = 0; c < cfg.K; ++c)
     hipLaunchKernelGGL(bc_leaf_entries, dim3(gP), dim3(256), 0, stream, st, c, rag.d_pa, rag.d_pb, rag.c_prec[c], rag.d_rlabel, partner,
@@ -1156,6 +1169,7 @@ int GLIA_BC_ENTRY(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier
   uint32_t E0 = 0;
   GLIA_HIP_TRY(hipMemcpyAsync(&E0, eidx + P, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   GLIA_HIP_TRY(hipStreamSynchronize(stream));
+  if (trace) fprintf(stderr, "[trace] greedy_bc: leaf entries + record flags done at %.2f ms\n", tr_ms());
   if (E0 == 0) return GLIA_HMT_OK;
 
   st.Ecap = (uint32_t)std::min<unsigned long long>(0xFFFFFF00ull, (unsigned long long)E0 * 6ull + (1u << 16));
@@ -1221,6 +1235,7 @@ int GLIA_BC_ENTRY(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier
   uint32_t* cursor;
   if ((rc = buf.get(&cursor, R2, true, stream))) return rc;
 
+  if (trace) fprintf(stderr, "[trace] greedy_bc: buffers taken at %.2f ms\n", tr_ms());
   hipLaunchKernelGGL(bc_init_dead, dim3((st.Ecap + 255) / 256), dim3(256), 0, stream, st, 0u);
   for (int c = 0; c < cfg.K; ++c) {
     hipLaunchKernelGGL(bc_leaf_regions, dim3((R + 255) / 256), dim3(256), 0, stream, st, c, rag.c_rrec[c], cfg.cbins[c]);
@@ -1249,6 +1264,8 @@ int GLIA_BC_ENTRY(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier
   GLIA_HIP_TRY(hipMemcpyAsync(st.ctrl, ctrl, sizeof(ctrl), hipMemcpyHostToDevice, stream));
   GLIA_HIP_TRY(hipEventRecord(ev[2], stream));
 
+  if (trace) fprintf(stderr, "[trace] greedy_bc: kernels launched at %.2f ms\n", tr_ms());
+  if (trace) { (void)hipStreamSynchronize(stream); fprintf(stderr, "[trace] greedy_bc: set-up + initial scores %.2f ms since the replay started; %zu of %zu device blocks (%.1f MB) were not in the block cache\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count(), buf.misses, buf.all.size(), (double)buf.miss_bytes / 1048576.0); }
   if (init_only) {     // features + scores of the initial table edges only (TBoundaryTable::init)
     uint32_t* d_cnt;
     if ((rc = buf.get(&d_cnt, 1, true, stream))) return rc;
@@ -1259,12 +1276,12 @@ int GLIA_BC_ENTRY(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier
     for (auto& e : ev) (void)hipEventDestroy(e);
     *ms_table = t01; *ms_init = t12; *ms_loop = 0;
     std::vector<uint8_t> tab(E0);
-    GLIA_HIP_TRY(hipMemcpy(tab.data(), st.e_table, E0, hipMemcpyDeviceToHost));
+    if ((rc = copy_to_host_staged(tab.data(), st.e_table, E0))) return rc;
     int64_t nt = 0;
     for (uint8_t t : tab) nt += t;
     *n_scored = nt;
     *n_merges = (int64_t)E0;            // init-only calls report the number of records here
-    if (h_scores) GLIA_HIP_TRY(hipMemcpy(h_scores, st.pq.leaf_sal, sizeof(double) * E0, hipMemcpyDeviceToHost));
+    if (h_scores && (rc = copy_to_host_staged(h_scores, st.pq.leaf_sal, sizeof(double) * E0))) return rc;
     return GLIA_HMT_OK;
   }
   st.max_iters = 1ull << 14;
@@ -1325,9 +1342,9 @@ int GLIA_BC_ENTRY(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier
   *n_scored = (int64_t)ctrl[1];
   if (n > capacity) { set_error("merge_order_bc: output capacity too small"); return GLIA_HMT_ERR_CAPACITY; }
   if (n) {
-    GLIA_HIP_TRY(hipMemcpy(h_order, st.order, sizeof(uint32_t) * 3 * n, hipMemcpyDeviceToHost));
-    GLIA_HIP_TRY(hipMemcpy(h_sal, st.sal_out, sizeof(double) * n, hipMemcpyDeviceToHost));
-    if (h_feats) GLIA_HIP_TRY(hipMemcpy(h_feats, st.feats_out, sizeof(double) * (size_t)n * cfg.fdim, hipMemcpyDeviceToHost));
+    if ((rc = copy_to_host_staged(h_order, st.order, sizeof(uint32_t) * 3 * n))) return rc;
+    if ((rc = copy_to_host_staged(h_sal, st.sal_out, sizeof(double) * n))) return rc;
+    if (h_feats && (rc = copy_to_host_staged(h_feats, st.feats_out, sizeof(double) * (size_t)n * cfg.fdim))) return rc;
   }
   *n_merges = n;
   return GLIA_HMT_OK;

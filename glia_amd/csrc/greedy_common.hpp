@@ -1,6 +1,7 @@
 // glia_amd/csrc/greedy_common.hpp -- pieces shared by the greedy merge kernels (pb-mean and classifier linkage):
 // the 64-ary tournament tree used as priority queue and small host helpers.
 #pragma once
+#include <cstring>
 #include <mutex>
 
 #include "hmt_internal.hpp"
@@ -394,6 +395,40 @@ inline __device__ double sdivide(double l, double r, double d) { return fabs(r) 
 // Device allocations owned by one call.  Freed blocks go to a small process-wide cache instead of back to the driver: a merge
 // order at 1024^3 allocates ~5 GB in a few dozen blocks, and hipMalloc / hipFree of that cost more than the edge table
 // and the feature kernel together (measured: ~80 ms of a 1.36 s step).  Every call ends synchronised, so a cached block is idle.
+// Page-locked staging memory for the few host <-> device copies of a call (one buffer per thread, grown on demand, never
+// freed): an asynchronous copy to or from pageable memory makes the runtime lock the pages first, which was measured at up to
+// 20 ms for 1 MB when the pages came fresh from the allocator.
+struct PinnedHost {
+  void* p = nullptr; size_t cap = 0;
+  int get(void** out, size_t bytes) {
+    if (bytes > cap) {
+      if (p) (void)hipHostFree(p);
+      p = nullptr; cap = 0;
+      const size_t want = bytes + bytes / 2 + 4096;
+      GLIA_HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+      cap = want;
+    }
+    *out = p;
+    return GLIA_HMT_OK;
+  }
+  static PinnedHost& mine() { static thread_local PinnedHost h; return h; }
+};
+// device -> caller's host buffer through the page-locked staging area, in pieces.  Copying straight into pageable memory makes
+// the runtime register those pages with the driver; when the caller frees them (a numpy array going out of scope), the
+// driver's invalidation of that registration stalls the process's GPU queues for ~20 ms -- measured in bench.py as "the next
+// call after a result array was freed is slow".
+inline int copy_to_host_staged(void* h_dst, const void* d_src, size_t bytes) {
+  constexpr size_t kPiece = 8u << 20;
+  char* stage = nullptr;
+  int rc = PinnedHost::mine().get((void**)&stage, bytes < kPiece ? bytes : kPiece);
+  if (rc) return rc;
+  for (size_t off = 0; off < bytes; off += kPiece) {
+    const size_t n = bytes - off < kPiece ? bytes - off : kPiece;
+    GLIA_HIP_TRY(hipMemcpy(stage, (const char*)d_src + off, n, hipMemcpyDeviceToHost));
+    memcpy((char*)h_dst + off, stage, n);
+  }
+  return GLIA_HMT_OK;
+}
 struct BlockCache {
   struct Block { void* p; size_t bytes; int device; };
   std::vector<Block> free_blocks;
@@ -425,12 +460,14 @@ struct DeviceBuffers {
   std::vector<void*> all;
   std::vector<size_t> sizes;
   int device = -1;
+  size_t misses = 0, miss_bytes = 0;         // allocations the block cache could not serve (GLIA_HMT_TRACE reports them)
   ~DeviceBuffers() { for (size_t i = 0; i < all.size(); ++i) BlockCache::get().give(all[i], sizes[i], device); }
   int raw(void** p, size_t bytes) {
     if (device < 0) GLIA_HIP_TRY(hipGetDevice(&device));
     bytes = (bytes + 255) & ~(size_t)255;
     void* q = BlockCache::get().take(bytes, device);
     if (!q) {
+      ++misses; miss_bytes += bytes;
       hipError_t e = hipMalloc(&q, bytes);
       if (e != hipSuccess) {                     // out of memory with blocks parked in the cache: release them and retry
         BlockCache& c = BlockCache::get();
