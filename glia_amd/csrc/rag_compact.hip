@@ -5,6 +5,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "hmt_internal.hpp"
+#include "greedy_common.hpp"
 
 namespace glia {
 namespace {
@@ -71,38 +72,35 @@ __global__ void decode_pair_keys(const unsigned long long* keys, uint32_t* a, ui
   }
 }
 
+// (scratch comes from the process-wide block cache, greedy_common.hpp: a hipMalloc / hipFree pair per temporary cost the
+// build several milliseconds and a device-wide synchronisation each)
 template <typename K>
-int sort_used(K* d_keys, uint32_t cap, K** d_sorted_keys, uint32_t** d_sorted_slots, int64_t* n_out,
+int sort_used(DeviceBuffers& buf, K* d_keys, uint32_t cap, K** d_sorted_keys, uint32_t** d_sorted_slots, int64_t* n_out,
               hipStream_t stream) {
+  int rc;
   uint32_t* d_counter = nullptr;
-  GLIA_HIP_TRY(hipMalloc(&d_counter, sizeof(uint32_t)));
-  GLIA_HIP_TRY(hipMemsetAsync(d_counter, 0, sizeof(uint32_t), stream));
+  if ((rc = buf.get(&d_counter, 1, true, stream))) return rc;
   K* d_k = nullptr;
   uint32_t* d_s = nullptr;
   // first pass only counts (outputs sized afterwards would need two passes; cap-sized scratch is fine here)
-  GLIA_HIP_TRY(hipMalloc(&d_k, sizeof(K) * (size_t)cap));
-  GLIA_HIP_TRY(hipMalloc(&d_s, sizeof(uint32_t) * (size_t)cap));
+  if ((rc = buf.get(&d_k, (size_t)cap, false, stream))) return rc;
+  if ((rc = buf.get(&d_s, (size_t)cap, false, stream))) return rc;
   hipLaunchKernelGGL(gather_used<K>, dim3((cap + kGatherIters * 256 - 1) / (kGatherIters * 256)), dim3(256), 0, stream, d_keys, cap, d_k, d_s,
                      d_counter);
   uint32_t n = 0;
   GLIA_HIP_TRY(hipMemcpyAsync(&n, d_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   GLIA_HIP_TRY(hipStreamSynchronize(stream));
-  GLIA_HIP_TRY(hipFree(d_counter));
   K* d_k2 = nullptr;
   uint32_t* d_s2 = nullptr;
-  GLIA_HIP_TRY(hipMalloc(&d_k2, sizeof(K) * (size_t)(n ? n : 1)));
-  GLIA_HIP_TRY(hipMalloc(&d_s2, sizeof(uint32_t) * (size_t)(n ? n : 1)));
+  if ((rc = buf.get(&d_k2, (size_t)(n ? n : 1), false, stream))) return rc;
+  if ((rc = buf.get(&d_s2, (size_t)(n ? n : 1), false, stream))) return rc;
   if (n) {
     size_t tmp_bytes = 0;
     GLIA_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_k, d_k2, d_s, d_s2, (size_t)n, 0, sizeof(K) * 8, stream));
-    void* d_tmp = nullptr;
-    GLIA_HIP_TRY(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
-    GLIA_HIP_TRY(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_k, d_k2, d_s, d_s2, (size_t)n, 0, sizeof(K) * 8, stream));
-    GLIA_HIP_TRY(hipStreamSynchronize(stream));
-    GLIA_HIP_TRY(hipFree(d_tmp));
+    char* d_tmp = nullptr;
+    if ((rc = buf.get(&d_tmp, tmp_bytes ? tmp_bytes : 16, false, stream))) return rc;
+    GLIA_HIP_TRY(rocprim::radix_sort_pairs((void*)d_tmp, tmp_bytes, d_k, d_k2, d_s, d_s2, (size_t)n, 0, sizeof(K) * 8, stream));
   }
-  GLIA_HIP_TRY(hipFree(d_k));
-  GLIA_HIP_TRY(hipFree(d_s));
   *d_sorted_keys = d_k2;
   *d_sorted_slots = d_s2;
   *n_out = n;
@@ -114,9 +112,10 @@ int sort_used(K* d_keys, uint32_t cap, K** d_sorted_keys, uint32_t** d_sorted_sl
 int compact_tables(const AccParams& p, uint32_t rcap, uint32_t pcap, RagArrays* out, hipStream_t stream) {
   uint32_t* d_rk = nullptr; uint32_t* d_rs = nullptr;
   unsigned long long* d_pk = nullptr; uint32_t* d_ps = nullptr;
-  int rc = sort_used<uint32_t>(p.rkeys, rcap, &d_rk, &d_rs, &out->R, stream);
+  DeviceBuffers buf;                               // (returns its blocks to the cache when this function ends: after the last sync)
+  int rc = sort_used<uint32_t>(buf, p.rkeys, rcap, &d_rk, &d_rs, &out->R, stream);
   if (rc) return rc;
-  rc = sort_used<unsigned long long>(p.pkeys, pcap, &d_pk, &d_ps, &out->P, stream);
+  rc = sort_used<unsigned long long>(buf, p.pkeys, pcap, &d_pk, &d_ps, &out->P, stream);
   if (rc) return rc;
   const int64_t R = out->R, P = out->P;
   GLIA_HIP_TRY(hipMalloc(&out->d_rlabel, sizeof(uint32_t) * (size_t)(R ? R : 1)));
@@ -136,8 +135,6 @@ int compact_tables(const AccParams& p, uint32_t rcap, uint32_t pcap, RagArrays* 
   }
   GLIA_HIP_TRY(hipGetLastError());
   GLIA_HIP_TRY(hipStreamSynchronize(stream));
-  GLIA_HIP_TRY(hipFree(d_rk)); GLIA_HIP_TRY(hipFree(d_rs));
-  GLIA_HIP_TRY(hipFree(d_pk)); GLIA_HIP_TRY(hipFree(d_ps));
   return GLIA_HMT_OK;
 }
 
