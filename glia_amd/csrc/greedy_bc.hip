@@ -526,7 +526,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
   unsigned long long k = st.ctrl[0], ne = st.ctrl[1], pool_used = st.ctrl[2];
   uint32_t status = ST_RUN;
   const int fdim = st.cfg.fdim;
-  const int K = st.cfg.K;
+  const int K = BC_K(st.cfg);
   const BcLayout L = bc_layout(st.cfg, s.pool);
   if (tid == 0) { s.pq.wln[0] = s.pq.wln[1] = 0; s.pq.ovf = 0; s.pq.spill = 0; s.lost = 0; s.nlog = (uint32_t)feat::log_slots(st.cfg, s.logpos); }
   for (int i = tid; i < glibc::kLog2TabWords; i += blockDim.x) s.log2tab[i] = i < 18 ? glibc::kLog2Head[i] : i < 18 + 128 ? glibc::kLog2Tab[i - 18] : glibc::kLog2Tab2[i - 18 - 128];
@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
         }
       }
       __syncthreads();
-      if (st.cfg.use_log) {
+      if (BC_LOG(st.cfg)) {
         // feat.hxx:46-52, 103-106: the logarithms, one (record, slot) pair per thread
         const uint32_t nlog = s.nlog;
         for (uint32_t i = tid; i < cn * nlog; i += kBcThreads) {

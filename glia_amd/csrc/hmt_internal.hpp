@@ -116,7 +116,7 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
                 bool size_weight = false);
 struct BcCfg;
 struct DeviceClassifier;
-// greedy_bc.hip is compiled three times: with the libm restatements of the feature code (glibc_math.hpp) selected at run time
+// greedy_bc.hip is compiled five times: with the libm restatements of the feature code (glibc_math.hpp) selected at run time
 // (any combination, incl. "unpinned"), and with the two combinations real hosts have -- glibc's FMA build and its non-FMA
 // build -- fixed at compile time (a run-time choice between three logarithms at every call site costs the classifier loop
 // 5 %).  greedy_bc() picks the instance from cfg.libm_* (api.cpp).
@@ -128,6 +128,8 @@ struct DeviceClassifier;
 GLIA_DECLARE_GREEDY_BC(greedy_bc_generic);
 GLIA_DECLARE_GREEDY_BC(greedy_bc_fma);
 GLIA_DECLARE_GREEDY_BC(greedy_bc_sse2);
+GLIA_DECLARE_GREEDY_BC(greedy_bc_fma_common);      // + GLIA_BC_COMMON (bc_features.hpp): one channel, no --logs / --simpf / histogram columns
+GLIA_DECLARE_GREEDY_BC(greedy_bc_sse2_common);
 int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& clf, hipStream_t stream, uint32_t* h_order,
               double* h_sal, double* h_feats, int64_t capacity, int64_t* n_merges, double* ms_table, double* ms_init,
               double* ms_loop, int64_t* n_scored, bool init_only, const uint32_t* h_forced = nullptr,
