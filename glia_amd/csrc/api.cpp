@@ -100,7 +100,8 @@ int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& cl
               double* ms_loop, int64_t* n_scored, bool init_only, const uint32_t* h_forced, int64_t n_forced, int shard,
               int n_shards, double* h_scores) {
   auto* fn = &greedy_bc_generic;
-  const bool common = cfg.K == 1 && !cfg.use_hist && !cfg.use_log && !cfg.use_simple && !getenv("GLIA_HMT_BC_NOCOMMON");
+  const bool common = cfg.K == 1 && cfg.n_region == 1 && cfg.n_rlabel == 0 && cfg.n_boundary == 1 && !cfg.use_hist && !cfg.use_log &&
+                      !cfg.use_simple && !getenv("GLIA_HMT_BC_NOCOMMON");
   if (cfg.libm_log2 == kLibmSse2 && cfg.libm_log == kLibmFma && cfg.libm_pow == kLibmFma) fn = common ? &greedy_bc_fma_common : &greedy_bc_fma;
   else if (cfg.libm_log2 == kLibmSse2 && cfg.libm_log == kLibmSse2 && cfg.libm_pow == kLibmSse2) fn = common ? &greedy_bc_sse2_common : &greedy_bc_sse2;
   if (getenv("GLIA_HMT_BC_GENERIC")) fn = &greedy_bc_generic;       // tests: the run-time-dispatch instance

@@ -79,34 +79,41 @@ struct BcCfg {
   int libm_log2, libm_log, libm_pow;    // which restatement of the host libm log2 / log / pow use (glibc_math.hpp)
 };
 
-// GLIA_BC_COMMON (one more pair of greedy_bc instances, hmt_internal.hpp): the configuration nearly every run has -- one image
-// channel, full feature vector, no --logs, no histogram columns -- with those switches fixed at compile time (-3.5 % loop time)
+// GLIA_BC_COMMON (one more pair of greedy_bc instances, hmt_internal.hpp): the configuration nearly every run has -- ONE image
+// (the boundary probability map, on the region and the boundary list: "--rbi pb"), full feature vector, no --logs, no
+// histogram columns -- with those switches and list lengths fixed at compile time (-7 % loop time)
 #ifdef GLIA_BC_COMMON
 #define BC_HIST(c) 0
 #define BC_LOG(c) 0
 #define BC_SIMPLE(c) 0
 #define BC_K(c) 1
+#define BC_NR(c) 1
+#define BC_NL(c) 0
+#define BC_NB(c) 1
 #else
 #define BC_HIST(c) (c).use_hist
 #define BC_LOG(c) (c).use_log
 #define BC_SIMPLE(c) (c).use_simple
 #define BC_K(c) (c).K
+#define BC_NR(c) (c).n_region
+#define BC_NL(c) (c).n_rlabel
+#define BC_NB(c) (c).n_boundary
 #endif
 // histogram columns of the image lists (0 unless use_hist): ImageLabelFeats::dim = histBin + 1 (type/feat.hxx:608-612)
 __host__ __device__ inline int bc_hist_cols(const BcCfg& c, int kind) {
   if (!BC_HIST(c)) return 0;
   int n = 0;
-  const int cnt = kind == 0 ? c.n_region : kind == 1 ? c.n_rlabel : c.n_boundary;
+  const int cnt = kind == 0 ? BC_NR(c) : kind == 1 ? BC_NL(c) : BC_NB(c);
   for (int i = 0; i < cnt; ++i) n += c.cbins[kind == 0 ? c.rc[i] : kind == 1 ? c.lc[i] : c.bc[i]];
   return n;
 }
 __host__ __device__ inline int bc_rf_dim(const BcCfg& c) {
-  return 4 + c.D + 2 * c.T + 5 * c.n_region + c.n_rlabel + 5 * c.n_boundary + bc_hist_cols(c, 0) + bc_hist_cols(c, 1) + bc_hist_cols(c, 2);
+  return 4 + c.D + 2 * c.T + 5 * BC_NR(c) + BC_NL(c) + 5 * BC_NB(c) + bc_hist_cols(c, 0) + bc_hist_cols(c, 1) + bc_hist_cols(c, 2);
 }
-__host__ __device__ inline int bc_bf_dim(const BcCfg& c) { return 11 + 4 * c.T + 7 * c.n_region + 3 * c.n_rlabel + 5 * c.n_boundary + bc_hist_cols(c, 2); }
+__host__ __device__ inline int bc_bf_dim(const BcCfg& c) { return 11 + 4 * c.T + 7 * BC_NR(c) + 3 * BC_NL(c) + 5 * BC_NB(c) + bc_hist_cols(c, 2); }
 __host__ __device__ inline int bc_full_dim(const BcCfg& c) { return bc_bf_dim(c) + 3 * bc_rf_dim(c); }
 __host__ __device__ inline int bc_feat_dim(const BcCfg& c) {
-  return BC_SIMPLE(c) ? 5 + c.n_boundary + 4 * c.n_region + 2 * c.n_rlabel : bc_bf_dim(c) + 3 * bc_rf_dim(c);
+  return BC_SIMPLE(c) ? 5 + BC_NB(c) + 4 * BC_NR(c) + 2 * BC_NL(c) : bc_bf_dim(c) + 3 * bc_rf_dim(c);
 }
 
 namespace feat {
@@ -231,9 +238,9 @@ struct ShapeIn { uint32_t n, border; int lo[3], hi[3]; uint32_t bn; uint32_t thr
 // layout of the values the lane-parallel pass precomputes per record: region / label entry i -> 5 doubles (entropy of
 // the first, second, merged voxel set, L1, chi-square), boundary entry i -> 4 (entropy of the first, second, merged
 // boundary set and of the shared boundary)
-__host__ __device__ inline int pre_region(const BcCfg& c, int kind, int i) { return 5 * ((kind ? c.n_region : 0) + i); }
-__host__ __device__ inline int pre_boundary(const BcCfg& c, int i) { return 5 * (c.n_region + c.n_rlabel) + 4 * i; }
-__host__ __device__ inline int pre_count(const BcCfg& c) { return 5 * (c.n_region + c.n_rlabel) + 4 * c.n_boundary; }
+__host__ __device__ inline int pre_region(const BcCfg& c, int kind, int i) { return 5 * ((kind ? BC_NR(c) : 0) + i); }
+__host__ __device__ inline int pre_boundary(const BcCfg& c, int i) { return 5 * (BC_NR(c) + BC_NL(c)) + 4 * i; }
+__host__ __device__ inline int pre_count(const BcCfg& c) { return 5 * (BC_NR(c) + BC_NL(c)) + 4 * BC_NB(c); }
 
 template <class Src>
 __device__ __forceinline__ void region_feats_multi(const BcCfg& c, const ShapeIn& r, Src src, double* out, double& area_o, double& perim_o) {
@@ -260,18 +267,18 @@ __device__ __forceinline__ void region_feats_multi(const BcCfg& c, const ShapeIn
   for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) if (i < T) out[k + T + i] = sdiv((double)r.thr[i], (double)r.bn, 0.0);
   k += 2 * T;
   area_o = area; perim_o = perim;
-  for (int i = 0; i < c.n_region; ++i) {
+  for (int i = 0; i < BC_NR(c); ++i) {
     const ImgSrc s = src(0, i);
     const ImgFeats f = image_feats_src(s, c.cbins[c.rc[i]], c.libm_log2);
     if (BC_HIST(c)) k += put_hist(s, c.cbins[c.rc[i]], out + k);
     out[k++] = f.entropy; out[k++] = f.mean; out[k++] = f.stddev; out[k++] = f.mn; out[k++] = f.mx;
   }
-  for (int i = 0; i < c.n_rlabel; ++i) {
+  for (int i = 0; i < BC_NL(c); ++i) {
     const ImgSrc s = src(1, i);
     if (BC_HIST(c)) k += put_hist(s, c.cbins[c.lc[i]], out + k);
     out[k++] = image_feats_src(s, c.cbins[c.lc[i]], c.libm_log2).entropy;
   }
-  for (int i = 0; i < c.n_boundary; ++i) {
+  for (int i = 0; i < BC_NB(c); ++i) {
     const ImgSrc s = src(2, i);
     const ImgFeats f = image_feats_src(s, c.cbins[c.bc[i]], c.libm_log2);
     if (BC_HIST(c)) k += put_hist(s, c.cbins[c.bc[i]], out + k);
@@ -304,7 +311,7 @@ __device__ __forceinline__ void boundary_feats_multi(const BcCfg& c, uint32_t sh
   }
   k += 4 * T;
   for (int kind = 0; kind < 2; ++kind) {
-    const int cnt = kind ? c.n_rlabel : c.n_region;
+    const int cnt = kind ? BC_NL(c) : BC_NR(c);
     for (int i = 0; i < cnt; ++i) {
       const ImgSrc s0 = src0(kind, i), s1 = src1(kind, i);
       const int bins = c.cbins[kind ? c.lc[i] : c.rc[i]];
@@ -328,7 +335,7 @@ __device__ __forceinline__ void boundary_feats_multi(const BcCfg& c, uint32_t sh
       }
     }
   }
-  for (int i = 0; i < c.n_boundary; ++i) {
+  for (int i = 0; i < BC_NB(c); ++i) {
     const ImgSrc s = srcSh(i);
     const ImgFeats f = image_feats_src(s, c.cbins[c.bc[i]], c.libm_log2);
     if (BC_HIST(c)) k += put_hist(s, c.cbins[c.bc[i]], out + k);
@@ -363,19 +370,19 @@ __device__ __forceinline__ void simple_selection(const BcCfg& c, double* out) {
   if (BC_SIMPLE(c)) {   // hmt/bc_feat.hxx:247-279; every source index lies beyond the slot it is copied to
     const double* bf = out; const double* x1 = out + c.bfdim; const double* x2 = out + c.bfdim + c.rfdim;
     const double v0 = x1[0], v1 = x2[0], v2 = x1[1], v3 = x2[1], v4 = bf[6];
-    const int r = 11 + 4 * c.T, rl = r + 7 * c.n_region, bimg = rl + 3 * c.n_rlabel;
+    const int r = 11 + 4 * c.T, rl = r + 7 * BC_NR(c), bimg = rl + 3 * BC_NL(c);
     int k = 0;
     out[k++] = v0; out[k++] = v1; out[k++] = v2; out[k++] = v3; out[k++] = v4;     // slots 0..4 < every source below (>= 11)
-    for (int i = 0, o = bimg; i < c.n_boundary; ++i) {            // the mean of the shared boundary on boundary image i
+    for (int i = 0, o = bimg; i < BC_NB(c); ++i) {            // the mean of the shared boundary on boundary image i
       const int hb = BC_HIST(c) ? c.cbins[c.bc[i]] : 0;
       out[k++] = bf[o + hb + 1];
       o += hb + 5;
     }
-    for (int i = 0; i < c.n_region; ++i) {
+    for (int i = 0; i < BC_NR(c); ++i) {
       const double m = bf[r + 7 * i + 3], l1 = bf[r + 7 * i + 0], xx = bf[r + 7 * i + 1], en = bf[r + 7 * i + 2];
       out[k++] = m; out[k++] = l1; out[k++] = xx; out[k++] = en;
     }
-    for (int i = 0; i < c.n_rlabel; ++i) { const double l1 = bf[rl + 3 * i + 0], xx = bf[rl + 3 * i + 1]; out[k++] = l1; out[k++] = xx; }
+    for (int i = 0; i < BC_NL(c); ++i) { const double l1 = bf[rl + 3 * i + 0], xx = bf[rl + 3 * i + 1]; out[k++] = l1; out[k++] = xx; }
   }
 }
 

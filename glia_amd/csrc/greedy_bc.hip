@@ -937,7 +937,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
             return acc;
           };
           for (int kind = 0; kind < 2; ++kind) {
-            const int cnt = kind ? cf.n_rlabel : cf.n_region;
+            const int cnt = kind ? BC_NL(cf) : BC_NR(cf);
             for (int i = 0; i < cnt; ++i) {
               const int cc = kind ? cf.lc[i] : cf.rc[i];
               const int bins = cf.cbins[cc];
@@ -960,7 +960,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
               if ((int)l16 == bins - 1) { double* q = fx + feat::pre_region(cf, kind, i); q[0] = e0; q[1] = e1; q[2] = e2; q[3] = dl; q[4] = dx; }
             }
           }
-          for (int i = 0; i < cf.n_boundary; ++i) {
+          for (int i = 0; i < BC_NB(cf); ++i) {
             const int cc = cf.bc[i];
             const int bins = cf.cbins[cc];
             double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;

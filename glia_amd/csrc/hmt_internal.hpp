@@ -128,7 +128,7 @@ struct DeviceClassifier;
 GLIA_DECLARE_GREEDY_BC(greedy_bc_generic);
 GLIA_DECLARE_GREEDY_BC(greedy_bc_fma);
 GLIA_DECLARE_GREEDY_BC(greedy_bc_sse2);
-GLIA_DECLARE_GREEDY_BC(greedy_bc_fma_common);      // + GLIA_BC_COMMON (bc_features.hpp): one channel, no --logs / --simpf / histogram columns
+GLIA_DECLARE_GREEDY_BC(greedy_bc_fma_common);      // + GLIA_BC_COMMON (bc_features.hpp): one image on the region and boundary lists, no --logs / --simpf / histogram columns
 GLIA_DECLARE_GREEDY_BC(greedy_bc_sse2_common);
 int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& clf, hipStream_t stream, uint32_t* h_order,
               double* h_sal, double* h_feats, int64_t capacity, int64_t* n_merges, double* ms_table, double* ms_init,
