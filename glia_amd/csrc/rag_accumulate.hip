@@ -380,16 +380,21 @@ __global__ __launch_bounds__(kThreads, 2) void rag_accumulate_kernel(const AccPa
   const float t0 = p.thr_f[0], t1 = p.thr_f[1], t2 = p.thr_f[2], t3 = p.thr_f[3];   // +inf beyond nthr
 
   // one voxel: neighbour rule, run bookkeeping, accumulation
-  auto voxel = [&](auto I, const U4& Lp, const U4& Lc, const U4& Cc, const U4& Ln, const U4& Up, const U4& Dn, const F4& V,
+  // INNER (a workgroup-uniform compile-time tag): the tile and its one-voxel halo lie inside the volume and there is no mask,
+  // so every voxel is valid, every neighbour exists and no voxel is a border voxel -- the validity logic (six flags, their
+  // count, the border test) folds away: ~25 of ~220 vector instructions per voxel.
+  auto voxel = [&](auto INNER_T, auto I, const U4& Lp, const U4& Lc, const U4& Cc, const U4& Ln, const U4& Up, const U4& Dn, const F4& V,
                    uint32_t left, uint32_t right, int zrel, bool zmv, bool zpv, bool ymv, bool ypv)
                    __attribute__((always_inline)) {
     constexpr int i = decltype(I)::value;
+    constexpr bool INNER = decltype(INNER_T)::value;
     const int64_t x = x0 + i;
     const uint32_t L = MASK ? Cc.v[i] : Lc.v[i];
-    const bool ok = rowOk && (VEC || x < nx) && !(dbg & 4) && (!MASK || L != kMaskedLabel);
+    const bool ok = INNER || (rowOk && (VEC || x < nx) && !(dbg & 4) && (!MASK || L != kMaskedLabel));
     const uint32_t xm = (i == 0) ? left : Lc.v[i > 0 ? i - 1 : 0];
     const uint32_t xp = (i == kVX - 1) ? right : Lc.v[i < kVX - 1 ? i + 1 : kVX - 1];
-    bool xmv = x > 0, xpv = x + 1 < nx;
+    bool xmv = INNER || x > 0, xpv = INNER || x + 1 < nx;
+    if (INNER) { zmv = zpv = ymv = ypv = true; }
     if (MASK) {
       xmv = xmv && xm != kMaskedLabel; xpv = xpv && xp != kMaskedLabel;
       ymv = ymv && Up.v[i] != kMaskedLabel; ypv = ypv && Dn.v[i] != kMaskedLabel;
@@ -402,9 +407,9 @@ __global__ __launch_bounds__(kThreads, 2) void rag_accumulate_kernel(const AccPa
     b = (ymv && Up.v[i] != L) ? Up.v[i] : b;
     b = (xpv && xp != L) ? xp : b;
     b = (xmv && xm != L) ? xm : b;
-    const int nvalid = (int)xmv + (int)xpv + (int)ymv + (int)ypv + (int)zmv + (int)zpv;
+    const int nvalid = INNER ? 0 : (int)xmv + (int)xpv + (int)ymv + (int)ypv + (int)zmv + (int)zpv;
     const bool boundary = ok && (b != L);
-    const bool border = ok && !boundary && nvalid < nfull;
+    const bool border = !INNER && ok && !boundary && nvalid < nfull;
     const float v = V.v[i];
     // reference bin rule (util/image_stats.hxx:24-35) with float-exact thresholds
     int c = 0;
@@ -479,6 +484,10 @@ __global__ __launch_bounds__(kThreads, 2) void rag_accumulate_kernel(const AccPa
   F4 V = loadImg(y, tile.z0);
   uint32_t hl, hr;
   halo(tile.z0, hl, hr);
+  // is this an inner tile?  (full tile, not masked, 3D, one voxel away from every face of the -- global -- volume)
+  const bool inner_tile = !MASK && VEC && is3d && dbg == 0 && tile.x0 > 0 && tile.x0 + kTileX < nx && tile.y0 > 0 && tile.y0 + kTileY < ny &&
+                          tile.z0 + gz0 > 0 && z1 + gz0 < gnz && tile.z0 > 0 && z1 < nz;
+  auto march = [&](auto INNER_T) __attribute__((always_inline)) {
   for (int64_t z = tile.z0; z < z1; ++z) {
     const int zrel = (int)(z - tile.z0);
     // requests for the next plane
@@ -501,18 +510,20 @@ __global__ __launch_bounds__(kThreads, 2) void rag_accumulate_kernel(const AccPa
     // a run lasts at most kTZ planes x 4 voxels = 128 voxels, so the 8-bit packed counters cannot overflow.
     // Serpentine x order: a lane that straddles a wall changes key once per plane instead of twice.
     if ((zrel & 1) == 0) {
-      voxel(std::integral_constant<int, 0>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
-      voxel(std::integral_constant<int, 1>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
-      voxel(std::integral_constant<int, 2>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
-      voxel(std::integral_constant<int, 3>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
+      voxel(INNER_T, std::integral_constant<int, 0>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
+      voxel(INNER_T, std::integral_constant<int, 1>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
+      voxel(INNER_T, std::integral_constant<int, 2>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
+      voxel(INNER_T, std::integral_constant<int, 3>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
     } else {
-      voxel(std::integral_constant<int, 3>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
-      voxel(std::integral_constant<int, 2>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
-      voxel(std::integral_constant<int, 1>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
-      voxel(std::integral_constant<int, 0>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
+      voxel(INNER_T, std::integral_constant<int, 3>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
+      voxel(INNER_T, std::integral_constant<int, 2>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
+      voxel(INNER_T, std::integral_constant<int, 1>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
+      voxel(INNER_T, std::integral_constant<int, 0>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
     }
     Lp = Lc; Lc = Ln; Ln = Ln2; Up = Up2; Dn = Dn2; V = V2; hl = hl2; hr = hr2;
   }
+  };
+  if (inner_tile) march(std::true_type{}); else march(std::false_type{});
   {
     if (!(dbg & 1)) enqueue(rr.klo != 0, rr, true);
     if (!(dbg & 2)) enqueue(pr.klo != 0, pr, false);
