@@ -396,3 +396,34 @@ def test_sharded_initial_edge_scoring(ctx):
     order, sal = rm.merge_order_bc(clf)
     assert sal[0] == full[np.isfinite(full)].max()
     rm.close()
+
+
+@pytest.mark.parametrize("shape,S,G", [((40, 36, 28), 6, 12), ((72, 72), 4, 16)])
+def test_loop_instances_agree(ctx, shape, S, G):
+    """greedy_bc.hip is compiled five times (hmt_internal.hpp): everything chosen at run time, the libm variants fixed, and
+    libm + the common configuration (one image, full vector) fixed.  The dispatcher's two overrides force the less specialised
+    instances; all three tiers must return the oracle's merge order and saliencies and bit-identical feature rows."""
+    from glia_amd import hmt
+    from oracle import pyoracle as O
+    labels, pb = O.synth(shape, S, G)
+    stub = 11 + 4 * 3 + 7 + 1
+    results = []
+    for env in ({}, {"GLIA_HMT_BC_NOCOMMON": "1"}, {"GLIA_HMT_BC_GENERIC": "1"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            rm = _gpu_rm(ctx, labels, pb)
+            results.append(rm.merge_order_bc(hmt.FeatureStubClassifier(ctx, stub), want_feats=True))
+            rm.close()
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+    cfg = O.make_cfg(pb, rb=[(pb, 8, 0.0, 1.0)])
+    o_ref, s_ref, f_ref = O.Rag(labels).merge_order_bc(cfg, None, stub_index=stub, want_feats=True)
+    for o, s, f in results:
+        assert o.shape == o_ref.shape and (o == o_ref).all() and (s == s_ref).all()
+        assert (f.view(np.uint64) == results[0][2].view(np.uint64)).all()
+    assert (results[0][2].view(np.uint64) == f_ref.view(np.uint64)).all(), "feature rows are bit-identical to the oracle on Q8 inputs"

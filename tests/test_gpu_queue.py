@@ -73,6 +73,18 @@ def test_window_queue_rare_paths(ctx, shape, S, variant, levels, env):
     assert o.shape == tree[0].shape and (o == tree[0]).all() and (s == tree[1]).all()
 
 
+@pytest.mark.parametrize("env", [dict(GLIA_HMT_HORIZON=0), dict(GLIA_HMT_HORIZON=0.25, GLIA_HMT_REBASE=5000),
+                                 dict(GLIA_HMT_HORIZON=8, GLIA_HMT_REBASE=20000), dict(GLIA_HMT_HORIZON=0.05, GLIA_HMT_REBASE=2000, GLIA_HMT_WINCAP=64)])
+def test_horizon_placements(ctx, env):
+    """the horizon below which created edges are not queued until the next baseline (WinState::wch): switched off, placed far
+    too tight (reloads run into it and end the launch early), far too loose, and tight with a tiny window"""
+    d_lab, d_pb = _volume(ctx, (128, 128, 128), 8, 0, None)
+    tree = _order(ctx, d_lab, d_pb, GLIA_HMT_PB_WINDOW=0)
+    assert len(tree[0]) == 4095
+    o, s = _order(ctx, d_lab, d_pb, **env)
+    assert o.shape == tree[0].shape and (o == tree[0]).all() and (s == tree[1]).all()
+
+
 def test_constant_pb_on_every_queue(ctx):
     """every saliency equal: one saliency cell holds the whole queue, the order is the tie rule alone"""
     import torch
