@@ -7,8 +7,6 @@ from glia_amd.synth_forest import synthetic_forest, write_model
 
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-if os.environ.get('BD_SETDEV'):
-    torch.cuda.set_device(0)
 ctx = hmt.Context(0)
 labels, pb = ctx.synth((size,) * 3, S, 8 * S, seed=0x9E3779B97F4A7C15)
 cfg = hmt.make_config(pb, rb=[(pb, 8, 0.0, 1.0)], thresholds=(0.2, 0.5, 0.8))
@@ -26,9 +24,7 @@ def clock():
 for rep in range(3):
     t0 = clock()
     rm = hmt.RegionMap(ctx, labels, pb=pb, only_contour=False, cfg=cfg)
-    if os.environ.get('BD_LASTPASS'):
-        rm.last_pass()
-    t1 = clock() if not os.environ.get('BD_NOSYNC') else time.time()
+    t1 = clock()
     n_edges, ms_score = rm.score_initial_edges(clf)
     t2 = clock()
     order, sal = rm.merge_order_pb(type=2)
