@@ -55,6 +55,8 @@ CASES = [
     ((96, 96), 8, 32, 0, 8),           # 2D
     ((33, 70, 300), 5, 20, 1, 16),     # 16 bins, ragged
     ((3, 5, 7), 2, 4, 0, 8),           # tiny
+    ((128, 128, 256), 8, 32, 0, 8),    # 4 x 4 x 4 tiles: the eight in the middle are "inner" tiles (instance without validity logic)
+    ((100, 128, 200), 6, 24, 1, 16),   # inner tiles next to ragged ones, 16 bins, f32 pb
 ]
 
 
