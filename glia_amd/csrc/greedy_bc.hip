@@ -1056,6 +1056,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
       __syncthreads();
     }
     if (pending) collect_pending();
+    PH(11);                                 // (the wait for the helpers' last votes)
     for (uint32_t j = tid; j < newcount; j += kBcThreads) st.e_posv[(uint32_t)ne + j] &= 0x3FFFFFFFu;
     PH(3);
     if (!forced) pq_propagate<kBcThreads>(st.pq, s.pq, tid);
@@ -1069,7 +1070,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
   if (tid == 0) printf("[bc profile] pq propagations by dirty level-0 nodes (<=8, <=16, more): %llu %llu %llu\n", g_pqprof[28], g_pqprof[29], g_pqprof[30]);
   if (tid == 0) printf("[bc profile] edge_features of thread 0: gather %llu  bc_features %llu  calls %llu (cycles)\n", g_pqprof[24], g_pqprof[25], g_pqprof[26]);
   if (tid == 0) printf("[bc profile] scoring: neighbour min/max %llu  shared sets %llu  entropies %llu  assemble %llu (cycles)\n", tph[8], tph[9], tph[10], tph[4]);
-  if (tid == 0) printf("[bc profile] merges %llu: pop+feats_out %llu  region+mark %llu  build %llu  top2 %llu  features %llu  forest %llu  pq %llu  loop-top %llu (cycles)\n", k, tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], tph[6], tph[7]);
+  if (tid == 0) printf("[bc profile] merges %llu: pop+feats_out %llu  region+mark %llu  build %llu  top2 %llu  features %llu  forest %llu  pq %llu  loop-top %llu  wait-for-last-votes %llu (cycles)\n", k, tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], tph[6], tph[7], tph[11]);
 #endif
 }
 
