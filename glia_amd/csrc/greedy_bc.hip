@@ -493,6 +493,9 @@ __device__ void bc_helper_loop(const BcState& st, BcShared& s) {
     last = v;
     const uint32_t cn = v & 0xFFu, tag = v >> 8;
     if (h >= cn) continue;                              // nothing for this workgroup in the job
+#ifdef GLIA_HMT_PROFILE
+    unsigned long long hp0 = __builtin_readcyclecounter();
+#endif
     for (uint32_t j = h; j < cn; j += H) {
       // the record's model and vector are requested together (agent-scope loads are long round trips)
       const uint32_t pj = (tag & 1u) * (uint32_t)kChunk + j;      // jobs alternate between two buffers (see the chunk loop)
@@ -501,6 +504,9 @@ __device__ void bc_helper_loop(const BcState& st, BcShared& s) {
       for (int i = tid; i < fstride; i += kBcThreads) hfeat[i] = ld_agent(&st.featbuf[(size_t)pj * fstride + i]);
       if (tid == 0) s.votes[0] = 0;
       __syncthreads();
+#ifdef GLIA_HMT_PROFILE
+      if (tid == 0 && h == 0) { const unsigned long long t = __builtin_readcyclecounter(); atomicAdd(&g_pqprof[40], t - hp0); hp0 = t; }
+#endif
       if (m >= 0) {
         const DeviceForest& f = st.clf.f[m];
         int mine = 0;
@@ -509,8 +515,14 @@ __device__ void bc_helper_loop(const BcState& st, BcShared& s) {
       }
       __syncthreads();
       // the answer carries the job's sequence number: the contraction workgroup polls the slot itself, no counter
+#ifdef GLIA_HMT_PROFILE
+      if (tid == 0 && h == 0) { const unsigned long long t = __builtin_readcyclecounter(); atomicAdd(&g_pqprof[41], t - hp0); hp0 = t; atomicAdd(&g_pqprof[43], 1ull); }
+#endif
       if (tid == 0 && m >= 0) st_agent(&st.hvotes[pj], ((unsigned long long)tag << 32) | (unsigned long long)(uint32_t)s.votes[0]);
       __syncthreads();
+#ifdef GLIA_HMT_PROFILE
+      if (tid == 0 && h == 0) { const unsigned long long t = __builtin_readcyclecounter(); atomicAdd(&g_pqprof[42], t - hp0); hp0 = t; }
+#endif
     }
   }
 }
@@ -1067,6 +1079,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
   if (tid == 0 && st.n_helpers) st_release(&st.hctl[0], 0xFFFFFFFFu);
   if (tid == 0) { st.ctrl[0] = k; st.ctrl[1] = ne; st.ctrl[2] = pool_used; st.ctrl[3] = status; }
 #ifdef GLIA_HMT_PROFILE
+  if (tid == 0) printf("[bc profile] helper 0 (cumulative cycles): vector fetch %llu  walk + vote sum %llu  vote store %llu  records %llu\n", g_pqprof[40], g_pqprof[41], g_pqprof[42], g_pqprof[43]);
   if (tid == 0) printf("[bc profile] pq propagations by dirty level-0 nodes (<=8, <=16, more): %llu %llu %llu\n", g_pqprof[28], g_pqprof[29], g_pqprof[30]);
   if (tid == 0) printf("[bc profile] edge_features of thread 0: gather %llu  bc_features %llu  calls %llu (cycles)\n", g_pqprof[24], g_pqprof[25], g_pqprof[26]);
   if (tid == 0) printf("[bc profile] scoring: neighbour min/max %llu  shared sets %llu  entropies %llu  assemble %llu (cycles)\n", tph[8], tph[9], tph[10], tph[4]);

@@ -228,7 +228,7 @@ __device__ __forceinline__ void pq_touch(const PqTree& t, PqWork& w, int level, 
 }
 
 #ifdef GLIA_HMT_PROFILE
-__device__ unsigned long long g_pqprof[32];     // [l] cycles of level l, [8+l] nodes recomputed at level l, [16+l] spilled nodes
+__device__ unsigned long long g_pqprof[48];     // [l] cycles of level l, [8+l] nodes recomputed at level l, [16+l] spilled nodes
 #endif
 // the root: one round trip over the last stored level by the whole workgroup (every thread calls; the caller has put a
 // barrier after the last store into that level; ends with a barrier)
