@@ -1067,6 +1067,10 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
       score_records(c0, cn, cur, st.clf.kind == 1);
       __syncthreads();
     }
+    // While the helpers walk the forest for the last chunk this workgroup has nothing to do: the priority tree is brought up
+    // to date for everything known so far (the removals of this contraction, the records of earlier chunks); the records of
+    // the last chunk get their own, small propagation below.
+    if (pending && !forced) { PH(3); pq_propagate<kBcThreads>(st.pq, s.pq, tid); PH(6); }
     if (pending) collect_pending();
     PH(11);                                 // (the wait for the helpers' last votes)
     for (uint32_t j = tid; j < newcount; j += kBcThreads) st.e_posv[(uint32_t)ne + j] &= 0x3FFFFFFFu;
