@@ -555,6 +555,10 @@ struct WinState {
   // entries are all that is written (the baseline is rebuilt from the records).  A reload that would have to go below the
   // horizon ends the launch with ST_REBASE instead.  0 = no horizon.
   uint32_t wch;
+  // regions that have been merged away (batch kernel).  An edge that dies BELOW the horizon is not marked in its record (one
+  // scattered store per dying edge less in the contraction's store stream): no reload can reach it before the next baseline,
+  // and the baseline's collection pass recognises it by its dead region.
+  uint8_t* rdead;
 };
 constexpr uint32_t kWinCap = 1536;          // window slots (live items + holes)
 constexpr uint32_t kWinBudget = 768;        // a reload stops before exceeding this many items ...
@@ -1300,6 +1304,7 @@ __device__ __forceinline__ uint32_t batch_contract_wide(const WinState& st, WinS
     st.order[3 * k + 0] = r0; st.order[3 * k + 1] = r1; st.order[3 * k + 2] = r2;
     st.sal_out[k] = rootsal;
     st.er[e].seq = 0;
+    st.rdead[r0] = 1; st.rdead[r1] = 1;
   }
   const bool small = total <= kMarkMax;
   for (uint32_t i = tid; i < total; i += kGreedyThreads) {
@@ -1407,10 +1412,12 @@ __device__ __forceinline__ uint32_t batch_contract_wide(const WinState& st, WinS
         // an edge is treated as a window item instead: a kill that matches nothing is harmless, and its cell's count stays one
         // too high until the next baseline (counts are upper bounds: a reload walks a list whenever its count is not zero).
         const bool tie = (int)dc == cthr && dsal == tsal;
-        st.er[de].seq = 0;
-        if (tie || win_above(cthr, tsal, tseq, (int)dc, dsal, 0ull)) {
-          const uint32_t j = atomicAdd(&b.nkill, 1u); if (j < kBatchKill) b.kill[j] = de; else b.kovf = 1;
-        } else if (dc >= st.wch) atomicSub(&st.wcnt[dc], 1u);
+        if (dc >= st.wch) {                                  // (below the horizon: WinState::rdead speaks for the edge)
+          st.er[de].seq = 0;
+          if (tie || win_above(cthr, tsal, tseq, (int)dc, dsal, 0ull)) {
+            const uint32_t j = atomicAdd(&b.nkill, 1u); if (j < kBatchKill) b.kill[j] = de; else b.kovf = 1;
+          } else atomicSub(&st.wcnt[dc], 1u);
+        }
       }
     }
   };
@@ -1658,6 +1665,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
         st.order[3 * kk + 0] = r0; st.order[3 * kk + 1] = r1; st.order[3 * kk + 2] = r2;
         st.sal_out[kk] = me.sal;
         st.er[e].seq = 0;
+        st.rdead[r0] = 1; st.rdead[r1] = 1;
         st.adj_off[r2] = r2off; st.adj_len[r2] = newcount;
       }
 #pragma unroll
@@ -1704,10 +1712,12 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
           const double dsal = -((side && both[p]) ? p_mean[p] : fe[p].mean);
           const uint32_t dc = win_cell(dsal, smin, scale, st.wB);
           const bool tie = (int)dc == cthr && dsal == tsal;                // (no look at the record's seq: see batch_contract_wide)
-          st.er[de].seq = 0;
-          if (tie || win_above(cthr, tsal, tseq, (int)dc, dsal, 0ull)) {
-            const uint32_t j = atomicAdd(&b.nkill, 1u); if (j < kBatchKill) b.kill[j] = de; else b.kovf = 1;
-          } else if (dc >= st.wch) atomicSub(&st.wcnt[dc], 1u);
+          if (dc >= st.wch) {                                // (below the horizon: WinState::rdead speaks for the edge)
+            st.er[de].seq = 0;
+            if (tie || win_above(cthr, tsal, tseq, (int)dc, dsal, 0ull)) {
+              const uint32_t j = atomicAdd(&b.nkill, 1u); if (j < kBatchKill) b.kill[j] = de; else b.kovf = 1;
+            } else atomicSub(&st.wcnt[dc], 1u);
+          }
         }
       }
     }
@@ -1756,11 +1766,13 @@ __global__ void win_params_kernel(const unsigned long long* mm, uint32_t B, doub
   range[1] = smax > smin ? (double)B / (smax - smin) : 0.0;
 }
 // ---- baseline: every live queue item, sorted by descending (saliency, seq) (whole-GPU kernels between launches) ----
-__global__ void win_collect_kernel(const EdgeRec* er, uint32_t n_edges, unsigned long long* kseq, uint32_t* vals, uint32_t* counter) {
+__global__ void win_collect_kernel(const EdgeRec* er, uint32_t n_edges, const uint8_t* rdead, unsigned long long* kseq, uint32_t* vals, uint32_t* counter) {
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_edges) return;
   const unsigned long long q = er[e].seq;
   if (q == 0) return;
+  const uint2 uv = *reinterpret_cast<const uint2*>(&er[e].u);
+  if (rdead[uv.x] | rdead[uv.y]) return;         // died below the horizon: its record was not touched (WinState::rdead)
   const uint32_t i = atomicAdd(counter, 1u);
   kseq[i] = q; vals[i] = e;
 }
@@ -1805,12 +1817,12 @@ __global__ void fat_to_thin(const FatEntry* f, uint2* out, unsigned long long n)
   const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { const FatEntry fe = f[i]; out[i] = make_uint2(fe.eid, fe.eid == kNone ? 0u : fe.rs); }
 }
-__global__ void edge_unpack(GreedyState g, const EdgeRec* er, uint32_t n) {
+__global__ void edge_unpack(GreedyState g, const EdgeRec* er, const uint8_t* rdead, uint32_t n) {
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   const EdgeRec r = er[e];
   g.e_u[e] = r.u; g.e_v[e] = r.v; g.e_posu[e] = r.posu; g.e_posv[e] = r.posv; g.e_mean[e] = r.mean; g.e_n[e] = r.n;
-  g.pq.leaf_sal[e] = r.sal; g.pq.leaf_seq[e] = r.seq;
+  g.pq.leaf_sal[e] = r.sal; g.pq.leaf_seq[e] = (rdead[r.u] | rdead[r.v]) ? 0ull : r.seq;
 }
 
 // ---- edge table construction --------------------------------------------------------------------------
@@ -2050,7 +2062,7 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
   double horizon_factor = 0.0;                                           // 0 = no horizon (set below for the batch kernel)
   auto win_rebaseline = [&](uint32_t n_edges) -> int {
     GLIA_HIP_TRY(hipMemsetAsync(rb_counter, 0, sizeof(uint32_t), stream));
-    hipLaunchKernelGGL(win_collect_kernel, dim3((n_edges + 255) / 256), dim3(256), 0, stream, ws.er, n_edges, rb_kseq, rb_vals, rb_counter);
+    hipLaunchKernelGGL(win_collect_kernel, dim3((n_edges + 255) / 256), dim3(256), 0, stream, ws.er, n_edges, ws.rdead, rb_kseq, rb_vals, rb_counter);
     uint32_t n = 0;
     GLIA_HIP_TRY(hipMemcpyAsync(&n, rb_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     GLIA_HIP_TRY(hipStreamSynchronize(stream));
@@ -2102,6 +2114,7 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
       if (c >= 16 && c <= kWinCap) { ws.wcap = c; ws.wbudget = c / 2; }
     }
     unsigned long long* mm; double* range;
+    if ((rc = buf.get(&ws.rdead, 2 * (size_t)R, true, stream))) return rc;
     if ((rc = buf.get(&ws.whead, B, false, stream))) return rc;
     if ((rc = buf.get(&ws.wcnt, B, true, stream))) return rc;
     if ((rc = buf.get(&rb_isort, E0, false, stream))) return rc;
@@ -2164,7 +2177,7 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
       // from the same state -- leaf keys are the ground truth of both queues, the lists get their thin entries
       if ((rc = buf.get(&st.pool, st.pool_cap, false, stream))) return rc;
       hipLaunchKernelGGL(fat_to_thin, dim3((unsigned)((ctrl[2] + 255) / 256)), dim3(256), 0, stream, ws.fpool, st.pool, ctrl[2]);
-      hipLaunchKernelGGL(edge_unpack, dim3((unsigned)((ctrl[1] + 255) / 256)), dim3(256), 0, stream, st, ws.er, (uint32_t)ctrl[1]);
+      hipLaunchKernelGGL(edge_unpack, dim3((unsigned)((ctrl[1] + 255) / 256)), dim3(256), 0, stream, st, ws.er, ws.rdead, (uint32_t)ctrl[1]);
       GLIA_HIP_TRY(hipGetLastError());
       if ((rc = pq_setup(buf, st.pq, stream))) return rc;
       window = false;
