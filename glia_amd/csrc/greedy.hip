@@ -2083,7 +2083,8 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
     const char* renv = getenv("GLIA_HMT_REBASE");                          // created edges between baselines (tuning)
     ws.rebase_after = renv ? strtoull(renv, nullptr, 10) : std::max<unsigned long long>(800000ull, (unsigned long long)n / 2ull);
     // the horizon (WinState::wch): the top of the queue sank by d cells while the last interval's edges were created; the next
-    // interval is given twice that (scaled to its planned length) before a reload would run into the horizon
+    // interval is given horizon_factor times that (scaled to its planned length; at least 1/512 of the cells) before a reload
+    // would run into the horizon
     ws.wch = 0;
     if (horizon_factor > 0.0 && n > 4096) {
       unsigned long long topkey = 0;
@@ -2145,8 +2146,8 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
     GLIA_HIP_TRY(hipStreamSynchronize(stream));
     {
       const char* benv = getenv("GLIA_HMT_PB_BATCH");
-      const char* henv = getenv("GLIA_HMT_HORIZON");                     // 0 = off; else the factor on the measured descent (default 2)
-      if (cond_n <= 0 && !(benv && benv[0] == '0')) horizon_factor = henv ? atof(henv) : 2.0;
+      const char* henv = getenv("GLIA_HMT_HORIZON");                     // 0 = off; else the factor on the measured descent (default 0.5)
+      if (cond_n <= 0 && !(benv && benv[0] == '0')) horizon_factor = henv ? atof(henv) : 0.5;   // (swept 0.05 .. 8 at 1024^3: flat from 0.1 to 0.5, +1 % at 2, +2 % at 4)
     }
     if ((rc = win_rebaseline(E0))) return rc;
   } else if ((rc = pq_setup(buf, st.pq, stream))) return rc;
