@@ -55,6 +55,10 @@ struct BcChan {
   EStats* Bn;          // non-mutual out-entries of the region's leaves
   EStats* Bt;          // additive totals of the whole boundary set (min/max fields unused)
   float* Bmn; float* Bmx;   // min / max over the whole boundary set
+  // histogram entropies of pts[r] and Bt[r] (both fixed for the lifetime of region r): the leaf kernel files them for the
+  // leaves, the scoring pass of the contraction that creates r for merged regions; a record's neighbour-side entropies are
+  // then two loads instead of two passes over the bins (a division and a logarithm per bin)
+  double* entP; double* entB;
   // records [Ecap]
   EStats* e_A;         // mutual entries, both directions
   EStats* e_NA;        // always-alive non-mutual entries, both directions
@@ -328,6 +332,12 @@ __global__ void bc_leaf_regions(BcState st, int c, const uint32_t* rrec, int bin
     if (!st.le_mutual[i]) estats_add(bn, ch.le_stats[i]);
   }
   ch.Bn[r] = bn; ch.Bt[r] = bt; ch.Bmn[r] = bt.mn; ch.Bmx[r] = bt.mx;
+  {
+    // the same sums, in bin order from +0.0, as the scoring pass forms them (util/stats.hxx:145-152)
+    double ep = 0.0, eb = 0.0;
+    for (int k = 0; k < bins; ++k) { ep = ep - feat::entropy_term(p.hist[k], p.n, st.cfg.libm_log2); eb = eb - feat::entropy_term(bt.hist[k], bt.n, st.cfg.libm_log2); }
+    ch.entP[r] = ep; ch.entB[r] = eb;
+  }
   if (c == 0) st.parent[r] = r;
 }
 
@@ -932,6 +942,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
         for (uint32_t j = sub; j < cn; j += kBcThreads / 16) {
           const uint32_t rec = (uint32_t)ne + c0 + j;
           const bool on = st.e_table[rec] != 0;              // uniform over the 16 lanes
+          const bool files_r2 = c0 + j == 0u;                // the contraction's first record: its group files r2's entropies (BcChan::entP)
           const uint32_t rs = st.e_u[rec];
           double* fx = L.fx + (size_t)j * L.npre;
           // The bins' terms are added in bin order, as the reference does: a 16-step chain over DPP row_shr:1 (lane l
@@ -953,45 +964,55 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
             for (int i = 0; i < cnt; ++i) {
               const int cc = kind ? cf.lc[i] : cf.rc[i];
               const int bins = cf.cbins[cc];
-              double t0 = 0.0, t1 = 0.0, t2 = 0.0, tl = 0.0, tx = 0.0;
+              double t1 = 0.0, t2 = 0.0, tl = 0.0, tx = 0.0;
               const PStats* P0 = &st.ch[cc].pts[rs]; const PStats* P1 = &st.ch[cc].pts[r2];
               const uint32_t h0 = P0->hist[l16], h1 = P1->hist[l16], pn0 = P0->n, pn1 = P1->n;     // unconditional loads
-              if (on && (int)l16 < bins) {
+              const double e0 = st.ch[cc].entP[rs];           // filed when rs was created (BcChan::entP)
+              if ((on || files_r2) && (int)l16 < bins) {
                 // (one inlined copy of the logarithm per loop, not one per term: seven copies of the glibc restatement cost
                 // the loop 8 % through register pressure alone)
+                const int qn = on ? 3 : 2;
 #pragma unroll 1
-                for (int q = 0; q < 3; ++q) {
-                  const uint32_t cq = q == 0 ? h0 : q == 1 ? h1 : h0 + h1, nq = q == 0 ? pn0 : q == 1 ? pn1 : pn0 + pn1;
+                for (int q = 1; q < qn; ++q) {
+                  const uint32_t cq = q == 1 ? h1 : h0 + h1, nq = q == 1 ? pn1 : pn0 + pn1;
                   const double t = feat::entropy_term(cq, nq, cf.libm_log2, s.log2tab);
-                  t0 = q == 0 ? t : t0; t1 = q == 1 ? t : t1; t2 = q == 2 ? t : t2;
+                  t1 = q == 1 ? t : t1; t2 = q == 2 ? t : t2;
                 }
-                feat::dist_terms(h0, pn0, h1, pn1, tl, tx);
+                if (on) feat::dist_terms(h0, pn0, h1, pn1, tl, tx);
               }
-              const double e0 = bin_sum(t0, bins, true), e1 = bin_sum(t1, bins, true), e2 = bin_sum(t2, bins, true);
+              const double e1 = bin_sum(t1, bins, true), e2 = bin_sum(t2, bins, true);
               const double dl = bin_sum(tl, bins, false), dx = bin_sum(tx, bins, false);
-              if ((int)l16 == bins - 1) { double* q = fx + feat::pre_region(cf, kind, i); q[0] = e0; q[1] = e1; q[2] = e2; q[3] = dl; q[4] = dx; }
+              if ((int)l16 == bins - 1) {
+                double* q = fx + feat::pre_region(cf, kind, i); q[0] = e0; q[1] = e1; q[2] = e2; q[3] = dl; q[4] = dx;
+                if (files_r2) st.ch[cc].entP[r2] = e1;
+              }
             }
           }
           for (int i = 0; i < BC_NB(cf); ++i) {
             const int cc = cf.bc[i];
             const int bins = cf.cbins[cc];
-            double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+            double t1 = 0.0, t2 = 0.0, t3 = 0.0;
             const EStats* B0 = &st.ch[cc].Bt[rs]; const EStats* B1 = &st.ch[cc].Bt[r2];
             const EStats* A = &st.ch[cc].e_A[rec];
             const EStats* sh = &L.shs[j * K + cc];
             const uint32_t g0 = B0->hist[l16], g1 = B1->hist[l16], ga = A->hist[l16], bn0 = B0->n, bn1 = B1->n, an = A->n;
-            if (on && (int)l16 < bins) {
+            const double e0 = st.ch[cc].entB[rs];             // filed when rs was created (BcChan::entB)
+            if ((on || files_r2) && (int)l16 < bins) {
               const uint32_t gs = sh->hist[l16], sn = sh->n;
+              const int qn = on ? 4 : 2;
 #pragma unroll 1
-              for (int q = 0; q < 4; ++q) {
-                const uint32_t cq = q == 0 ? g0 : q == 1 ? g1 : q == 2 ? g0 + g1 - ga : gs;
-                const uint32_t nq = q == 0 ? bn0 : q == 1 ? bn1 : q == 2 ? bn0 + bn1 - an : sn;
+              for (int q = 1; q < qn; ++q) {
+                const uint32_t cq = q == 1 ? g1 : q == 2 ? g0 + g1 - ga : gs;
+                const uint32_t nq = q == 1 ? bn1 : q == 2 ? bn0 + bn1 - an : sn;
                 const double t = feat::entropy_term(cq, nq, cf.libm_log2, s.log2tab);
-                t0 = q == 0 ? t : t0; t1 = q == 1 ? t : t1; t2 = q == 2 ? t : t2; t3 = q == 3 ? t : t3;
+                t1 = q == 1 ? t : t1; t2 = q == 2 ? t : t2; t3 = q == 3 ? t : t3;
               }
             }
-            const double e0 = bin_sum(t0, bins, true), e1 = bin_sum(t1, bins, true), e2 = bin_sum(t2, bins, true), e3 = bin_sum(t3, bins, true);
-            if ((int)l16 == bins - 1) { double* q = fx + feat::pre_boundary(cf, i); q[0] = e0; q[1] = e1; q[2] = e2; q[3] = e3; }
+            const double e1 = bin_sum(t1, bins, true), e2 = bin_sum(t2, bins, true), e3 = bin_sum(t3, bins, true);
+            if ((int)l16 == bins - 1) {
+              double* q = fx + feat::pre_boundary(cf, i); q[0] = e0; q[1] = e1; q[2] = e2; q[3] = e3;
+              if (files_r2) st.ch[cc].entB[r2] = e1;
+            }
           }
         }
       }
@@ -1200,6 +1221,8 @@ int GLIA_BC_ENTRY(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier
     if ((rc = buf.get(&ch.Bt, R2, false, stream))) return rc;
     if ((rc = buf.get(&ch.Bmn, R2, false, stream))) return rc;
     if ((rc = buf.get(&ch.Bmx, R2, false, stream))) return rc;
+    if ((rc = buf.get(&ch.entP, R2, false, stream))) return rc;
+    if ((rc = buf.get(&ch.entB, R2, false, stream))) return rc;
     if ((rc = buf.get(&ch.e_A, st.Ecap, false, stream))) return rc;
     if ((rc = buf.get(&ch.e_NA, st.Ecap, false, stream))) return rc;
     if ((rc = buf.get(&ch.e_dir, (size_t)st.Ecap * 4, false, stream))) return rc;
