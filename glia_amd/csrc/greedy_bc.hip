@@ -421,6 +421,21 @@ __global__ void bc_init_score(BcState st, uint32_t E0) {
 }
 
 // ---- the loop ----------------------------------------------------------------------------------------------
+// The bins' terms of a sum are added in bin order, as the reference does: a chain over DPP row_shr:1 inside a group of 16
+// lanes (lane l ends with t_0 .. t_l; lane 0's predecessor reads +0.0, the reference's start value); the lane of the last
+// bin holds the sum.  Every lane of the 16 must be active.
+__device__ __forceinline__ double bin_chain(double t, int bins, bool negate) {
+  double acc = 0.0;
+  for (int b = 0; b < bins; ++b) {
+    const unsigned long long ab = (unsigned long long)__double_as_longlong(acc);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)ab, 0x111, 0xf, 0xf, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(ab >> 32), 0x111, 0xf, 0xf, true);
+    const double prev = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    acc = negate ? prev - t : prev + t;
+  }
+  return acc;
+}
+
 constexpr int kPoolBytes = 112 * 1024;   // LDS workspace of the scoring phase, partitioned at run time (bc_layout)
 struct BcShared {
   uint32_t r0, r1, e, stop, len0, len1, off0, off1, newcount;
@@ -431,6 +446,7 @@ struct BcShared {
   int model[2][kChunk];          // [job parity]: a job's models are needed again when its votes come back
   uint32_t nlog;                 // slots of the full vector that take a logarithm
   uint32_t lost;                 // a helper did not answer in time
+  double r2ent[2][kMaxChannels]; // histogram entropies of the region being created: [0] its voxels, [1] its boundary set (per channel)
   alignas(16) uint64_t log2tab[glibc::kLog2TabWords];   // glibc's log2 tables (glibc_math.hpp): head | tab | tab2
   uint16_t logpos[feat::kMaxLogSlots];
   PqWork pq;
@@ -775,6 +791,20 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
       st.pool[r2off + idx] = newE;
       st.e_posv[newE] = idx | (cat << 30);
     }
+    // r2's own histogram entropies (BcChan::entP / entB), worked out once -- every new record needs them -- by the last wave,
+    // which like most of the workgroup has little to do in this phase: one lane per bin, 16 lanes per (channel, set)
+    if (tid >= (int)kBcThreads - 64) {
+      const uint32_t g = ((uint32_t)tid & 63u) >> 4, l16 = (uint32_t)tid & 15u;
+      for (uint32_t wq = g; wq < 2u * (uint32_t)K; wq += 4u) {
+        const int cc = (int)(wq >> 1); const bool isB = (wq & 1u) != 0u;
+        const int bins = st.cfg.cbins[cc];
+        const PStats* P = &st.ch[cc].pts[r2]; const EStats* B = &st.ch[cc].Bt[r2];
+        const uint32_t cnt = isB ? B->hist[l16] : P->hist[l16], n = isB ? B->n : P->n;
+        const double t = (int)l16 < bins ? feat::entropy_term(cnt, n, st.cfg.libm_log2, s.log2tab) : 0.0;
+        const double en = bin_chain(t, bins, true);
+        if ((int)l16 == bins - 1) { s.r2ent[isB ? 1 : 0][cc] = en; (isB ? st.ch[cc].entB : st.ch[cc].entP)[r2] = en; }
+      }
+    }
     __syncthreads();
     PH(2);
     const uint32_t newcount = s.newcount;
@@ -942,77 +972,55 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
         for (uint32_t j = sub; j < cn; j += kBcThreads / 16) {
           const uint32_t rec = (uint32_t)ne + c0 + j;
           const bool on = st.e_table[rec] != 0;              // uniform over the 16 lanes
-          const bool files_r2 = c0 + j == 0u;                // the contraction's first record: its group files r2's entropies (BcChan::entP)
           const uint32_t rs = st.e_u[rec];
           double* fx = L.fx + (size_t)j * L.npre;
           // The bins' terms are added in bin order, as the reference does: a 16-step chain over DPP row_shr:1 (lane l
           // ends with t_0 .. t_l; lane 0's predecessor reads +0.0, the reference's start value), the lane of the last
           // bin holds the sum.  (Sixteen broadcasts through ds_bpermute per sum were the longest stretch of the pass.)
-          auto bin_sum = [&](double t, int bins, bool negate) -> double {
-            double acc = 0.0;
-            for (int b = 0; b < bins; ++b) {
-              const unsigned long long ab = (unsigned long long)__double_as_longlong(acc);
-              const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)ab, 0x111, 0xf, 0xf, true);
-              const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(ab >> 32), 0x111, 0xf, 0xf, true);
-              const double prev = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-              acc = negate ? prev - t : prev + t;
-            }
-            return acc;
-          };
+          auto bin_sum = [&](double t, int bins, bool negate) -> double { return bin_chain(t, bins, negate); };
           for (int kind = 0; kind < 2; ++kind) {
             const int cnt = kind ? BC_NL(cf) : BC_NR(cf);
             for (int i = 0; i < cnt; ++i) {
               const int cc = kind ? cf.lc[i] : cf.rc[i];
               const int bins = cf.cbins[cc];
-              double t1 = 0.0, t2 = 0.0, tl = 0.0, tx = 0.0;
+              double t2 = 0.0, tl = 0.0, tx = 0.0;
               const PStats* P0 = &st.ch[cc].pts[rs]; const PStats* P1 = &st.ch[cc].pts[r2];
               const uint32_t h0 = P0->hist[l16], h1 = P1->hist[l16], pn0 = P0->n, pn1 = P1->n;     // unconditional loads
               const double e0 = st.ch[cc].entP[rs];           // filed when rs was created (BcChan::entP)
-              if ((on || files_r2) && (int)l16 < bins) {
-                // (one inlined copy of the logarithm per loop, not one per term: seven copies of the glibc restatement cost
-                // the loop 8 % through register pressure alone)
-                const int qn = on ? 3 : 2;
-#pragma unroll 1
-                for (int q = 1; q < qn; ++q) {
-                  const uint32_t cq = q == 1 ? h1 : h0 + h1, nq = q == 1 ? pn1 : pn0 + pn1;
-                  const double t = feat::entropy_term(cq, nq, cf.libm_log2, s.log2tab);
-                  t1 = q == 1 ? t : t1; t2 = q == 2 ? t : t2;
-                }
-                if (on) feat::dist_terms(h0, pn0, h1, pn1, tl, tx);
+              const double e1 = s.r2ent[0][cc];               // r2's: worked out once per contraction (end of phase B)
+              if (on && (int)l16 < bins) {
+                t2 = feat::entropy_term(h0 + h1, pn0 + pn1, cf.libm_log2, s.log2tab);
+                feat::dist_terms(h0, pn0, h1, pn1, tl, tx);
               }
-              const double e1 = bin_sum(t1, bins, true), e2 = bin_sum(t2, bins, true);
+              const double e2 = bin_sum(t2, bins, true);
               const double dl = bin_sum(tl, bins, false), dx = bin_sum(tx, bins, false);
-              if ((int)l16 == bins - 1) {
-                double* q = fx + feat::pre_region(cf, kind, i); q[0] = e0; q[1] = e1; q[2] = e2; q[3] = dl; q[4] = dx;
-                if (files_r2) st.ch[cc].entP[r2] = e1;
-              }
+              if ((int)l16 == bins - 1) { double* q = fx + feat::pre_region(cf, kind, i); q[0] = e0; q[1] = e1; q[2] = e2; q[3] = dl; q[4] = dx; }
             }
           }
           for (int i = 0; i < BC_NB(cf); ++i) {
             const int cc = cf.bc[i];
             const int bins = cf.cbins[cc];
-            double t1 = 0.0, t2 = 0.0, t3 = 0.0;
+            double t2 = 0.0, t3 = 0.0;
             const EStats* B0 = &st.ch[cc].Bt[rs]; const EStats* B1 = &st.ch[cc].Bt[r2];
             const EStats* A = &st.ch[cc].e_A[rec];
             const EStats* sh = &L.shs[j * K + cc];
             const uint32_t g0 = B0->hist[l16], g1 = B1->hist[l16], ga = A->hist[l16], bn0 = B0->n, bn1 = B1->n, an = A->n;
             const double e0 = st.ch[cc].entB[rs];             // filed when rs was created (BcChan::entB)
-            if ((on || files_r2) && (int)l16 < bins) {
+            const double e1 = s.r2ent[1][cc];                 // r2's: worked out once per contraction (end of phase B)
+            if (on && (int)l16 < bins) {
               const uint32_t gs = sh->hist[l16], sn = sh->n;
-              const int qn = on ? 4 : 2;
+              // (one inlined copy of the logarithm per loop, not one per term: copies of the glibc restatement cost the loop
+              // through register pressure alone)
 #pragma unroll 1
-              for (int q = 1; q < qn; ++q) {
-                const uint32_t cq = q == 1 ? g1 : q == 2 ? g0 + g1 - ga : gs;
-                const uint32_t nq = q == 1 ? bn1 : q == 2 ? bn0 + bn1 - an : sn;
+              for (int q = 2; q < 4; ++q) {
+                const uint32_t cq = q == 2 ? g0 + g1 - ga : gs;
+                const uint32_t nq = q == 2 ? bn0 + bn1 - an : sn;
                 const double t = feat::entropy_term(cq, nq, cf.libm_log2, s.log2tab);
-                t1 = q == 1 ? t : t1; t2 = q == 2 ? t : t2; t3 = q == 3 ? t : t3;
+                t2 = q == 2 ? t : t2; t3 = q == 3 ? t : t3;
               }
             }
-            const double e1 = bin_sum(t1, bins, true), e2 = bin_sum(t2, bins, true), e3 = bin_sum(t3, bins, true);
-            if ((int)l16 == bins - 1) {
-              double* q = fx + feat::pre_boundary(cf, i); q[0] = e0; q[1] = e1; q[2] = e2; q[3] = e3;
-              if (files_r2) st.ch[cc].entB[r2] = e1;
-            }
+            const double e2 = bin_sum(t2, bins, true), e3 = bin_sum(t3, bins, true);
+            if ((int)l16 == bins - 1) { double* q = fx + feat::pre_boundary(cf, i); q[0] = e0; q[1] = e1; q[2] = e2; q[3] = e3; }
           }
         }
       }
