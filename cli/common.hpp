@@ -19,13 +19,10 @@
 #include <vector>
 
 #include "../include/glia_hmt.h"
+#include "text_io.hpp"      // perr, writeOrder / writeDoubles / writeRows: util/text_io.hxx:103-133 (host-only header, also built into cli/text_io_check)
 
 namespace cli {
 
-[[noreturn]] inline void perr(const std::string& msg) {   // glia_base.hxx:66-69
-  std::cerr << msg << std::endl;
-  exit(EXIT_FAILURE);
-}
 inline void check(int rc) { if (rc) perr(glia_hmt_last_error()); }
 inline void hipCheck(hipError_t e) { if (e != hipSuccess) perr(std::string("Error: HIP: ") + hipGetErrorString(e)); }
 
@@ -95,25 +92,6 @@ template <typename T> T* upload(const std::vector<T>& v) {
   hipCheck(hipMalloc(&d, sizeof(T) * (v.empty() ? 1 : v.size())));
   hipCheck(hipMemcpy(d, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
   return d;
-}
-
-// writeData(file, data, delim[, precision]) of util/text_io.hxx:103-133: every element is followed by the delimiter
-inline void writeOrder(const std::string& file, const std::vector<uint32_t>& o, int64_t n) {
-  std::ofstream os(file);
-  if (!os) perr("Error: cannot create file " + file);
-  for (int64_t i = 0; i < n; ++i) os << o[3 * i] << " " << o[3 * i + 1] << " " << o[3 * i + 2] << "\n";
-}
-inline void writeDoubles(const std::string& file, const double* d, int64_t n, int precision = -1) {
-  std::ofstream os(file);
-  if (!os) perr("Error: cannot create file " + file);
-  if (precision > 0) os.precision(precision);
-  for (int64_t i = 0; i < n; ++i) os << d[i] << "\n";
-}
-inline void writeRows(const std::string& file, const double* d, int64_t rows, int cols, int precision) {
-  std::ofstream os(file);
-  if (!os) perr("Error: cannot create file " + file);
-  if (precision > 0) os.precision(precision);
-  for (int64_t i = 0; i < rows; ++i) { for (int k = 0; k < cols; ++k) os << d[i * cols + k] << " "; os << "\n"; }
 }
 
 // boost::program_options-like parsing: --long value | -s value | multitoken | repeated options accumulate

@@ -1018,6 +1018,10 @@ int orc_feat_dim(int dim, const orc_feat_cfg* c) {
 // orc_merge_order_bc_ensemble for the duration of one call.
 struct EnsembleSel { const orc_forest* const* models; int dim0, dim1; double threshold; };
 static const EnsembleSel* g_ensemble = nullptr;
+// type/function.hxx:80-84: model 0 if x[dim1] < thr, else 1 if x[dim0] < thr, else 2 (pinned by oracle/_ref/ref_misc)
+int orc_pick_model(int dim0, int dim1, double threshold, const double* x) {
+  return x[dim1] < threshold ? 0 : x[dim0] < threshold ? 1 : 2;
+}
 
 int64_t orc_merge_order_bc(orc_rag* h, const orc_feat_cfg* c, const orc_forest* forest, int stub_index,
                            orc_label* order_out, double* sal_out, double* feats_out, int64_t cap,
@@ -1044,7 +1048,7 @@ int64_t orc_merge_order_bc(orc_rag* h, const orc_feat_cfg* c, const orc_forest* 
   auto pred = [&](ItemData const& data) -> double {
     if (g_ensemble) {   // type/function.hxx:80-84: model 0 if x[dim1] < thr, else 1 if x[dim0] < thr, else 2
       const EnsembleSel& e = *g_ensemble;
-      const int m = data[e.dim1] < e.threshold ? 0 : data[e.dim0] < e.threshold ? 1 : 2;
+      const int m = orc_pick_model(e.dim0, e.dim1, e.threshold, data.data());
       return forestPredict(e.models[m], data.data(), (int)data.size());   // alg/rf.hxx:97-98
     }
     if (forest) return forestPredict(forest, data.data(), (int)data.size());

@@ -157,6 +157,8 @@ int orc_boundary_confidence(orc_rag* h, int n_trees, const orc_label* const* ord
 int64_t orc_label_transform(const orc_label* node_label, const int32_t* child0, const int32_t* child1, int64_t n,
                             const int32_t* picks, int64_t n_picks, orc_label key, orc_label* src, orc_label* dst, int64_t cap);
 
+// opt::ThresholdModelDistributor (type/function.hxx:71-85): the ensemble member that scores vector x
+int orc_pick_model(int dim0, int dim1, double threshold, const double* x);
 // label-volume rewrites (util/struct_merge.hxx:188-210, util/image.hxx:227-242, :992-1001)
 int64_t orc_transform_keys(const orc_label* order, int64_t n_merges, orc_label* src, orc_label* dst, int64_t cap);
 void orc_transform_image(orc_label* lab, int64_t n, const orc_label* src, const orc_label* dst, int64_t m,

@@ -292,6 +292,11 @@ def gen_tree(order):
     return lab[:n], par[:n], c0[:n], c1[:n]
 
 
+def pick_model(dim0, dim1, threshold, x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    return lib().orc_pick_model(C.c_int(dim0), C.c_int(dim1), C.c_double(threshold), _p(x))
+
+
 def transform_keys(order):
     order = np.ascontiguousarray(order, dtype=np.uint32)
     cap = 2 * len(order) + 1

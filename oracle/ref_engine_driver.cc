@@ -12,12 +12,18 @@
 // The region map's three public leaf maps are filled from a dump of our own RAG, and the
 // linkage lambdas below restate util/struct_merge.hxx:45-76 (mean) and :98-132 (median).
 //
+// Round 3: the size-rule condition of gadget/main_pre_merge.cxx:27-76 is restated here as the fcond handed to the reference's
+// TBoundaryTable::top (type/boundary_table.hxx:46-52), so that the condition path of the reference's own queue walk runs, and the
+// reference's transformKeys (util/struct_merge.hxx:188-210, same translation unit) is printed for the order it produced.
+//
 // stdin:  R  P  B  type(1 median / 2 mean) updateRegion
 //         R lines:  label nPoints  p0 p1 ...          (voxel ids, raster order)
 //         P lines:  label nBorder  p0 p1 ...
 //         B lines:  a b n  p0 p1 ...                  (directed boundary voxel ids)
 //         then N pb values (N = number of voxels, first line gives N)
-// stdout: one "x0 x1 x2 saliency" line per merge (saliency printed with %.17g)
+//         optionally:  nThresholds t0 [t1] rpbThreshold      (type 2 only: the pre_merge condition, updateRegion is forced on)
+// stdout: one "x0 x1 x2 saliency" line per merge (saliency printed with %.17g), then one "K src dst" line per entry of
+//         transformKeys(order), sorted by src
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -60,6 +66,14 @@ int main() {
   std::vector<float> pb(N);
   for (long i = 0; i < N; ++i) if (scanf("%f", &pb[i]) != 1) return 2;
   if (R > 0) rmap.init(); else rmap.initContour();
+  int nThr = 0;
+  std::vector<int> sizeThresholds;
+  double rpbThreshold = 0.0;
+  if (scanf("%d", &nThr) == 1 && nThr > 0) {
+    sizeThresholds.resize(nThr);
+    for (int i = 0; i < nThr; ++i) if (scanf("%d", &sizeThresholds[i]) != 1) return 2;
+    if (scanf("%lf", &rpbThreshold) != 1) return 2;
+  }
 
   std::vector<TTriple<Label>> order;
   std::vector<double> sal;
@@ -84,6 +98,33 @@ int main() {
       d2.first = sdivide(d2.first, d2.second, 0.0);
     };
     const auto t0 = std::chrono::steady_clock::now();
+    if (nThr > 0) {
+      // gadget/main_pre_merge.cxx:27-76 with pbImage->GetPixel(p) = pb[p.id]
+      std::unordered_map<Label, double> rpbs;
+      auto fcond = [&](BT const&, BT::iterator btit) -> bool {
+        Label key0 = btit->first.first, key1 = btit->first.second;
+        auto const* pr0 = &rmap.find(key0)->second;
+        auto const* pr1 = &rmap.find(key1)->second;
+        auto sz0 = pr0->size(), sz1 = pr1->size();
+        if (sz0 > sz1) { std::swap(key0, key1); std::swap(pr0, pr1); std::swap(sz0, sz1); }
+        if (sz0 < sizeThresholds[0]) return true;
+        if (sizeThresholds.size() > 1) {
+          auto test = [&](Label key, decltype(pr0) pr, decltype(sz0) sz) -> bool {
+            auto it = rpbs.find(key);
+            if (it != rpbs.end()) return it->second > rpbThreshold;
+            double rpb = 0.0;
+            pr->traverse([&](VoxelId const& p) { rpb += pb[p.id]; });
+            rpb = sdivide(rpb, sz, 0.0);
+            rpbs[key] = rpb;
+            return rpb > rpbThreshold;
+          };
+          if (sz0 < sizeThresholds[1] && test(key0, pr0, sz0)) return true;
+          if (sz1 < sizeThresholds[1] && test(key1, pr1, sz1)) return true;
+        }
+        return false;
+      };
+      genMergeOrderGreedy<ItemData>(order, sal, rmap, true, initFb, fsal, updateFb, fsal, fcond);
+    } else
     genMergeOrderGreedy<ItemData>(order, sal, rmap, updateRegion != 0, initFb, fsal, updateFb, fsal,
                                   f_true<BT&, BT::iterator>);
     fprintf(stderr, "engine_seconds %.6f\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
@@ -110,5 +151,9 @@ int main() {
   }
   for (size_t i = 0; i < order.size(); ++i)
     printf("%u %u %u %.17g\n", order[i].x0, order[i].x1, order[i].x2, sal[i]);
+  std::unordered_map<Label, Label> lmap;
+  transformKeys(lmap, order);                                     // util/struct_merge.hxx:188-210
+  std::map<Label, Label> sorted(lmap.begin(), lmap.end());
+  for (auto const& kv : sorted) printf("K %u %u\n", kv.first, kv.second);
   return 0;
 }

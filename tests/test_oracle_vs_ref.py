@@ -23,15 +23,24 @@ def _ensure_ref():
         pytest.skip("oracle/_ref/ref_engine not built and /root/reference absent")
 
 
-def run_ref(rag, pb, type, upd):
+def run_ref(rag, pb, type, upd, cond=None, want_keys=False):
+    """cond = (size thresholds, rpb threshold): the pre_merge condition as fcond of the reference's TBoundaryTable::top"""
     with tempfile.TemporaryDirectory() as d:
         p = os.path.join(d, "dump.txt")
         rag.dump(pb, type, upd, p)
+        if cond is not None:
+            with open(p, "a") as f:
+                f.write("%d %s %r\n" % (len(cond[0]), " ".join(str(int(t)) for t in cond[0]), float(cond[1])))
         with open(p) as f:
             out = subprocess.run([REF], stdin=f, capture_output=True, text=True, check=True).stdout
     rows = [l.split() for l in out.strip().split("\n") if l]
+    keys = [r for r in rows if r[0] == "K"]
+    rows = [r for r in rows if r[0] != "K"]
     order = np.array([[int(r[0]), int(r[1]), int(r[2])] for r in rows], dtype=np.uint32).reshape(-1, 3)
-    return order, np.array([float(r[3]) for r in rows])
+    sal = np.array([float(r[3]) for r in rows])
+    if want_keys:
+        return order, sal, np.array([[int(r[1]), int(r[2])] for r in keys], dtype=np.uint32).reshape(-1, 2)
+    return order, sal
 
 
 CASES = [((32, 32, 32), 8, 16, 0), ((40, 36, 28), 6, 12, 1), ((96, 96), 8, 32, 0), ((64, 64), 4, 16, 1)]
@@ -58,6 +67,103 @@ def test_constant_pb_tie_torture():
     ro, rs = run_ref(rag, pb, 2, False)
     oo, os_ = rag.merge_order_pb(pb, 2, False)
     assert (ro == oo).all() and (rs == os_).all()
+
+
+@pytest.mark.parametrize("shape,S,G,variant", CASES)
+@pytest.mark.parametrize("only_contour,type,upd", [(True, 2, False), (False, 1, True)])
+def test_transform_keys_matches_reference(shape, S, G, variant, only_contour, type, upd):
+    """transformKeys (util/struct_merge.hxx:188-210) of the reference's own order vs the oracle's restatement"""
+    _ensure_ref()
+    lab, pb = O.synth(shape, S, G, variant=variant)
+    rag = O.Rag(lab, only_contour=only_contour)
+    ro, _, keys = run_ref(rag, pb, type, upd, want_keys=True)
+    src, dst = O.transform_keys(ro)
+    o = np.argsort(src)
+    assert len(keys) == len(src) and (keys[:, 0] == src[o]).all() and (keys[:, 1] == dst[o]).all()
+
+
+def test_transform_keys_of_a_partial_order_matches_reference():
+    """a pre_merge order is a forest: several final keys, untouched labels absent from the map"""
+    _ensure_ref()
+    lab, pb = O.synth((36, 40, 28), 6, 12)
+    rag = O.Rag(lab, only_contour=False)
+    ro, _, keys = run_ref(rag, pb, 2, True, cond=([150], 0.0), want_keys=True)
+    assert 0 < len(ro) < rag.num_regions - 1
+    src, dst = O.transform_keys(ro)
+    o = np.argsort(src)
+    assert len(keys) == len(src) and (keys[:, 0] == src[o]).all() and (keys[:, 1] == dst[o]).all()
+    assert len(np.unique(dst)) > 1
+
+
+PRE_MERGE = [((32, 32, 32), 8, 16, 0, [300], 0.0), ((32, 32, 32), 8, 16, 0, [200, 700], 0.3),
+             ((40, 36, 28), 6, 12, 1, [100, 400], 0.25), ((96, 96), 8, 32, 0, [40, 90], 0.2),
+             ((64, 64), 4, 16, 1, [10, 30], 0.35), ((40, 36, 28), 6, 12, 0, [1000000], 0.0)]
+
+
+@pytest.mark.parametrize("shape,S,G,variant,sizes,rpb", PRE_MERGE)
+def test_pre_merge_condition_matches_reference(shape, S, G, variant, sizes, rpb):
+    """the fcond path of TBoundaryTable::top (type/boundary_table.hxx:46-52) in the reference's own code, with the size rule of
+    gadget/main_pre_merge.cxx:27-76 restated in the driver, vs the oracle's pre_merge"""
+    _ensure_ref()
+    lab, pb = O.synth(shape, S, G, variant=variant)
+    rag = O.Rag(lab, only_contour=False)
+    ro, rs = run_ref(rag, pb, 2, True, cond=(sizes, rpb))
+    oo, os_ = O.Rag(lab, only_contour=False).pre_merge(pb, sizes, rpb)
+    assert ro.shape == oo.shape and (ro == oo).all()
+    assert np.allclose(rs, os_, rtol=0, atol=1e-12)
+    if sizes[0] < 1000000:
+        assert len(ro) < rag.num_regions - 1            # the condition did reject edges
+
+
+# ---- type/function.hxx ThresholdModelDistributor, util/text_io.hxx writeData / readData (oracle/_ref/ref_misc) ----
+REF_MISC = os.path.join(os.path.dirname(REF), "ref_misc")
+TEXT_IO_CHECK = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cli", "text_io_check")
+
+
+def _ensure_misc():
+    _ensure_ref()
+    if not os.path.exists(REF_MISC):
+        pytest.skip("oracle/_ref/ref_misc not built")
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_model_distributor_matches_reference(seed):
+    _ensure_misc()
+    rng = np.random.default_rng(500 + seed)
+    D = int(rng.integers(2, 12)); n = 200
+    dim0, dim1 = int(rng.integers(0, D)), int(rng.integers(0, D))
+    thr = float(np.round(1 + rng.random() * 6) / 8)
+    x = np.round(rng.random((n, D)) * 8) / 8                 # exact hits on the threshold included
+    text = "%d %d %r %d %d\n" % (dim0, dim1, thr, n, D) + "\n".join(" ".join(repr(float(v)) for v in row) for row in x) + "\n"
+    out = subprocess.run([REF_MISC, "dist"], input=text, capture_output=True, text=True, check=True).stdout.split()
+    ref = np.array([int(t) for t in out])
+    got = np.array([O.pick_model(dim0, dim1, thr, row) for row in x])
+    assert (ref == got).all() and len(set(ref)) > 1
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_text_writers_match_reference_bytes(seed):
+    """merge order / saliency / feature-row files of the tools (cli/text_io.hpp) vs writeData of util/text_io.hxx:103-133 at the
+    call sites' precisions (default, FLT_PREC = 8), byte for byte; and the reference's readData reads them back"""
+    _ensure_misc()
+    if not os.path.exists(TEXT_IO_CHECK):
+        subprocess.check_call(["make", "-C", os.path.dirname(TEXT_IO_CHECK), "text_io_check"], stdout=subprocess.DEVNULL)
+    rng = np.random.default_rng(900 + seed)
+    lab, pb = O.synth((20, 24, 16), 4, 8, variant=seed % 2)
+    order, sal = O.Rag(lab, only_contour=True).merge_order_pb(pb, type=2)
+    rows, cols = 37, 11
+    feats = rng.standard_normal((rows, cols)) * 10.0 ** rng.integers(-12, 12, size=(rows, cols))
+    feats[0, :4] = [0.0, 1.0, -1.0, 0.5]; feats[1, :3] = [1e-300, 123456789.0, 1.0 / 3.0]        # fixed / scientific / rounding cases
+    sal = np.concatenate([sal, [0.0, -0.0, 1e-7, 123456.7, 1234567.0]])
+    text = "%d\n" % len(order) + "".join("%d %d %d\n" % tuple(r) for r in order) + "%d\n" % len(sal) + \
+           "".join("%r\n" % float(v) for v in sal) + "%d %d\n" % (rows, cols) + "".join("%r\n" % float(v) for v in feats.ravel())
+    with tempfile.TemporaryDirectory() as a, tempfile.TemporaryDirectory() as b:
+        out = subprocess.run([REF_MISC, "write", a], input=text, capture_output=True, text=True, check=True).stdout.split()
+        subprocess.run([TEXT_IO_CHECK, b], input=text, capture_output=True, text=True, check=True)
+        for name in ("order.txt", "sal.txt", "feats.txt"):
+            with open(os.path.join(a, name), "rb") as fa, open(os.path.join(b, name), "rb") as fb:
+                assert fa.read() == fb.read(), name
+    assert out == ["roundtrip", "1", "1", str(rows), str(cols), str(rows * cols)]
 
 
 # ---- merge tree: genTree / genTreeWithNodePotentials / resolveTreeGreedy (hmt/tree_build.hxx, hmt/tree_greedy.hxx) ----
