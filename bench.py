@@ -151,15 +151,21 @@ def slab_phase(ctx, hmt, dist, torch, size, S, world, rank, clf):
         out["regions"] = merged.num_regions; out["pairs"] = merged.num_pairs
     # the merged map lives on the loop owner only: the others receive its compact records for the sharded scoring below
     rec = merged.to_tensors() if rank == 0 else None
-    shapes = torch.tensor([rec["rlabel"].numel(), rec["pa"].numel()] if rank == 0 else [0, 0], dtype=torch.int64, device="cuda")
+    # every rank must issue the SAME sequence of collectives: the number of image channels travels with the shapes and the
+    # receivers allocate the per-channel record tensors (rrec1 / prec1 ...) the owner's map carries
+    nchan = 1 + sum(1 for k_ in rec if k_.startswith("rrec") and k_ != "rrec") if rank == 0 else 0
+    shapes = torch.tensor([rec["rlabel"].numel(), rec["pa"].numel(), nchan] if rank == 0 else [0, 0, 0], dtype=torch.int64, device="cuda")
     dist.broadcast(shapes, 0)
     if rank != 0:
         like = hmt.RegionMap(ctx, sl, pb=sp, cfg=cfg, slab=(lo, size, zb, ze))
         lt = like.to_tensors()
-        R_, P_ = int(shapes[0].item()), int(shapes[1].item())
+        R_, P_, nchan = int(shapes[0].item()), int(shapes[1].item()), int(shapes[2].item())
         rec = dict(rlabel=torch.empty(R_, dtype=torch.int32, device="cuda"), rrec=torch.empty((R_, lt["rrec"].shape[1]), dtype=torch.int32, device="cuda"),
                    pa=torch.empty(P_, dtype=torch.int32, device="cuda"), pb=torch.empty(P_, dtype=torch.int32, device="cuda"),
                    prec=torch.empty((P_, lt["prec"].shape[1]), dtype=torch.int32, device="cuda"))
+        for c_ in range(1, nchan):
+            rec["rrec%d" % c_] = torch.empty((R_, lt["rrec"].shape[1]), dtype=torch.int32, device="cuda")
+            rec["prec%d" % c_] = torch.empty((P_, lt["prec"].shape[1]), dtype=torch.int32, device="cuda")
     for k_ in sorted(rec.keys()):
         dist.broadcast(rec[k_], 0)
     if rank != 0:
@@ -353,7 +359,7 @@ def main():
 
         def give_up():
             emit({"error": "slab phase did not finish within %d s" % args.slab_timeout})
-            os._exit(0)
+            os._exit(3)         # a process that touched the GPU and lost a collective: the line is out, the exit status says so
 
         dog = threading.Timer(args.slab_timeout, give_up)
         dog.daemon = True

@@ -21,6 +21,7 @@ int main(int argc, char* argv[]) {
   loadFeatInputs(a, f);
   glia_hmt_ctx* ctx; glia_hmt_rag* rag; glia_hmt_forest* bc;
   check(glia_hmt_ctx_create(0, nullptr, &ctx));
+  if (glia_hmt_ctx_libm_status(ctx) == 0) std::cerr << glia_hmt_last_error() << std::endl;     // host libm not reproduced: features within 1 ulp, unpinned
   uint32_t* dMask = loadMask(a, "maskImage", f.seg.size());
   check(glia_hmt_rag_build(ctx, f.seg.dim, f.seg.dims, f.dLab, dMask, /*only_contour=*/0, f.dPb, &f.cfg, &rag));
   auto models = a.all("bcm");

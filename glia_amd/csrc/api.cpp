@@ -204,6 +204,12 @@ int glia_hmt_ctx_create(int device, void* hip_stream, glia_hmt_ctx** out) {
   static const LibmSel sel = probe_host_libm();
   c->libm = sel;
   *out = c;
+  // The call succeeds either way; a host libm none of the restatements reproduces is reported through glia_hmt_last_error()
+  // (and glia_hmt_ctx_libm_status): entropy, --logs and compactness columns are then within 1 ulp of the host's, not pinned.
+  if (sel.log2_variant == 0 || sel.log_variant == 0 || sel.pow_variant == 0)
+    set_error(std::string("warning: the host libm's ") + (sel.log2_variant == 0 ? "log2 " : "") + (sel.log_variant == 0 ? "log " : "") +
+              (sel.pow_variant == 0 ? "pow " : "") + "is not reproduced bit for bit by a restatement (glibc 2.35 FMA / non-FMA builds): "
+              "the entropy / log / compactness feature columns are within 1 ulp of this host's values, unpinned; equal classifier scores may order differently");
   return GLIA_HMT_OK;
 }
 
@@ -212,6 +218,11 @@ int glia_hmt_ctx_libm(const glia_hmt_ctx* c, int* log2_variant, int* log_variant
   if (log2_variant) *log2_variant = c->libm.log2_variant;
   if (log_variant) *log_variant = c->libm.log_variant;
   return GLIA_HMT_OK;
+}
+
+int glia_hmt_ctx_libm_status(const glia_hmt_ctx* c) {
+  if (!c) return GLIA_HMT_ERR_ARG;
+  return (c->libm.log2_variant != 0 && c->libm.log_variant != 0 && c->libm.pow_variant != 0) ? 1 : 0;
 }
 
 int glia_hmt_ctx_libm_pow(const glia_hmt_ctx* c, int* pow_variant) {
@@ -327,7 +338,7 @@ static int rag_build_impl(glia_hmt_ctx* c, int dim, const int64_t dims[3], int64
     if (cfg->n_region < 0 || cfg->n_rlabel < 0 || cfg->n_boundary < 0 || cfg->n_region > kMaxListed ||
         cfg->n_rlabel > kMaxListed || cfg->n_boundary > kMaxListed ||
         cfg->n_thresholds < 0 || cfg->n_thresholds > GLIA_HMT_MAX_THRESH) {
-      set_error("rag_build: feature configuration out of range (at most 4 images per list, 4 thresholds)");
+      set_error("rag_build: feature configuration out of range (at most " + std::to_string(kMaxListed) + " images per list, " + std::to_string(GLIA_HMT_MAX_THRESH) + " thresholds)");
       return GLIA_HMT_ERR_ARG;
     }
     const float* pbv = cfg->d_pb ? cfg->d_pb : d_pb;

@@ -1144,7 +1144,12 @@ int GLIA_BC_ENTRY(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier
   const uint32_t R = (uint32_t)rag.R;
   *n_merges = 0;
   if (R == 0 || P == 0) return GLIA_HMT_OK;
-  if (cfg.fdim > kMaxFeat) { set_error("merge_order_bc: feature vector too long"); return GLIA_HMT_ERR_ARG; }
+  // the vector is assembled at FULL length (bc_full_dim) and the simple selection compacted in place afterwards: the full length
+  // is what the per-thread buffers (double x[kMaxFeat]) hold, not cfg.fdim
+  if (bc_full_dim(cfg) > kMaxFeat || cfg.fdim > kMaxFeat) {
+    set_error("merge_order_bc: feature vector too long (" + std::to_string(bc_full_dim(cfg)) + " columns before --simpf, limit " + std::to_string(kMaxFeat) + ")");
+    return GLIA_HMT_ERR_ARG;
+  }
   hipEvent_t ev[4];
   for (auto& e : ev) GLIA_HIP_TRY(hipEventCreate(&e));
   GLIA_HIP_TRY(hipEventRecord(ev[0], stream));

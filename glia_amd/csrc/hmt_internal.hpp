@@ -75,7 +75,7 @@ struct AccParams {
 };
 
 constexpr int kMaxChannels = 4;     // distinct (image volume, histogram) pairs over all feature lists
-constexpr int kMaxListed = 4;       // images per feature list (region / label / boundary)
+constexpr int kMaxListed = GLIA_HMT_MAX_IMAGES;   // images per feature list (region / label / boundary); the vector they give must still fit kMaxFeat columns
 
 // compact, sorted RAG as produced by the edge-table step
 struct RagArrays {

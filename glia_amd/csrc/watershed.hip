@@ -3,14 +3,16 @@
 // Reference: glia::watershed (util/image_alg.hxx:9-21, gadget/main_watershed.cxx) = itk::MorphologicalWatershedImageFilter
 // with SetLevel(level), MarkWatershedLineOff(), face connectivity.  ITK is not available here and its flooding resolves ties
 // by the arrival order of a sequential hierarchical queue, which no parallel algorithm reproduces in general: PARITY WITH ITK IS
-// UNPINNED BY CONSTRUCTION.  What is implemented -- here and, independently, in oracle/hmt_oracle.cc (orc_watershed), bit for
+// UNPINNED BY CONSTRUCTION (tie order only: the pipeline below is the filter's).  What is implemented -- here and, independently, in oracle/hmt_oracle.cc (orc_watershed), bit for
 // bit the same labels -- is the same morphological watershed with every tie decided by a rule that does not depend on any order:
 //   1. g = h-minima transform of f: reconstruction by erosion of (float)(f + level) above f (ITK's HMinima step);
 //   2. markers = regional minima of g (face-connected plateaus without a lower neighbour), numbered 1..n in raster order of
 //      their first voxel (ITK's RegionalMinima + ConnectedComponent steps);
-//   3. flooding: every voxel takes the label of the marker that reaches it at the lowest cost (L, d): L = the highest g on
-//      the path (the flood level), d = steps walked since the level last rose (distance on the plateau); equal costs: the
-//      smaller label.  Markers keep their label.
+//   3. flooding ON THE ORIGINAL IMAGE f (MorphologicalWatershedFromMarkers keeps the filter's input; only the regional-minima
+//      step sees the h-minima image): every voxel takes the label of the marker that reaches it at the lowest cost (L, d):
+//      L = the highest f on the path (the flood level), d = steps walked since the level last rose (distance on the plateau);
+//      equal costs: the smaller label.  Markers keep their label.  (Rounds 1-2 flooded on g: where g > f -- filled shallow
+//      minima -- basins were then split by plateau distance on g instead of by f's relief.)
 // Each step is a fixed point of a local rule, computed by whole-volume sweeps until nothing changes (HBM-streaming passes:
 // 4..28 B per voxel and sweep); the sweeps of step 3 are double-buffered (a voxel's state is three words).
 #include <rocprim/device/device_scan.hpp>
@@ -80,20 +82,20 @@ __global__ void ws_root_flag(WsGrid G, const unsigned long long* comp, const uin
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p < G.n) root[p] = (comp[p] == (unsigned long long)p && !haslower[p]) ? 1u : 0u;
 }
-__global__ void ws_init_flood(WsGrid G, const float* g, const unsigned long long* comp, const uint32_t* haslower, const uint32_t* rank, float* L,
+__global__ void ws_init_flood(WsGrid G, const float* f, const unsigned long long* comp, const uint32_t* haslower, const uint32_t* rank, float* L,
                               uint32_t* d, uint32_t* lab, uint32_t* marker) {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= G.n) return;
   const unsigned long long c = comp[p];
   const bool m = !haslower[c];
   marker[p] = m ? 1u : 0u;
-  L[p] = m ? g[p] : __builtin_inff();
+  L[p] = m ? f[p] : __builtin_inff();
   d[p] = m ? 0u : 0xFFFFFFFFu;
   lab[p] = m ? rank[c] + 1u : 0u;
 }
 // one sweep of the flooding: a voxel's state (L, d, label) = the lexicographic minimum over its labelled neighbours q of
-// (max(L_q, g_p), L unchanged ? d_q + 1 : 0, label_q); markers are fixed sources
-__global__ void ws_flood_sweep(WsGrid G, const float* g, const uint32_t* marker, const float* Li, const uint32_t* di, const uint32_t* li,
+// (max(L_q, f_p), L unchanged ? d_q + 1 : 0, label_q); markers are fixed sources
+__global__ void ws_flood_sweep(WsGrid G, const float* f, const uint32_t* marker, const float* Li, const uint32_t* di, const uint32_t* li,
                                float* Lo, uint32_t* dout, uint32_t* lo, uint32_t* changed) {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= G.n) return;
@@ -104,7 +106,7 @@ __global__ void ws_flood_sweep(WsGrid G, const float* g, const uint32_t* marker,
     // kept from before would then rest on nothing.  Costs settle first (their rule is monotone), then labels along the acyclic
     // relation "best predecessor".
     bL = __builtin_inff(); bd = 0xFFFFFFFFu; bl = 0u;
-    const float gp = g[p];
+    const float gp = f[p];
     ws_neighbours(G, p, [&](long long q) {
       const uint32_t lq = li[q];
       if (lq == 0u) return;
@@ -183,13 +185,13 @@ int watershed_labels(int dim, const int64_t dims[3], const float* d_img, double 
   WS_TRY(hipMalloc(&L0, 4 * n)); WS_TRY(hipMalloc(&L1, 4 * n)); WS_TRY(hipMalloc(&d0, 4 * n)); WS_TRY(hipMalloc(&d1, 4 * n));
   WS_TRY(hipMalloc(&l1, 4 * n)); WS_TRY(hipMalloc(&marker, 4 * n));
   uint32_t* l0 = d_out;
-  hipLaunchKernelGGL(ws_init_flood, dim3(blocks), dim3(256), 0, stream, G, g, comp, haslower, rank, L0, d0, l0, marker);
+  hipLaunchKernelGGL(ws_init_flood, dim3(blocks), dim3(256), 0, stream, G, d_img, comp, haslower, rank, L0, d0, l0, marker);
   for (;;) {
     uint32_t h = 0;
     WS_TRY(hipMemsetAsync(changed, 0, 4, stream));
     for (int rep = 0; rep < 4; ++rep) {        // an even number of sweeps: the current state ends in (L0, d0, d_out)
-      hipLaunchKernelGGL(ws_flood_sweep, dim3(blocks), dim3(256), 0, stream, G, g, marker, L0, d0, l0, L1, d1, l1, changed);
-      hipLaunchKernelGGL(ws_flood_sweep, dim3(blocks), dim3(256), 0, stream, G, g, marker, L1, d1, l1, L0, d0, l0, changed);
+      hipLaunchKernelGGL(ws_flood_sweep, dim3(blocks), dim3(256), 0, stream, G, d_img, marker, L0, d0, l0, L1, d1, l1, changed);
+      hipLaunchKernelGGL(ws_flood_sweep, dim3(blocks), dim3(256), 0, stream, G, d_img, marker, L1, d1, l1, L0, d0, l0, changed);
       total_sweeps += 2;
     }
     WS_TRY(hipMemcpyAsync(&h, changed, 4, hipMemcpyDeviceToHost, stream));

@@ -91,6 +91,9 @@ class Context:
         self.h = C.c_void_p()
         _check(lib().glia_hmt_ctx_create(C.c_int(device), C.c_void_p(stream) if stream else None, C.byref(self.h)))
         self.device = device
+        if lib().glia_hmt_ctx_libm_status(self.h) == 0:
+            import warnings
+            warnings.warn(lib().glia_hmt_last_error().decode())
 
     def close(self):
         if self.h:
@@ -111,6 +114,10 @@ class Context:
         a, b = C.c_int(0), C.c_int(0)
         _check(lib().glia_hmt_ctx_libm(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def libm_pinned(self):
+        """True when log2, log and pow of the host libm are all reproduced bit for bit (glia_hmt_ctx_libm_status)."""
+        return lib().glia_hmt_ctx_libm_status(self.h) == 1
 
     def libm_pow(self):
         """variant of std::pow(perim, 1.5) the kernels use (same codes as libm())"""

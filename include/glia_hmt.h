@@ -57,6 +57,9 @@ int glia_hmt_ctx_sync(glia_hmt_ctx* ctx);
  * 2 = the pow(perim, 1.5) of type/feat.hxx:78-79) in the given variant over a device array (parity tests). */
 int glia_hmt_ctx_libm(const glia_hmt_ctx* ctx, int* log2_variant, int* log_variant);
 int glia_hmt_ctx_libm_pow(const glia_hmt_ctx* ctx, int* pow_variant);        /* same, for std::pow(perim, 1.5) (type/feat.hxx:78-79) */
+/* 1 = all three host functions are reproduced bit for bit, 0 = at least one is not (glia_hmt_ctx_create then also leaves a
+ * "warning: ..." text in glia_hmt_last_error(); the tools print it to stderr), < 0 = error */
+int glia_hmt_ctx_libm_status(const glia_hmt_ctx* ctx);
 int glia_hmt_host_libm_probe(int* log2_variant, int* log_variant);
 int glia_hmt_host_libm_probe_pow(int* pow_variant);
 int glia_hmt_host_libm_eval(int function, int variant, const double* h_in, double* h_out, int64_t n);  /* host code of the same restatement, no GPU */
@@ -122,8 +125,10 @@ int glia_hmt_rag_build(glia_hmt_ctx* ctx, int dim, const int64_t dims[3], const 
  * one halo plane on each side that is not a face of the volume (dims_local[2] = planes handed in).  The result is a
  * PARTIAL region map: every statistic is a commutative monoid, so partial maps of all slabs are combined with
  * glia_hmt_rag_merge into exactly the map glia_hmt_rag_build gives for the whole volume.  Between ranks the partial
- * records travel as the plain device arrays glia_hmt_rag_device_arrays exposes (all-gather over RCCL: glia_amd/slab.py)
- * and are wrapped again with glia_hmt_rag_from_arrays (`like` supplies configuration and dimensions). */
+ * records travel as the plain device arrays glia_hmt_rag_device_arrays exposes -- only the records glia_hmt_rag_cut_flags marks
+ * take the keyed owner exchange (unpadded point-to-point messages over RCCL), everything goes once to the rank that runs the
+ * merge loop (glia_amd/slab.py) -- and are wrapped again with glia_hmt_rag_from_arrays (`like` supplies configuration and
+ * dimensions). */
 int glia_hmt_rag_build_slab(glia_hmt_ctx* ctx, const int64_t dims_local[3], int64_t z_global_of_plane0,
                             int64_t nz_global, int64_t z_begin, int64_t z_end, const uint32_t* d_labels,
                             int only_contour, const float* d_pb, const glia_hmt_feat_config* cfg, glia_hmt_rag** out);

@@ -1465,7 +1465,8 @@ int64_t orc_label_transform(const orc_label* node_label, const int32_t* child0, 
 
 // ---- morphological watershed (util/image_alg.hxx:9-21 = itk::MorphologicalWatershedImageFilter, level, no watershed line,
 // face connectivity).  PARITY WITH ITK IS UNPINNED (ITK is not in this image, the reference holds no fixture): this restates the
-// documented pipeline -- h-minima transform, regional minima as markers numbered in raster order, flooding -- with the same
+// documented pipeline -- h-minima transform, regional minima of it as markers numbered in raster order, flooding of the ORIGINAL
+// image from those markers (MorphologicalWatershedFromMarkers keeps the filter's input) -- with the same
 // order-free tie rules as the device code (lowest flood level, then fewest steps since the level last rose, then the smaller
 // label), by sequential algorithms of its own: a worklist reconstruction, breadth-first plateaus, Dijkstra flooding.
 int64_t orc_watershed(int dim, const int64_t* dims, const float* img, double level, orc_label* out) {
@@ -1526,7 +1527,7 @@ int64_t orc_watershed(int dim, const int64_t* dims, const float* img, double lev
   std::vector<float> L(n, std::numeric_limits<float>::infinity());
   std::vector<uint32_t> D(n, 0xFFFFFFFFu);
   std::vector<char> marker(n, 0), done(n, 0);
-  for (int64_t p = 0; p < n; ++p) if (lab[p]) { marker[p] = 1; L[p] = g[p]; D[p] = 0; pq.push(St{g[p], 0u, lab[p], p}); }
+  for (int64_t p = 0; p < n; ++p) if (lab[p]) { marker[p] = 1; L[p] = img[p]; D[p] = 0; pq.push(St{img[p], 0u, lab[p], p}); }
   int64_t q[6];
   while (!pq.empty()) {
     const St s1 = pq.top(); pq.pop();
@@ -1536,7 +1537,7 @@ int64_t orc_watershed(int dim, const int64_t* dims, const float* img, double lev
     for (int i = 0; i < k; ++i) {
       const int64_t t = q[i];
       if (marker[t] || done[t]) continue;
-      const float Lc = std::max(s1.L, g[t]);
+      const float Lc = std::max(s1.L, img[t]);
       const uint32_t dc = Lc == s1.L ? s1.d + 1u : 0u;
       if (lab[t] == 0 || Lc < L[t] || (Lc == L[t] && (dc < D[t] || (dc == D[t] && s1.l < lab[t])))) {
         L[t] = Lc; D[t] = dc; lab[t] = s1.l; pq.push(St{Lc, dc, s1.l, t});

@@ -230,6 +230,43 @@ def test_histogram_as_features_layout(ctx, shape, S, G, layout):
         hmt.RegionMap(ctx, d_lab, pb=d_pb, cfg=hmt.make_config(d_pb, use_median_features=True, **dkw))
 
 
+def test_full_vector_longer_than_the_kernel_buffers_is_refused(ctx):
+    """with --histf the FULL vector (assembled before --simpf compacts it) of three 16-bin images on the region
+    and the boundary list has 524 columns although the --simpf selection keeps 20: the per-thread buffers hold kMaxFeat = 384, so
+    the call must come back with an error, not overrun them; a layout that fits still matches the oracle."""
+    import torch
+    from glia_amd import hmt
+    from oracle import pyoracle as O
+    shape = (32, 32, 32)
+    labels, pb = O.synth(shape, 8, 16)
+    rng = np.random.default_rng(77)
+    raws = [(np.round(rng.random(shape) * 255) / 256.0).astype(np.float32) for _ in range(2)]
+    d_lab = torch.from_numpy(labels.view(np.int32)).cuda()
+    d_pb = torch.from_numpy(pb).cuda()
+    d_raws = [torch.from_numpy(r).cuda() for r in raws]
+    big = hmt.make_config(d_pb, use_histogram_features=True, use_simple_features=True,
+                          rb=[(d_pb, 16, 0.0, 1.0), (d_raws[0], 16, 0.0, 1.0), (d_raws[1], 16, 0.0, 1.0)])
+    rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, cfg=big)
+    assert rm.feat_dim() < 64                                    # the selection is short ...
+    with pytest.raises(hmt.HmtError) as ei:
+        rm.merge_order_bc(hmt.FeatureStubClassifier(ctx, 5))
+    assert "too long" in str(ei.value)                           # ... the full vector is not
+    with pytest.raises(hmt.HmtError):
+        rm.bc_feat(O.Rag(labels, only_contour=True).merge_order_pb(pb, type=2)[0])
+    rm.close()
+    # five images on one list (more than the old limit of four), three distinct volumes, 4 bins: fits, and matches the oracle
+    okw = dict(r=[(raws[0], 4, 0.0, 1.0), (raws[1], 4, 0.0, 1.0), (pb, 4, 0.0, 1.0), (raws[0], 4, 0.0, 1.0), (raws[1], 4, 0.0, 1.0)])
+    dkw = dict(r=[(d_raws[0], 4, 0.0, 1.0), (d_raws[1], 4, 0.0, 1.0), (d_pb, 4, 0.0, 1.0), (d_raws[0], 4, 0.0, 1.0), (d_raws[1], 4, 0.0, 1.0)])
+    ocfg = O.make_cfg(pb, **okw)
+    rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, cfg=hmt.make_config(d_pb, **dkw))
+    fd = rm.feat_dim()
+    assert fd == O.feat_dim(3, ocfg)
+    order, sal, feats = rm.merge_order_bc(hmt.FeatureStubClassifier(ctx, fd - 3), want_feats=True)
+    o_ref, s_ref, f_ref = O.Rag(labels).merge_order_bc(ocfg, None, stub_index=fd - 3, want_feats=True)
+    assert (order == o_ref).all() and (sal == s_ref).all() and _feat_close(feats, f_ref)
+    rm.close()
+
+
 @pytest.mark.parametrize("shape,S,G", [((32, 32, 32), 8, 16), ((40, 36, 28), 6, 12), ((64, 64), 4, 16)])
 def test_bc_feat_for_a_given_order(ctx, shape, S, G):
     """hmt/main_bc_feat.cxx path: features of every merge of a GIVEN order (here: the pb-mean order)."""

@@ -26,4 +26,7 @@ for rep in range(2):
     print("size=%d S=%d R=%d P=%d merges=%d  rag %.1f ms  bc total %.1f ms  (table %.1f init %.1f loop %.1f)  edges scored %d  -> %.0f merges/s, %.0f edge-features/s; sal[0..3]=%s" % (
         size, S, rm.num_regions, rm.num_pairs, len(order), (t1 - t0) * 1e3, (t2 - t1) * 1e3, tm["ms_table"], tm["ms_init"], tm["ms_loop"],
         tm["n_edges_scored"], len(order) / (tm["ms_loop"] * 1e-3), tm["n_edges_scored"] / ((tm["ms_init"] + tm["ms_loop"]) * 1e-3), sal[:3]))
+    if os.environ.get("GLIA_BC_HASH"):     # kernel experiments: the whole result must not change
+        import hashlib
+        print("sha1 order %s sal %s" % (hashlib.sha1(np.ascontiguousarray(order).tobytes()).hexdigest(), hashlib.sha1(np.ascontiguousarray(sal).tobytes()).hexdigest()), flush=True)
     rm.close()
