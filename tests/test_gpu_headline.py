@@ -15,8 +15,8 @@ pytestmark = pytest.mark.gpu
 # recorded with tools/pb_bench.py 1024 16 2 (profiles/r02q_pb_hash.txt) and tools/bc_bench.py 512 16 (profiles/r03_bc_hash.txt)
 PB_1024 = ("977022085e1a37a4d143841a51ea8834b6f53c59", "7923436b47d4484f1e95962ac87ff409d4f2c617")
 PB_512 = ("652c84e7efe781bacc9df8c0a16675ca7e34cf17", "d78663710b1699d331a62c40471ba2d90ffc6515")
-BC_512 = ("@BC512_ORDER@", "@BC512_SAL@")
-BC_256 = ("@BC256_ORDER@", "@BC256_SAL@")
+BC_512 = ("8e620b69eab2cc31991eaca662446f52ad2231df", "8e30e7ba92d7b89dc09c413260a0841df1cbf886")
+BC_256 = ("51b7b5316e0d8fd648ab2b444527633d8eaf65c5", "5eadbd683d6a042f7bf950aa2352ef93bdc12956")
 
 
 @pytest.fixture(scope="module")
