@@ -89,11 +89,14 @@ struct BcState {
   uint32_t* nm_out;              // [R0] non-mutual out-entries per leaf
   uint32_t *mark0, *mark1;       // [2*R0]
   uint32_t* order; double* sal_out; double* feats_out;
-  double* featbuf;               // [2][kChunk][full feature dim]: the chunk's vectors for the helper workgroups (two jobs in flight)
-  uint32_t* hctl;                // helper protocol: [0] job word = sequence << 8 | records in the job (0xFFFFFFFF = quit)
-  unsigned long long* hvotes;    // [2][kChunk] sequence << 32 | votes: the contraction workgroup polls the slots it waits for
-  int* hmodel;                   // [2][kChunk]
-  uint32_t n_helpers;            // workgroups 1..n_helpers evaluate the forest; 0 = the loop's own workgroup does
+  // Helper workgroups score WHOLE records (round 3): the loop's workgroup publishes a job -- "records ne0 .. ne0 + cnt of the region
+  // r2 just created" -- and helper h takes the records h, h + H, ...: it stages everything a record's vector needs with agent-scope
+  // loads, computes neighbour extremes, shared-boundary set, entropies, the vector and the forest's votes, and answers with one
+  // 64-bit word per record.  Everything a helper reads that this launch writes is stored write-through (st_agent) by the loop.
+  uint32_t* hctl;                // [0] job sequence number (never 0; 0xFFFFFFFF = quit)
+  unsigned long long* hjob;      // [kJobBufs][kJobWords] job descriptors, slot = sequence % kJobBufs
+  unsigned long long* hvotes;    // [kJobMax] sequence << 32 | model << 24 | votes, indexed by the record's position in the job
+  uint32_t n_helpers;            // workgroups 1..n_helpers score records; 0 = the loop's own workgroup does
   uint32_t shard, n_shards;      // initial scoring: this call scores the records e with e % n_shards == shard (multi-GPU K7)
   unsigned long long* ctrl;
   unsigned long long max_iters;
@@ -105,22 +108,68 @@ struct BcState {
 
 namespace {
 
+// ---- memory access forms -----------------------------------------------------------------------------------------------
+// Everything the loop's workgroup and the helpers exchange goes through agent-scope accesses: write-through (sc1) stores by the
+// producer, "my stores are acknowledged" (s_waitcnt vmcnt(0) in every storing wave + the workgroup's barrier) before ONE lane
+// stores the flag, and sc1 loads -- which bypass the reader's L1 -- for EVERY load of such bytes by the consumer
+// (cdna_hip_programming.md Guideline 16, form R1 with sc1 loads in place of the acquire).  A release / acquire fence pair at
+// agent scope would write back and invalidate whole caches at every hand-off (measured in round 1: -12 % loop time without).
+__device__ __forceinline__ uint32_t ld_relaxed(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_release(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(reinterpret_cast<uint32_t*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(uint8_t* p, uint8_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(float2* p, float2 v) {
+  st_agent(reinterpret_cast<unsigned long long*>(p), ((unsigned long long)__float_as_uint(v.y) << 32) | (unsigned long long)__float_as_uint(v.x));
+}
+// a statistics struct (a whole number of 8-byte words, 8-byte aligned) with write-through stores
+template <class T>
+__device__ __forceinline__ void st_agent_struct(T* dst, const T& v) {
+  static_assert(sizeof(T) % 8 == 0 && alignof(T) >= 8, "8-byte words");
+  unsigned long long w[sizeof(T) / 8];
+  __builtin_memcpy(w, &v, sizeof(T));
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(T) / 8); ++i) st_agent(reinterpret_cast<unsigned long long*>(dst) + i, w[i]);
+}
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// loads of bytes another workgroup may have written in this launch: AG = true in the helpers (sc1: past the L1), plain in the
+// loop's own workgroup (the only writer of that state)
+template <bool AG> __device__ __forceinline__ uint32_t ldm(const uint32_t* p) { if (AG) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return *p; }
+template <bool AG> __device__ __forceinline__ uint8_t ldm(const uint8_t* p) { if (AG) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return *p; }
+template <bool AG> __device__ __forceinline__ unsigned long long ldm(const unsigned long long* p) { if (AG) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return *p; }
+template <bool AG> __device__ __forceinline__ float ldm(const float* p) { return __uint_as_float(ldm<AG>(reinterpret_cast<const uint32_t*>(p))); }
+template <bool AG> __device__ __forceinline__ double ldm(const double* p) { return __longlong_as_double((long long)ldm<AG>(reinterpret_cast<const unsigned long long*>(p))); }
+template <bool AG> __device__ __forceinline__ float2 ldm(const float2* p) {
+  const unsigned long long w = ldm<AG>(reinterpret_cast<const unsigned long long*>(p));
+  return make_float2(__uint_as_float((uint32_t)w), __uint_as_float((uint32_t)(w >> 32)));
+}
+// this wave's earlier stores have been acknowledged (and the compiler keeps later accesses behind this point)
+__device__ __forceinline__ void stores_done() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void after_flag() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+
+template <bool AG>
 __device__ __forceinline__ uint32_t find_root(const BcState& st, uint32_t x) {
-  uint32_t p = st.parent[x];
+  uint32_t p = ldm<AG>(&st.parent[x]);
   while (p != x) {
-    const uint32_t g = st.parent[p];
-    if (g != p) st.parent[x] = g;    // path halving (benign race: only ever points to an ancestor)
+    const uint32_t g = ldm<AG>(&st.parent[p]);
+    if (g != p) st_agent(&st.parent[x], g);    // path halving (benign race: only ever points to an ancestor)
     x = p; p = g;
   }
   return x;
 }
 
-// does leaf x still own an un-cancelled boundary entry inside its region?
+// does leaf x still own an un-cancelled boundary entry inside its region?  (nm_out, le_* are constant during the loop)
+template <bool AG>
 __device__ bool leaf_alive(const BcState& st, uint32_t x) {
   if (st.nm_out[x]) return true;
-  const uint32_t rx = find_root(st, x);
+  const uint32_t rx = find_root<AG>(st, x);
   for (uint32_t i = st.le_start[x]; i < st.le_start[x + 1]; ++i)
-    if (st.le_mutual[i] && find_root(st, st.le_dst[i]) != rx) return true;
+    if (st.le_mutual[i] && find_root<AG>(st, st.le_dst[i]) != rx) return true;
   return false;
 }
 
@@ -146,29 +195,75 @@ __device__ void shared_boundary(const BcState& st, int c, uint32_t rec, EStats& 
     sh = ch.e_A[rec];
     estats_add(sh, ch.e_NA[rec]);
     for (uint32_t f = st.e_fhead[rec]; f != kNone; f = st.le_next[f])
-      if (leaf_alive(st, st.le_dst[f])) estats_add(sh, ch.le_stats[f]);
+      if (leaf_alive<false>(st, st.le_dst[f])) estats_add(sh, ch.le_stats[f]);
   }
 }
 
-// feature vector of record rec (regions `first`, `second` in the reference's orientation); `out` must hold
-// bc_full_dim doubles (the simple selection is compacted in place).  No private arrays: see bc_features.hpp.
+// ---- where a vector's statistics live ------------------------------------------------------------------------------------
+// edge_features reads them through a view: the global arrays (initial edges, the popped edge's vector), or the copies a scoring
+// round has staged in LDS (RecIn / R2In below).  cc = image channel.
+struct GlobalView {
+  const BcState* st; uint32_t first, second, rec; const EStats* shv;      // shv[cc]: shared boundary sets, computed beforehand
+  __device__ __forceinline__ const PStats* P0(int cc) const { return &st->ch[cc].pts[first]; }
+  __device__ __forceinline__ const PStats* P1(int cc) const { return &st->ch[cc].pts[second]; }
+  __device__ __forceinline__ const EStats* B0(int cc) const { return &st->ch[cc].Bt[first]; }
+  __device__ __forceinline__ const EStats* B1(int cc) const { return &st->ch[cc].Bt[second]; }
+  __device__ __forceinline__ const EStats* A(int cc) const { return rec != kNone ? &st->ch[cc].e_A[rec] : nullptr; }   // kNone: no shared record (bc_feat on non-neighbours)
+  __device__ __forceinline__ const EStats* sh(int cc) const { return &shv[cc]; }
+  __device__ __forceinline__ float bmn0(int cc) const { return st->ch[cc].Bmn[first]; }
+  __device__ __forceinline__ float bmx0(int cc) const { return st->ch[cc].Bmx[first]; }
+  __device__ __forceinline__ float bmn1(int cc) const { return st->ch[cc].Bmn[second]; }
+  __device__ __forceinline__ float bmx1(int cc) const { return st->ch[cc].Bmx[second]; }
+};
+// one record's staged inputs on one channel (first = the neighbour rs) ...
+struct alignas(16) RecIn {
+  PStats P; uint32_t padP[2];     // pts[rs]
+  EStats B;                       // Bt[rs]
+  EStats A;                       // e_A[rec]
+  EStats sh;                      // staged: e_NA[rec]; then the shared boundary set (A + NA + alive fragile entries)
+  float bnmn, bnmx;               // Bn[rs] extremes
+  float bmn, bmx;                 // Bmn / Bmx[rs]
+  float exmn, exmx;               // extremes of rs's boundary set without this record's mutual entries
+  uint32_t pad[2];
+  double entP, entB;              // entropies of pts[rs], Bt[rs]
+};
+static_assert(sizeof(PStats) == 120 && sizeof(EStats) == 112 && sizeof(RecIn) == 512, "staging layout");
+// ... and the region being created (second = r2), once per round
+struct alignas(16) R2In {
+  PStats P; uint32_t padP[2];
+  EStats B;
+  float bnmn, bnmx, bmn, bmx;
+  double entP, entB;
+};
+static_assert(sizeof(R2In) == 272, "staging layout");
+struct StagedView {
+  const RecIn* in; const R2In* r2;        // [K] each
+  __device__ __forceinline__ const PStats* P0(int cc) const { return &in[cc].P; }
+  __device__ __forceinline__ const PStats* P1(int cc) const { return &r2[cc].P; }
+  __device__ __forceinline__ const EStats* B0(int cc) const { return &in[cc].B; }
+  __device__ __forceinline__ const EStats* B1(int cc) const { return &r2[cc].B; }
+  __device__ __forceinline__ const EStats* A(int cc) const { return &in[cc].A; }
+  __device__ __forceinline__ const EStats* sh(int cc) const { return &in[cc].sh; }
+  __device__ __forceinline__ float bmn0(int cc) const { return in[cc].bmn; }
+  __device__ __forceinline__ float bmx0(int cc) const { return in[cc].bmx; }
+  __device__ __forceinline__ float bmn1(int cc) const { return r2[cc].bmn; }
+  __device__ __forceinline__ float bmx1(int cc) const { return r2[cc].bmx; }
+};
+
+// feature vector of one record, read through a view V (above); `out` must hold bc_full_dim doubles (the simple selection is
+// compacted in place).  No private arrays: see bc_features.hpp.
 // ex: per channel {min, max of first's boundary set without the record's mutual entries, the same for second};
-// pre (optional): values of the lane-parallel pass (feat::pre_region / pre_boundary); sh_pre (optional): the shared
-// boundary set of every channel
+// pre (optional): values of the lane-parallel pass (feat::pre_region / pre_boundary)
 // parts: which blocks to write (1 first region, 2 second region, 4 merged region, 8 boundary block) -- the greedy loop
 // gives each block to a different wave; finish: apply the log / simple selection (the loop does both lane-parallel)
-__device__ void edge_features(const BcState& st, uint32_t first, uint32_t second, uint32_t rec, const float* ex, double* out,
-                              const double* pre = nullptr, const EStats* sh_pre = nullptr, int parts = 15, bool finish = true) {
-#ifdef GLIA_HMT_PROFILE
-  const unsigned long long tq_in = __builtin_readcyclecounter();
-#endif
-  const BcCfg& c = st.cfg;
-  const BcChan& c0 = st.ch[0];
-  const PStats* P0 = &c0.pts[first];
-  const PStats* P1 = &c0.pts[second];
-  const EStats* B0 = &c0.Bt[first];
-  const EStats* B1 = &c0.Bt[second];
-  const EStats* A0 = rec != kNone ? &c0.e_A[rec] : nullptr;     // kNone: no shared record (bc_feat on non-neighbours)
+template <class V>
+__device__ __forceinline__ void edge_features(const BcCfg& c, const V& v, const float* ex, double* out, const double* pre = nullptr, int parts = 15,
+                                              bool finish = true) {
+  const PStats* P0 = v.P0(0);
+  const PStats* P1 = v.P1(0);
+  const EStats* B0 = v.B0(0);
+  const EStats* B1 = v.B1(0);
+  const EStats* A0 = v.A(0);
   const uint32_t n0 = P0->n, n1 = P1->n;
   // keep region 0 area <= region 1 area (main_merge_order_bc.cxx:77-80): decides the slots of the two region blocks
   const bool swap = feat::sdiv((double)n0, c.norm_area, 0.0) > feat::sdiv((double)n1, c.norm_area, 0.0);
@@ -178,23 +273,22 @@ __device__ void edge_features(const BcState& st, uint32_t first, uint32_t second
   double* o_merged = out + c.bfdim + 2 * c.rfdim;
   // statistics sources of one region (which = 0 first, 1 second) and of the scratch-merged region (which = 2)
   auto src_of = [&](int which) {
-    return [&st, &c, first, second, rec, ex, pre, which](int kind, int i) -> feat::ImgSrc {
+    return [&c, &v, ex, pre, which](int kind, int i) -> feat::ImgSrc {
       const int cc = kind == 0 ? c.rc[i] : (kind == 1 ? c.lc[i] : c.bc[i]);
-      const BcChan& ch = st.ch[cc];
       const double* pe = nullptr;
       if (pre) pe = kind < 2 ? pre + feat::pre_region(c, kind, i) + which : pre + feat::pre_boundary(c, i) + which;
       if (kind < 2) {
-        const PStats* p0 = &ch.pts[first]; const PStats* p1 = &ch.pts[second];
+        const PStats* p0 = v.P0(cc); const PStats* p1 = v.P1(cc);
         if (which == 0) return feat::ImgSrc{p0->hist, nullptr, nullptr, p0->n, p0->sum, p0->sq, p0->mn, p0->mx, pe};
         if (which == 1) return feat::ImgSrc{p1->hist, nullptr, nullptr, p1->n, p1->sum, p1->sq, p1->mn, p1->mx, pe};
         return feat::ImgSrc{p0->hist, p1->hist, nullptr, p0->n + p1->n, p0->sum + p1->sum, p0->sq + p1->sq,
                             p1->mn < p0->mn ? p1->mn : p0->mn, p1->mx > p0->mx ? p1->mx : p0->mx, pe};
       }
-      const EStats* b0 = &ch.Bt[first]; const EStats* b1 = &ch.Bt[second];
-      if (which == 0) return feat::ImgSrc{b0->hist, nullptr, nullptr, b0->n, b0->sum, b0->sq, ch.Bmn[first], ch.Bmx[first], pe};
-      if (which == 1) return feat::ImgSrc{b1->hist, nullptr, nullptr, b1->n, b1->sum, b1->sq, ch.Bmn[second], ch.Bmx[second], pe};
+      const EStats* b0 = v.B0(cc); const EStats* b1 = v.B1(cc);
+      if (which == 0) return feat::ImgSrc{b0->hist, nullptr, nullptr, b0->n, b0->sum, b0->sq, v.bmn0(cc), v.bmx0(cc), pe};
+      if (which == 1) return feat::ImgSrc{b1->hist, nullptr, nullptr, b1->n, b1->sum, b1->sq, v.bmn1(cc), v.bmx1(cc), pe};
       // the merged boundary set: both sets minus the mutual entries of the shared record
-      const EStats* a = rec != kNone ? &ch.e_A[rec] : nullptr;
+      const EStats* a = v.A(cc);
       uint32_t bn = b0->n + b1->n;
       double bsum = b0->sum + b1->sum, bsq = b0->sq + b1->sq;
       if (a) { bn -= a->n; bsum -= a->sum; bsq -= a->sq; }
@@ -234,23 +328,22 @@ __device__ void edge_features(const BcState& st, uint32_t first, uint32_t second
   }
   if (parts & 8) {
     // shared boundary: counts from channel 0, image statistics from each boundary-list channel
-    EStats sh_local;
-    if (!sh_pre) shared_boundary(st, 0, rec, sh_local);
-    const EStats& sh0 = sh_pre ? sh_pre[0] : sh_local;
-    EStats sh_tmp;
+    const EStats* sh0 = v.sh(0);
     auto srcSh = [&](int i) -> feat::ImgSrc {
-      const int cc = c.bc[i];
-      const EStats* sh = &sh0;
-      if (cc != 0) { if (sh_pre) sh = &sh_pre[cc]; else { shared_boundary(st, cc, rec, sh_tmp); sh = &sh_tmp; } }
+      const EStats* sh = v.sh(c.bc[i]);
       return feat::ImgSrc{sh->hist, nullptr, nullptr, sh->n, sh->sum, sh->sq, sh->mn, sh->mx, pre ? pre + feat::pre_boundary(c, i) + 3 : nullptr};
     };
-    if (swap) feat::boundary_feats_multi(c, sh0.n, sh0.thr, ar_second, pe_second, ar_first, pe_first, src_of(1), src_of(0), srcSh, pre, o_bf);
-    else feat::boundary_feats_multi(c, sh0.n, sh0.thr, ar_first, pe_first, ar_second, pe_second, src_of(0), src_of(1), srcSh, pre, o_bf);
+    if (swap) feat::boundary_feats_multi(c, sh0->n, sh0->thr, ar_second, pe_second, ar_first, pe_first, src_of(1), src_of(0), srcSh, pre, o_bf);
+    else feat::boundary_feats_multi(c, sh0->n, sh0->thr, ar_first, pe_first, ar_second, pe_second, src_of(0), src_of(1), srcSh, pre, o_bf);
   }
   if (finish) feat::finish_features(c, out);
-#ifdef GLIA_HMT_PROFILE
-  if (threadIdx.x == 0) { g_pqprof[25] += __builtin_readcyclecounter() - tq_in; g_pqprof[26] += 1; }
-#endif
+}
+// ... from the global arrays (one thread; the shared boundary sets of all channels are formed first)
+__device__ void edge_features_global(const BcState& st, uint32_t first, uint32_t second, uint32_t rec, const float* ex, double* out) {
+  EStats shv[kMaxChannels];
+  for (int cc = 0; cc < st.cfg.K; ++cc) shared_boundary(st, cc, rec, shv[cc]);
+  const GlobalView v{&st, first, second, rec, shv};
+  edge_features(st.cfg, v, ex, out);
 }
 
 __device__ __forceinline__ int forest_vote(const DeviceForest& f, int tree, const double* x) {
@@ -416,7 +509,7 @@ __global__ void bc_init_score(BcState st, uint32_t E0) {
     else { ex[4 * c + 0] = ex[4 * c + 1] = ex[4 * c + 2] = ex[4 * c + 3] = 0.f; }
   }
   double x[kMaxFeat];
-  edge_features(st, first, second, e, ex, x);
+  edge_features_global(st, first, second, e, ex, x);
   st.pq.leaf_sal[e] = classify_serial(st.clf, x);
 }
 
@@ -436,118 +529,369 @@ __device__ __forceinline__ double bin_chain(double t, int bins, bool negate) {
   return acc;
 }
 
-constexpr int kPoolBytes = 112 * 1024;   // LDS workspace of the scoring phase, partitioned at run time (bc_layout)
+constexpr int kPoolBytes = 112 * 1024;   // LDS workspace of the scoring phase, partitioned at run time (ws_layout)
+constexpr uint32_t kJobMax = 1u << 16;    // records per job = slots of the votes array
+constexpr uint32_t kJobBufs = 4;          // job descriptors in flight (slot = sequence % kJobBufs; see bc_helper_loop)
+constexpr uint32_t kJobWords = 4 + 4 * kMaxChannels;
+constexpr uint32_t kHelpChunk = 8;        // records a helper scores per round (two fill one pass of a 255-tree forest)
+struct RecHdr { uint32_t rec, rs, own, on, fhead, off, len; int model; };
 struct BcShared {
   uint32_t r0, r1, e, stop, len0, len1, off0, off1, newcount;
   // per channel: ord(value) << 32 | record over r2's new records (their r2 -> rs extremes), best and runner-up
   unsigned long long best_mn[kMaxChannels], best_mx[kMaxChannels], second_mn[kMaxChannels], second_mx[kMaxChannels];
   uint32_t ex[kMaxChannels][4];
   int votes[kChunk];
-  int model[2][kChunk];          // [job parity]: a job's models are needed again when its votes come back
   uint32_t nlog;                 // slots of the full vector that take a logarithm
   uint32_t lost;                 // a helper did not answer in time
-  double r2ent[2][kMaxChannels]; // histogram entropies of the region being created: [0] its voxels, [1] its boundary set (per channel)
+  uint32_t job_seq, job_ne0, job_cnt, job_r2, job_newcount, job_ok;     // helper side: the job being worked on
   alignas(16) uint64_t log2tab[glibc::kLog2TabWords];   // glibc's log2 tables (glibc_math.hpp): head | tab | tab2
   uint16_t logpos[feat::kMaxLogSlots];
   PqWork pq;
   __attribute__((aligned(16))) unsigned char pool[kPoolBytes];
 };
-// workspace of one scoring round of `chunk` records: feature vectors | precomputed entropies/distances | shared
-// boundary sets per channel | neighbour extremes per channel
-struct BcLayout { uint32_t chunk; int fstride, npre; double* feat; double* fx; EStats* shs; float* exmn; float* exmx; };
-__device__ __forceinline__ BcLayout bc_layout(const BcCfg& c, unsigned char* pool) {
-  BcLayout L;
-  L.fstride = bc_full_dim(c); L.npre = feat::pre_count(c);
-  const uint32_t per = 8u * (uint32_t)L.fstride + 8u * (uint32_t)L.npre + (uint32_t)sizeof(EStats) * (uint32_t)c.K + 8u * (uint32_t)c.K;
-  uint32_t chunk = (uint32_t)kPoolBytes / per;
-  L.chunk = chunk < (uint32_t)kChunk ? chunk : (uint32_t)kChunk;
-  L.feat = reinterpret_cast<double*>(pool);
-  L.fx = L.feat + (size_t)L.chunk * L.fstride;
-  L.shs = reinterpret_cast<EStats*>(L.fx + (size_t)L.chunk * L.npre);
-  L.exmn = reinterpret_cast<float*>(L.shs + (size_t)L.chunk * c.K);
-  L.exmx = L.exmn + (size_t)L.chunk * c.K;
-  return L;
+// workspace of one scoring round of up to `cap` records: the staged copy of the region being created (per channel) | the records'
+// staged inputs (per record and channel) | feature vectors | precomputed entropies / distances | headers
+struct ScoreWs { uint32_t cap; int fstride, npre; R2In* r2; RecIn* in; double* feat; double* fx; RecHdr* hdr; };
+__device__ __forceinline__ ScoreWs ws_layout(const BcCfg& c, unsigned char* pool) {
+  ScoreWs W;
+  const uint32_t K = (uint32_t)BC_K(c);
+  W.fstride = bc_full_dim(c); W.npre = feat::pre_count(c);
+  const uint32_t per = (uint32_t)sizeof(RecHdr) + (uint32_t)sizeof(RecIn) * K + 8u * (uint32_t)W.fstride + 8u * (uint32_t)W.npre;
+  const uint32_t cap = ((uint32_t)kPoolBytes - (uint32_t)sizeof(R2In) * K) / per;
+  W.cap = cap < (uint32_t)kChunk ? cap : (uint32_t)kChunk;
+  W.r2 = reinterpret_cast<R2In*>(pool);
+  W.in = reinterpret_cast<RecIn*>(pool + sizeof(R2In) * K);
+  W.feat = reinterpret_cast<double*>(W.in + (size_t)W.cap * K);
+  W.fx = W.feat + (size_t)W.cap * W.fstride;
+  W.hdr = reinterpret_cast<RecHdr*>(W.fx + (size_t)W.cap * W.npre);
+  return W;
 }
 
 constexpr unsigned long long kHelperSpinLimit = 1ull << 27;     // polls (with s_sleep) before a side gives up: ~60 s
 
-__device__ __forceinline__ uint32_t ld_relaxed(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_release(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
-// Everything the contraction workgroup and the helpers exchange goes through agent-scope accesses (write-through
-// stores, loads that miss the XCD-local caches), ordered by "my stores have completed" + a flag.  A full agent-scope
-// release / acquire pair would write back and INVALIDATE the whole L2 of the XCD at every chunk: the loop's working
-// set (and the helpers' forest nodes) would be re-fetched from memory each time.
-__device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(double* p, double v) {
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// per channel: extremes of r2's boundary set with all / all but one of its new records (the top two of the contraction)
+__device__ __forceinline__ void r2_extremes_of(const BcShared& s, uint32_t newcount, int c, uint32_t rec, float bnmn, float bnmx, float& mn, float& mx) {
+  const float best_mn = newcount ? ord_float((uint32_t)(s.best_mn[c] >> 32)) : __builtin_inff();
+  const float best_mx = newcount ? ord_float((uint32_t)(s.best_mx[c] >> 32)) : -__builtin_inff();
+  const float second_mn = (s.second_mn[c] != ~0ull) ? ord_float((uint32_t)(s.second_mn[c] >> 32)) : __builtin_inff();
+  const float second_mx = (s.second_mx[c] != 0ull) ? ord_float((uint32_t)(s.second_mx[c] >> 32)) : -__builtin_inff();
+  const uint32_t arg_mn = (uint32_t)(s.best_mn[c] & 0xFFFFFFFFull), arg_mx = (uint32_t)(s.best_mx[c] & 0xFFFFFFFFull);
+  mn = fminf(bnmn, rec == arg_mn ? second_mn : best_mn);
+  mx = fmaxf(bnmx, rec == arg_mx ? second_mx : best_mx);
 }
-__device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ double ld_agent(const double* p) {
-  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-// this wave's earlier stores have been acknowledged (and the compiler keeps later accesses behind this point)
-__device__ __forceinline__ void stores_done() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_waitcnt(0); }
-__device__ __forceinline__ void after_flag() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 
-// Forest evaluation on the rest of the chip.  The contraction loop is one workgroup; scoring its new records is a
-// gather over ~100 records x 255 trees x ~12 levels that a single CU can only run at its own load-issue rate.  Helper
-// workgroups wait for a job (the chunk's feature vectors in global memory), take the records h, h + H, ... and walk one
-// tree per thread.  Hand-off in both directions is release/acquire at agent scope (the XCDs' L2s are not coherent).
+// One scoring round: the feature vectors (and the ensemble member) of the records W.hdr[0 .. n).rec, all edges (rs, r2) of the
+// region r2 just created.  Every thread of the workgroup calls; the caller has filled hdr[j].rec and put a barrier; s.best_* /
+// s.second_* hold the top two of r2's new records.  AG: the caller is a helper workgroup -- everything this launch has written is
+// read with agent-scope loads (the loop's workgroup stored it write-through).
+//   S0 headers + the staged copy of r2   S1 the records' statistics, one 8-byte word per lane   S2 shared boundary sets (one
+//   lane per record and channel) and the neighbours' "all but this record" extremes (16 lanes per record)   S3 entropies and
+//   histogram distances (one lane per bin)   S4 the vector, one of its four blocks per wave   S5 logarithms, selection, model
+#ifdef GLIA_HMT_PROFILE
+#define SPH(i) do { if (prof && threadIdx.x == 0) { const unsigned long long tn = __builtin_readcyclecounter(); atomicAdd(&g_pqprof[32 + (i)], tn - tsp); tsp = tn; } } while (0)
+#else
+#define SPH(i) do {} while (0)
+#endif
+template <bool AG>
+__device__ void score_chunk(const BcState& st, BcShared& s, const ScoreWs& W, uint32_t n, uint32_t r2, uint32_t newcount, bool prof = false) {
+  const int tid = threadIdx.x;
+  const int K = BC_K(st.cfg);
+  const BcCfg& cf = st.cfg;
+#ifdef GLIA_HMT_PROFILE
+  unsigned long long tsp = __builtin_readcyclecounter();
+#endif
+  // ---- S0 ----
+  if ((uint32_t)tid < n) {
+    RecHdr h;
+    h.rec = W.hdr[tid].rec;
+    h.rs = ldm<AG>(&st.e_u[h.rec]); h.on = ldm<AG>(&st.e_table[h.rec]); h.own = ldm<AG>(&st.e_posu[h.rec]); h.fhead = ldm<AG>(&st.e_fhead[h.rec]);
+    h.off = ldm<AG>(&st.adj_off[h.rs]);
+    const uint32_t len = ldm<AG>(&st.adj_len[h.rs]);
+    h.len = h.on ? len : 0u;
+    h.model = -1;
+    W.hdr[tid] = h;
+  }
+  for (uint32_t t = tid; t < (uint32_t)K * 64u; t += kBcThreads) {
+    const int c = (int)(t >> 6); const uint32_t w = t & 63u;
+    const BcChan& ch = st.ch[c];
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&W.r2[c]);
+    if (w < 15u) dst[w] = ldm<AG>(reinterpret_cast<const unsigned long long*>(&ch.pts[r2]) + w);
+    else if (w < 29u) dst[16u + (w - 15u)] = ldm<AG>(reinterpret_cast<const unsigned long long*>(&ch.Bt[r2]) + (w - 15u));
+    else if (w == 29u) W.r2[c].bnmn = ldm<AG>(&ch.Bn[r2].mn);
+    else if (w == 30u) W.r2[c].bnmx = ldm<AG>(&ch.Bn[r2].mx);
+    else if (w == 31u) W.r2[c].bmn = ldm<AG>(&ch.Bmn[r2]);
+    else if (w == 32u) W.r2[c].bmx = ldm<AG>(&ch.Bmx[r2]);
+    else if (w == 33u) W.r2[c].entP = ldm<AG>(&ch.entP[r2]);
+    else if (w == 34u) W.r2[c].entB = ldm<AG>(&ch.entB[r2]);
+  }
+  __syncthreads();
+  SPH(0);
+  // ---- S1 ----
+  for (uint32_t t = tid; t < n * (uint32_t)K * 64u; t += kBcThreads) {
+    const uint32_t j = t / ((uint32_t)K * 64u); const int c = (int)((t >> 6) % (uint32_t)K); const uint32_t w = t & 63u;
+    const RecHdr h = W.hdr[j];
+    if (!h.on) continue;
+    const BcChan& ch = st.ch[c];
+    RecIn& in = W.in[j * K + c];
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&in);
+    if (w < 15u) dst[w] = ldm<AG>(reinterpret_cast<const unsigned long long*>(&ch.pts[h.rs]) + w);
+    else if (w < 29u) dst[16u + (w - 15u)] = ldm<AG>(reinterpret_cast<const unsigned long long*>(&ch.Bt[h.rs]) + (w - 15u));
+    else if (w < 43u) dst[30u + (w - 29u)] = ldm<AG>(reinterpret_cast<const unsigned long long*>(&ch.e_A[h.rec]) + (w - 29u));
+    else if (w < 57u) dst[44u + (w - 43u)] = ldm<AG>(reinterpret_cast<const unsigned long long*>(&ch.e_NA[h.rec]) + (w - 43u));
+    else if (w == 57u) in.bnmn = ldm<AG>(&ch.Bn[h.rs].mn);
+    else if (w == 58u) in.bnmx = ldm<AG>(&ch.Bn[h.rs].mx);
+    else if (w == 59u) in.bmn = ldm<AG>(&ch.Bmn[h.rs]);
+    else if (w == 60u) in.bmx = ldm<AG>(&ch.Bmx[h.rs]);
+    else if (w == 61u) in.entP = ldm<AG>(&ch.entP[h.rs]);
+    else if (w == 62u) in.entB = ldm<AG>(&ch.entB[h.rs]);
+  }
+  __syncthreads();
+  SPH(1);
+  // ---- S2 ----
+  for (uint32_t w = tid; w < n * (uint32_t)K; w += kBcThreads) {
+    // shared boundary (getBoundary / boundaryWith): mutual entries + always-alive non-mutual ones + the fragile ones whose target
+    // leaf still owns an un-cancelled entry
+    const uint32_t j = w / (uint32_t)K; const int c = (int)(w % (uint32_t)K);
+    const RecHdr h = W.hdr[j];
+    if (!h.on) continue;
+    RecIn& in = W.in[j * K + c];
+    EStats sh = in.A;
+    estats_add(sh, in.sh);
+    for (uint32_t f = h.fhead; f != kNone; f = ldm<AG>(&st.le_next[f])) if (leaf_alive<AG>(st, st.le_dst[f])) estats_add(sh, st.ch[c].le_stats[f]);
+    in.sh = sh;
+  }
+  {
+    // excl_minmax of every record's neighbour region, 16 lanes per record: unconditional, batched loads (a load behind a branch
+    // is a round trip of its own), the list four entries per lane at a time.  A clamped index re-reads the last entry (harmless
+    // for min / max), the record's own slot is masked out; dead entries hold (+inf, -inf).
+    const uint32_t sub = (uint32_t)tid >> 4, l16 = (uint32_t)tid & 15u;
+    for (uint32_t j = sub; j < n; j += kBcThreads / 16) {
+      const RecHdr h = W.hdr[j];
+      float mn[kMaxChannels], mx[kMaxChannels];
+#pragma unroll
+      for (int c = 0; c < kMaxChannels; ++c) { mn[c] = __builtin_inff(); mx[c] = -__builtin_inff(); }
+      for (uint32_t i0 = 0; i0 < h.len; i0 += 64) {
+#pragma unroll
+        for (int c = 0; c < kMaxChannels; ++c) {
+          if (c < K) {
+            float2 d[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const uint32_t i = i0 + q * 16 + l16;
+              d[q] = ldm<AG>(&st.ch[c].pool_dir[h.off + (i < h.len ? i : h.len - 1u)]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const uint32_t i = i0 + q * 16 + l16;
+              if (i < h.len && i != h.own) { mn[c] = fminf(mn[c], d[q].x); mx[c] = fmaxf(mx[c], d[q].y); }
+            }
+          }
+        }
+      }
+      if (h.on && l16 == 0) {
+#pragma unroll
+        for (int c = 0; c < kMaxChannels; ++c) if (c < K) { mn[c] = fminf(mn[c], W.in[j * K + c].bnmn); mx[c] = fmaxf(mx[c], W.in[j * K + c].bnmx); }
+      }
+#pragma unroll
+      for (int c = 0; c < kMaxChannels; ++c) {
+        if (c < K) {
+          float a = mn[c], b = mx[c];
+#pragma unroll
+          for (int o = 8; o >= 1; o >>= 1) { a = fminf(a, __shfl_xor(a, o, 16)); b = fmaxf(b, __shfl_xor(b, o, 16)); }
+          if (l16 == 0 && h.on) { W.in[j * K + c].exmn = a; W.in[j * K + c].exmx = b; }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  SPH(2);
+  // ---- S3 ----
+  {
+    // entropies and histogram distances, one lane per bin (16 lanes per record): the log2 and divisions of a vector are by far its
+    // longest serial stretch.  The bins' terms are added IN BIN ORDER, as the reference does (bin_chain).
+    const uint32_t sub = (uint32_t)tid >> 4, l16 = (uint32_t)tid & 15u;
+    for (uint32_t j = sub; j < n; j += kBcThreads / 16) {
+      const bool on = W.hdr[j].on != 0;              // uniform over the 16 lanes
+      const RecIn* in = &W.in[j * K];
+      double* fx = W.fx + (size_t)j * W.npre;
+      for (int kind = 0; kind < 2; ++kind) {
+        const int cnt = kind ? BC_NL(cf) : BC_NR(cf);
+        for (int i = 0; i < cnt; ++i) {
+          const int cc = kind ? cf.lc[i] : cf.rc[i];
+          const int bins = cf.cbins[cc];
+          double t2 = 0.0, tl = 0.0, tx = 0.0;
+          const PStats* P0 = &in[cc].P; const PStats* P1 = &W.r2[cc].P;
+          const uint32_t h0 = P0->hist[l16], h1 = P1->hist[l16], pn0 = P0->n, pn1 = P1->n;
+          const double e0 = in[cc].entP;                  // filed when rs was created (BcChan::entP)
+          const double e1 = W.r2[cc].entP;                // r2's: worked out once per contraction
+          if (on && (int)l16 < bins) {
+            t2 = feat::entropy_term(h0 + h1, pn0 + pn1, cf.libm_log2, s.log2tab);
+            feat::dist_terms(h0, pn0, h1, pn1, tl, tx);
+          }
+          const double e2 = bin_chain(t2, bins, true);
+          const double dl = bin_chain(tl, bins, false), dx = bin_chain(tx, bins, false);
+          if (on && (int)l16 == bins - 1) { double* q = fx + feat::pre_region(cf, kind, i); q[0] = e0; q[1] = e1; q[2] = e2; q[3] = dl; q[4] = dx; }
+        }
+      }
+      for (int i = 0; i < BC_NB(cf); ++i) {
+        const int cc = cf.bc[i];
+        const int bins = cf.cbins[cc];
+        double t2 = 0.0, t3 = 0.0;
+        const EStats* B0 = &in[cc].B; const EStats* B1 = &W.r2[cc].B;
+        const EStats* A = &in[cc].A;
+        const EStats* sh = &in[cc].sh;
+        const uint32_t g0 = B0->hist[l16], g1 = B1->hist[l16], ga = A->hist[l16], bn0 = B0->n, bn1 = B1->n, an = A->n;
+        const double e0 = in[cc].entB;
+        const double e1 = W.r2[cc].entB;
+        if (on && (int)l16 < bins) {
+          const uint32_t gs = sh->hist[l16], sn = sh->n;
+          // (one inlined copy of the logarithm per loop, not one per term: copies of the glibc restatement cost the loop
+          // through register pressure alone)
+#pragma unroll 1
+          for (int q = 2; q < 4; ++q) {
+            const uint32_t cq = q == 2 ? g0 + g1 - ga : gs;
+            const uint32_t nq = q == 2 ? bn0 + bn1 - an : sn;
+            const double t = feat::entropy_term(cq, nq, cf.libm_log2, s.log2tab);
+            t2 = q == 2 ? t : t2; t3 = q == 3 ? t : t3;
+          }
+        }
+        const double e2 = bin_chain(t2, bins, true), e3 = bin_chain(t3, bins, true);
+        if (on && (int)l16 == bins - 1) { double* q = fx + feat::pre_boundary(cf, i); q[0] = e0; q[1] = e1; q[2] = e2; q[3] = e3; }
+      }
+    }
+  }
+  __syncthreads();
+  SPH(3);
+  // ---- S4 ----
+  {
+    // one block of the vector per wave: waves 4g..4g+3 write the four blocks of the records 64g..64g+63
+    const int wave = tid >> 6, part = wave & 3;
+    const uint32_t slot = (uint32_t)(wave >> 2) * 64u + (uint32_t)(tid & 63);
+    if (slot < n && W.hdr[slot].on) {
+      const uint32_t rec = W.hdr[slot].rec;
+      const RecIn* in = &W.in[slot * K];
+      float ex[4 * kMaxChannels];
+#pragma unroll
+      for (int c = 0; c < kMaxChannels; ++c) {
+        float a = 0.f, b = 0.f, cm = 0.f, dm = 0.f;
+        if (c < K) { a = in[c].exmn; b = in[c].exmx; r2_extremes_of(s, newcount, c, rec, W.r2[c].bnmn, W.r2[c].bnmx, cm, dm); }
+        ex[4 * c + 0] = a; ex[4 * c + 1] = b; ex[4 * c + 2] = cm; ex[4 * c + 3] = dm;
+      }
+      const StagedView v{in, W.r2};
+      edge_features(cf, v, ex, &W.feat[slot * W.fstride], W.fx + (size_t)slot * W.npre, 1 << part, false);   // updateFb passes (rs, r2)
+    }
+  }
+  __syncthreads();
+  SPH(4);
+  // ---- S5 ----
+  if (BC_LOG(cf)) {
+    // feat.hxx:46-52, 103-106: the logarithms, one (record, slot) pair per thread
+    const uint32_t nlog = s.nlog;
+    for (uint32_t i = tid; i < n * nlog; i += kBcThreads) {
+      const uint32_t j = i / nlog;
+      if (!W.hdr[j].on) continue;
+      double* q = &W.feat[j * W.fstride + s.logpos[i - j * nlog]];
+      *q = feat::slog(*q, 0.0, cf.libm_log);
+    }
+    __syncthreads();
+  }
+  if ((uint32_t)tid < n && W.hdr[tid].on) {
+    double* x = &W.feat[tid * W.fstride];
+    feat::simple_selection(cf, x);
+    W.hdr[tid].model = st.clf.kind == 1 ? 0 : pick_model(st.clf, x);
+  }
+  __syncthreads();
+  SPH(5);
+}
+
+// the forest's votes for the n vectors of a scoring round into s.votes (every thread calls; ends with a barrier)
+__device__ void forest_chunk(const BcState& st, BcShared& s, const ScoreWs& W, uint32_t n) {
+  const int tid = threadIdx.x;
+  if ((uint32_t)tid < n) s.votes[tid] = 0;
+  __syncthreads();
+  int ntree = st.clf.f[0].ntree;          // ensemble members may differ in size: iterate over the largest
+  for (int m = 1; m < st.clf.n_models; ++m) ntree = st.clf.f[m].ntree > ntree ? st.clf.f[m].ntree : ntree;
+  for (uint32_t i = tid; i < n * (uint32_t)ntree; i += kBcThreads) {
+    const uint32_t j = i / (uint32_t)ntree, t = i % (uint32_t)ntree;
+    const int m = W.hdr[j].model;
+    if (m < 0 || (int)t >= st.clf.f[m].ntree) continue;
+    if (forest_vote(st.clf.f[m], (int)t, &W.feat[j * W.fstride])) atomicAdd(&s.votes[j], 1);
+  }
+  __syncthreads();
+}
+
+// Helper workgroups: wait for a job, score the records h, h + H, ... of it from start to finish (staging, extremes, shared sets,
+// entropies, vector, forest), answer with one tagged 64-bit word per record.  The job descriptor is one of kJobBufs slots; a
+// helper that had no record in the last jobs may find its slot being rewritten: the descriptor carries its sequence number and
+// the flag is read again after it -- a helper WITH records in job v always finds it intact, because the loop's workgroup does
+// not publish v + 1 before it has every answer of v.
 __device__ void bc_helper_loop(const BcState& st, BcShared& s) {
   const int tid = threadIdx.x;
   const uint32_t H = gridDim.x - 1u, h = blockIdx.x - 1u;
-  const int fstride = bc_full_dim(st.cfg);
+  const ScoreWs W = ws_layout(st.cfg, s.pool);
+  const uint32_t cap = W.cap < kHelpChunk ? W.cap : kHelpChunk;
+  if (tid == 0) s.nlog = (uint32_t)feat::log_slots(st.cfg, s.logpos);
+  for (int i = tid; i < glibc::kLog2TabWords; i += kBcThreads) s.log2tab[i] = i < 18 ? glibc::kLog2Head[i] : i < 18 + 128 ? glibc::kLog2Tab[i - 18] : glibc::kLog2Tab2[i - 18 - 128];
   uint32_t last = 0;
   for (;;) {
+    __syncthreads();
     if (tid == 0) {
       uint32_t v = last;
-      // poll relaxed (an acquire per poll would invalidate the XCD's caches every time), acquire once it changed
+      // poll relaxed, one lane, with a sleep (255 workgroups poll this word)
       for (unsigned long long spins = 0; spins < kHelperSpinLimit; ++spins) {
         v = ld_relaxed(&st.hctl[0]);
         if (v != last) break;
-        __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_s_sleep(2);
       }
-      after_flag();
-      s.ex[0][0] = v;
+      s.job_seq = v;
     }
     __syncthreads();
-    const uint32_t v = s.ex[0][0];
+    const uint32_t v = s.job_seq;
     if (v == last || v == 0xFFFFFFFFu) return;          // gave up waiting / the loop is over
+    after_flag();
+#ifdef GLIA_HMT_PROFILE
+    const bool prof = h == 0;
+    unsigned long long tsp = __builtin_readcyclecounter();
+#endif
+    const unsigned long long* jb = st.hjob + (size_t)(v % kJobBufs) * kJobWords;
+    unsigned long long wv = 0;
+    if ((uint32_t)tid < kJobWords) wv = ld_agent(jb + tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the descriptor has arrived before the flag is read again (all its lanes are in wave 0)
+    if (tid == 0) { s.job_ne0 = (uint32_t)wv; s.job_cnt = (uint32_t)(wv >> 32); }
+    if (tid == 1) { s.job_r2 = (uint32_t)wv; s.job_newcount = (uint32_t)(wv >> 32); }
+    if (tid == 2) {
+      const uint32_t f2 = ld_relaxed(&st.hctl[0]);
+      s.job_ok = ((uint32_t)wv == v && f2 != 0xFFFFFFFFu && f2 - v < kJobBufs - 1u) ? 1u : 0u;
+    }
+    if ((uint32_t)tid >= 4u && (uint32_t)tid < kJobWords) {
+      const int c = (tid - 4) >> 2, q = (tid - 4) & 3;
+      (q == 0 ? s.best_mn : q == 1 ? s.best_mx : q == 2 ? s.second_mn : s.second_mx)[c] = wv;
+    }
+    __syncthreads();
     last = v;
-    const uint32_t cn = v & 0xFFu, tag = v >> 8;
-    if (h >= cn) continue;                              // nothing for this workgroup in the job
-#ifdef GLIA_HMT_PROFILE
-    unsigned long long hp0 = __builtin_readcyclecounter();
-#endif
-    for (uint32_t j = h; j < cn; j += H) {
-      // the record's model and vector are requested together (agent-scope loads are long round trips)
-      const uint32_t pj = (tag & 1u) * (uint32_t)kChunk + j;      // jobs alternate between two buffers (see the chunk loop)
-      const int m = ld_agent(&st.hmodel[pj]);
-      double* hfeat = reinterpret_cast<double*>(s.pool);
-      for (int i = tid; i < fstride; i += kBcThreads) hfeat[i] = ld_agent(&st.featbuf[(size_t)pj * fstride + i]);
-      if (tid == 0) s.votes[0] = 0;
+    SPH(6);
+    if (!s.job_ok) continue;                            // torn descriptor: this helper had nothing in that job anyway
+    const uint32_t cnt = s.job_cnt, ne0 = s.job_ne0, r2 = s.job_r2, newcount = s.job_newcount;
+    if (h >= cnt) continue;
+    const uint32_t m = (cnt - h + H - 1u) / H;          // records h, h + H, ...
+    for (uint32_t i0 = 0; i0 < m; i0 += cap) {
+      const uint32_t n = m - i0 < cap ? m - i0 : cap;
+      if ((uint32_t)tid < n) W.hdr[tid].rec = ne0 + h + (i0 + (uint32_t)tid) * H;
       __syncthreads();
 #ifdef GLIA_HMT_PROFILE
-      if (tid == 0 && h == 0) { const unsigned long long t = __builtin_readcyclecounter(); atomicAdd(&g_pqprof[40], t - hp0); hp0 = t; }
+      score_chunk<true>(st, s, W, n, r2, newcount, prof);
+      tsp = __builtin_readcyclecounter();
+#else
+      score_chunk<true>(st, s, W, n, r2, newcount);
 #endif
-      if (m >= 0) {
-        const DeviceForest& f = st.clf.f[m];
-        int mine = 0;
-        for (int t = tid; t < f.ntree; t += kBcThreads) mine += forest_vote(f, t, hfeat);
-        if (mine) atomicAdd(&s.votes[0], mine);
-      }
+      forest_chunk(st, s, W, n);
+      SPH(7);
+      if ((uint32_t)tid < n && W.hdr[tid].on)
+        st_agent(&st.hvotes[h + (i0 + (uint32_t)tid) * H], ((unsigned long long)v << 32) | ((unsigned long long)(uint32_t)W.hdr[tid].model << 24) | (unsigned long long)(uint32_t)s.votes[tid]);
       __syncthreads();
-      // the answer carries the job's sequence number: the contraction workgroup polls the slot itself, no counter
+      SPH(8);
 #ifdef GLIA_HMT_PROFILE
-      if (tid == 0 && h == 0) { const unsigned long long t = __builtin_readcyclecounter(); atomicAdd(&g_pqprof[41], t - hp0); hp0 = t; atomicAdd(&g_pqprof[43], 1ull); }
-#endif
-      if (tid == 0 && m >= 0) st_agent(&st.hvotes[pj], ((unsigned long long)tag << 32) | (unsigned long long)(uint32_t)s.votes[0]);
-      __syncthreads();
-#ifdef GLIA_HMT_PROFILE
-      if (tid == 0 && h == 0) { const unsigned long long t = __builtin_readcyclecounter(); atomicAdd(&g_pqprof[42], t - hp0); hp0 = t; }
+      if (prof && tid == 0) atomicAdd(&g_pqprof[32 + 9], (unsigned long long)n);
 #endif
     }
   }
@@ -565,7 +909,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
   uint32_t status = ST_RUN;
   const int fdim = st.cfg.fdim;
   const int K = BC_K(st.cfg);
-  const BcLayout L = bc_layout(st.cfg, s.pool);
+  const ScoreWs W = ws_layout(st.cfg, s.pool);
   if (tid == 0) { s.pq.wln[0] = s.pq.wln[1] = 0; s.pq.ovf = 0; s.pq.spill = 0; s.lost = 0; s.nlog = (uint32_t)feat::log_slots(st.cfg, s.logpos); }
   for (int i = tid; i < glibc::kLog2TabWords; i += blockDim.x) s.log2tab[i] = i < 18 ? glibc::kLog2Head[i] : i < 18 + 128 ? glibc::kLog2Tab[i - 18] : glibc::kLog2Tab2[i - 18 - 128];
   for (int i = tid; i < kSetSlots; i += blockDim.x) { s.pq.set[0][i] = 0; s.pq.set[1][i] = 0; }
@@ -651,8 +995,8 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
           ex[4 * c + 0] = keep ? m0 : m1; ex[4 * c + 1] = keep ? x0 : x1; ex[4 * c + 2] = keep ? m1 : m0; ex[4 * c + 3] = keep ? x1 : x0;
         }
         double x[kMaxFeat];
-        if (keep) edge_features(st, r0, r1, e, ex, x);
-        else edge_features(st, r1, r0, e, ex, x);
+        if (keep) edge_features_global(st, r0, r1, e, ex, x);
+        else edge_features_global(st, r1, r0, e, ex, x);
         for (int i = 0; i < fdim; ++i) st.feats_out[(size_t)k * fdim + i] = x[i];
       }
       __syncthreads();
@@ -660,7 +1004,8 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
 
     PH(0);
     // ---- the merged region (TRegionMap::merge, type/region_map.hxx:113-118) ----
-    // one (channel, statistics set) pair per wave 1.. lane: each is two loads and a store, all in flight together
+    // one (channel, statistics set) pair per wave 1.. lane: each is two loads and a store, all in flight together.  Region and
+    // record statistics, list headers and set extremes are what the helper workgroups read: stored write-through (st_agent).
     if (tid >= 64 && tid < 64 + 3 * K) {
       const int c = (tid - 64) / 3, kind = (tid - 64) % 3;
       const BcChan& ch = st.ch[c];
@@ -668,23 +1013,23 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
         PStats p = ch.pts[r0];
         const PStats q = ch.pts[r1];
         pstats_add(p, q);
-        ch.pts[r2] = p;
+        st_agent_struct(&ch.pts[r2], p);
       } else if (kind == 1) {
         EStats bn = ch.Bn[r0];
         const EStats q = ch.Bn[r1];
         estats_add(bn, q);
-        ch.Bn[r2] = bn;
+        st_agent_struct(&ch.Bn[r2], bn);
       } else {
         EStats bt = ch.Bt[r0];
         const EStats q = ch.Bt[r1];
         const EStats a = ch.e_A[e != kNone ? e : 0u];
         estats_add(bt, q);
         if (e != kNone) estats_sub_additive(bt, a);
-        ch.Bt[r2] = bt;
+        st_agent_struct(&ch.Bt[r2], bt);
       }
     }
     if (tid == 0) {
-      st.parent[r0] = r2; st.parent[r1] = r2; st.parent[r2] = r2;
+      st_agent(&st.parent[r0], r2); st_agent(&st.parent[r1], r2); st_agent(&st.parent[r2], r2);
       if (e != kNone) { st.e_alive[e] = 0; if (!forced) { st.pq.leaf_seq[e] = 0; pq_touch(st.pq, s.pq, 0, 0, e);   /* the root is the maximum of its node */ } }
     }
     // ---- phase A: mark the neighbours of r0 / r1 with the record that reaches them ----
@@ -755,11 +1100,11 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
           d[0] = fminf(d[0], rsIsU ? d2.x : d2.z); d[1] = fmaxf(d[1], rsIsU ? d2.y : d2.w);
           d[2] = fminf(d[2], rsIsU ? d2.z : d2.x); d[3] = fmaxf(d[3], rsIsU ? d2.w : d2.y);
         }
-        ch.e_A[newE] = A; ch.e_NA[newE] = NA;
+        st_agent_struct(&ch.e_A[newE], A); st_agent_struct(&ch.e_NA[newE], NA);
         *reinterpret_cast<float4*>(&ch.e_dir[(size_t)newE * 4]) = make_float4(d[0], d[1], d[2], d[3]);
-        ch.pool_dir[offRs + posRs] = make_float2(d[0], d[1]);
-        ch.pool_dir[r2off + idx] = make_float2(d[2], d[3]);
-        if (posDead != kNone) ch.pool_dir[offRs + posDead] = make_float2(__builtin_inff(), -__builtin_inff());
+        st_agent(&ch.pool_dir[offRs + posRs], make_float2(d[0], d[1]));
+        st_agent(&ch.pool_dir[r2off + idx], make_float2(d[2], d[3]));
+        if (posDead != kNone) st_agent(&ch.pool_dir[offRs + posDead], make_float2(__builtin_inff(), -__builtin_inff()));
         // r2's mutual boundary extremes (entries r2 -> rs) for B(r2) and the "all but one" queries
         atomicMin(&s.best_mn[c], ((unsigned long long)float_ord(d[2]) << 32) | newE);
         atomicMax(&s.best_mx[c], ((unsigned long long)float_ord(d[3]) << 32) | newE);
@@ -769,7 +1114,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
       if (fh1 != kNone) { fh = fh1; ft = ft1; }
       if (both && fh2 != kNone) {
         if (fh == kNone) { fh = fh2; ft = ft2; }
-        else { st.le_next[ft] = fh2; ft = ft2; }
+        else { st_agent(&st.le_next[ft], fh2); ft = ft2; }
       }
       // the record is the r1-side parent exactly when it was found from r1
       const bool t0 = !side1 && tb1, t1 = side1 ? (tb1 != 0) : (both && tb2);
@@ -779,9 +1124,9 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
         st.e_alive[partner] = 0;
         if (tb2 && !forced) { st.pq.leaf_seq[partner] = 0; if (top2 == partner) pq_touch(st.pq, s.pq, 0, 0, partner); }
       }
-      st.e_u[newE] = rs; st.e_v[newE] = r2; st.e_posu[newE] = posRs;
-      st.e_alive[newE] = 1; st.e_table[newE] = (t0 || t1) ? 1 : 0; st.e_orient[newE] = 1;
-      st.e_fhead[newE] = fh; st.e_ftail[newE] = ft;
+      st_agent(&st.e_u[newE], rs); st.e_v[newE] = r2; st_agent(&st.e_posu[newE], posRs);
+      st.e_alive[newE] = 1; st_agent(&st.e_table[newE], (uint8_t)((t0 || t1) ? 1 : 0)); st.e_orient[newE] = 1;
+      st_agent(&st.e_fhead[newE], fh); st.e_ftail[newE] = ft;
       // queue position (only meaningful for table edges): reference visit order, see greedy.hip; the category rides in
       // posv's upper bits until the record has been scored
       const uint32_t cat = rs < r0 ? 0u : (t0 ? 1u : 2u);
@@ -802,7 +1147,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
         const uint32_t cnt = isB ? B->hist[l16] : P->hist[l16], n = isB ? B->n : P->n;
         const double t = (int)l16 < bins ? feat::entropy_term(cnt, n, st.cfg.libm_log2, s.log2tab) : 0.0;
         const double en = bin_chain(t, bins, true);
-        if ((int)l16 == bins - 1) { s.r2ent[isB ? 1 : 0][cc] = en; (isB ? st.ch[cc].entB : st.ch[cc].entP)[r2] = en; }
+        if ((int)l16 == bins - 1) st_agent(&(isB ? st.ch[cc].entB : st.ch[cc].entP)[r2], en);
       }
     }
     __syncthreads();
@@ -828,280 +1173,79 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
       }
     }
     __syncthreads();
-    // per channel: extremes of r2's boundary set with all / all but one of its new records
-    auto r2_extremes_of = [&](int c, uint32_t rec, float bnmn, float bnmx, float& mn, float& mx) {
-      const float best_mn = newcount ? ord_float((uint32_t)(s.best_mn[c] >> 32)) : __builtin_inff();
-      const float best_mx = newcount ? ord_float((uint32_t)(s.best_mx[c] >> 32)) : -__builtin_inff();
-      const float second_mn = (s.second_mn[c] != ~0ull) ? ord_float((uint32_t)(s.second_mn[c] >> 32)) : __builtin_inff();
-      const float second_mx = (s.second_mx[c] != 0ull) ? ord_float((uint32_t)(s.second_mx[c] >> 32)) : -__builtin_inff();
-      const uint32_t arg_mn = (uint32_t)(s.best_mn[c] & 0xFFFFFFFFull), arg_mx = (uint32_t)(s.best_mx[c] & 0xFFFFFFFFull);
-      mn = fminf(bnmn, rec == arg_mn ? second_mn : best_mn);
-      mx = fmaxf(bnmx, rec == arg_mx ? second_mx : best_mx);
-    };
-    auto r2_extremes = [&](int c, uint32_t rec, float& mn, float& mx) {
-      r2_extremes_of(c, rec, st.ch[c].Bn[r2].mn, st.ch[c].Bn[r2].mx, mn, mx);
-    };
     if (tid == kBcThreads - 1) {
-      st.adj_off[r2] = r2off; st.adj_len[r2] = newcount;
+      st_agent(&st.adj_off[r2], r2off); st_agent(&st.adj_len[r2], newcount);
 #pragma unroll
       for (int c = 0; c < kMaxChannels; ++c)
-        if (c < K) { float mn, mx; r2_extremes_of(c, kNone, pre_mn[c], pre_mx[c], mn, mx); st.ch[c].Bmn[r2] = mn; st.ch[c].Bmx[r2] = mx; }
+        if (c < K) { float mn, mx; r2_extremes_of(s, newcount, c, kNone, pre_mn[c], pre_mx[c], mn, mx); st_agent(&st.ch[c].Bmn[r2], mn); st_agent(&st.ch[c].Bmx[r2], mx); }
     }
-    __syncthreads();
+    stores_done();          // every wave: what this contraction wrote is acknowledged ...
+    __syncthreads();        // ... before anybody (this workgroup's staging pass, a helper after the flag) reads it
 
     PH(3);
-    // ---- score the new table edges: features (one thread per edge) -> forest ((edge, tree) per thread) ----
-    const int fstride = L.fstride;      // vectors are assembled at full length, the simple selection is compacted in place
-    const uint32_t chunk = L.chunk;
-    // With helper workgroups the chunks are pipelined: the forest of chunk c runs in the helpers while this workgroup
-    // builds the vectors of chunk c + 1; the votes of c are collected (and its records enter the queue) just before
-    // c + 1 is handed over.  Jobs alternate between two global buffers and two model arrays (parity of the sequence).
-    bool pending = false;
-    uint32_t pend_c0 = 0, pend_cn = 0, pend_seq = 0;
-    int pend_par = 0;
-    auto score_records = [&](uint32_t c0r, uint32_t cnr, int par, bool stub_from_lds) __attribute__((always_inline)) {
-      if ((uint32_t)tid < cnr && s.model[par][tid] >= 0) {
-        const uint32_t rec = (uint32_t)ne + c0r + tid;
-        const double sal = stub_from_lds ? 1.0 - L.feat[tid * L.fstride + st.clf.stub_index]
-                                         : (double)s.votes[tid] / (double)st.clf.f[s.model[par][tid]].ntree;
-        const uint32_t cat = st.e_posv[rec] >> 30;
-        st.pq.leaf_sal[rec] = sal;
-        st.pq.leaf_seq[rec] = ((k + 1ull) << 32) | ((unsigned long long)cat << 30) | st.e_u[rec];
-        pq_leaf_added(st.pq, s.pq, rec);
-      }
-    };
-    auto collect_pending = [&]() __attribute__((always_inline)) {
-      if ((uint32_t)tid < pend_cn && s.model[pend_par][tid] >= 0) {
-        unsigned long long w = 0, spins = 0;
-        for (;;) {
-          w = ld_agent(&st.hvotes[pend_par * kChunk + tid]);
-          if ((uint32_t)(w >> 32) == pend_seq) break;
-          __builtin_amdgcn_s_sleep(1);
-          if (++spins > kHelperSpinLimit) { s.lost = 1u; break; }     // helpers lost: reported as a failed run at the next pop
+    // ---- score the new table edges ----
+    if (!forced && newcount && st.clf.kind == 0 && st.n_helpers) {
+      // Helper workgroups score whole records.  One job per kJobMax records (one job, nearly always).
+      for (uint32_t seg0 = 0; seg0 < newcount; seg0 += kJobMax) {
+        const uint32_t cnt = newcount - seg0 < kJobMax ? newcount - seg0 : kJobMax;
+        hseq += 1u;
+        unsigned long long* jb = st.hjob + (size_t)(hseq % kJobBufs) * kJobWords;
+        if ((uint32_t)tid < kJobWords) {
+          unsigned long long w = 0;
+          if (tid == 0) w = (unsigned long long)((uint32_t)ne + seg0) | ((unsigned long long)cnt << 32);
+          else if (tid == 1) w = (unsigned long long)r2 | ((unsigned long long)newcount << 32);
+          else if (tid == 2) w = (unsigned long long)hseq;
+          else if (tid >= 4) { const int c = (tid - 4) >> 2, q = (tid - 4) & 3; w = (q == 0 ? s.best_mn : q == 1 ? s.best_mx : q == 2 ? s.second_mn : s.second_mx)[c]; }
+          st_agent(jb + tid, w);
         }
-        s.votes[tid] = (int)(uint32_t)w;
-      }
-      score_records(pend_c0, pend_cn, pend_par, false);
-      __syncthreads();
-      pending = false;
-    };
-    for (uint32_t c0 = 0; c0 < (forced ? 0u : newcount); c0 += chunk) {
-      const uint32_t cn = min(chunk, newcount - c0);
-      const uint32_t nseq = hseq >= 0xFFFFFEu ? 1u : hseq + 1u;     // job sequence: never 0 (the slots' initial tag), never the quit word
-      const int cur = (int)(nseq & 1u);                             // consecutive jobs use different buffers
-      {
-        // excl_minmax of every new record's neighbour region, 16 lanes per record: the scan of rs's incident list is
-        // a chain of dependent loads per entry, far too slow for the one thread that assembles the feature vector
-        const uint32_t sub = (uint32_t)tid >> 4, l16 = (uint32_t)tid & 15u;
-        for (uint32_t j = sub; j < cn; j += kBcThreads / 16) {
-          const uint32_t rec = (uint32_t)ne + c0 + j;
-          float mn[kMaxChannels], mx[kMaxChannels];
-#pragma unroll
-          for (int c = 0; c < kMaxChannels; ++c) { mn[c] = __builtin_inff(); mx[c] = -__builtin_inff(); }
-          {
-            // unconditional, batched loads (a load behind a branch is a round trip of its own): the record's fields,
-            // then rs's list header and set extremes, then the list four entries per lane at a time.  A clamped index
-            // re-reads the last entry (harmless for min / max), the record's own slot is masked out.
-            const bool on = st.e_table[rec] != 0;
-            const uint32_t rs = st.e_u[rec];
-            const uint32_t own = st.e_posu[rec];             // the record's own slot in rs's list (e_u = rs)
-            const uint32_t off = st.adj_off[rs], len = on ? st.adj_len[rs] : 0u;
-            float bmn[kMaxChannels], bmx[kMaxChannels];
-#pragma unroll
-            for (int c = 0; c < kMaxChannels; ++c) if (c < K) { bmn[c] = st.ch[c].Bn[rs].mn; bmx[c] = st.ch[c].Bn[rs].mx; }
-            for (uint32_t i0 = 0; i0 < len; i0 += 64) {
-#pragma unroll
-              for (int c = 0; c < kMaxChannels; ++c) {
-                if (c < K) {
-                  float2 d[4];
-#pragma unroll
-                  for (int q = 0; q < 4; ++q) {
-                    const uint32_t i = i0 + q * 16 + l16;
-                    d[q] = st.ch[c].pool_dir[off + (i < len ? i : len - 1u)];     // dead entries hold (+inf, -inf)
-                  }
-#pragma unroll
-                  for (int q = 0; q < 4; ++q) {
-                    const uint32_t i = i0 + q * 16 + l16;
-                    if (i < len && i != own) { mn[c] = fminf(mn[c], d[q].x); mx[c] = fmaxf(mx[c], d[q].y); }
-                  }
-                }
-              }
-            }
-            if (on && l16 == 0) {
-#pragma unroll
-              for (int c = 0; c < kMaxChannels; ++c) if (c < K) { mn[c] = fminf(mn[c], bmn[c]); mx[c] = fmaxf(mx[c], bmx[c]); }
-            }
-          }
-#pragma unroll
-          for (int c = 0; c < kMaxChannels; ++c) {
-            if (c < K) {
-              float a = mn[c], b = mx[c];
-#pragma unroll
-              for (int o = 8; o >= 1; o >>= 1) { a = fminf(a, __shfl_xor(a, o, 16)); b = fmaxf(b, __shfl_xor(b, o, 16)); }
-              if (l16 == 0) { L.exmn[j * K + c] = a; L.exmx[j * K + c] = b; }
-            }
-          }
-        }
-      }
-#ifdef GLIA_HMT_PROFILE
-      __syncthreads();          // attribution only: the phases below would otherwise absorb the stragglers of this one
-#endif
-      PH(8);
-      for (uint32_t w = tid; w < cn * (uint32_t)K; w += kBcThreads) {
-        const uint32_t j = w / (uint32_t)K; const int c = (int)(w % (uint32_t)K);
-        const uint32_t rec = (uint32_t)ne + c0 + j;
-        // shared_boundary() with its loads hoisted in front of the branch (one round trip instead of three)
-        const BcChan& ch = st.ch[c];
-        const uint8_t on = st.e_table[rec];
-        EStats sh = ch.e_A[rec];
-        const EStats na = ch.e_NA[rec];
-        uint32_t f = st.e_fhead[rec];
-        if (on) {
-          estats_add(sh, na);
-          for (; f != kNone; f = st.le_next[f]) if (leaf_alive(st, st.le_dst[f])) estats_add(sh, ch.le_stats[f]);
-          L.shs[j * K + c] = sh;
-        }
-      }
-      __syncthreads();
-      PH(9);
-      {
-        // entropies and histogram distances, one lane per bin (16 lanes per record): the log2 and divisions of a vector
-        // are by far its longest serial stretch.  Lane 0 adds the bins' terms in bin order, as the reference does.
-        const uint32_t sub = (uint32_t)tid >> 4, l16 = (uint32_t)tid & 15u;
-        const BcCfg& cf = st.cfg;
-        for (uint32_t j = sub; j < cn; j += kBcThreads / 16) {
-          const uint32_t rec = (uint32_t)ne + c0 + j;
-          const bool on = st.e_table[rec] != 0;              // uniform over the 16 lanes
-          const uint32_t rs = st.e_u[rec];
-          double* fx = L.fx + (size_t)j * L.npre;
-          // The bins' terms are added in bin order, as the reference does: a 16-step chain over DPP row_shr:1 (lane l
-          // ends with t_0 .. t_l; lane 0's predecessor reads +0.0, the reference's start value), the lane of the last
-          // bin holds the sum.  (Sixteen broadcasts through ds_bpermute per sum were the longest stretch of the pass.)
-          auto bin_sum = [&](double t, int bins, bool negate) -> double { return bin_chain(t, bins, negate); };
-          for (int kind = 0; kind < 2; ++kind) {
-            const int cnt = kind ? BC_NL(cf) : BC_NR(cf);
-            for (int i = 0; i < cnt; ++i) {
-              const int cc = kind ? cf.lc[i] : cf.rc[i];
-              const int bins = cf.cbins[cc];
-              double t2 = 0.0, tl = 0.0, tx = 0.0;
-              const PStats* P0 = &st.ch[cc].pts[rs]; const PStats* P1 = &st.ch[cc].pts[r2];
-              const uint32_t h0 = P0->hist[l16], h1 = P1->hist[l16], pn0 = P0->n, pn1 = P1->n;     // unconditional loads
-              const double e0 = st.ch[cc].entP[rs];           // filed when rs was created (BcChan::entP)
-              const double e1 = s.r2ent[0][cc];               // r2's: worked out once per contraction (end of phase B)
-              if (on && (int)l16 < bins) {
-                t2 = feat::entropy_term(h0 + h1, pn0 + pn1, cf.libm_log2, s.log2tab);
-                feat::dist_terms(h0, pn0, h1, pn1, tl, tx);
-              }
-              const double e2 = bin_sum(t2, bins, true);
-              const double dl = bin_sum(tl, bins, false), dx = bin_sum(tx, bins, false);
-              if ((int)l16 == bins - 1) { double* q = fx + feat::pre_region(cf, kind, i); q[0] = e0; q[1] = e1; q[2] = e2; q[3] = dl; q[4] = dx; }
-            }
-          }
-          for (int i = 0; i < BC_NB(cf); ++i) {
-            const int cc = cf.bc[i];
-            const int bins = cf.cbins[cc];
-            double t2 = 0.0, t3 = 0.0;
-            const EStats* B0 = &st.ch[cc].Bt[rs]; const EStats* B1 = &st.ch[cc].Bt[r2];
-            const EStats* A = &st.ch[cc].e_A[rec];
-            const EStats* sh = &L.shs[j * K + cc];
-            const uint32_t g0 = B0->hist[l16], g1 = B1->hist[l16], ga = A->hist[l16], bn0 = B0->n, bn1 = B1->n, an = A->n;
-            const double e0 = st.ch[cc].entB[rs];             // filed when rs was created (BcChan::entB)
-            const double e1 = s.r2ent[1][cc];                 // r2's: worked out once per contraction (end of phase B)
-            if (on && (int)l16 < bins) {
-              const uint32_t gs = sh->hist[l16], sn = sh->n;
-              // (one inlined copy of the logarithm per loop, not one per term: copies of the glibc restatement cost the loop
-              // through register pressure alone)
-#pragma unroll 1
-              for (int q = 2; q < 4; ++q) {
-                const uint32_t cq = q == 2 ? g0 + g1 - ga : gs;
-                const uint32_t nq = q == 2 ? bn0 + bn1 - an : sn;
-                const double t = feat::entropy_term(cq, nq, cf.libm_log2, s.log2tab);
-                t2 = q == 2 ? t : t2; t3 = q == 3 ? t : t3;
-              }
-            }
-            const double e2 = bin_sum(t2, bins, true), e3 = bin_sum(t3, bins, true);
-            if ((int)l16 == bins - 1) { double* q = fx + feat::pre_boundary(cf, i); q[0] = e0; q[1] = e1; q[2] = e2; q[3] = e3; }
-          }
-        }
-      }
-      __syncthreads();
-      PH(10);
-      {
-        // one block of the vector per wave: waves 4g..4g+3 write the four blocks of the records 64g..64g+63
-        const int wave = tid >> 6, part = wave & 3;
-        const uint32_t slot = (uint32_t)(wave >> 2) * 64u + (uint32_t)(tid & 63);
-        if (slot < cn) {
-          const uint32_t rec = (uint32_t)ne + c0 + slot;
-          if (part == 0) { s.votes[slot] = 0; s.model[cur][slot] = -1; }
-          if (st.e_table[rec]) {
-            const uint32_t rs = st.e_u[rec];
-            float ex[4 * kMaxChannels];
-#pragma unroll
-            for (int c = 0; c < kMaxChannels; ++c) {
-              float a = 0.f, b = 0.f, cm = 0.f, dm = 0.f;
-              if (c < K) { a = L.exmn[slot * K + c]; b = L.exmx[slot * K + c]; r2_extremes(c, rec, cm, dm); }
-              ex[4 * c + 0] = a; ex[4 * c + 1] = b; ex[4 * c + 2] = cm; ex[4 * c + 3] = dm;
-            }
-            edge_features(st, rs, r2, rec, ex, &L.feat[slot * fstride], L.fx + (size_t)slot * L.npre, &L.shs[slot * K], 1 << part, false);   // updateFb passes (rs, r2)
-          }
-        }
-      }
-      __syncthreads();
-      if (BC_LOG(st.cfg)) {
-        // feat.hxx:46-52, 103-106: the logarithms, one (record, slot) pair per thread
-        const uint32_t nlog = s.nlog;
-        for (uint32_t i = tid; i < cn * nlog; i += kBcThreads) {
-          const uint32_t j = i / nlog;
-          if (!st.e_table[(uint32_t)ne + c0 + j]) continue;
-          double* q = &L.feat[j * fstride + s.logpos[i - j * nlog]];
-          *q = feat::slog(*q, 0.0, st.cfg.libm_log);
-        }
-        __syncthreads();
-      }
-      if ((uint32_t)tid < cn) {
-        const uint32_t rec = (uint32_t)ne + c0 + tid;
-        if (st.e_table[rec]) {
-          double* x = &L.feat[tid * fstride];
-          feat::simple_selection(st.cfg, x);
-          s.model[cur][tid] = st.clf.kind == 1 ? 0 : pick_model(st.clf, x);
-        }
-      }
-      __syncthreads();
-      PH(4);
-      if (st.clf.kind == 0 && st.n_helpers) {
-        if (pending) collect_pending();           // the previous chunk's forest ran while this chunk's vectors were built
-        // hand the chunk to the helper workgroups
-        const size_t fb = (size_t)cur * kChunk * (size_t)fstride;
-        for (uint32_t i = tid; i < cn * (uint32_t)fstride; i += kBcThreads) st_agent(&st.featbuf[fb + i], L.feat[i]);
-        if ((uint32_t)tid < cn) st_agent(&st.hmodel[cur * kChunk + tid], s.model[cur][tid]);
         stores_done();
         __syncthreads();
-        hseq = nseq;
-        if (tid == 0) st_agent(&st.hctl[0], (hseq << 8) | cn);
-        pending = true; pend_c0 = c0; pend_cn = cn; pend_seq = hseq; pend_par = cur;
+        if (tid == 0) st_agent(&st.hctl[0], hseq);
         PH(5);
-        continue;
-      } else if (st.clf.kind == 0) {
-        int ntree = st.clf.f[0].ntree;          // ensemble members may differ in size: iterate over the largest
-        for (int m = 1; m < st.clf.n_models; ++m) ntree = st.clf.f[m].ntree > ntree ? st.clf.f[m].ntree : ntree;
-        for (uint32_t i = tid; i < cn * (uint32_t)ntree; i += kBcThreads) {
-          const uint32_t j = i / ntree, t = i % ntree;
-          const int m = s.model[cur][j];
-          if (m < 0 || (int)t >= st.clf.f[m].ntree) continue;
-          if (forest_vote(st.clf.f[m], (int)t, &L.feat[j * fstride])) atomicAdd(&s.votes[j], 1);
+        // while the helpers work: the priority tree is brought up to date for the removals of this contraction
+        if (seg0 == 0) { pq_propagate<kBcThreads>(st.pq, s.pq, tid); PH(6); }
+        for (uint32_t j = tid; j < cnt; j += kBcThreads) {
+          const uint32_t rec = (uint32_t)ne + seg0 + j;
+          if (!st.e_table[rec]) continue;
+          unsigned long long w = 0, spins = 0;
+          for (;;) {
+            w = ld_agent(&st.hvotes[j]);
+            if ((uint32_t)(w >> 32) == hseq) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kHelperSpinLimit) { s.lost = 1u; break; }     // helpers lost: reported as a failed run at the next pop
+          }
+          const int model = (int)((w >> 24) & 0xFFu);
+          const double sal = (double)(uint32_t)(w & 0xFFFFFFu) / (double)st.clf.f[model < st.clf.n_models ? model : 0].ntree;
+          const uint32_t cat = st.e_posv[rec] >> 30;
+          st.pq.leaf_sal[rec] = sal;
+          st.pq.leaf_seq[rec] = ((k + 1ull) << 32) | ((unsigned long long)cat << 30) | st.e_u[rec];
+          pq_leaf_added(st.pq, s.pq, rec);
         }
+        __syncthreads();
+        PH(11);
       }
-      __syncthreads();
-      PH(5);
-      score_records(c0, cn, cur, st.clf.kind == 1);
-      __syncthreads();
+    } else if (!forced && newcount) {
+      // the loop's own workgroup scores (no helpers, or the stub scorer of the tests), W.cap records per round
+      for (uint32_t c0 = 0; c0 < newcount; c0 += W.cap) {
+        const uint32_t cn = newcount - c0 < W.cap ? newcount - c0 : W.cap;
+        if ((uint32_t)tid < cn) W.hdr[tid].rec = (uint32_t)ne + c0 + (uint32_t)tid;
+        __syncthreads();
+        score_chunk<false>(st, s, W, cn, r2, newcount);
+        PH(4);
+        if (st.clf.kind == 0) forest_chunk(st, s, W, cn);
+        PH(5);
+        if ((uint32_t)tid < cn && W.hdr[tid].model >= 0) {
+          const uint32_t rec = W.hdr[tid].rec;
+          const double sal = st.clf.kind == 1 ? 1.0 - W.feat[tid * W.fstride + st.clf.stub_index]
+                                              : (double)s.votes[tid] / (double)st.clf.f[W.hdr[tid].model].ntree;
+          const uint32_t cat = st.e_posv[rec] >> 30;
+          st.pq.leaf_sal[rec] = sal;
+          st.pq.leaf_seq[rec] = ((k + 1ull) << 32) | ((unsigned long long)cat << 30) | W.hdr[tid].rs;
+          pq_leaf_added(st.pq, s.pq, rec);
+        }
+        __syncthreads();
+      }
     }
-    // While the helpers walk the forest for the last chunk this workgroup has nothing to do: the priority tree is brought up
-    // to date for everything known so far (the removals of this contraction, the records of earlier chunks); the records of
-    // the last chunk get their own, small propagation below.
-    if (pending && !forced) { PH(3); pq_propagate<kBcThreads>(st.pq, s.pq, tid); PH(6); }
-    if (pending) collect_pending();
-    PH(11);                                 // (the wait for the helpers' last votes)
     for (uint32_t j = tid; j < newcount; j += kBcThreads) st.e_posv[(uint32_t)ne + j] &= 0x3FFFFFFFu;
     PH(3);
     if (!forced) pq_propagate<kBcThreads>(st.pq, s.pq, tid);
@@ -1112,11 +1256,10 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
   if (tid == 0 && st.n_helpers) st_release(&st.hctl[0], 0xFFFFFFFFu);
   if (tid == 0) { st.ctrl[0] = k; st.ctrl[1] = ne; st.ctrl[2] = pool_used; st.ctrl[3] = status; }
 #ifdef GLIA_HMT_PROFILE
-  if (tid == 0) printf("[bc profile] helper 0 (cumulative cycles): vector fetch %llu  walk + vote sum %llu  vote store %llu  records %llu\n", g_pqprof[40], g_pqprof[41], g_pqprof[42], g_pqprof[43]);
   if (tid == 0) printf("[bc profile] pq propagations by dirty level-0 nodes (<=8, <=16, more): %llu %llu %llu\n", g_pqprof[28], g_pqprof[29], g_pqprof[30]);
-  if (tid == 0) printf("[bc profile] edge_features of thread 0: gather %llu  bc_features %llu  calls %llu (cycles)\n", g_pqprof[24], g_pqprof[25], g_pqprof[26]);
-  if (tid == 0) printf("[bc profile] scoring: neighbour min/max %llu  shared sets %llu  entropies %llu  assemble %llu (cycles)\n", tph[8], tph[9], tph[10], tph[4]);
-  if (tid == 0) printf("[bc profile] merges %llu: pop+feats_out %llu  region+mark %llu  build %llu  top2 %llu  features %llu  forest %llu  pq %llu  loop-top %llu  wait-for-last-votes %llu (cycles)\n", k, tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], tph[6], tph[7], tph[11]);
+  if (tid == 0) printf("[bc profile] helper 0 (cumulative cycles): descriptor %llu  S0 headers %llu  S1 words %llu  S2 shared+extremes %llu  S3 entropies %llu  S4 assembly %llu  S5 finish %llu  forest %llu  publish %llu  records %llu\n",
+                       g_pqprof[38], g_pqprof[32], g_pqprof[33], g_pqprof[34], g_pqprof[35], g_pqprof[36], g_pqprof[37], g_pqprof[39], g_pqprof[40], g_pqprof[41]);
+  if (tid == 0) printf("[bc profile] merges %llu: pop+feats_out %llu  region+mark %llu  build %llu  top2 %llu  local scoring %llu  forest/publish %llu  pq %llu  loop-top %llu  wait-for-votes %llu (cycles)\n", k, tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], tph[6], tph[7], tph[11]);
 #endif
 }
 
@@ -1262,16 +1405,16 @@ int GLIA_BC_ENTRY(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier
   if ((rc = buf.get(&st.order, 3 * (size_t)R, false, stream))) return rc;
   if ((rc = buf.get(&st.sal_out, (size_t)R, false, stream))) return rc;
   if (h_feats) { if ((rc = buf.get(&st.feats_out, (size_t)R * cfg.fdim, false, stream))) return rc; }
-  if ((rc = buf.get(&st.featbuf, (size_t)2 * kChunk * bc_full_dim(cfg), false, stream))) return rc;      // two jobs in flight
   if ((rc = buf.get(&st.hctl, 4, true, stream))) return rc;
-  if ((rc = buf.get(&st.hvotes, 2 * kChunk, true, stream))) return rc;
-  if ((rc = buf.get(&st.hmodel, 2 * kChunk, true, stream))) return rc;
+  if ((rc = buf.get(&st.hjob, (size_t)kJobBufs * kJobWords, true, stream))) return rc;
+  if ((rc = buf.get(&st.hvotes, kJobMax, true, stream))) return rc;
   {
-    // helper workgroups for the forest (only a real forest in a scoring run needs them); GLIA_HMT_HELPERS overrides
+    // helper workgroups that score whole records (only a real forest in a scoring run needs them): one per compute unit
+    // beside the loop's; GLIA_HMT_HELPERS overrides
     const char* env = getenv("GLIA_HMT_HELPERS");
-    int nh = env ? atoi(env) : 63;
+    int nh = env ? atoi(env) : 255;
     if (nh < 0) nh = 0;
-    if (nh > 200) nh = 200;
+    if (nh > 1023) nh = 1023;
     // the loop's workgroup and its helpers talk through polled flags, so they must all be resident at once: never ask for
     // more workgroups than the device can hold of this kernel (a helper that still does not answer -- the device is shared --
     // is noticed by the spin limit and reported as a failed run)
@@ -1343,7 +1486,8 @@ int GLIA_BC_ENTRY(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier
   if ((rc = buf.get(&d_st, 1, false, stream))) return rc;
   while (true) {
     GLIA_HIP_TRY(hipMemsetAsync(st.hctl, 0, 4 * sizeof(uint32_t), stream));
-    GLIA_HIP_TRY(hipMemsetAsync(st.hvotes, 0, 2 * kChunk * sizeof(unsigned long long), stream));
+    GLIA_HIP_TRY(hipMemsetAsync(st.hjob, 0, (size_t)kJobBufs * kJobWords * sizeof(unsigned long long), stream));
+    GLIA_HIP_TRY(hipMemsetAsync(st.hvotes, 0, (size_t)kJobMax * sizeof(unsigned long long), stream));
     GLIA_HIP_TRY(hipMemcpyAsync(d_st, &st, sizeof(BcState), hipMemcpyHostToDevice, stream));
     GLIA_HIP_TRY(hipStreamSynchronize(stream));       // st lives on this stack: the copy must have read it before it changes
     hipLaunchKernelGGL(greedy_bc_kernel, dim3(1 + st.n_helpers), dim3(kBcThreads), 0, stream, (const BcState*)d_st);
