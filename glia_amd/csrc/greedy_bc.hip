@@ -26,6 +26,7 @@
 // forest is evaluated with (edge, tree) pairs spread over the whole workgroup.
 #include <algorithm>
 #include <chrono>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -93,9 +94,15 @@ struct BcState {
   // r2 just created" -- and helper h takes the records h, h + H, ...: it stages everything a record's vector needs with agent-scope
   // loads, computes neighbour extremes, shared-boundary set, entropies, the vector and the forest's votes, and answers with one
   // 64-bit word per record.  Everything a helper reads that this launch writes is stored write-through (st_agent) by the loop.
-  uint32_t* hctl;                // [0] job sequence number (never 0; 0xFFFFFFFF = quit)
+  // What the loop's workgroup re-reads itself (the records' own fields and statistics, list headers) it keeps in plain stores --
+  // a write-through store drops the line from its XCD's L2 and every later read of it went to memory (measured: +10 k cycles
+  // per contraction) -- and hands the helpers a COPY: one packed 256-byte row per new record and channel (hrec), hadj for the
+  // list headers.  Region statistics, set extremes, entropies, pool_dir and the merge forest are stored write-through only.
+  uint32_t* hctl;                // [kFlagReps * kFlagStride] job sequence number (never 0; 0xFFFFFFFF = quit), replicated: helper h polls copy h % kFlagReps
   unsigned long long* hjob;      // [kJobBufs][kJobWords] job descriptors, slot = sequence % kJobBufs
   unsigned long long* hvotes;    // [kJobMax] sequence << 32 | model << 24 | votes, indexed by the record's position in the job
+  unsigned long long* hrec;      // [kJobMax][K][kRowWords] rows of the current job: e_A | e_NA | rs, own slot | table flag, fragile head
+  unsigned long long* hadj;      // [2*R0] adj_off | adj_len << 32 for the helpers
   uint32_t n_helpers;            // workgroups 1..n_helpers score records; 0 = the loop's own workgroup does
   uint32_t shard, n_shards;      // initial scoring: this call scores the records e with e % n_shards == shard (multi-GPU K7)
   unsigned long long* ctrl;
@@ -107,6 +114,22 @@ struct BcState {
 };
 
 namespace {
+
+// Channel c of the state BY VALUE, field by field.  The loop kernel takes its state as a kernel argument (pointers read from the
+// kernel-argument segment are known to be GLOBAL pointers: global_load / global_store; through a pointer to a state in memory
+// every access was a FLAT instruction, which counts in lgkmcnt too and ties every LDS wait to the stores in flight).  A pointer
+// fetched with a run-time index loses that, and selecting a whole struct goes through private memory: hence the field-wise
+// selects (c is uniform: scalar selects).  GLIA_BC_COMMON instances have one channel.
+__device__ __forceinline__ BcChan chan_of(const BcState& st, int c) {
+  BcChan r = st.ch[0];
+#ifndef GLIA_BC_COMMON
+#define GLIA_SEL(f) r.f = c == 1 ? st.ch[1].f : c == 2 ? st.ch[2].f : c == 3 ? st.ch[3].f : r.f
+  GLIA_SEL(pts); GLIA_SEL(Bn); GLIA_SEL(Bt); GLIA_SEL(Bmn); GLIA_SEL(Bmx); GLIA_SEL(entP); GLIA_SEL(entB); GLIA_SEL(e_A); GLIA_SEL(e_NA);
+  GLIA_SEL(e_dir); GLIA_SEL(pool_dir); GLIA_SEL(le_stats);
+#undef GLIA_SEL
+#endif
+  return r;
+}
 
 // ---- memory access forms -----------------------------------------------------------------------------------------------
 // Everything the loop's workgroup and the helpers exchange goes through agent-scope accesses: write-through (sc1) stores by the
@@ -165,7 +188,7 @@ __device__ __forceinline__ uint32_t find_root(const BcState& st, uint32_t x) {
 
 // does leaf x still own an un-cancelled boundary entry inside its region?  (nm_out, le_* are constant during the loop)
 template <bool AG>
-__device__ bool leaf_alive(const BcState& st, uint32_t x) {
+__device__ __forceinline__ bool leaf_alive(const BcState& st, uint32_t x) {
   if (st.nm_out[x]) return true;
   const uint32_t rx = find_root<AG>(st, x);
   for (uint32_t i = st.le_start[x]; i < st.le_start[x + 1]; ++i)
@@ -174,8 +197,8 @@ __device__ bool leaf_alive(const BcState& st, uint32_t x) {
 }
 
 // min / max (channel c) over region r's boundary set without the mutual entries it sends along record `skip`
-__device__ void excl_minmax(const BcState& st, int c, uint32_t r, uint32_t skip, float& mn, float& mx) {
-  const BcChan& ch = st.ch[c];
+__device__ __forceinline__ void excl_minmax(const BcState& st, int c, uint32_t r, uint32_t skip, float& mn, float& mx) {
+  const BcChan ch = chan_of(st, c);
   mn = ch.Bn[r].mn; mx = ch.Bn[r].mx;
   const uint32_t off = st.adj_off[r], len = st.adj_len[r];
   for (uint32_t i = 0; i < len; ++i) {
@@ -188,10 +211,10 @@ __device__ void excl_minmax(const BcState& st, int c, uint32_t r, uint32_t skip,
 
 // shared boundary of the two regions of record rec on channel c: mutual entries + always-alive non-mutual ones + the
 // fragile ones whose target leaf is still alive
-__device__ void shared_boundary(const BcState& st, int c, uint32_t rec, EStats& sh) {
+__device__ __forceinline__ void shared_boundary(const BcState& st, int c, uint32_t rec, EStats& sh) {
   estats_clear(sh);
   if (rec != kNone) {
-    const BcChan& ch = st.ch[c];
+    const BcChan ch = chan_of(st, c);
     sh = ch.e_A[rec];
     estats_add(sh, ch.e_NA[rec]);
     for (uint32_t f = st.e_fhead[rec]; f != kNone; f = st.le_next[f])
@@ -204,16 +227,16 @@ __device__ void shared_boundary(const BcState& st, int c, uint32_t rec, EStats& 
 // round has staged in LDS (RecIn / R2In below).  cc = image channel.
 struct GlobalView {
   const BcState* st; uint32_t first, second, rec; const EStats* shv;      // shv[cc]: shared boundary sets, computed beforehand
-  __device__ __forceinline__ const PStats* P0(int cc) const { return &st->ch[cc].pts[first]; }
-  __device__ __forceinline__ const PStats* P1(int cc) const { return &st->ch[cc].pts[second]; }
-  __device__ __forceinline__ const EStats* B0(int cc) const { return &st->ch[cc].Bt[first]; }
-  __device__ __forceinline__ const EStats* B1(int cc) const { return &st->ch[cc].Bt[second]; }
-  __device__ __forceinline__ const EStats* A(int cc) const { return rec != kNone ? &st->ch[cc].e_A[rec] : nullptr; }   // kNone: no shared record (bc_feat on non-neighbours)
+  __device__ __forceinline__ const PStats* P0(int cc) const { return &chan_of(*st, cc).pts[first]; }
+  __device__ __forceinline__ const PStats* P1(int cc) const { return &chan_of(*st, cc).pts[second]; }
+  __device__ __forceinline__ const EStats* B0(int cc) const { return &chan_of(*st, cc).Bt[first]; }
+  __device__ __forceinline__ const EStats* B1(int cc) const { return &chan_of(*st, cc).Bt[second]; }
+  __device__ __forceinline__ const EStats* A(int cc) const { return rec != kNone ? &chan_of(*st, cc).e_A[rec] : nullptr; }   // kNone: no shared record (bc_feat on non-neighbours)
   __device__ __forceinline__ const EStats* sh(int cc) const { return &shv[cc]; }
-  __device__ __forceinline__ float bmn0(int cc) const { return st->ch[cc].Bmn[first]; }
-  __device__ __forceinline__ float bmx0(int cc) const { return st->ch[cc].Bmx[first]; }
-  __device__ __forceinline__ float bmn1(int cc) const { return st->ch[cc].Bmn[second]; }
-  __device__ __forceinline__ float bmx1(int cc) const { return st->ch[cc].Bmx[second]; }
+  __device__ __forceinline__ float bmn0(int cc) const { return chan_of(*st, cc).Bmn[first]; }
+  __device__ __forceinline__ float bmx0(int cc) const { return chan_of(*st, cc).Bmx[first]; }
+  __device__ __forceinline__ float bmn1(int cc) const { return chan_of(*st, cc).Bmn[second]; }
+  __device__ __forceinline__ float bmx1(int cc) const { return chan_of(*st, cc).Bmx[second]; }
 };
 // one record's staged inputs on one channel (first = the neighbour rs) ...
 struct alignas(16) RecIn {
@@ -339,7 +362,7 @@ __device__ __forceinline__ void edge_features(const BcCfg& c, const V& v, const 
   if (finish) feat::finish_features(c, out);
 }
 // ... from the global arrays (one thread; the shared boundary sets of all channels are formed first)
-__device__ void edge_features_global(const BcState& st, uint32_t first, uint32_t second, uint32_t rec, const float* ex, double* out) {
+__device__ __forceinline__ void edge_features_global(const BcState& st, uint32_t first, uint32_t second, uint32_t rec, const float* ex, double* out) {
   EStats shv[kMaxChannels];
   for (int cc = 0; cc < st.cfg.K; ++cc) shared_boundary(st, cc, rec, shv[cc]);
   const GlobalView v{&st, first, second, rec, shv};
@@ -361,7 +384,7 @@ __device__ __forceinline__ int pick_model(const DeviceClassifier& c, const doubl
   if (x[c.dim0] < c.threshold) return 1;
   return 2;
 }
-__device__ double classify_serial(const DeviceClassifier& c, const double* x) {
+__device__ __forceinline__ double classify_serial(const DeviceClassifier& c, const double* x) {
   if (c.kind == 1) return 1.0 - x[c.stub_index];
   const DeviceForest& f = c.f[pick_model(c, x)];
   int votes = 0;
@@ -491,6 +514,12 @@ __global__ void bc_adj_fill(BcState st, uint32_t E0, uint32_t* cursor) {
   }
 }
 
+// the helpers' copy of the leaves' list headers (BcState::hadj)
+__global__ void bc_hadj_fill(BcState st) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < st.R0) st.hadj[r] = (unsigned long long)st.adj_off[r] | ((unsigned long long)st.adj_len[r] << 32);
+}
+
 __global__ void bc_init_dead(BcState st, uint32_t from) {
   uint32_t i = from + blockIdx.x * blockDim.x + threadIdx.x;
   if (i < st.Ecap) { st.pq.leaf_seq[i] = 0; st.pq.leaf_sal[i] = -__builtin_inf(); st.e_alive[i] = 0; st.e_table[i] = 0; }
@@ -530,7 +559,14 @@ __device__ __forceinline__ double bin_chain(double t, int bins, bool negate) {
 }
 
 constexpr int kPoolBytes = 112 * 1024;   // LDS workspace of the scoring phase, partitioned at run time (ws_layout)
-constexpr uint32_t kJobMax = 1u << 16;    // records per job = slots of the votes array
+// The loop's workgroup matches the neighbours of r0 and r1 in an LDS table at the END of the pool (keys: neighbour + 1; values: the
+// record that reaches it from r0 / from r1, + 1); contractions with more incident entries use the global mark arrays.
+constexpr uint32_t kMarkSlots = 2048, kMarkMax = 1408;
+constexpr uint32_t kMarkBytes = 3u * kMarkSlots * 4u;
+constexpr uint32_t kWsBytes = (uint32_t)kPoolBytes - kMarkBytes;      // what ws_layout and the per-record scratch of phase B may use
+constexpr uint32_t kJobMax = 1u << 14;    // records per job = slots of the votes array and rows of hrec; a contraction with more scores locally
+constexpr uint32_t kRowWords = 32;        // 8-byte words of a record's row in hrec
+constexpr uint32_t kFlagReps = 16, kFlagStride = 64;     // copies of the job flag, 256 bytes apart: 255 pollers on ONE word queue up at its memory channel
 constexpr uint32_t kJobBufs = 4;          // job descriptors in flight (slot = sequence % kJobBufs; see bc_helper_loop)
 constexpr uint32_t kJobWords = 4 + 4 * kMaxChannels;
 constexpr uint32_t kHelpChunk = 8;        // records a helper scores per round (two fill one pass of a 255-tree forest)
@@ -544,6 +580,9 @@ struct BcShared {
   uint32_t nlog;                 // slots of the full vector that take a logarithm
   uint32_t lost;                 // a helper did not answer in time
   uint32_t job_seq, job_ne0, job_cnt, job_r2, job_newcount, job_ok;     // helper side: the job being worked on
+  // loop side: what the contraction keeps of the region it creates (its statistics are stored write-through for the helpers;
+  // reading them back would go to memory): histograms and counts of pts[r2] / Bt[r2], extremes of Bn[r2]
+  uint32_t r2hist[kMaxChannels][2][GLIA_HMT_MAX_BINS]; uint32_t r2n[kMaxChannels][2]; float r2bn[kMaxChannels][2];
   alignas(16) uint64_t log2tab[glibc::kLog2TabWords];   // glibc's log2 tables (glibc_math.hpp): head | tab | tab2
   uint16_t logpos[feat::kMaxLogSlots];
   PqWork pq;
@@ -557,7 +596,7 @@ __device__ __forceinline__ ScoreWs ws_layout(const BcCfg& c, unsigned char* pool
   const uint32_t K = (uint32_t)BC_K(c);
   W.fstride = bc_full_dim(c); W.npre = feat::pre_count(c);
   const uint32_t per = (uint32_t)sizeof(RecHdr) + (uint32_t)sizeof(RecIn) * K + 8u * (uint32_t)W.fstride + 8u * (uint32_t)W.npre;
-  const uint32_t cap = ((uint32_t)kPoolBytes - (uint32_t)sizeof(R2In) * K) / per;
+  const uint32_t cap = (kWsBytes - (uint32_t)sizeof(R2In) * K) / per;
   W.cap = cap < (uint32_t)kChunk ? cap : (uint32_t)kChunk;
   W.r2 = reinterpret_cast<R2In*>(pool);
   W.in = reinterpret_cast<RecIn*>(pool + sizeof(R2In) * K);
@@ -580,73 +619,129 @@ __device__ __forceinline__ void r2_extremes_of(const BcShared& s, uint32_t newco
   mx = fmaxf(bnmx, rec == arg_mx ? second_mx : best_mx);
 }
 
-// One scoring round: the feature vectors (and the ensemble member) of the records W.hdr[0 .. n).rec, all edges (rs, r2) of the
-// region r2 just created.  Every thread of the workgroup calls; the caller has filled hdr[j].rec and put a barrier; s.best_* /
-// s.second_* hold the top two of r2's new records.  AG: the caller is a helper workgroup -- everything this launch has written is
-// read with agent-scope loads (the loop's workgroup stored it write-through).
-//   S0 headers + the staged copy of r2   S1 the records' statistics, one 8-byte word per lane   S2 shared boundary sets (one
-//   lane per record and channel) and the neighbours' "all but this record" extremes (16 lanes per record)   S3 entropies and
-//   histogram distances (one lane per bin)   S4 the vector, one of its four blocks per wave   S5 logarithms, selection, model
 #ifdef GLIA_HMT_PROFILE
 #define SPH(i) do { if (prof && threadIdx.x == 0) { const unsigned long long tn = __builtin_readcyclecounter(); atomicAdd(&g_pqprof[32 + (i)], tn - tsp); tsp = tn; } } while (0)
 #else
 #define SPH(i) do {} while (0)
 #endif
+// One scoring round = the feature vectors (and the ensemble member) of up to W.cap records, all edges (rs, r2) of the region r2
+// just created: a STAGING step copies what the vectors need into LDS (stage_local in the loop's own workgroup, from the arrays;
+// stage_rows + stage_regions in a helper, from the job's rows, with agent-scope loads), score_chunk computes from LDS alone apart
+// from the neighbours' incident lists.  s.best_* / s.second_* hold the top two of r2's new records.
+// Region-side words of a staged set (RecIn for region rs, R2In for r2): lane w < 35 of 64 fetches ONE word -- w < 15 of pts[r],
+// w < 29 of Bt[r], 29..32 the four extremes (4 bytes), 33 / 34 the entropies.  The address is selected, the loads are
+// unconditional (one 8-byte and one 4-byte load per lane, all in flight together): a load inside each branch of an if-chain is a
+// round trip per branch (measured: 6 k cycles for this step instead of 1.5 k).
 template <bool AG>
-__device__ void score_chunk(const BcState& st, BcShared& s, const ScoreWs& W, uint32_t n, uint32_t r2, uint32_t newcount, bool prof = false) {
+__device__ __forceinline__ unsigned long long stage_region_word(const BcChan& ch, uint32_t r, uint32_t w, unsigned long long* dst8, float* dst4, uint32_t ext4, uint32_t ent8,
+                                                                const unsigned long long* lane35 = nullptr) {
+  const unsigned long long* p8 = reinterpret_cast<const unsigned long long*>(&ch.pts[r]);
+  if (w < 15u) p8 += w;
+  else if (w < 29u) p8 = reinterpret_cast<const unsigned long long*>(&ch.Bt[r]) + (w - 15u);
+  else if (w == 33u) p8 = reinterpret_cast<const unsigned long long*>(&ch.entP[r]);
+  else if (w == 34u) p8 = reinterpret_cast<const unsigned long long*>(&ch.entB[r]);
+  else if (w == 35u && lane35) p8 = lane35;          // (the caller's own word: returned, not stored)
+  const float* p4 = w == 29u ? &ch.Bn[r].mn : w == 30u ? &ch.Bn[r].mx : w == 31u ? &ch.Bmn[r] : &ch.Bmx[r];
+  const unsigned long long v8 = ldm<AG>(p8);
+  const float v4 = ldm<AG>(p4);
+  if (w < 15u) dst8[w] = v8;
+  else if (w < 29u) dst8[16u + (w - 15u)] = v8;
+  else if (w < 33u) dst4[ext4 + (w - 29u)] = v4;
+  else if (w < 35u) dst8[ent8 + (w - 33u)] = v8;
+  return v8;
+}
+// staged copy of region r2 (K x 64 lanes)
+template <bool AG>
+__device__ __forceinline__ void stage_r2_word(const BcState& st, const ScoreWs& W, uint32_t r2, uint32_t t) {
+  const int c = (int)(t >> 6);
+  stage_region_word<AG>(chan_of(st, c), r2, t & 63u, reinterpret_cast<unsigned long long*>(&W.r2[c]), reinterpret_cast<float*>(&W.r2[c]), 60u, 32u);
+}
+// the neighbour-side statistics of record j on channel c
+template <bool AG>
+__device__ __forceinline__ unsigned long long stage_rs_word(const BcState& st, const ScoreWs& W, uint32_t j, int c, uint32_t w, int K, const unsigned long long* lane35 = nullptr) {
+  RecIn& in = W.in[j * K + c];
+  return stage_region_word<AG>(chan_of(st, c), W.hdr[j].rs, w, reinterpret_cast<unsigned long long*>(&in), reinterpret_cast<float*>(&in), 116u, 62u, lane35);
+}
+static_assert(offsetof(RecIn, bnmn) == 464 && offsetof(RecIn, entP) == 496 && offsetof(R2In, bnmn) == 240 && offsetof(R2In, entP) == 256, "staging layout");
+// loop's own workgroup: headers and record statistics from the arrays it has just written (plain loads).  The caller has filled
+// hdr[j].rec and put a barrier; ends with a barrier.
+__device__ __forceinline__ void stage_local(const BcState& st, const ScoreWs& W, uint32_t n, uint32_t r2) {
+  const int tid = threadIdx.x;
+  const int K = BC_K(st.cfg);
+  if ((uint32_t)tid < n) {
+    RecHdr h;
+    h.rec = W.hdr[tid].rec;
+    h.rs = st.e_u[h.rec]; h.on = st.e_table[h.rec]; h.own = st.e_posu[h.rec]; h.fhead = st.e_fhead[h.rec];
+    h.off = st.adj_off[h.rs];
+    const uint32_t len = st.adj_len[h.rs];
+    h.len = h.on ? len : 0u;
+    h.model = -1;
+    W.hdr[tid] = h;
+  }
+  for (uint32_t t = tid; t < (uint32_t)K * 64u; t += kBcThreads) stage_r2_word<false>(st, W, r2, t);
+  __syncthreads();
+  for (uint32_t t = tid; t < n * (uint32_t)K * 64u; t += kBcThreads) {
+    const uint32_t j = t / ((uint32_t)K * 64u); const int c = (int)((t >> 6) % (uint32_t)K); const uint32_t w = t & 63u;
+    const RecHdr h = W.hdr[j];
+    if (!h.on) continue;
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&W.in[j * K + c]);
+    if (w < 35u) stage_rs_word<false>(st, W, j, c, w, K);
+    else {
+      const unsigned long long* pa = reinterpret_cast<const unsigned long long*>(&chan_of(st, c).e_A[h.rec]);
+      const unsigned long long* pn = reinterpret_cast<const unsigned long long*>(&chan_of(st, c).e_NA[h.rec]);
+      const unsigned long long v = *(w < 49u ? pa + (w - 35u) : pn + (w < 63u ? w - 49u : 0u));
+      if (w < 49u) dst[30u + (w - 35u)] = v;
+      else if (w < 63u) dst[44u + (w - 49u)] = v;
+    }
+  }
+  __syncthreads();
+}
+// helper: the rows of the job's records pos[0 .. n) (positions in the job; clamped, a row past the job's end is read and ignored)
+// into headers, RecIn::A and RecIn::sh (= e_NA until score_chunk completes it).  No barrier: the caller waits for its loads.
+__device__ __forceinline__ void stage_rows(const BcState& st, const ScoreWs& W, uint32_t n, uint32_t h, uint32_t H, uint32_t i0, uint32_t ne0, int first_tid) {
+  const int K = BC_K(st.cfg);
+  const int t0 = (int)threadIdx.x - first_tid;
+  if (t0 < 0) return;
+  for (uint32_t t = (uint32_t)t0; t < n * (uint32_t)K * kRowWords; t += kBcThreads - (uint32_t)first_tid) {
+    const uint32_t i = t / ((uint32_t)K * kRowWords); const int c = (int)((t / kRowWords) % (uint32_t)K); const uint32_t w = t % kRowWords;
+    uint32_t pos = h + (i0 + i) * H;
+    pos = pos < kJobMax ? pos : kJobMax - 1u;
+    const unsigned long long v = ld_agent(st.hrec + ((size_t)pos * K + c) * kRowWords + w);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&W.in[i * K + c]);
+    if (w < 14u) dst[30u + w] = v;
+    else if (w < 28u) dst[44u + (w - 14u)] = v;
+    else if (c == 0 && w == 28u) { W.hdr[i].rs = (uint32_t)v; W.hdr[i].own = (uint32_t)(v >> 32); W.hdr[i].rec = ne0 + pos; W.hdr[i].model = -1; }
+    else if (c == 0 && w == 29u) { W.hdr[i].on = (uint32_t)v; W.hdr[i].fhead = (uint32_t)(v >> 32); W.hdr[i].off = 0u; W.hdr[i].len = 0u; }
+  }
+}
+// helper: neighbour-side statistics, list headers, and the staged copy of r2 (one round trip).  Ends with a barrier.
+__device__ __forceinline__ void stage_regions(const BcState& st, const ScoreWs& W, uint32_t n, uint32_t r2) {
+  const int tid = threadIdx.x;
+  const int K = BC_K(st.cfg);
+  for (uint32_t t = tid; t < (n + 1u) * (uint32_t)K * 64u; t += kBcThreads) {
+    if (t < (uint32_t)K * 64u) { stage_r2_word<true>(st, W, r2, t); continue; }
+    const uint32_t u = t - (uint32_t)K * 64u;
+    const uint32_t j = u / ((uint32_t)K * 64u); const int c = (int)((u >> 6) % (uint32_t)K); const uint32_t w = u & 63u;
+    if (!W.hdr[j].on || w > 35u) continue;
+    const unsigned long long a = stage_rs_word<true>(st, W, j, c, w, K, &st.hadj[W.hdr[j].rs]);      // lane 35: the list header of rs
+    if (w == 35u && c == 0) { W.hdr[j].off = (uint32_t)a; W.hdr[j].len = (uint32_t)(a >> 32); }
+  }
+  __syncthreads();
+}
+
+// Every thread of the workgroup calls, after a staging step.  AG: the caller is a helper workgroup -- what is still read from
+// global memory (incident lists, fragile-entry chains, the merge forest) is read with agent-scope loads.
+//   S2 shared boundary sets (one lane per record and channel) and the neighbours' "all but this record" extremes (16 lanes per
+//   record)   S3 entropies and histogram distances (one lane per bin)   S4 the vector, one of its four blocks per wave
+//   S5 logarithms, selection, model
+template <bool AG>
+__device__ __forceinline__ void score_chunk(const BcState& st, BcShared& s, const ScoreWs& W, uint32_t n, uint32_t newcount, bool prof = false) {
   const int tid = threadIdx.x;
   const int K = BC_K(st.cfg);
   const BcCfg& cf = st.cfg;
 #ifdef GLIA_HMT_PROFILE
   unsigned long long tsp = __builtin_readcyclecounter();
 #endif
-  // ---- S0 ----
-  if ((uint32_t)tid < n) {
-    RecHdr h;
-    h.rec = W.hdr[tid].rec;
-    h.rs = ldm<AG>(&st.e_u[h.rec]); h.on = ldm<AG>(&st.e_table[h.rec]); h.own = ldm<AG>(&st.e_posu[h.rec]); h.fhead = ldm<AG>(&st.e_fhead[h.rec]);
-    h.off = ldm<AG>(&st.adj_off[h.rs]);
-    const uint32_t len = ldm<AG>(&st.adj_len[h.rs]);
-    h.len = h.on ? len : 0u;
-    h.model = -1;
-    W.hdr[tid] = h;
-  }
-  for (uint32_t t = tid; t < (uint32_t)K * 64u; t += kBcThreads) {
-    const int c = (int)(t >> 6); const uint32_t w = t & 63u;
-    const BcChan& ch = st.ch[c];
-    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&W.r2[c]);
-    if (w < 15u) dst[w] = ldm<AG>(reinterpret_cast<const unsigned long long*>(&ch.pts[r2]) + w);
-    else if (w < 29u) dst[16u + (w - 15u)] = ldm<AG>(reinterpret_cast<const unsigned long long*>(&ch.Bt[r2]) + (w - 15u));
-    else if (w == 29u) W.r2[c].bnmn = ldm<AG>(&ch.Bn[r2].mn);
-    else if (w == 30u) W.r2[c].bnmx = ldm<AG>(&ch.Bn[r2].mx);
-    else if (w == 31u) W.r2[c].bmn = ldm<AG>(&ch.Bmn[r2]);
-    else if (w == 32u) W.r2[c].bmx = ldm<AG>(&ch.Bmx[r2]);
-    else if (w == 33u) W.r2[c].entP = ldm<AG>(&ch.entP[r2]);
-    else if (w == 34u) W.r2[c].entB = ldm<AG>(&ch.entB[r2]);
-  }
-  __syncthreads();
-  SPH(0);
-  // ---- S1 ----
-  for (uint32_t t = tid; t < n * (uint32_t)K * 64u; t += kBcThreads) {
-    const uint32_t j = t / ((uint32_t)K * 64u); const int c = (int)((t >> 6) % (uint32_t)K); const uint32_t w = t & 63u;
-    const RecHdr h = W.hdr[j];
-    if (!h.on) continue;
-    const BcChan& ch = st.ch[c];
-    RecIn& in = W.in[j * K + c];
-    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&in);
-    if (w < 15u) dst[w] = ldm<AG>(reinterpret_cast<const unsigned long long*>(&ch.pts[h.rs]) + w);
-    else if (w < 29u) dst[16u + (w - 15u)] = ldm<AG>(reinterpret_cast<const unsigned long long*>(&ch.Bt[h.rs]) + (w - 15u));
-    else if (w < 43u) dst[30u + (w - 29u)] = ldm<AG>(reinterpret_cast<const unsigned long long*>(&ch.e_A[h.rec]) + (w - 29u));
-    else if (w < 57u) dst[44u + (w - 43u)] = ldm<AG>(reinterpret_cast<const unsigned long long*>(&ch.e_NA[h.rec]) + (w - 43u));
-    else if (w == 57u) in.bnmn = ldm<AG>(&ch.Bn[h.rs].mn);
-    else if (w == 58u) in.bnmx = ldm<AG>(&ch.Bn[h.rs].mx);
-    else if (w == 59u) in.bmn = ldm<AG>(&ch.Bmn[h.rs]);
-    else if (w == 60u) in.bmx = ldm<AG>(&ch.Bmx[h.rs]);
-    else if (w == 61u) in.entP = ldm<AG>(&ch.entP[h.rs]);
-    else if (w == 62u) in.entB = ldm<AG>(&ch.entB[h.rs]);
-  }
-  __syncthreads();
-  SPH(1);
   // ---- S2 ----
   for (uint32_t w = tid; w < n * (uint32_t)K; w += kBcThreads) {
     // shared boundary (getBoundary / boundaryWith): mutual entries + always-alive non-mutual ones + the fragile ones whose target
@@ -657,7 +752,7 @@ __device__ void score_chunk(const BcState& st, BcShared& s, const ScoreWs& W, ui
     RecIn& in = W.in[j * K + c];
     EStats sh = in.A;
     estats_add(sh, in.sh);
-    for (uint32_t f = h.fhead; f != kNone; f = ldm<AG>(&st.le_next[f])) if (leaf_alive<AG>(st, st.le_dst[f])) estats_add(sh, st.ch[c].le_stats[f]);
+    for (uint32_t f = h.fhead; f != kNone; f = ldm<AG>(&st.le_next[f])) if (leaf_alive<AG>(st, st.le_dst[f])) estats_add(sh, chan_of(st, c).le_stats[f]);
     in.sh = sh;
   }
   {
@@ -678,7 +773,7 @@ __device__ void score_chunk(const BcState& st, BcShared& s, const ScoreWs& W, ui
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const uint32_t i = i0 + q * 16 + l16;
-              d[q] = ldm<AG>(&st.ch[c].pool_dir[h.off + (i < h.len ? i : h.len - 1u)]);
+              d[q] = ldm<AG>(&chan_of(st, c).pool_dir[h.off + (i < h.len ? i : h.len - 1u)]);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -805,7 +900,7 @@ __device__ void score_chunk(const BcState& st, BcShared& s, const ScoreWs& W, ui
 }
 
 // the forest's votes for the n vectors of a scoring round into s.votes (every thread calls; ends with a barrier)
-__device__ void forest_chunk(const BcState& st, BcShared& s, const ScoreWs& W, uint32_t n) {
+__device__ __forceinline__ void forest_chunk(const BcState& st, BcShared& s, const ScoreWs& W, uint32_t n) {
   const int tid = threadIdx.x;
   if ((uint32_t)tid < n) s.votes[tid] = 0;
   __syncthreads();
@@ -825,7 +920,7 @@ __device__ void forest_chunk(const BcState& st, BcShared& s, const ScoreWs& W, u
 // helper that had no record in the last jobs may find its slot being rewritten: the descriptor carries its sequence number and
 // the flag is read again after it -- a helper WITH records in job v always finds it intact, because the loop's workgroup does
 // not publish v + 1 before it has every answer of v.
-__device__ void bc_helper_loop(const BcState& st, BcShared& s) {
+__device__ __forceinline__ void bc_helper_loop(const BcState& st, BcShared& s) {
   const int tid = threadIdx.x;
   const uint32_t H = gridDim.x - 1u, h = blockIdx.x - 1u;
   const ScoreWs W = ws_layout(st.cfg, s.pool);
@@ -839,9 +934,9 @@ __device__ void bc_helper_loop(const BcState& st, BcShared& s) {
       uint32_t v = last;
       // poll relaxed, one lane, with a sleep (255 workgroups poll this word)
       for (unsigned long long spins = 0; spins < kHelperSpinLimit; ++spins) {
-        v = ld_relaxed(&st.hctl[0]);
+        v = ld_relaxed(&st.hctl[(h % kFlagReps) * kFlagStride]);
         if (v != last) break;
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(3);
       }
       s.job_seq = v;
     }
@@ -856,11 +951,13 @@ __device__ void bc_helper_loop(const BcState& st, BcShared& s) {
     const unsigned long long* jb = st.hjob + (size_t)(v % kJobBufs) * kJobWords;
     unsigned long long wv = 0;
     if ((uint32_t)tid < kJobWords) wv = ld_agent(jb + tid);
+    // in the same round trip, before the job's size is known: the rows of this helper's first records (waves 1..)
+    stage_rows(st, W, cap, h, H, 0u, 0u, 64);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the descriptor has arrived before the flag is read again (all its lanes are in wave 0)
     if (tid == 0) { s.job_ne0 = (uint32_t)wv; s.job_cnt = (uint32_t)(wv >> 32); }
     if (tid == 1) { s.job_r2 = (uint32_t)wv; s.job_newcount = (uint32_t)(wv >> 32); }
     if (tid == 2) {
-      const uint32_t f2 = ld_relaxed(&st.hctl[0]);
+      const uint32_t f2 = ld_relaxed(&st.hctl[(h % kFlagReps) * kFlagStride]);
       s.job_ok = ((uint32_t)wv == v && f2 != 0xFFFFFFFFu && f2 - v < kJobBufs - 1u) ? 1u : 0u;
     }
     if ((uint32_t)tid >= 4u && (uint32_t)tid < kJobWords) {
@@ -873,21 +970,25 @@ __device__ void bc_helper_loop(const BcState& st, BcShared& s) {
     if (!s.job_ok) continue;                            // torn descriptor: this helper had nothing in that job anyway
     const uint32_t cnt = s.job_cnt, ne0 = s.job_ne0, r2 = s.job_r2, newcount = s.job_newcount;
     if (h >= cnt) continue;
-    const uint32_t m = (cnt - h + H - 1u) / H;          // records h, h + H, ...
+    const uint32_t m = (cnt - h + H - 1u) / H;          // records at the job's positions h, h + H, ...
     for (uint32_t i0 = 0; i0 < m; i0 += cap) {
       const uint32_t n = m - i0 < cap ? m - i0 : cap;
-      if ((uint32_t)tid < n) W.hdr[tid].rec = ne0 + h + (i0 + (uint32_t)tid) * H;
+      if (i0) { stage_rows(st, W, n, h, H, i0, 0u, 0); __syncthreads(); }
+      if ((uint32_t)tid < n) W.hdr[tid].rec += ne0;     // (stage_rows left the position in the job)
       __syncthreads();
+      SPH(0);
+      stage_regions(st, W, n, r2);
+      SPH(1);
 #ifdef GLIA_HMT_PROFILE
-      score_chunk<true>(st, s, W, n, r2, newcount, prof);
+      score_chunk<true>(st, s, W, n, newcount, prof);
       tsp = __builtin_readcyclecounter();
 #else
-      score_chunk<true>(st, s, W, n, r2, newcount);
+      score_chunk<true>(st, s, W, n, newcount);
 #endif
       forest_chunk(st, s, W, n);
       SPH(7);
       if ((uint32_t)tid < n && W.hdr[tid].on)
-        st_agent(&st.hvotes[h + (i0 + (uint32_t)tid) * H], ((unsigned long long)v << 32) | ((unsigned long long)(uint32_t)W.hdr[tid].model << 24) | (unsigned long long)(uint32_t)s.votes[tid]);
+        st_agent(&st.hvotes[W.hdr[tid].rec - ne0], ((unsigned long long)v << 32) | ((unsigned long long)(uint32_t)W.hdr[tid].model << 24) | (unsigned long long)(uint32_t)s.votes[tid]);
       __syncthreads();
       SPH(8);
 #ifdef GLIA_HMT_PROFILE
@@ -897,10 +998,10 @@ __device__ void bc_helper_loop(const BcState& st, BcShared& s) {
   }
 }
 
-// The state comes through a pointer: device functions take it by reference, and a by-value kernel argument whose address
-// escapes is copied to private memory -- every st.pq.lv[l] / st.ch[c] then became a scratch load in front of the real one.
-__global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __restrict__ stp) {
-  const BcState& st = *stp;
+// The state is a by-value kernel argument and every function that takes it is inlined: its pointers are then known to be global
+// pointers (see chan_of).  (Round 2 passed a pointer to the state because a by-value argument whose address escapes to a
+// NON-inlined function is copied to private memory; the price was flat memory instructions throughout.)
+__global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState st) {
   __shared__ BcShared s;
   if (blockIdx.x != 0) { bc_helper_loop(st, s); return; }
   const int tid = threadIdx.x;
@@ -913,6 +1014,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
   if (tid == 0) { s.pq.wln[0] = s.pq.wln[1] = 0; s.pq.ovf = 0; s.pq.spill = 0; s.lost = 0; s.nlog = (uint32_t)feat::log_slots(st.cfg, s.logpos); }
   for (int i = tid; i < glibc::kLog2TabWords; i += blockDim.x) s.log2tab[i] = i < 18 ? glibc::kLog2Head[i] : i < 18 + 128 ? glibc::kLog2Tab[i - 18] : glibc::kLog2Tab2[i - 18 - 128];
   for (int i = tid; i < kSetSlots; i += blockDim.x) { s.pq.set[0][i] = 0; s.pq.set[1][i] = 0; }
+  for (uint32_t i = tid; i < 3u * kMarkSlots; i += kBcThreads) reinterpret_cast<uint32_t*>(s.pool + kWsBytes)[i] = 0u;      // the neighbour table
   __syncthreads();
   pq_top<kBcThreads>(st.pq, s.pq, tid);      // the root lives in LDS: rebuilt at every launch
 
@@ -976,7 +1078,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
         if (eid == e || !st.e_alive[eid]) continue;
         const int sel = st.e_u[eid] == r ? 0 : 2;
         for (int c = 0; c < K; ++c) {
-          const float* d = &st.ch[c].e_dir[(size_t)eid * 4 + sel];
+          const float* d = &chan_of(st, c).e_dir[(size_t)eid * 4 + sel];
           atomicMin(&s.ex[c][side1 ? 2 : 0], float_ord(d[0]));
           atomicMax(&s.ex[c][side1 ? 3 : 1], float_ord(d[1]));
         }
@@ -989,8 +1091,8 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
         for (int c = 0; c < kMaxChannels; ++c) {
           float m0 = 0.f, x0 = 0.f, m1 = 0.f, x1 = 0.f;
           if (c < K) {
-            m0 = fminf(st.ch[c].Bn[r0].mn, ord_float(s.ex[c][0])); x0 = fmaxf(st.ch[c].Bn[r0].mx, ord_float(s.ex[c][1]));
-            m1 = fminf(st.ch[c].Bn[r1].mn, ord_float(s.ex[c][2])); x1 = fmaxf(st.ch[c].Bn[r1].mx, ord_float(s.ex[c][3]));
+            m0 = fminf(chan_of(st, c).Bn[r0].mn, ord_float(s.ex[c][0])); x0 = fmaxf(chan_of(st, c).Bn[r0].mx, ord_float(s.ex[c][1]));
+            m1 = fminf(chan_of(st, c).Bn[r1].mn, ord_float(s.ex[c][2])); x1 = fmaxf(chan_of(st, c).Bn[r1].mx, ord_float(s.ex[c][3]));
           }
           ex[4 * c + 0] = keep ? m0 : m1; ex[4 * c + 1] = keep ? x0 : x1; ex[4 * c + 2] = keep ? m1 : m0; ex[4 * c + 3] = keep ? x1 : x0;
         }
@@ -1008,17 +1110,20 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
     // record statistics, list headers and set extremes are what the helper workgroups read: stored write-through (st_agent).
     if (tid >= 64 && tid < 64 + 3 * K) {
       const int c = (tid - 64) / 3, kind = (tid - 64) % 3;
-      const BcChan& ch = st.ch[c];
+      const BcChan ch = chan_of(st, c);
       if (kind == 0) {
         PStats p = ch.pts[r0];
         const PStats q = ch.pts[r1];
         pstats_add(p, q);
         st_agent_struct(&ch.pts[r2], p);
+        for (int b = 0; b < GLIA_HMT_MAX_BINS; ++b) s.r2hist[c][0][b] = p.hist[b];
+        s.r2n[c][0] = p.n;
       } else if (kind == 1) {
         EStats bn = ch.Bn[r0];
         const EStats q = ch.Bn[r1];
         estats_add(bn, q);
         st_agent_struct(&ch.Bn[r2], bn);
+        s.r2bn[c][0] = bn.mn; s.r2bn[c][1] = bn.mx;
       } else {
         EStats bt = ch.Bt[r0];
         const EStats q = ch.Bt[r1];
@@ -1026,6 +1131,8 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
         estats_add(bt, q);
         if (e != kNone) estats_sub_additive(bt, a);
         st_agent_struct(&ch.Bt[r2], bt);
+        for (int b = 0; b < GLIA_HMT_MAX_BINS; ++b) s.r2hist[c][1][b] = bt.hist[b];
+        s.r2n[c][1] = bt.n;
       }
     }
     if (tid == 0) {
@@ -1033,6 +1140,10 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
       if (e != kNone) { st.e_alive[e] = 0; if (!forced) { st.pq.leaf_seq[e] = 0; pq_touch(st.pq, s.pq, 0, 0, e);   /* the root is the maximum of its node */ } }
     }
     // ---- phase A: mark the neighbours of r0 / r1 with the record that reaches them ----
+    const bool rows = !forced && st.clf.kind == 0 && st.n_helpers != 0 && total <= kJobMax;      // helpers score this contraction
+    const bool small = total <= kMarkMax;                 // neighbour table in LDS
+    uint32_t* mk = reinterpret_cast<uint32_t*>(s.pool + kWsBytes);
+    uint32_t* mv0 = mk + kMarkSlots; uint32_t* mv1 = mv0 + kMarkSlots;
     for (uint32_t i = tid; i < total; i += kBcThreads) {
       const bool side1 = i >= len0;
       const uint32_t eid = st.pool[side1 ? off1 + (i - len0) : off0 + i];
@@ -1041,14 +1152,28 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
       if (eid == e || !alive) continue;
       const uint32_t r = side1 ? r1 : r0;
       const uint32_t rs = (u == r) ? v : u;
-      (side1 ? st.mark1 : st.mark0)[rs] = eid + 1u;
+      if (small) {
+        uint32_t h = (rs * 2654435761u) >> 21;
+        for (;;) {
+          const uint32_t old = atomicCAS(&mk[h], 0u, rs + 1u);
+          if (old == 0u || old == rs + 1u) break;
+          h = (h + 1u) & (kMarkSlots - 1u);
+        }
+        (side1 ? mv1 : mv0)[h] = eid + 1u;
+      } else (side1 ? st.mark1 : st.mark0)[rs] = eid + 1u;
     }
     __syncthreads();
 
     PH(1);
+    // The loop's own LDS workspace is idle while it builds records: it keeps, per new record, (rs, queue category, table flag)
+    // and the r2 -> rs extremes of every channel there, for the top-two pass and for the queue inserts (no global re-reads).
+    const uint32_t ldsCap = kWsBytes / (8u + 8u * (uint32_t)K);
+    unsigned long long* smeta = reinterpret_cast<unsigned long long*>(s.pool);
+    float2* sdd = reinterpret_cast<float2*>(s.pool + (size_t)ldsCap * 8u);
     // ---- phase B: one new record (rs, r2) per distinct neighbour ----
-    // Loads are grouped into four unconditional round trips (pool entry; the record; the neighbour's marks; everything
-    // about the record and its partner): a load behind a branch costs a round trip of its own.
+    // Three unconditional round trips (pool entry; the record; everything about the record, its partner and the neighbour): a load
+    // behind a branch costs a round trip of its own, so the partner's statistics are fetched whether there is a partner or not
+    // (without one they are the record's own: a cache hit).
     for (uint32_t i = tid; i < total; i += kBcThreads) {
       const bool side1 = i >= len0;
       const uint32_t eid = st.pool[side1 ? off1 + (i - len0) : off0 + i];
@@ -1057,7 +1182,16 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
       const uint32_t r = side1 ? r1 : r0;
       if (u != r && v != r) continue;
       const uint32_t rs = (u == r) ? v : u;
-      const uint32_t mk0 = st.mark0[rs], mk1 = st.mark1[rs], offRs = st.adj_off[rs];
+      uint32_t mk0 = 0u, mk1 = 0u;
+      if (small) {
+        uint32_t h = (rs * 2654435761u) >> 21;
+        for (;;) {
+          const uint32_t key = mk[h];
+          if (key == rs + 1u) { mk0 = mv0[h]; mk1 = mv1[h]; break; }
+          if (key == 0u) break;                       // (a dead record's neighbour may be in nobody's list)
+          h = (h + 1u) & (kMarkSlots - 1u);
+        }
+      } else { mk0 = st.mark0[rs]; mk1 = st.mark1[rs]; }
       // the record itself is the first (and maybe only) parent of the new record; a common neighbour is handled from
       // the r0 side, where the r1-side record is the second parent
       uint32_t partner = kNone;
@@ -1073,6 +1207,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
       const uint32_t idx = atomicAdd(&s.newcount, 1u);
       const uint32_t newE = (uint32_t)ne + idx;
       const uint32_t posRs = (u == rs) ? pu : pv;
+      const uint32_t offRs = st.adj_off[rs];
       const uint32_t u1 = st.e_u[a1], pu1 = st.e_posu[a1], pv1 = st.e_posv[a1];
       const uint32_t fh1 = st.e_fhead[eid], ft1 = st.e_ftail[eid], fh2 = st.e_fhead[a1], ft2 = st.e_ftail[a1];
       const uint8_t tb1 = st.e_table[eid], tb2 = st.e_table[a1];
@@ -1081,14 +1216,15 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
       const uint32_t posDead = both ? ((u1 == rs) ? pu1 : pv1) : kNone;
       // image statistics of the new record, channel by channel
       for (int c = 0; c < K; ++c) {
-        const BcChan& ch = st.ch[c];
+        const BcChan ch = chan_of(st, c);
         const EStats A1 = ch.e_A[eid], N1 = ch.e_NA[eid];
+        const EStats A2 = ch.e_A[a1], N2 = ch.e_NA[a1];
         const float4 d1 = *reinterpret_cast<const float4*>(&ch.e_dir[(size_t)eid * 4]);
         const float4 d2 = *reinterpret_cast<const float4*>(&ch.e_dir[(size_t)a1 * 4]);
         EStats A, NA;
         estats_clear(A); estats_clear(NA);
         estats_add(A, A1); estats_add(NA, N1);
-        if (both) { estats_add(A, ch.e_A[partner]); estats_add(NA, ch.e_NA[partner]); }
+        if (both) { estats_add(A, A2); estats_add(NA, N2); }
         float d[4] = {__builtin_inff(), -__builtin_inff(), __builtin_inff(), -__builtin_inff()};   // rs->r2, r2->rs
         {
           const bool rsIsU = u == rs;                   // d1.x, d1.y = u->v
@@ -1100,7 +1236,15 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
           d[0] = fminf(d[0], rsIsU ? d2.x : d2.z); d[1] = fmaxf(d[1], rsIsU ? d2.y : d2.w);
           d[2] = fminf(d[2], rsIsU ? d2.z : d2.x); d[3] = fmaxf(d[3], rsIsU ? d2.w : d2.y);
         }
-        st_agent_struct(&ch.e_A[newE], A); st_agent_struct(&ch.e_NA[newE], NA);
+        ch.e_A[newE] = A; ch.e_NA[newE] = NA;
+        if (rows) {          // the helpers' copy: one packed row per record and channel
+          unsigned long long* row = st.hrec + ((size_t)idx * K + c) * kRowWords;
+          unsigned long long wa[14], wn[14];
+          __builtin_memcpy(wa, &A, 112); __builtin_memcpy(wn, &NA, 112);
+#pragma unroll
+          for (int q = 0; q < 14; ++q) { st_agent(row + q, wa[q]); st_agent(row + 14 + q, wn[q]); }
+        }
+        if (idx < ldsCap) sdd[idx * K + c] = make_float2(d[2], d[3]);
         *reinterpret_cast<float4*>(&ch.e_dir[(size_t)newE * 4]) = make_float4(d[0], d[1], d[2], d[3]);
         st_agent(&ch.pool_dir[offRs + posRs], make_float2(d[0], d[1]));
         st_agent(&ch.pool_dir[r2off + idx], make_float2(d[2], d[3]));
@@ -1124,12 +1268,19 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
         st.e_alive[partner] = 0;
         if (tb2 && !forced) { st.pq.leaf_seq[partner] = 0; if (top2 == partner) pq_touch(st.pq, s.pq, 0, 0, partner); }
       }
-      st_agent(&st.e_u[newE], rs); st.e_v[newE] = r2; st_agent(&st.e_posu[newE], posRs);
-      st.e_alive[newE] = 1; st_agent(&st.e_table[newE], (uint8_t)((t0 || t1) ? 1 : 0)); st.e_orient[newE] = 1;
-      st_agent(&st.e_fhead[newE], fh); st.e_ftail[newE] = ft;
+      const uint32_t on = (t0 || t1) ? 1u : 0u;
+      st.e_u[newE] = rs; st.e_v[newE] = r2; st.e_posu[newE] = posRs;
+      st.e_alive[newE] = 1; st.e_table[newE] = (uint8_t)on; st.e_orient[newE] = 1;
+      st.e_fhead[newE] = fh; st.e_ftail[newE] = ft;
       // queue position (only meaningful for table edges): reference visit order, see greedy.hip; the category rides in
       // posv's upper bits until the record has been scored
       const uint32_t cat = rs < r0 ? 0u : (t0 ? 1u : 2u);
+      if (rows) {
+        unsigned long long* row = st.hrec + (size_t)idx * K * kRowWords;
+        st_agent(row + 28, (unsigned long long)rs | ((unsigned long long)posRs << 32));
+        st_agent(row + 29, (unsigned long long)on | ((unsigned long long)fh << 32));
+      }
+      if (idx < ldsCap) smeta[idx] = (unsigned long long)rs | ((unsigned long long)(cat | (on << 2)) << 32);
       st.pq.leaf_seq[newE] = 0;
       st.pq.leaf_sal[newE] = -__builtin_inf();
       st.pool[offRs + posRs] = newE;
@@ -1143,11 +1294,10 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
       for (uint32_t wq = g; wq < 2u * (uint32_t)K; wq += 4u) {
         const int cc = (int)(wq >> 1); const bool isB = (wq & 1u) != 0u;
         const int bins = st.cfg.cbins[cc];
-        const PStats* P = &st.ch[cc].pts[r2]; const EStats* B = &st.ch[cc].Bt[r2];
-        const uint32_t cnt = isB ? B->hist[l16] : P->hist[l16], n = isB ? B->n : P->n;
+        const uint32_t cnt = s.r2hist[cc][isB ? 1 : 0][l16], n = s.r2n[cc][isB ? 1 : 0];
         const double t = (int)l16 < bins ? feat::entropy_term(cnt, n, st.cfg.libm_log2, s.log2tab) : 0.0;
         const double en = bin_chain(t, bins, true);
-        if ((int)l16 == bins - 1) st_agent(&(isB ? st.ch[cc].entB : st.ch[cc].entP)[r2], en);
+        if ((int)l16 == bins - 1) { const BcChan chq = chan_of(st, cc); st_agent(&(isB ? chq.entB : chq.entP)[r2], en); }
       }
     }
     __syncthreads();
@@ -1160,77 +1310,84 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
     for (int c = 0; c < kMaxChannels; ++c) { pre_mn[c] = 0.f; pre_mx[c] = 0.f; }
     if (tid == kBcThreads - 1) {
 #pragma unroll
-      for (int c = 0; c < kMaxChannels; ++c) if (c < K) { pre_mn[c] = st.ch[c].Bn[r2].mn; pre_mx[c] = st.ch[c].Bn[r2].mx; }
+      for (int c = 0; c < kMaxChannels; ++c) if (c < K) { pre_mn[c] = s.r2bn[c][0]; pre_mx[c] = s.r2bn[c][1]; }
     }
     for (uint32_t j = tid; j < newcount; j += kBcThreads) {
       const uint32_t rec = (uint32_t)ne + j;
-      const uint32_t rs = st.e_u[rec];
-      st.mark0[rs] = 0; st.mark1[rs] = 0;
+      const bool lds = j < ldsCap;
+      if (!small) { const uint32_t rs = lds ? (uint32_t)smeta[j] : st.e_u[rec]; st.mark0[rs] = 0; st.mark1[rs] = 0; }
       for (int c = 0; c < K; ++c) {
-        const float* nd = &st.ch[c].e_dir[(size_t)rec * 4];
-        if (rec != (uint32_t)(s.best_mn[c] & 0xFFFFFFFFull)) atomicMin(&s.second_mn[c], ((unsigned long long)float_ord(nd[2]) << 32) | rec);
-        if (rec != (uint32_t)(s.best_mx[c] & 0xFFFFFFFFull)) atomicMax(&s.second_mx[c], ((unsigned long long)float_ord(nd[3]) << 32) | rec);
+        float2 nd;
+        if (lds) nd = sdd[j * K + c];
+        else { const float* g = &chan_of(st, c).e_dir[(size_t)rec * 4]; nd = make_float2(g[2], g[3]); }
+        if (rec != (uint32_t)(s.best_mn[c] & 0xFFFFFFFFull)) atomicMin(&s.second_mn[c], ((unsigned long long)float_ord(nd.x) << 32) | rec);
+        if (rec != (uint32_t)(s.best_mx[c] & 0xFFFFFFFFull)) atomicMax(&s.second_mx[c], ((unsigned long long)float_ord(nd.y) << 32) | rec);
       }
     }
+    if (small) for (uint32_t i = tid; i < 3u * kMarkSlots; i += kBcThreads) mk[i] = 0u;      // the neighbour table is empty again
     __syncthreads();
     if (tid == kBcThreads - 1) {
-      st_agent(&st.adj_off[r2], r2off); st_agent(&st.adj_len[r2], newcount);
+      st.adj_off[r2] = r2off; st.adj_len[r2] = newcount;
+      st_agent(&st.hadj[r2], (unsigned long long)r2off | ((unsigned long long)newcount << 32));
 #pragma unroll
       for (int c = 0; c < kMaxChannels; ++c)
-        if (c < K) { float mn, mx; r2_extremes_of(s, newcount, c, kNone, pre_mn[c], pre_mx[c], mn, mx); st_agent(&st.ch[c].Bmn[r2], mn); st_agent(&st.ch[c].Bmx[r2], mx); }
+        if (c < K) { float mn, mx; r2_extremes_of(s, newcount, c, kNone, pre_mn[c], pre_mx[c], mn, mx); st_agent(&chan_of(st, c).Bmn[r2], mn); st_agent(&chan_of(st, c).Bmx[r2], mx); }
+    }
+    const bool job = rows && newcount != 0u;
+    if (job) {
+      // the job's descriptor goes out with the contraction's other stores: one drain for both
+      hseq += 1u;
+      unsigned long long* jb = st.hjob + (size_t)(hseq % kJobBufs) * kJobWords;
+      if ((uint32_t)tid < kJobWords) {
+        unsigned long long w = 0;
+        if (tid == 0) w = (unsigned long long)(uint32_t)ne | ((unsigned long long)newcount << 32);
+        else if (tid == 1) w = (unsigned long long)r2 | ((unsigned long long)newcount << 32);
+        else if (tid == 2) w = (unsigned long long)hseq;
+        else if (tid >= 4) { const int c = (tid - 4) >> 2, q = (tid - 4) & 3; w = (q == 0 ? s.best_mn : q == 1 ? s.best_mx : q == 2 ? s.second_mn : s.second_mx)[c]; }
+        st_agent(jb + tid, w);
+      }
     }
     stores_done();          // every wave: what this contraction wrote is acknowledged ...
     __syncthreads();        // ... before anybody (this workgroup's staging pass, a helper after the flag) reads it
 
     PH(3);
     // ---- score the new table edges ----
-    if (!forced && newcount && st.clf.kind == 0 && st.n_helpers) {
-      // Helper workgroups score whole records.  One job per kJobMax records (one job, nearly always).
-      for (uint32_t seg0 = 0; seg0 < newcount; seg0 += kJobMax) {
-        const uint32_t cnt = newcount - seg0 < kJobMax ? newcount - seg0 : kJobMax;
-        hseq += 1u;
-        unsigned long long* jb = st.hjob + (size_t)(hseq % kJobBufs) * kJobWords;
-        if ((uint32_t)tid < kJobWords) {
-          unsigned long long w = 0;
-          if (tid == 0) w = (unsigned long long)((uint32_t)ne + seg0) | ((unsigned long long)cnt << 32);
-          else if (tid == 1) w = (unsigned long long)r2 | ((unsigned long long)newcount << 32);
-          else if (tid == 2) w = (unsigned long long)hseq;
-          else if (tid >= 4) { const int c = (tid - 4) >> 2, q = (tid - 4) & 3; w = (q == 0 ? s.best_mn : q == 1 ? s.best_mx : q == 2 ? s.second_mn : s.second_mx)[c]; }
-          st_agent(jb + tid, w);
+    if (job) {
+      // Helper workgroups score whole records (at most kJobMax: larger contractions take the branch below).
+      if ((uint32_t)tid < kFlagReps) st_agent(&st.hctl[(uint32_t)tid * kFlagStride], hseq);
+      PH(5);
+      // while the helpers work: the priority tree is brought up to date for the removals of this contraction
+      pq_propagate<kBcThreads>(st.pq, s.pq, tid);
+      PH(6);
+      for (uint32_t j = tid; j < newcount; j += kBcThreads) {
+        const uint32_t rec = (uint32_t)ne + j;
+        const bool lds = j < ldsCap;
+        const unsigned long long meta = lds ? smeta[j] : 0ull;
+        if (!(lds ? (uint32_t)((meta >> 34) & 1ull) : (uint32_t)st.e_table[rec])) continue;
+        unsigned long long w = 0, spins = 0;
+        for (;;) {
+          w = ld_agent(&st.hvotes[j]);
+          if ((uint32_t)(w >> 32) == hseq) break;
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > kHelperSpinLimit) { s.lost = 1u; break; }     // helpers lost: reported as a failed run at the next pop
         }
-        stores_done();
-        __syncthreads();
-        if (tid == 0) st_agent(&st.hctl[0], hseq);
-        PH(5);
-        // while the helpers work: the priority tree is brought up to date for the removals of this contraction
-        if (seg0 == 0) { pq_propagate<kBcThreads>(st.pq, s.pq, tid); PH(6); }
-        for (uint32_t j = tid; j < cnt; j += kBcThreads) {
-          const uint32_t rec = (uint32_t)ne + seg0 + j;
-          if (!st.e_table[rec]) continue;
-          unsigned long long w = 0, spins = 0;
-          for (;;) {
-            w = ld_agent(&st.hvotes[j]);
-            if ((uint32_t)(w >> 32) == hseq) break;
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > kHelperSpinLimit) { s.lost = 1u; break; }     // helpers lost: reported as a failed run at the next pop
-          }
-          const int model = (int)((w >> 24) & 0xFFu);
-          const double sal = (double)(uint32_t)(w & 0xFFFFFFu) / (double)st.clf.f[model < st.clf.n_models ? model : 0].ntree;
-          const uint32_t cat = st.e_posv[rec] >> 30;
-          st.pq.leaf_sal[rec] = sal;
-          st.pq.leaf_seq[rec] = ((k + 1ull) << 32) | ((unsigned long long)cat << 30) | st.e_u[rec];
-          pq_leaf_added(st.pq, s.pq, rec);
-        }
-        __syncthreads();
-        PH(11);
+        const int model = (int)((w >> 24) & 0xFFu);
+        const double sal = (double)(uint32_t)(w & 0xFFFFFFu) / (double)st.clf.f[model < st.clf.n_models ? model : 0].ntree;
+        const uint32_t cat = lds ? (uint32_t)((meta >> 32) & 3ull) : st.e_posv[rec] >> 30;
+        st.pq.leaf_sal[rec] = sal;
+        st.pq.leaf_seq[rec] = ((k + 1ull) << 32) | ((unsigned long long)cat << 30) | (lds ? (uint32_t)meta : st.e_u[rec]);
+        pq_leaf_added(st.pq, s.pq, rec);
       }
+      __syncthreads();
+      PH(11);
     } else if (!forced && newcount) {
       // the loop's own workgroup scores (no helpers, or the stub scorer of the tests), W.cap records per round
       for (uint32_t c0 = 0; c0 < newcount; c0 += W.cap) {
         const uint32_t cn = newcount - c0 < W.cap ? newcount - c0 : W.cap;
         if ((uint32_t)tid < cn) W.hdr[tid].rec = (uint32_t)ne + c0 + (uint32_t)tid;
         __syncthreads();
-        score_chunk<false>(st, s, W, cn, r2, newcount);
+        stage_local(st, W, cn, r2);
+        score_chunk<false>(st, s, W, cn, newcount);
         PH(4);
         if (st.clf.kind == 0) forest_chunk(st, s, W, cn);
         PH(5);
@@ -1253,7 +1410,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState* __
     PH(6);
     k += 1; ne += newcount; pool_used += total;
   }
-  if (tid == 0 && st.n_helpers) st_release(&st.hctl[0], 0xFFFFFFFFu);
+  if ((uint32_t)tid < kFlagReps && st.n_helpers) st_release(&st.hctl[(uint32_t)tid * kFlagStride], 0xFFFFFFFFu);
   if (tid == 0) { st.ctrl[0] = k; st.ctrl[1] = ne; st.ctrl[2] = pool_used; st.ctrl[3] = status; }
 #ifdef GLIA_HMT_PROFILE
   if (tid == 0) printf("[bc profile] pq propagations by dirty level-0 nodes (<=8, <=16, more): %llu %llu %llu\n", g_pqprof[28], g_pqprof[29], g_pqprof[30]);
@@ -1405,7 +1562,9 @@ int GLIA_BC_ENTRY(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier
   if ((rc = buf.get(&st.order, 3 * (size_t)R, false, stream))) return rc;
   if ((rc = buf.get(&st.sal_out, (size_t)R, false, stream))) return rc;
   if (h_feats) { if ((rc = buf.get(&st.feats_out, (size_t)R * cfg.fdim, false, stream))) return rc; }
-  if ((rc = buf.get(&st.hctl, 4, true, stream))) return rc;
+  if ((rc = buf.get(&st.hctl, (size_t)kFlagReps * kFlagStride, true, stream))) return rc;
+  if ((rc = buf.get(&st.hrec, (size_t)kJobMax * cfg.K * kRowWords, false, stream))) return rc;
+  if ((rc = buf.get(&st.hadj, R2, true, stream))) return rc;
   if ((rc = buf.get(&st.hjob, (size_t)kJobBufs * kJobWords, true, stream))) return rc;
   if ((rc = buf.get(&st.hvotes, kJobMax, true, stream))) return rc;
   {
@@ -1446,6 +1605,7 @@ int GLIA_BC_ENTRY(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier
     GLIA_HIP_TRY(rocprim::exclusive_scan((void*)d_tmp, tmp, st.adj_len, st.adj_off, 0u, (size_t)R, rocprim::plus<uint32_t>(), stream));
   }
   hipLaunchKernelGGL(bc_adj_fill, dim3((E0 + 255) / 256), dim3(256), 0, stream, st, E0, cursor);
+  hipLaunchKernelGGL(bc_hadj_fill, dim3((R + 255) / 256), dim3(256), 0, stream, st);
   GLIA_HIP_TRY(hipGetLastError());
   GLIA_HIP_TRY(hipEventRecord(ev[1], stream));
   if (!h_forced) hipLaunchKernelGGL(bc_init_score, dim3((E0 + 127) / 128), dim3(128), 0, stream, st, E0);
@@ -1482,15 +1642,11 @@ int GLIA_BC_ENTRY(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier
     return GLIA_HMT_OK;
   }
   st.max_iters = 1ull << 14;
-  BcState* d_st = nullptr;
-  if ((rc = buf.get(&d_st, 1, false, stream))) return rc;
   while (true) {
-    GLIA_HIP_TRY(hipMemsetAsync(st.hctl, 0, 4 * sizeof(uint32_t), stream));
+    GLIA_HIP_TRY(hipMemsetAsync(st.hctl, 0, (size_t)kFlagReps * kFlagStride * sizeof(uint32_t), stream));
     GLIA_HIP_TRY(hipMemsetAsync(st.hjob, 0, (size_t)kJobBufs * kJobWords * sizeof(unsigned long long), stream));
     GLIA_HIP_TRY(hipMemsetAsync(st.hvotes, 0, (size_t)kJobMax * sizeof(unsigned long long), stream));
-    GLIA_HIP_TRY(hipMemcpyAsync(d_st, &st, sizeof(BcState), hipMemcpyHostToDevice, stream));
-    GLIA_HIP_TRY(hipStreamSynchronize(stream));       // st lives on this stack: the copy must have read it before it changes
-    hipLaunchKernelGGL(greedy_bc_kernel, dim3(1 + st.n_helpers), dim3(kBcThreads), 0, stream, (const BcState*)d_st);
+    hipLaunchKernelGGL(greedy_bc_kernel, dim3(1 + st.n_helpers), dim3(kBcThreads), 0, stream, st);
     GLIA_HIP_TRY(hipGetLastError());
     GLIA_HIP_TRY(hipMemcpyAsync(ctrl, st.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, stream));
     GLIA_HIP_TRY(hipStreamSynchronize(stream));
