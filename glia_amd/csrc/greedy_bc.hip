@@ -577,6 +577,10 @@ struct BcShared {
   unsigned long long best_mn[kMaxChannels], best_mx[kMaxChannels], second_mn[kMaxChannels], second_mx[kMaxChannels];
   uint32_t ex[kMaxChannels][4];
   int votes[kChunk];
+  // the best of the records the last contraction inserted: they are in the tree's worklist but not propagated yet -- that
+  // happens while the helpers score the NEXT contraction's records -- so a pop compares the tree's root with this candidate
+  Key cand; Key cand_part[kBcThreads / 64];
+  unsigned long long t2[kBcThreads / 64][kMaxChannels][4];      // per wave: (best, second) of the min keys, of the complemented max keys
   uint32_t nlog;                 // slots of the full vector that take a logarithm
   uint32_t lost;                 // a helper did not answer in time
   uint32_t job_seq, job_ne0, job_cnt, job_r2, job_newcount, job_ok;     // helper side: the job being worked on
@@ -998,6 +1002,34 @@ __device__ __forceinline__ void bc_helper_loop(const BcState& st, BcShared& s) {
   }
 }
 
+// The two smallest of a set of distinct 64-bit keys over a wave: every lane brings its own (best, second); a butterfly over
+// disjoint lane sets (quad_perm xor 1, xor 2, row_ror 4, row_ror 8 inside a row, then xor 16 / 32 across rows), so a key is never
+// merged with itself.  All 64 lanes must call.  (Sixty lanes updating ONE 64-bit LDS word with atomicMin are a
+// compare-and-swap loop of sixty rounds: measured 7-9 k cycles per contraction for the four extremes.)
+__device__ __forceinline__ void top2_merge(unsigned long long& b, unsigned long long& s2, unsigned long long ob, unsigned long long os) {
+  const unsigned long long nb = ob < b ? ob : b, mx = ob < b ? b : ob;
+  unsigned long long ns = s2 < os ? s2 : os;
+  ns = mx < ns ? mx : ns;
+  b = nb; s2 = ns;
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp64(unsigned long long v) {
+  const uint32_t lo = dpp_u32<CTRL, 0xf>((uint32_t)v), hi = dpp_u32<CTRL, 0xf>((uint32_t)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long xor64(unsigned long long v, int m) {
+  const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ void wave_top2_min(unsigned long long& b, unsigned long long& s2) {
+  top2_merge(b, s2, dpp64<0xB1>(b), dpp64<0xB1>(s2));
+  top2_merge(b, s2, dpp64<0x4E>(b), dpp64<0x4E>(s2));
+  top2_merge(b, s2, dpp64<0x124>(b), dpp64<0x124>(s2));
+  top2_merge(b, s2, dpp64<0x128>(b), dpp64<0x128>(s2));
+  top2_merge(b, s2, xor64(b, 16), xor64(s2, 16));
+  top2_merge(b, s2, xor64(b, 32), xor64(s2, 32));
+}
+
 // The state is a by-value kernel argument and every function that takes it is inlined: its pointers are then known to be global
 // pointers (see chan_of).  (Round 2 passed a pointer to the state because a by-value argument whose address escapes to a
 // NON-inlined function is copied to private memory; the price was flat memory instructions throughout.)
@@ -1011,7 +1043,8 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState st)
   const int fdim = st.cfg.fdim;
   const int K = BC_K(st.cfg);
   const ScoreWs W = ws_layout(st.cfg, s.pool);
-  if (tid == 0) { s.pq.wln[0] = s.pq.wln[1] = 0; s.pq.ovf = 0; s.pq.spill = 0; s.lost = 0; s.nlog = (uint32_t)feat::log_slots(st.cfg, s.logpos); }
+  if (tid == 0) { s.pq.wln[0] = s.pq.wln[1] = 0; s.pq.ovf = 0; s.pq.spill = 0; s.lost = 0; s.nlog = (uint32_t)feat::log_slots(st.cfg, s.logpos); s.cand.sal = -__builtin_inf(); s.cand.seq = 0; s.cand.arg = 0; }
+  bool deferred = false;         // inserts of the last contraction are waiting in the worklist (uniform)
   for (int i = tid; i < glibc::kLog2TabWords; i += blockDim.x) s.log2tab[i] = i < 18 ? glibc::kLog2Head[i] : i < 18 + 128 ? glibc::kLog2Tab[i - 18] : glibc::kLog2Tab2[i - 18 - 128];
   for (int i = tid; i < kSetSlots; i += blockDim.x) { s.pq.set[0][i] = 0; s.pq.set[1][i] = 0; }
   for (uint32_t i = tid; i < 3u * kMarkSlots; i += kBcThreads) reinterpret_cast<uint32_t*>(s.pool + kWsBytes)[i] = 0u;      // the neighbour table
@@ -1027,7 +1060,9 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState st)
   for (unsigned long long it = 0; it < st.max_iters; ++it) {
     PH(7);
     if (tid == 0) {
-      const Key root = pq_root<kBcThreads>(s.pq);
+      Key root = pq_root<kBcThreads>(s.pq);
+      if (better(s.cand, root)) root = s.cand;          // (an empty candidate has seq 0 and -inf: never better)
+      s.cand.sal = -__builtin_inf(); s.cand.seq = 0; s.cand.arg = 0;
       s.stop = ST_RUN; s.newcount = 0;
       for (int c = 0; c < kMaxChannels; ++c) {
         s.best_mn[c] = s.second_mn[c] = ~0ull; s.best_mx[c] = s.second_mx[c] = 0ull;
@@ -1249,9 +1284,6 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState st)
         st_agent(&ch.pool_dir[offRs + posRs], make_float2(d[0], d[1]));
         st_agent(&ch.pool_dir[r2off + idx], make_float2(d[2], d[3]));
         if (posDead != kNone) st_agent(&ch.pool_dir[offRs + posDead], make_float2(__builtin_inff(), -__builtin_inff()));
-        // r2's mutual boundary extremes (entries r2 -> rs) for B(r2) and the "all but one" queries
-        atomicMin(&s.best_mn[c], ((unsigned long long)float_ord(d[2]) << 32) | newE);
-        atomicMax(&s.best_mx[c], ((unsigned long long)float_ord(d[3]) << 32) | newE);
       }
       // the fragile-entry chains of the parents, concatenated in (r0 side, r1 side) order
       uint32_t fh = kNone, ft = kNone;
@@ -1312,19 +1344,46 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState st)
 #pragma unroll
       for (int c = 0; c < kMaxChannels; ++c) if (c < K) { pre_mn[c] = s.r2bn[c][0]; pre_mx[c] = s.r2bn[c][1]; }
     }
-    for (uint32_t j = tid; j < newcount; j += kBcThreads) {
-      const uint32_t rec = (uint32_t)ne + j;
-      const bool lds = j < ldsCap;
-      if (!small) { const uint32_t rs = lds ? (uint32_t)smeta[j] : st.e_u[rec]; st.mark0[rs] = 0; st.mark1[rs] = 0; }
-      for (int c = 0; c < K; ++c) {
-        float2 nd;
-        if (lds) nd = sdd[j * K + c];
-        else { const float* g = &chan_of(st, c).e_dir[(size_t)rec * 4]; nd = make_float2(g[2], g[3]); }
-        if (rec != (uint32_t)(s.best_mn[c] & 0xFFFFFFFFull)) atomicMin(&s.second_mn[c], ((unsigned long long)float_ord(nd.x) << 32) | rec);
-        if (rec != (uint32_t)(s.best_mx[c] & 0xFFFFFFFFull)) atomicMax(&s.second_mx[c], ((unsigned long long)float_ord(nd.y) << 32) | rec);
+    // r2's mutual boundary extremes (its entries r2 -> rs) per channel: the best and the runner-up of the new records, for B(r2)
+    // and the "all but this record" queries of the vectors
+    {
+      unsigned long long kb[kMaxChannels][2], ks[kMaxChannels][2];
+#pragma unroll
+      for (int c = 0; c < kMaxChannels; ++c) { kb[c][0] = kb[c][1] = ~0ull; ks[c][0] = ks[c][1] = ~0ull; }
+      for (uint32_t j = tid; j < newcount; j += kBcThreads) {
+        const uint32_t rec = (uint32_t)ne + j;
+        const bool lds = j < ldsCap;
+        if (!small) { const uint32_t rs = lds ? (uint32_t)smeta[j] : st.e_u[rec]; st.mark0[rs] = 0; st.mark1[rs] = 0; }
+#pragma unroll
+        for (int c = 0; c < kMaxChannels; ++c) {
+          if (c < K) {
+            float2 nd;
+            if (lds) nd = sdd[j * K + c];
+            else { const float* g = &chan_of(st, c).e_dir[(size_t)rec * 4]; nd = make_float2(g[2], g[3]); }
+            top2_merge(kb[c][0], ks[c][0], ((unsigned long long)float_ord(nd.x) << 32) | rec, ~0ull);
+            top2_merge(kb[c][1], ks[c][1], ~(((unsigned long long)float_ord(nd.y) << 32) | rec), ~0ull);      // the largest = the smallest complement
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < kMaxChannels; ++c) {
+        if (c < K) {
+          wave_top2_min(kb[c][0], ks[c][0]);
+          wave_top2_min(kb[c][1], ks[c][1]);
+          if ((tid & 63) == 0) { s.t2[tid >> 6][c][0] = kb[c][0]; s.t2[tid >> 6][c][1] = ks[c][0]; s.t2[tid >> 6][c][2] = kb[c][1]; s.t2[tid >> 6][c][3] = ks[c][1]; }
+        }
       }
     }
+    PH(9);
     if (small) for (uint32_t i = tid; i < 3u * kMarkSlots; i += kBcThreads) mk[i] = 0u;      // the neighbour table is empty again
+    __syncthreads();
+    PH(10);
+    if (tid < K) {
+      unsigned long long b0 = ~0ull, s0 = ~0ull, b1 = ~0ull, s1 = ~0ull;
+#pragma unroll
+      for (int w = 0; w < kBcThreads / 64; ++w) { top2_merge(b0, s0, s.t2[w][tid][0], s.t2[w][tid][1]); top2_merge(b1, s1, s.t2[w][tid][2], s.t2[w][tid][3]); }
+      s.best_mn[tid] = b0; s.second_mn[tid] = s0; s.best_mx[tid] = ~b1; s.second_mx[tid] = ~s1;      // (empty: ~0 / ~0 / 0 / 0, as the pop initialised them)
+    }
     __syncthreads();
     if (tid == kBcThreads - 1) {
       st.adj_off[r2] = r2off; st.adj_len[r2] = newcount;
@@ -1347,10 +1406,11 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState st)
         st_agent(jb + tid, w);
       }
     }
+    PH(3);
     stores_done();          // every wave: what this contraction wrote is acknowledged ...
     __syncthreads();        // ... before anybody (this workgroup's staging pass, a helper after the flag) reads it
 
-    PH(3);
+    PH(8);
     // ---- score the new table edges ----
     if (job) {
       // Helper workgroups score whole records (at most kJobMax: larger contractions take the branch below).
@@ -1359,6 +1419,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState st)
       // while the helpers work: the priority tree is brought up to date for the removals of this contraction
       pq_propagate<kBcThreads>(st.pq, s.pq, tid);
       PH(6);
+      Key mine; mine.sal = -__builtin_inf(); mine.seq = 0; mine.arg = 0;
       for (uint32_t j = tid; j < newcount; j += kBcThreads) {
         const uint32_t rec = (uint32_t)ne + j;
         const bool lds = j < ldsCap;
@@ -1374,11 +1435,22 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState st)
         const int model = (int)((w >> 24) & 0xFFu);
         const double sal = (double)(uint32_t)(w & 0xFFFFFFu) / (double)st.clf.f[model < st.clf.n_models ? model : 0].ntree;
         const uint32_t cat = lds ? (uint32_t)((meta >> 32) & 3ull) : st.e_posv[rec] >> 30;
+        Key c; c.sal = sal; c.seq = ((k + 1ull) << 32) | ((unsigned long long)cat << 30) | (lds ? (uint32_t)meta : st.e_u[rec]); c.arg = rec;
         st.pq.leaf_sal[rec] = sal;
-        st.pq.leaf_seq[rec] = ((k + 1ull) << 32) | ((unsigned long long)cat << 30) | (lds ? (uint32_t)meta : st.e_u[rec]);
+        st.pq.leaf_seq[rec] = c.seq;
         pq_leaf_added(st.pq, s.pq, rec);
+        if (better(c, mine)) mine = c;
       }
+      mine = wave_max(mine);
+      if ((tid & 63) == 0) s.cand_part[tid >> 6] = mine;
       __syncthreads();
+      if (tid == 0) {
+        Key b = s.cand_part[0];
+#pragma unroll
+        for (int w = 1; w < kBcThreads / 64; ++w) if (better(s.cand_part[w], b)) b = s.cand_part[w];
+        s.cand = b;
+      }
+      deferred = true;
       PH(11);
     } else if (!forced && newcount) {
       // the loop's own workgroup scores (no helpers, or the stub scorer of the tests), W.cap records per round
@@ -1405,18 +1477,22 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState st)
     }
     for (uint32_t j = tid; j < newcount; j += kBcThreads) st.e_posv[(uint32_t)ne + j] &= 0x3FFFFFFFu;
     PH(3);
-    if (!forced) pq_propagate<kBcThreads>(st.pq, s.pq, tid);
+    // the tree is brought up to date here unless the records just inserted can wait for the next contraction's helper round
+    // (their best is s.cand; the next pop looks at it)
+    if (!forced && !(job && deferred)) pq_propagate<kBcThreads>(st.pq, s.pq, tid);
     else __syncthreads();
+    if (!job) deferred = false;
     PH(6);
     k += 1; ne += newcount; pool_used += total;
   }
+  if (deferred) pq_propagate<kBcThreads>(st.pq, s.pq, tid);      // the worklist lives in LDS: nothing may be left in it
   if ((uint32_t)tid < kFlagReps && st.n_helpers) st_release(&st.hctl[(uint32_t)tid * kFlagStride], 0xFFFFFFFFu);
   if (tid == 0) { st.ctrl[0] = k; st.ctrl[1] = ne; st.ctrl[2] = pool_used; st.ctrl[3] = status; }
 #ifdef GLIA_HMT_PROFILE
   if (tid == 0) printf("[bc profile] pq propagations by dirty level-0 nodes (<=8, <=16, more): %llu %llu %llu\n", g_pqprof[28], g_pqprof[29], g_pqprof[30]);
   if (tid == 0) printf("[bc profile] helper 0 (cumulative cycles): descriptor %llu  S0 headers %llu  S1 words %llu  S2 shared+extremes %llu  S3 entropies %llu  S4 assembly %llu  S5 finish %llu  forest %llu  publish %llu  records %llu\n",
                        g_pqprof[38], g_pqprof[32], g_pqprof[33], g_pqprof[34], g_pqprof[35], g_pqprof[36], g_pqprof[37], g_pqprof[39], g_pqprof[40], g_pqprof[41]);
-  if (tid == 0) printf("[bc profile] merges %llu: pop+feats_out %llu  region+mark %llu  build %llu  top2 %llu  local scoring %llu  forest/publish %llu  pq %llu  loop-top %llu  wait-for-votes %llu (cycles)\n", k, tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], tph[6], tph[7], tph[11]);
+  if (tid == 0) printf("[bc profile] merges %llu: pop+feats_out %llu  region+mark %llu  build %llu  top2 %llu  store drain %llu  (top2: second-best pass %llu  table clear + barrier %llu)  local scoring %llu  forest/publish %llu  pq %llu  loop-top %llu  wait-for-votes %llu (cycles)\n", k, tph[0], tph[1], tph[2], tph[3] + tph[9] + tph[10], tph[8], tph[9], tph[10], tph[4], tph[5], tph[6], tph[7], tph[11]);
 #endif
 }
 
