@@ -766,7 +766,7 @@ static int upload_forest(const HostForest& hf, glia_hmt_forest* f, int slot, hip
   GLIA_HIP_TRY(hipMemcpyAsync(d_nodes, nodes.data(), sizeof(PackedNode) * nodes.size(), hipMemcpyHostToDevice, stream));
   GLIA_HIP_TRY(hipMemcpyAsync(d_roots, roots.data(), sizeof(int) * roots.size(), hipMemcpyHostToDevice, stream));
   GLIA_HIP_TRY(hipStreamSynchronize(stream));
-  f->dc.f[slot].ntree = hf.ntree; f->dc.f[slot].nrnodes = hf.nrnodes;
+  f->dc.f[slot].ntree = hf.ntree; f->dc.f[slot].nrnodes = hf.nrnodes; f->dc.f[slot].nnodes = (int)nodes.size();
   f->dc.f[slot].nodes = d_nodes; f->dc.f[slot].root = d_roots;
   if (hf.max_var > f->max_var) f->max_var = hf.max_var;
   return GLIA_HMT_OK;

@@ -20,6 +20,7 @@ struct PackedNode {
 };
 struct DeviceForest {
   int ntree, nrnodes;          // nrnodes: depth bound for the walk
+  int nnodes;                  // packed nodes of all trees
   const PackedNode* nodes;
   const int* root;             // [ntree] index of each tree's root
 };

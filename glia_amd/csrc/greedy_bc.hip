@@ -595,18 +595,19 @@ struct BcShared {
 // workspace of one scoring round of up to `cap` records: the staged copy of the region being created (per channel) | the records'
 // staged inputs (per record and channel) | feature vectors | precomputed entropies / distances | headers
 struct ScoreWs { uint32_t cap; int fstride, npre; R2In* r2; RecIn* in; double* feat; double* fx; RecHdr* hdr; };
-__device__ __forceinline__ ScoreWs ws_layout(const BcCfg& c, unsigned char* pool) {
+__device__ __forceinline__ ScoreWs ws_layout(const BcCfg& c, unsigned char* pool, uint32_t cap_limit = (uint32_t)kChunk, uint32_t* used = nullptr) {
   ScoreWs W;
   const uint32_t K = (uint32_t)BC_K(c);
   W.fstride = bc_full_dim(c); W.npre = feat::pre_count(c);
   const uint32_t per = (uint32_t)sizeof(RecHdr) + (uint32_t)sizeof(RecIn) * K + 8u * (uint32_t)W.fstride + 8u * (uint32_t)W.npre;
   const uint32_t cap = (kWsBytes - (uint32_t)sizeof(R2In) * K) / per;
-  W.cap = cap < (uint32_t)kChunk ? cap : (uint32_t)kChunk;
+  W.cap = cap < cap_limit ? cap : cap_limit;
   W.r2 = reinterpret_cast<R2In*>(pool);
   W.in = reinterpret_cast<RecIn*>(pool + sizeof(R2In) * K);
   W.feat = reinterpret_cast<double*>(W.in + (size_t)W.cap * K);
   W.fx = W.feat + (size_t)W.cap * W.fstride;
   W.hdr = reinterpret_cast<RecHdr*>(W.fx + (size_t)W.cap * W.npre);
+  if (used) *used = ((uint32_t)(reinterpret_cast<unsigned char*>(W.hdr + W.cap) - pool) + 15u) & ~15u;
   return W;
 }
 
@@ -806,56 +807,55 @@ __device__ __forceinline__ void score_chunk(const BcState& st, BcShared& s, cons
   SPH(2);
   // ---- S3 ----
   {
-    // entropies and histogram distances, one lane per bin (16 lanes per record): the log2 and divisions of a vector are by far its
-    // longest serial stretch.  The bins' terms are added IN BIN ORDER, as the reference does (bin_chain).
-    const uint32_t sub = (uint32_t)tid >> 4, l16 = (uint32_t)tid & 15u;
-    for (uint32_t j = sub; j < n; j += kBcThreads / 16) {
+    // entropies and histogram distances, one lane per bin: the log2 and divisions of a vector are by far its longest serial
+    // stretch.  A TASK = 16 lanes on one group of sums of one record -- region / label list entry i: entropy of the merged voxel
+    // set + L1 + chi-square; boundary list entry i: entropy of the merged boundary set; the same entry: entropy of the shared
+    // boundary -- so the (usually three) logarithm passes of a record run side by side.  The bins' terms are added IN BIN ORDER, as
+    // the reference does (bin_chain).
+    // (consecutive tasks go to different WAVES: sixteen-lane groups of one wave would run their logarithms one after the other)
+    const uint32_t sub = ((uint32_t)tid >> 6) + (kBcThreads / 64) * (((uint32_t)tid & 63u) >> 4), l16 = (uint32_t)tid & 15u;
+    const uint32_t nrl = (uint32_t)(BC_NR(cf) + BC_NL(cf)), G = nrl + 2u * (uint32_t)BC_NB(cf);
+    for (uint32_t task = sub; task < n * G; task += kBcThreads / 16) {
+      const uint32_t j = task / G, g = task - j * G;
       const bool on = W.hdr[j].on != 0;              // uniform over the 16 lanes
       const RecIn* in = &W.in[j * K];
       double* fx = W.fx + (size_t)j * W.npre;
-      for (int kind = 0; kind < 2; ++kind) {
-        const int cnt = kind ? BC_NL(cf) : BC_NR(cf);
-        for (int i = 0; i < cnt; ++i) {
-          const int cc = kind ? cf.lc[i] : cf.rc[i];
-          const int bins = cf.cbins[cc];
-          double t2 = 0.0, tl = 0.0, tx = 0.0;
-          const PStats* P0 = &in[cc].P; const PStats* P1 = &W.r2[cc].P;
-          const uint32_t h0 = P0->hist[l16], h1 = P1->hist[l16], pn0 = P0->n, pn1 = P1->n;
-          const double e0 = in[cc].entP;                  // filed when rs was created (BcChan::entP)
-          const double e1 = W.r2[cc].entP;                // r2's: worked out once per contraction
-          if (on && (int)l16 < bins) {
-            t2 = feat::entropy_term(h0 + h1, pn0 + pn1, cf.libm_log2, s.log2tab);
-            feat::dist_terms(h0, pn0, h1, pn1, tl, tx);
-          }
-          const double e2 = bin_chain(t2, bins, true);
-          const double dl = bin_chain(tl, bins, false), dx = bin_chain(tx, bins, false);
-          if (on && (int)l16 == bins - 1) { double* q = fx + feat::pre_region(cf, kind, i); q[0] = e0; q[1] = e1; q[2] = e2; q[3] = dl; q[4] = dx; }
+      if (g < nrl) {
+        const int kind = g < (uint32_t)BC_NR(cf) ? 0 : 1;
+        const int i = kind ? (int)g - BC_NR(cf) : (int)g;
+        const int cc = kind ? cf.lc[i] : cf.rc[i];
+        const int bins = cf.cbins[cc];
+        double t2 = 0.0, tl = 0.0, tx = 0.0;
+        const PStats* P0 = &in[cc].P; const PStats* P1 = &W.r2[cc].P;
+        const uint32_t h0 = P0->hist[l16], h1 = P1->hist[l16], pn0 = P0->n, pn1 = P1->n;
+        const double e0 = in[cc].entP;                  // filed when rs was created (BcChan::entP)
+        const double e1 = W.r2[cc].entP;                // r2's: worked out once per contraction
+        if (on && (int)l16 < bins) {
+          t2 = feat::entropy_term(h0 + h1, pn0 + pn1, cf.libm_log2, s.log2tab);
+          feat::dist_terms(h0, pn0, h1, pn1, tl, tx);
         }
-      }
-      for (int i = 0; i < BC_NB(cf); ++i) {
+        const double e2 = bin_chain(t2, bins, true);
+        const double dl = bin_chain(tl, bins, false), dx = bin_chain(tx, bins, false);
+        if (on && (int)l16 == bins - 1) { double* q = fx + feat::pre_region(cf, kind, i); q[0] = e0; q[1] = e1; q[2] = e2; q[3] = dl; q[4] = dx; }
+      } else {
+        const uint32_t gb = g - nrl;
+        const int i = (int)(gb >> 1); const bool shared = (gb & 1u) != 0u;
         const int cc = cf.bc[i];
         const int bins = cf.cbins[cc];
-        double t2 = 0.0, t3 = 0.0;
         const EStats* B0 = &in[cc].B; const EStats* B1 = &W.r2[cc].B;
         const EStats* A = &in[cc].A;
         const EStats* sh = &in[cc].sh;
         const uint32_t g0 = B0->hist[l16], g1 = B1->hist[l16], ga = A->hist[l16], bn0 = B0->n, bn1 = B1->n, an = A->n;
-        const double e0 = in[cc].entB;
-        const double e1 = W.r2[cc].entB;
-        if (on && (int)l16 < bins) {
-          const uint32_t gs = sh->hist[l16], sn = sh->n;
-          // (one inlined copy of the logarithm per loop, not one per term: copies of the glibc restatement cost the loop
-          // through register pressure alone)
-#pragma unroll 1
-          for (int q = 2; q < 4; ++q) {
-            const uint32_t cq = q == 2 ? g0 + g1 - ga : gs;
-            const uint32_t nq = q == 2 ? bn0 + bn1 - an : sn;
-            const double t = feat::entropy_term(cq, nq, cf.libm_log2, s.log2tab);
-            t2 = q == 2 ? t : t2; t3 = q == 3 ? t : t3;
-          }
+        const uint32_t gs = sh->hist[l16], sn = sh->n;
+        const uint32_t cq = shared ? gs : g0 + g1 - ga, nq = shared ? sn : bn0 + bn1 - an;
+        double t = 0.0;
+        if (on && (int)l16 < bins) t = feat::entropy_term(cq, nq, cf.libm_log2, s.log2tab);
+        const double en = bin_chain(t, bins, true);
+        if (on && (int)l16 == bins - 1) {
+          double* q = fx + feat::pre_boundary(cf, i);
+          if (shared) q[3] = en;
+          else { q[0] = in[cc].entB; q[1] = W.r2[cc].entB; q[2] = en; }
         }
-        const double e2 = bin_chain(t2, bins, true), e3 = bin_chain(t3, bins, true);
-        if (on && (int)l16 == bins - 1) { double* q = fx + feat::pre_boundary(cf, i); q[0] = e0; q[1] = e1; q[2] = e2; q[3] = e3; }
       }
     }
   }
@@ -927,8 +927,9 @@ __device__ __forceinline__ void forest_chunk(const BcState& st, BcShared& s, con
 __device__ __forceinline__ void bc_helper_loop(const BcState& st, BcShared& s) {
   const int tid = threadIdx.x;
   const uint32_t H = gridDim.x - 1u, h = blockIdx.x - 1u;
-  const ScoreWs W = ws_layout(st.cfg, s.pool);
-  const uint32_t cap = W.cap < kHelpChunk ? W.cap : kHelpChunk;
+  uint32_t used = 0;
+  const ScoreWs W = ws_layout(st.cfg, s.pool, kHelpChunk, &used);
+  const uint32_t cap = W.cap;
   if (tid == 0) s.nlog = (uint32_t)feat::log_slots(st.cfg, s.logpos);
   for (int i = tid; i < glibc::kLog2TabWords; i += kBcThreads) s.log2tab[i] = i < 18 ? glibc::kLog2Head[i] : i < 18 + 128 ? glibc::kLog2Tab[i - 18] : glibc::kLog2Tab2[i - 18 - 128];
   uint32_t last = 0;
