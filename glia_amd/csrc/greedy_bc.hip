@@ -941,7 +941,7 @@ __device__ __forceinline__ void bc_helper_loop(const BcState& st, BcShared& s) {
       for (unsigned long long spins = 0; spins < kHelperSpinLimit; ++spins) {
         v = ld_relaxed(&st.hctl[(h % kFlagReps) * kFlagStride]);
         if (v != last) break;
-        __builtin_amdgcn_s_sleep(3);
+        __builtin_amdgcn_s_sleep(2);
       }
       s.job_seq = v;
     }
