@@ -340,6 +340,81 @@ class FeatureStubClassifier(RandomForest):
         _check(lib().glia_hmt_forest_stub(ctx.h, C.c_int(index), C.byref(self.h)))
 
 
+class Slab(C.Structure):
+    """glia_hmt_slab (include/glia_hmt.h)"""
+    _fields_ = [("dims_local", C.c_int64 * 3), ("z_global_of_plane0", C.c_int64), ("z_begin", C.c_int64), ("z_end", C.c_int64),
+                ("d_labels", C.c_void_p), ("d_pb", C.c_void_p), ("cfg", C.POINTER(FeatConfig))]
+
+
+class DistStats(C.Structure):
+    _fields_ = [("records", C.c_uint64), ("cut_records", C.c_uint64), ("bytes_cut_exchange", C.c_uint64), ("bytes_to_loop_owner", C.c_uint64)]
+
+
+class Comm:
+    """glia_hmt_comm: the ranks of this process in the slab route (glia_amd/csrc/slab_dist.cpp)."""
+
+    def __init__(self, ctx, world, rank=None, unique_id=None):
+        """rank None: all `world` ranks in this process on ctx's GPU (device copies); else one RCCL rank (unique_id: 128 bytes
+        from Comm.unique_id() on one rank)."""
+        self.ctx, self.world = ctx, world
+        self.h = C.c_void_p()
+        if rank is None:
+            _check(lib().glia_hmt_comm_create_local(ctx.h, C.c_int(world), C.byref(self.h)))
+            self.local = list(range(world))
+        else:
+            buf = (C.c_char * 128).from_buffer_copy(unique_id)
+            _check(lib().glia_hmt_comm_create_rccl(ctx.h, C.c_int(world), C.c_int(rank), buf, C.byref(self.h)))
+            self.local = [rank]
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_char * 128)()
+        _check(lib().glia_hmt_comm_unique_id(buf))
+        return bytes(buf)
+
+    def close(self):
+        if self.h:
+            lib().glia_hmt_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def slab_range(nz, world, rank):
+    """glia_hmt_slab_range -> (first plane handed in, planes handed in, z_begin, z_end)"""
+    a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+    _check(lib().glia_hmt_slab_range(C.c_int64(nz), C.c_int(world), C.c_int(rank), C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+    return a.value, b.value, c.value, d.value
+
+
+def build_distributed(ctx, comm, slabs, nz_global, only_contour=False, loop_owner=0):
+    """glia_hmt_rag_build_distributed.  slabs: one (labels, pb, first_plane, z_begin, z_end, cfg) per LOCAL rank of comm, in rank
+    order (labels / pb: CUDA tensors of the planes handed in).  Returns (RegionMap of the whole volume | None, DistStats)."""
+    arr = (Slab * len(slabs))()
+    keep = []
+    for i, (lab, pb, first, zb, ze, cfg) in enumerate(slabs):
+        assert lab.is_cuda and lab.is_contiguous() and lab.dim() == 3
+        _fence(lab)
+        arr[i].dims_local[0], arr[i].dims_local[1], arr[i].dims_local[2] = lab.shape[2], lab.shape[1], lab.shape[0]
+        arr[i].z_global_of_plane0, arr[i].z_begin, arr[i].z_end = first, zb, ze
+        arr[i].d_labels = lab.data_ptr()
+        arr[i].d_pb = pb.data_ptr() if pb is not None else None
+        arr[i].cfg = C.pointer(cfg) if cfg is not None else None
+        keep.append((lab, pb, cfg))
+    h = C.c_void_p()
+    st = DistStats()
+    _check(lib().glia_hmt_rag_build_distributed(ctx.h, comm.h, arr, C.c_int64(nz_global), C.c_int(int(only_contour)), C.c_int(loop_owner),
+                                                C.byref(h), C.byref(st)))
+    rm = RegionMap(ctx, None, cfg=slabs[0][5], _handle=h) if h else None
+    if rm is not None:
+        rm._keep = keep
+    return rm, st
+
+
 class RegionMap:
     """Device-resident region adjacency structure with sufficient statistics.
     Mirrors TRegionMap(image, mask, onlyContour) (type/region_map.hxx:38-40)."""
@@ -392,6 +467,9 @@ class RegionMap:
     @property
     def num_pairs(self):
         return lib().glia_hmt_rag_num_pairs(self.h)
+
+    def num_channels(self):
+        return lib().glia_hmt_rag_num_channels(self.h)
 
     @staticmethod
     def merge(ctx, parts):

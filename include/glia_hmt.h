@@ -133,6 +133,38 @@ int glia_hmt_rag_build_slab(glia_hmt_ctx* ctx, const int64_t dims_local[3], int6
                             int64_t nz_global, int64_t z_begin, int64_t z_end, const uint32_t* d_labels,
                             int only_contour, const float* d_pb, const glia_hmt_feat_config* cfg, glia_hmt_rag** out);
 int glia_hmt_rag_merge(glia_hmt_ctx* ctx, glia_hmt_rag* const* parts, int n_parts, glia_hmt_rag** out);
+/* ---- the slab route end to end (glia_amd/csrc/slab_dist.cpp): build, keyed owner exchange of the cut records, hand-over ----
+ * A communicator holds the ranks of ONE process.  glia_hmt_comm_create_rccl: one rank per process and GPU, transfers between
+ * processes are ncclSend / ncclRecv over RCCL (xGMI inside a node); the 128-byte id comes from glia_hmt_comm_unique_id on one rank
+ * and reaches the others through the launcher (a file, an environment variable).  glia_hmt_comm_create_local: all `world` ranks
+ * in this process on this context's GPU, transfers are device copies -- the same code path otherwise (single-GPU runs of volumes
+ * processed slab by slab, tests).  librccl.so is loaded when the first RCCL communicator is made, not linked. */
+typedef struct glia_hmt_comm glia_hmt_comm;
+int glia_hmt_comm_unique_id(void* id128);
+int glia_hmt_comm_create_rccl(glia_hmt_ctx* ctx, int world, int rank, const void* id128, glia_hmt_comm** out);
+int glia_hmt_comm_create_local(glia_hmt_ctx* ctx, int world, glia_hmt_comm** out);
+void glia_hmt_comm_destroy(glia_hmt_comm* comm);
+int glia_hmt_comm_world(const glia_hmt_comm* comm);
+int glia_hmt_comm_local_ranks(const glia_hmt_comm* comm, int* ranks, int capacity);      /* returns their number */
+/* the z range of rank `rank` of `world`: planes [first_plane, first_plane + n_planes) are handed in (owned planes + one halo
+ * plane per cut), of which the local planes [z_begin, z_end) are owned (the arguments of glia_hmt_rag_build_slab) */
+int glia_hmt_slab_range(int64_t nz, int world, int rank, int64_t* first_plane, int64_t* n_planes, int64_t* z_begin, int64_t* z_end);
+typedef struct {
+  int64_t dims_local[3];             /* x, y, planes handed in */
+  int64_t z_global_of_plane0;        /* global z of local plane 0 */
+  int64_t z_begin, z_end;            /* owned local planes */
+  const uint32_t* d_labels;          /* device, dims_local */
+  const float* d_pb;                 /* device, dims_local (or NULL when cfg lists the images) */
+  const glia_hmt_feat_config* cfg;   /* image lists of THIS slab's sub-volumes, or NULL */
+} glia_hmt_slab;
+typedef struct {
+  uint64_t records, cut_records;                     /* of the local ranks: all records / records that took the owner exchange */
+  uint64_t bytes_cut_exchange, bytes_to_loop_owner;  /* bytes the local ranks sent to OTHER ranks in step 2 / step 3 */
+} glia_hmt_dist_stats;
+/* slabs[i] belongs to the i-th local rank of the communicator (rank order).  *out = the whole volume's map when loop_owner is a
+ * local rank, NULL otherwise.  Collective: every process of the communicator calls it. */
+int glia_hmt_rag_build_distributed(glia_hmt_ctx* ctx, glia_hmt_comm* comm, const glia_hmt_slab* slabs, int64_t nz_global, int only_contour,
+                                   int loop_owner, glia_hmt_rag** out, glia_hmt_dist_stats* stats);
 /* Which records of a slab's partial map may have a counterpart in another slab ("exchanging only the cross-slab boundary
  * regions"): d_region_cut[i] / d_pair_cut[i] (device, one byte per record, in the order of glia_hmt_rag_device_arrays) = 1 iff
  * the region's label / one of the pair's labels occurs on a plane next to a cut (first / last owned plane, halo plane).  Only

@@ -214,6 +214,75 @@ def test_cut_record_exchange_reproduces_the_whole_map(ctx, shape, S, G, variant,
     assert (o1 == o2).all() and (s1 == s2).all()
 
 
+@pytest.mark.parametrize("shape,S,G,world,channels", [((64, 40, 64), 8, 16, 2, 1), ((96, 36, 28), 6, 12, 3, 1), ((128, 48, 64), 8, 32, 4, 1),
+                                                      ((48, 40, 36), 6, 12, 3, 2), ((40, 24, 32), 4, 8, 5, 1)])
+def test_distributed_build_through_the_c_abi(ctx, shape, S, G, world, channels):
+    """glia_hmt_rag_build_distributed (glia_amd/csrc/slab_dist.cpp): the whole slab route -- build, cut flags, records sorted by
+    destination, keyed owner exchange, reduction at the owners, hand-over, final reduction -- behind ONE C entry point, here
+    with a local communicator (all ranks in this process: the transfers are device copies, everything else is the code the
+    RCCL communicator runs).  The map at the loop owner is bit-identical to the single-pass map; only part of the records took
+    the owner exchange; the loop owner can be any rank."""
+    torch = _torch()
+    from glia_amd import hmt
+    from oracle import pyoracle as O
+    labels, pb = O.synth(shape, S, G)
+    rng = np.random.default_rng(5)
+    raw = (np.round(rng.random(shape) * 255) / 256.0).astype(np.float32)
+    d_lab = torch.from_numpy(labels.view(np.int32)).cuda()
+    d_pb, d_raw = torch.from_numpy(pb).cuda(), torch.from_numpy(raw).cuda()
+    mk = (lambda p_, r_: hmt.make_config(p_, rb=[(p_, 8, 0.0, 1.0)])) if channels == 1 else \
+         (lambda p_, r_: hmt.make_config(p_, rb=[(r_, 8, 0.0, 1.0), (p_, 8, 0.0, 1.0)]))
+    whole = hmt.RegionMap(ctx, d_lab, pb=d_pb, cfg=mk(d_pb, d_raw))
+    nz = shape[0]
+    comm = hmt.Comm(ctx, world)
+    slabs = []
+    for r in range(world):
+        first, n, zb, ze = hmt.slab_range(nz, world, r)
+        sl, sp, sr = d_lab[first:first + n].contiguous(), d_pb[first:first + n].contiguous(), d_raw[first:first + n].contiguous()
+        slabs.append((sl, sp, first, zb, ze, mk(sp, sr)))
+    for owner in (0, world - 1):
+        merged, st = hmt.build_distributed(ctx, comm, slabs, nz, loop_owner=owner)
+        assert merged is not None and 0 < st.cut_records < st.records
+        assert st.bytes_cut_exchange > 0 and st.bytes_to_loop_owner > 0
+        for get in ("regions", "pairs"):
+            a, b = getattr(whole, get)(), getattr(merged, get)()
+            for k in a:
+                assert (a[k] == b[k]).all(), (get, k, owner)
+        assert merged.num_channels() == channels
+        o1, s1 = whole.merge_order_pb(type=2)
+        o2, s2 = merged.merge_order_pb(type=2)
+        assert (o1 == o2).all() and (s1 == s2).all()
+        if channels == 2:
+            clf = hmt.FeatureStubClassifier(ctx, whole.feat_dim() - 3)
+            a, b = whole.merge_order_bc(clf), merged.merge_order_bc(clf)
+            assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
+        merged.close()
+    comm.close()
+
+
+def test_distributed_build_over_rccl_with_one_rank(ctx):
+    """the RCCL communicator (ncclCommInitRank, grouped ncclSend / ncclRecv, ncclAllGather loaded with dlopen) with the one rank a
+    one-GPU box allows: the transport is set up and torn down, the route degenerates to a single slab, the map is the whole map"""
+    torch = _torch()
+    from glia_amd import hmt
+    from oracle import pyoracle as O
+    shape = (40, 36, 28)
+    labels, pb = O.synth(shape, 6, 12)
+    d_lab = torch.from_numpy(labels.view(np.int32)).cuda()
+    d_pb = torch.from_numpy(pb).cuda()
+    cfg = hmt.make_config(d_pb, rb=[(d_pb, 8, 0.0, 1.0)])
+    whole = hmt.RegionMap(ctx, d_lab, pb=d_pb, only_contour=True, cfg=cfg)
+    comm = hmt.Comm(ctx, 1, rank=0, unique_id=hmt.Comm.unique_id())
+    first, n, zb, ze = hmt.slab_range(shape[0], 1, 0)
+    merged, st = hmt.build_distributed(ctx, comm, [(d_lab, d_pb, first, zb, ze, cfg)], shape[0], only_contour=True)
+    assert st.cut_records == 0 and st.bytes_cut_exchange == 0
+    for get in ("regions", "pairs"):
+        a, b = getattr(whole, get)(), getattr(merged, get)()
+        for k in a:
+            assert (a[k] == b[k]).all(), (get, k)
+    comm.close()
+
+
 def test_slab_partials_with_two_image_channels(ctx):
     """feature lists with two volumes (--rbi raw --rbi pb): every channel's records travel and merge with the common keys; the
     classifier-path merge order of the merged map equals the single-pass one"""
