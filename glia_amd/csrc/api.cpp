@@ -376,6 +376,11 @@ static int rag_build_impl(glia_hmt_ctx* c, int dim, const int64_t dims[3], int64
   if (zb == 0 && ze == nz && gz0 == 0 && gnz == nz) {
     rag->vol.lab = lab_c; rag->vol.lab_nb = lab_nb; rag->vol.pb = d_pb ? d_pb : img; rag->vol.dim = dim;
     rag->vol.nx = nx; rag->vol.ny = ny; rag->vol.nz = nz;
+  } else if (!d_mask && dim == 3) {
+    // a slab: the planes handed in, of which [zb, ze) are owned -- what collect_pair_values walks for the median linkage of the
+    // slab route (the caller keeps the planes alive until glia_hmt_rag_build_distributed returns)
+    rag->slab.lab = lab_c; rag->slab.lab_nb = lab_nb; rag->slab.pb = d_pb ? d_pb : img; rag->slab.dim = 3;
+    rag->slab.nx = nx; rag->slab.ny = ny; rag->slab.nz = nz; rag->slab.zb = zb; rag->slab.ze = ze;
   }
 
   memcpy(rag->map_region, map_region, sizeof(map_region)); memcpy(rag->map_rlabel, map_rlabel, sizeof(map_rlabel));
@@ -603,6 +608,8 @@ void glia_hmt_rag_free(glia_hmt_rag* r) {
   (void)hipFree(r->arr.d_rlabel); (void)hipFree(r->arr.d_rrec);
   (void)hipFree(r->arr.d_pa); (void)hipFree(r->arr.d_pb); (void)hipFree(r->arr.d_prec);
   for (int k = 1; k < r->arr.K; ++k) { (void)hipFree(r->arr.c_rrec[k]); (void)hipFree(r->arr.c_prec[k]); }
+  if (r->arr.d_pv_off) (void)hipFree(r->arr.d_pv_off);
+  if (r->arr.d_pv) (void)hipFree(r->arr.d_pv);
   if (r->d_folded) (void)hipFree(r->d_folded);
   delete r;
 }
@@ -685,8 +692,9 @@ int glia_hmt_merge_order_pb(glia_hmt_ctx* c, glia_hmt_rag* rag, int type, uint32
     set_error("merge_order_pb: the median x min-size linkage needs region sizes (only_contour = 0)");
     return GLIA_HMT_ERR_ARG;
   }
-  if ((type == 1 || type == 3) && !rag->vol.lab) {
-    set_error("merge_order_pb: median linkage needs the volumes the RAG was built from (whole-volume build)");
+  if ((type == 1 || type == 3) && !rag->vol.lab && !rag->arr.d_pv_off) {
+    set_error("merge_order_pb: median linkage needs the volumes the RAG was built from (whole-volume build) or a map that carries its "
+              "boundary values (glia_hmt_rag_build_distributed with with_values)");
     return GLIA_HMT_ERR_UNSUPPORTED;
   }
   if (type != 1 && type != 2 && type != 3) {   // hmt/main_merge_order_pb.cxx:36 (3: this library's name for ...AndMinSize)

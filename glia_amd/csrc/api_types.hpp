@@ -35,6 +35,7 @@ struct glia_hmt_rag {
   glia_hmt_feat_config cfg;
   bool has_cfg = false;
   VolumeRef vol;                 // whole-volume builds only: the caller keeps the volumes alive while the handle lives
+  VolumeRef slab;                // slab builds: the planes handed in and the owned range (valid while the caller keeps them)
   uint32_t* d_folded = nullptr;  // labels with the mask folded in (owned)
   int map_region[GLIA_HMT_MAX_IMAGES] = {0}, map_rlabel[GLIA_HMT_MAX_IMAGES] = {0}, map_boundary[GLIA_HMT_MAX_IMAGES] = {0};   // list entry -> channel
 };

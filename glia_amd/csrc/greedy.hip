@@ -1905,6 +1905,23 @@ __global__ void median_collect(VolumeRef vol, const uint32_t* pa, const uint32_t
   out[e_off[e] + atomicAdd(&cursor[e], 1u)] = vol.pb[p];
 }
 
+// the same from a map that carries its boundary values per directed pair (slab route, RagArrays::d_pv): the run of a table edge
+// = the runs of its two directions, one thread per value
+__global__ void median_from_runs(const unsigned long long* pv_off, const float* pv, unsigned long long nV, const uint32_t* pa, const uint32_t* pb, long long P,
+                                 const uint32_t* flag, const uint32_t* eidx, const unsigned long long* e_off, float* out) {
+  const unsigned long long v = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nV) return;
+  long long lo = 0, hi = P;                     // the pair whose run holds value v
+  while (lo < hi) { const long long mid = (lo + hi) >> 1; if (pv_off[mid + 1] <= v) lo = mid + 1; else hi = mid; }
+  const long long i = lo;
+  const uint32_t a = pa[i], b = pb[i];
+  // the (a < b) direction owns the edge slot when the boundary is mutual (edge_flags); its values come first
+  const long long owner = a < b ? i : find_pair(pa, pb, P, b, a);
+  if (owner < 0 || !flag[owner]) return;       // not a mutual boundary: no table edge
+  const unsigned long long first = owner == i ? 0ull : pv_off[owner + 1] - pv_off[owner];
+  out[e_off[eidx[owner]] + first + (v - pv_off[i])] = pv[v];
+}
+
 __global__ void median_init(GreedyState st, uint32_t E0) {
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E0) return;
@@ -2031,9 +2048,15 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
     if ((rc = buf.get(&unsorted, (size_t)n_values, false, stream))) return rc;
     uint32_t* vcursor;
     if ((rc = buf.get(&vcursor, (size_t)E0, true, stream))) return rc;
-    const long long N = median_of->nx * median_of->ny * median_of->nz;
-    hipLaunchKernelGGL(median_collect, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, *median_of, rag.d_pa, rag.d_pb, P,
-                       flag, eidx, st.e_off, vcursor, unsorted);
+    if (median_of->lab) {
+      const long long N = median_of->nx * median_of->ny * median_of->nz;
+      hipLaunchKernelGGL(median_collect, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, *median_of, rag.d_pa, rag.d_pb, P,
+                         flag, eidx, st.e_off, vcursor, unsorted);
+    } else {
+      if (!rag.d_pv_off) { set_error("merge_order_pb: median linkage needs the volume or the map's boundary values"); return GLIA_HMT_ERR_UNSUPPORTED; }
+      if (rag.nV) hipLaunchKernelGGL(median_from_runs, dim3((unsigned)((rag.nV + 255) / 256)), dim3(256), 0, stream, rag.d_pv_off, rag.d_pv, rag.nV, rag.d_pa, rag.d_pb,
+                                     (long long)P, flag, eidx, st.e_off, unsorted);
+    }
     GLIA_HIP_TRY(hipGetLastError());
     {
       size_t tmp = 0;

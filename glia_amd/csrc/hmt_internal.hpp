@@ -91,6 +91,12 @@ struct RagArrays {
   uint32_t* c_rrec[kMaxChannels] = {nullptr, nullptr, nullptr, nullptr};
   uint32_t* c_prec[kMaxChannels] = {nullptr, nullptr, nullptr, nullptr};
   int c_bins[kMaxChannels] = {0, 0, 0, 0};
+  // Optional (slab route, median linkage): the image value of every boundary voxel, grouped by directed pair -- values of pair i
+  // are d_pv[d_pv_off[i] .. d_pv_off[i + 1]) in no particular order (the median loop sorts its runs itself).  The reference keeps
+  // these lists per edge (util/struct_merge.hxx:97-111); a whole-volume map re-reads them from the volume instead.
+  unsigned long long* d_pv_off = nullptr;   // [P + 1]
+  float* d_pv = nullptr;                    // [nV]
+  unsigned long long nV = 0;
 };
 
 int launch_accumulate(const AccParams& p, hipStream_t stream);
@@ -109,6 +115,7 @@ struct VolumeRef {
   const float* pb = nullptr;
   int dim = 3;
   long long nx = 1, ny = 1, nz = 1;
+  long long zb = 0, ze = -1;           // planes whose voxels count (a slab's owned planes; ze < 0: all)
 };
 int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, double* h_sal, int64_t capacity,
                 int64_t* n_merges, double* ms_table, double* ms_loop, int64_t* n_scored, int cond_n = 0,
@@ -148,6 +155,11 @@ int watershed_labels(int dim, const int64_t dims[3], const float* d_img, double 
                      hipStream_t stream);
 int launch_libm_eval(int function, int variant, const double* d_in, double* d_out, int64_t n, hipStream_t stream);
 int merge_rag_arrays(const RagArrays* parts, int n_parts, RagArrays* out, hipStream_t stream);
+// boundary-voxel values per directed pair of a map built from `vol` (its owned planes): fills rag->d_pv_off / d_pv / nV (owned)
+int collect_pair_values(RagArrays* rag, const VolumeRef& vol, hipStream_t stream);
+// value runs in a new pair order: out run j = source run order[j] (counts from the source offsets); allocates *out_off [n + 1], *out_vals
+int gather_value_runs(const unsigned long long* src_off, const float* src_vals, const uint32_t* order, uint32_t n, unsigned long long** out_off,
+                      float** out_vals, unsigned long long* nV, hipStream_t stream);
 int rag_cut_flags(const RagArrays& rag, const uint32_t* d_lab, int64_t nx, int64_t ny, int64_t nzl, int64_t zb, int64_t ze,
                   uint8_t* d_rflag, uint8_t* d_pflag, hipStream_t stream);
 

@@ -73,6 +73,124 @@ __global__ void combine_records(const unsigned long long* keys, const uint32_t* 
   else d[w] = acc;
 }
 
+// ---- value runs (boundary-voxel values per directed pair) ----
+__global__ void run_counts(const unsigned long long* src_off, const uint32_t* order, uint32_t n, unsigned long long* cnt) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > n) return;
+  cnt[j] = j < n ? src_off[order[j] + 1] - src_off[order[j]] : 0ull;
+}
+__global__ void run_gather(const unsigned long long* src_off, const float* src_vals, const uint32_t* order, uint32_t n, const unsigned long long* new_off,
+                           unsigned long long nV, float* out) {
+  const unsigned long long v = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nV) return;
+  uint32_t lo = 0, hi = n;                      // the last run that starts at or before v (empty runs share a start: take the last)
+  while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (new_off[mid + 1] <= v) lo = mid + 1; else hi = mid; }
+  out[v] = src_vals[src_off[order[lo]] + (v - new_off[lo])];
+}
+}  // namespace
+int gather_value_runs(const unsigned long long* src_off, const float* src_vals, const uint32_t* order, uint32_t n, unsigned long long** out_off,
+                      float** out_vals, unsigned long long* nV, hipStream_t stream) {
+  GLIA_HIP_TRY(hipMalloc(out_off, sizeof(unsigned long long) * ((size_t)n + 1)));
+  *out_vals = nullptr; *nV = 0;
+  unsigned long long total = 0;
+  if (n) {
+    DeviceBuffers buf;
+    int rc;
+    unsigned long long* cnt;
+    if ((rc = buf.get(&cnt, (size_t)n + 1, false, stream))) return rc;
+    hipLaunchKernelGGL(run_counts, dim3((n + 256) / 256), dim3(256), 0, stream, src_off, order, n, cnt);
+    size_t tmp = 0;
+    GLIA_HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, cnt, *out_off, 0ull, (size_t)n + 1, rocprim::plus<unsigned long long>(), stream));
+    char* d_tmp;
+    if ((rc = buf.get(&d_tmp, tmp ? tmp : 16, false, stream))) return rc;
+    GLIA_HIP_TRY(rocprim::exclusive_scan((void*)d_tmp, tmp, cnt, *out_off, 0ull, (size_t)n + 1, rocprim::plus<unsigned long long>(), stream));
+    GLIA_HIP_TRY(hipMemcpyAsync(&total, *out_off + n, sizeof(total), hipMemcpyDeviceToHost, stream));
+    GLIA_HIP_TRY(hipStreamSynchronize(stream));
+  } else GLIA_HIP_TRY(hipMemsetAsync(*out_off, 0, sizeof(unsigned long long), stream));
+  GLIA_HIP_TRY(hipMalloc(out_vals, sizeof(float) * (size_t)(total ? total : 1)));
+  if (total) {
+    hipLaunchKernelGGL(run_gather, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src_off, src_vals, order, n, *out_off, total, *out_vals);
+    GLIA_HIP_TRY(hipGetLastError());
+    GLIA_HIP_TRY(hipStreamSynchronize(stream));
+  }
+  *nV = total;
+  return GLIA_HMT_OK;
+}
+namespace {
+__global__ void pair_counts_u64(const uint32_t* prec, uint32_t P, unsigned long long* cnt) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > P) return;
+  cnt[i] = i < P ? (unsigned long long)prec[(size_t)i * kPairWords + P_CNT] : 0ull;
+}
+// the neighbour rule of rag_accumulate.hip / type/neighbor.hxx:109-126 for the voxels of the owned planes: value -> its pair's run
+__global__ void pair_values_scatter(VolumeRef vol, const uint32_t* pa, const uint32_t* pb, long long P, const unsigned long long* off, uint32_t* cursor,
+                                    float* out) {
+  const long long plane = vol.nx * vol.ny;
+  const long long n_owned = (vol.ze - vol.zb) * plane;
+  const long long q0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q0 >= n_owned) return;
+  const long long p = q0 + vol.zb * plane;
+  const long long x = p % vol.nx, y = (p / vol.nx) % vol.ny, z = p / plane;
+  const uint32_t t = vol.lab[p];
+  uint32_t nb = t;
+  const long long sy = vol.nx, sz = plane;
+  const uint32_t* L = vol.lab_nb;
+  do {
+    uint32_t q;
+    if (x > 0 && (q = L[p - 1]) != t) { nb = q; break; }
+    if (x + 1 < vol.nx && (q = L[p + 1]) != t) { nb = q; break; }
+    if (y > 0 && (q = L[p - sy]) != t) { nb = q; break; }
+    if (y + 1 < vol.ny && (q = L[p + sy]) != t) { nb = q; break; }
+    if (z > 0 && (q = L[p - sz]) != t) { nb = q; break; }
+    if (z + 1 < vol.nz && (q = L[p + sz]) != t) { nb = q; break; }
+  } while (false);
+  if (nb == t) return;
+  const long long i = find_pair(pa, pb, P, t, nb);
+  if (i < 0) return;
+  out[off[i] + atomicAdd(&cursor[i], 1u)] = vol.pb[p];
+}
+}  // namespace
+int collect_pair_values(RagArrays* rag, const VolumeRef& vol, hipStream_t stream) {
+  const uint32_t P = (uint32_t)rag->P;
+  if (vol.dim != 3 || !vol.lab || !vol.pb || vol.ze < 0) { set_error("collect_pair_values: needs the slab's label and image planes"); return GLIA_HMT_ERR_ARG; }
+  DeviceBuffers buf;
+  int rc;
+  unsigned long long* cnt; uint32_t* cursor;
+  if ((rc = buf.get(&cnt, (size_t)P + 1, false, stream))) return rc;
+  if ((rc = buf.get(&cursor, (size_t)P + 1, true, stream))) return rc;
+  GLIA_HIP_TRY(hipMalloc(&rag->d_pv_off, sizeof(unsigned long long) * ((size_t)P + 1)));
+  hipLaunchKernelGGL(pair_counts_u64, dim3((P + 256) / 256), dim3(256), 0, stream, rag->d_prec, P, cnt);
+  size_t tmp = 0;
+  GLIA_HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, cnt, rag->d_pv_off, 0ull, (size_t)P + 1, rocprim::plus<unsigned long long>(), stream));
+  char* d_tmp;
+  if ((rc = buf.get(&d_tmp, tmp ? tmp : 16, false, stream))) return rc;
+  GLIA_HIP_TRY(rocprim::exclusive_scan((void*)d_tmp, tmp, cnt, rag->d_pv_off, 0ull, (size_t)P + 1, rocprim::plus<unsigned long long>(), stream));
+  unsigned long long total = 0;
+  GLIA_HIP_TRY(hipMemcpyAsync(&total, rag->d_pv_off + P, sizeof(total), hipMemcpyDeviceToHost, stream));
+  GLIA_HIP_TRY(hipStreamSynchronize(stream));
+  GLIA_HIP_TRY(hipMalloc(&rag->d_pv, sizeof(float) * (size_t)(total ? total : 1)));
+  rag->nV = total;
+  const long long n_owned = (vol.ze - vol.zb) * vol.nx * vol.ny;
+  if (total && n_owned > 0) {
+    hipLaunchKernelGGL(pair_values_scatter, dim3((unsigned)((n_owned + 255) / 256)), dim3(256), 0, stream, vol, rag->d_pa, rag->d_pb, (long long)P, rag->d_pv_off,
+                       cursor, rag->d_pv);
+    GLIA_HIP_TRY(hipGetLastError());
+    GLIA_HIP_TRY(hipStreamSynchronize(stream));
+  }
+  return GLIA_HMT_OK;
+}
+namespace {
+__global__ void concat_offsets(const unsigned long long* off, uint32_t m, unsigned long long vbase, unsigned long long* cat_off, uint32_t base) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) cat_off[base + i] = off[i] + vbase;
+}
+__global__ void merged_offsets(const uint32_t* flag, const uint32_t* oidx, const unsigned long long* gscan, uint32_t n, uint32_t nout, unsigned long long nV,
+                               unsigned long long* out_off) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n && flag[j]) out_off[oidx[j]] = gscan[j];
+  if (j == 0) out_off[nout] = nV;
+}
+
 template <bool REGION>
 int merge_kind(const RagArrays* parts, int n_parts, RagArrays* out, hipStream_t stream) {
   constexpr int W = REGION ? kRegionWords : kPairWords;
@@ -143,6 +261,38 @@ int merge_kind(const RagArrays* parts, int n_parts, RagArrays* out, hipStream_t 
   }
   if (REGION) { out->R = nout; out->d_rlabel = oa; }
   else { out->P = nout; out->d_pa = oa; out->d_pb = ob; }
+  if (!REGION) {
+    // value runs: when every part with pairs carries them, the merged pair's run is the concatenation of its sources' runs, i.e.
+    // the source runs laid out in the sorted order (a merged pair's offset = the offset of its first source)
+    bool all = n > 0;
+    for (int p = 0; p < n_parts; ++p) if (parts[p].P && !parts[p].d_pv_off) all = false;
+    if (all) {
+      unsigned long long vtot = 0;
+      for (int p = 0; p < n_parts; ++p) vtot += parts[p].P ? parts[p].nV : 0;
+      unsigned long long* cat_off; float* cat_vals;
+      if ((rc = buf.get(&cat_off, (size_t)n + 1, false, stream))) return rc;
+      if ((rc = buf.get(&cat_vals, (size_t)(vtot ? vtot : 1), false, stream))) return rc;
+      uint32_t b3 = 0; unsigned long long vb = 0;
+      for (int p = 0; p < n_parts; ++p) {
+        const uint32_t m = (uint32_t)parts[p].P;
+        if (!m) continue;
+        hipLaunchKernelGGL(concat_offsets, dim3((m + 255) / 256), dim3(256), 0, stream, parts[p].d_pv_off, m, vb, cat_off, b3);
+        if (parts[p].nV) GLIA_HIP_TRY(hipMemcpyAsync(cat_vals + vb, parts[p].d_pv, sizeof(float) * (size_t)parts[p].nV, hipMemcpyDeviceToDevice, stream));
+        b3 += m; vb += parts[p].nV;
+      }
+      GLIA_HIP_TRY(hipMemcpyAsync(cat_off + n, &vtot, sizeof(vtot), hipMemcpyHostToDevice, stream));
+      GLIA_HIP_TRY(hipStreamSynchronize(stream));      // (vtot lives on this stack)
+      unsigned long long* gscan; float* vals; unsigned long long nV = 0;
+      if ((rc = gather_value_runs(cat_off, cat_vals, i1, n, &gscan, &vals, &nV, stream))) return rc;
+      unsigned long long* ooff;
+      GLIA_HIP_TRY(hipMalloc(&ooff, sizeof(unsigned long long) * ((size_t)nout + 1)));
+      hipLaunchKernelGGL(merged_offsets, dim3((n + 255) / 256), dim3(256), 0, stream, flag, oidx, gscan, n, nout, nV, ooff);
+      GLIA_HIP_TRY(hipGetLastError());
+      GLIA_HIP_TRY(hipStreamSynchronize(stream));
+      (void)hipFree(gscan);
+      out->d_pv_off = ooff; out->d_pv = vals; out->nV = nV;
+    }
+  }
   out->K = K;
   for (int ch = 0; ch < K; ++ch) out->c_bins[ch] = parts[0].c_bins[ch];
   return GLIA_HMT_OK;

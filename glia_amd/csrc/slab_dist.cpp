@@ -17,6 +17,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include <cstring>
 #include <vector>
@@ -122,7 +123,7 @@ __global__ void permute_rows(const uint32_t* src, const uint32_t* idx, uint32_t 
 
 struct Sorted {                 // one rank's records in destination order (owned device arrays), counts per destination [world + 1]
   RagArrays arr;
-  std::vector<uint64_t> rcount, pcount;
+  std::vector<uint64_t> rcount, pcount, vcount;      // vcount: boundary values per destination (0 without value runs)
   std::vector<void*> owned;
   void release() { for (void* p : owned) (void)hipFree(p); owned.clear(); }
 };
@@ -166,6 +167,28 @@ int sort_by_destination(const RagArrays& a, const uint8_t* d_rcut, const uint8_t
     }
     if (kind) { out->arr.d_pa = lab; out->arr.d_pb = lab2; for (int c = 0; c < a.K; ++c) out->arr.c_prec[c] = recs[c]; out->arr.d_prec = recs[0]; }
     else { out->arr.d_rlabel = lab; for (int c = 0; c < a.K; ++c) out->arr.c_rrec[c] = recs[c]; out->arr.d_rrec = recs[0]; }
+    if (kind) {
+      out->vcount.assign((size_t)world + 1, 0);
+      if (a.d_pv_off && n) {
+        // the value runs follow their pairs into destination order; values per destination = differences of the new offsets
+        DeviceBuffers buf2;
+        uint32_t *k0, *k1, *i0, *i1, *d_cnt;
+        if ((rc = buf2.get(&k0, n, false, s)) || (rc = buf2.get(&k1, n, false, s)) || (rc = buf2.get(&i0, n, false, s)) || (rc = buf2.get(&i1, n, false, s)) ||
+            (rc = buf2.get(&d_cnt, (size_t)world + 1, true, s))) return rc;
+        hipLaunchKernelGGL(dest_keys, dim3((n + 255) / 256), dim3(256), 0, s, a.d_pa, d_pcut, n, (uint32_t)world, k0, i0, d_cnt);
+        size_t tmp = 0;
+        GLIA_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, k0, k1, i0, i1, (size_t)n, 0, 16, s));
+        char* d_tmp;
+        if ((rc = buf2.get(&d_tmp, tmp ? tmp : 16, false, s))) return rc;
+        GLIA_HIP_TRY(rocprim::radix_sort_pairs((void*)d_tmp, tmp, k0, k1, i0, i1, (size_t)n, 0, 16, s));
+        if ((rc = gather_value_runs(a.d_pv_off, a.d_pv, i1, n, &out->arr.d_pv_off, &out->arr.d_pv, &out->arr.nV, s))) return rc;
+        out->owned.push_back(out->arr.d_pv_off); out->owned.push_back(out->arr.d_pv);
+        std::vector<unsigned long long> off((size_t)n + 1);
+        GLIA_HIP_TRY(hipMemcpy(off.data(), out->arr.d_pv_off, sizeof(unsigned long long) * off.size(), hipMemcpyDeviceToHost));
+        uint64_t p0 = 0;
+        for (int d = 0; d <= world; ++d) { const uint64_t p1 = p0 + out->pcount[d]; out->vcount[d] = off[p1] - off[p0]; p0 = p1; }
+      }
+    }
   }
   GLIA_HIP_TRY(hipGetLastError());
   return GLIA_HMT_OK;
@@ -173,8 +196,10 @@ int sort_by_destination(const RagArrays& a, const uint8_t* d_rcut, const uint8_t
 
 // a block of records on the device: [R labels | K x R region records | P a | P b | K x P pair records]
 struct Block {
-  uint32_t* base = nullptr; uint64_t R = 0, P = 0; int K = 1;
-  static size_t words(uint64_t R, uint64_t P, int K) { return (size_t)R * (1 + (size_t)K * kRegionWords) + (size_t)P * (2 + (size_t)K * kPairWords); }
+  uint32_t* base = nullptr; uint64_t R = 0, P = 0, V = 0; int K = 1;
+  unsigned long long* pv_off = nullptr;         // offsets of the value runs, recomputed from the pair counts at the receiver
+  static size_t words(uint64_t R, uint64_t P, int K, uint64_t V = 0) { return (size_t)R * (1 + (size_t)K * kRegionWords) + (size_t)P * (2 + (size_t)K * kPairWords) + (size_t)V; }
+  float* pv() const { return reinterpret_cast<float*>(prec(K - 1) + P * kPairWords); }
   uint32_t* rlabel() const { return base; }
   uint32_t* rrec(int c) const { return base + R + (size_t)c * R * kRegionWords; }
   uint32_t* pa() const { return base + R * (1 + (size_t)K * kRegionWords); }
@@ -185,11 +210,36 @@ struct Block {
     a.d_rlabel = rlabel(); a.d_pa = pa(); a.d_pb = pb();
     for (int c = 0; c < K; ++c) { a.c_rrec[c] = rrec(c); a.c_prec[c] = prec(c); a.c_bins[c] = like.c_bins[c]; }
     a.d_rrec = a.c_rrec[0]; a.d_prec = a.c_prec[0];
+    if (pv_off) { a.d_pv_off = pv_off; a.d_pv = pv(); a.nV = V; }
     return a;
   }
 };
+// offsets of a received block's value runs = scan of its pairs' voxel counts
+__global__ void block_counts(const uint32_t* prec, uint32_t P, unsigned long long* cnt) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > P) return;
+  cnt[i] = i < P ? (unsigned long long)prec[(size_t)i * kPairWords + P_CNT] : 0ull;
+}
+int block_value_offsets(Block* b, hipStream_t s, std::vector<void*>* scratch) {
+  const uint32_t P = (uint32_t)b->P;
+  DeviceBuffers buf;
+  int rc;
+  unsigned long long* cnt;
+  if ((rc = buf.get(&cnt, (size_t)P + 1, false, s))) return rc;
+  GLIA_HIP_TRY(hipMalloc(&b->pv_off, sizeof(unsigned long long) * ((size_t)P + 1)));
+  scratch->push_back(b->pv_off);
+  hipLaunchKernelGGL(block_counts, dim3((P + 256) / 256), dim3(256), 0, s, b->prec(0), P, cnt);
+  size_t tmp = 0;
+  GLIA_HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, cnt, b->pv_off, 0ull, (size_t)P + 1, rocprim::plus<unsigned long long>(), s));
+  char* d_tmp;
+  if ((rc = buf.get(&d_tmp, tmp ? tmp : 16, false, s))) return rc;
+  GLIA_HIP_TRY(rocprim::exclusive_scan((void*)d_tmp, tmp, cnt, b->pv_off, 0ull, (size_t)P + 1, rocprim::plus<unsigned long long>(), s));
+  GLIA_HIP_TRY(hipStreamSynchronize(s));
+  return GLIA_HMT_OK;
+}
 // transfers that move rows [r0, r0 + nR) / [p0, p0 + nP) of `from` (any layout with per-array contiguity) into block `to`
-void add_record_transfers(std::vector<Transfer>* ts, int src, int dst, const RagArrays* from, uint64_t r0, uint64_t nR, uint64_t p0, uint64_t nP, const Block* to, int K) {
+void add_record_transfers(std::vector<Transfer>* ts, int src, int dst, const RagArrays* from, uint64_t r0, uint64_t nR, uint64_t p0, uint64_t nP, const Block* to, int K,
+                          uint64_t v0 = 0, uint64_t nV = 0) {
   auto add = [&](const uint32_t* f, uint64_t first, int words, uint64_t n, uint32_t* t) {
     ts->push_back(Transfer{src, dst, from ? (const void*)(f + first * words) : nullptr, to ? (void*)t : nullptr, (size_t)n * words * sizeof(uint32_t)});
   };
@@ -198,10 +248,13 @@ void add_record_transfers(std::vector<Transfer>* ts, int src, int dst, const Rag
   add(from ? from->d_pa : nullptr, p0, 1, nP, to ? to->pa() : nullptr);
   add(from ? from->d_pb : nullptr, p0, 1, nP, to ? to->pb() : nullptr);
   for (int c = 0; c < K; ++c) add(from ? from->c_prec[c] : nullptr, p0, kPairWords, nP, to ? to->prec(c) : nullptr);
+  if (nV) add(from ? reinterpret_cast<const uint32_t*>(from->d_pv) : nullptr, v0, 1, nV, to ? reinterpret_cast<uint32_t*>(to->pv()) : nullptr);
 }
 
 void free_arrays(RagArrays* a) {
   (void)hipFree(a->d_rlabel); (void)hipFree(a->d_pa); (void)hipFree(a->d_pb);
+  if (a->d_pv_off) (void)hipFree(a->d_pv_off);
+  if (a->d_pv) (void)hipFree(a->d_pv);
   for (int c = 0; c < a->K; ++c) { (void)hipFree(a->c_rrec[c]); (void)hipFree(a->c_prec[c]); }
   *a = RagArrays();
 }
@@ -269,8 +322,8 @@ int glia_hmt_slab_range(int64_t nz, int world, int rank, int64_t* first_plane, i
   return GLIA_HMT_OK;
 }
 
-int glia_hmt_rag_build_distributed(glia_hmt_ctx* c, glia_hmt_comm* cm, const glia_hmt_slab* slabs, int64_t nz_global, int only_contour, int loop_owner,
-                                   glia_hmt_rag** out, glia_hmt_dist_stats* stats) {
+int glia_hmt_rag_build_distributed(glia_hmt_ctx* c, glia_hmt_comm* cm, const glia_hmt_slab* slabs, int64_t nz_global, int only_contour, int with_values,
+                                   int loop_owner, glia_hmt_rag** out, glia_hmt_dist_stats* stats) {
   if (!c || !cm || cm->ctx != c || !slabs || !out || loop_owner < 0 || loop_owner >= cm->world) { set_error("rag_build_distributed: invalid argument"); return GLIA_HMT_ERR_ARG; }
   GLIA_HIP_TRY(hipSetDevice(c->device));
   hipStream_t s = c->stream;
@@ -300,19 +353,26 @@ int glia_hmt_rag_build_distributed(glia_hmt_ctx* c, glia_hmt_comm* cm, const gli
     if (hipMalloc(&rcut, (size_t)(a.R ? a.R : 1)) != hipSuccess || hipMalloc(&pcut, (size_t)(a.P ? a.P : 1)) != hipSuccess) { set_error("rag_build_distributed: out of memory"); rc = GLIA_HMT_ERR_HIP; break; }
     scratch.push_back(rcut); scratch.push_back(pcut);
     rc = rag_cut_flags(a, sl.d_labels, sl.dims_local[0], sl.dims_local[1], sl.dims_local[2], sl.z_begin, sl.z_end, rcut, pcut, s);
-    if (!rc) rc = sort_by_destination(a, rcut, pcut, world, s, &sorted[i]);
+    // median linkage downstream: the image value of every boundary voxel goes along with its directed pair
+    if (!rc && with_values) rc = collect_pair_values(&part[i]->arr, part[i]->slab, s);
+    if (!rc) rc = sort_by_destination(part[i]->arr, rcut, pcut, world, s, &sorted[i]);
     st.records += (uint64_t)(a.R + a.P);
   }
   if (rc) { cleanup(); return rc; }
   const int K = part[0]->arr.K;
   // counts of every (source, destination): [world][2 * (world + 1)]
   std::vector<std::vector<uint64_t>> mine((size_t)nl);
-  const int ncol = 2 * (world + 1);
-  for (int i = 0; i < nl; ++i) { mine[i] = sorted[i].rcount; mine[i].insert(mine[i].end(), sorted[i].pcount.begin(), sorted[i].pcount.end()); }
+  const int ncol = 3 * (world + 1);
+  for (int i = 0; i < nl; ++i) {
+    mine[i] = sorted[i].rcount;
+    mine[i].insert(mine[i].end(), sorted[i].pcount.begin(), sorted[i].pcount.end());
+    mine[i].insert(mine[i].end(), sorted[i].vcount.begin(), sorted[i].vcount.end());
+  }
   std::vector<uint64_t> cnt;
   if ((rc = all_gather_u64(cm, mine, ncol, &cnt))) { cleanup(); return rc; }
   auto cR = [&](int src, int d) { return cnt[(size_t)src * ncol + d]; };
   auto cP = [&](int src, int d) { return cnt[(size_t)src * ncol + (world + 1) + d]; };
+  auto cV = [&](int src, int d) { return cnt[(size_t)src * ncol + 2 * (world + 1) + d]; };
   for (int i = 0; i < nl; ++i) for (int d = 0; d < world; ++d) st.cut_records += cR(cm->local[i], d) + cP(cm->local[i], d);
   // ---- 2. keyed owner exchange of the cut records, reduction at the owner ----
   {
@@ -320,25 +380,27 @@ int glia_hmt_rag_build_distributed(glia_hmt_ctx* c, glia_hmt_comm* cm, const gli
     for (int i = 0; i < nl; ++i) recvA[i].assign((size_t)world, Block());
     for (int src = 0; src < world; ++src) {
       const int li = [&] { for (int i = 0; i < nl; ++i) if (cm->local[i] == src) return i; return -1; }();
-      uint64_t r0 = 0, p0 = 0;
+      uint64_t r0 = 0, p0 = 0, v0 = 0;
       for (int d = 0; d < world; ++d) {
-        const uint64_t nR = cR(src, d), nP = cP(src, d);
+        const uint64_t nR = cR(src, d), nP = cP(src, d), nV = cV(src, d);
         const int ld = [&] { for (int i = 0; i < nl; ++i) if (cm->local[i] == d) return i; return -1; }();
         Block* to = nullptr;
         if (ld >= 0) {
           Block& b = recvA[ld][src];
-          b.R = nR; b.P = nP; b.K = K;
-          if (hipMalloc(&b.base, sizeof(uint32_t) * (Block::words(nR, nP, K) + 1)) != hipSuccess) { set_error("rag_build_distributed: out of memory"); cleanup(); return GLIA_HMT_ERR_HIP; }
+          b.R = nR; b.P = nP; b.V = nV; b.K = K;
+          if (hipMalloc(&b.base, sizeof(uint32_t) * (Block::words(nR, nP, K, nV) + 1)) != hipSuccess) { set_error("rag_build_distributed: out of memory"); cleanup(); return GLIA_HMT_ERR_HIP; }
           scratch.push_back(b.base);
           to = &b;
         }
-        add_record_transfers(&ts, src, d, li >= 0 ? &sorted[li].arr : nullptr, r0, nR, p0, nP, to, K);
-        r0 += nR; p0 += nP;
+        add_record_transfers(&ts, src, d, li >= 0 ? &sorted[li].arr : nullptr, r0, nR, p0, nP, to, K, v0, nV);
+        r0 += nR; p0 += nP; v0 += nV;
       }
     }
     uint64_t sent = 0;
     if ((rc = run_transfers(cm, ts, &sent))) { cleanup(); return rc; }
     st.bytes_cut_exchange = sent;
+    if (with_values)
+      for (int i = 0; i < nl; ++i) for (int src = 0; src < world; ++src) if (recvA[i][src].P && (rc = block_value_offsets(&recvA[i][src], s, &scratch))) { cleanup(); return rc; }
   }
   for (int i = 0; i < nl; ++i) {
     std::vector<RagArrays> parts;
@@ -348,9 +410,9 @@ int glia_hmt_rag_build_distributed(glia_hmt_ctx* c, glia_hmt_comm* cm, const gli
   }
   // ---- 3. everything once to the loop owner, final reduction by key ----
   std::vector<std::vector<uint64_t>> mine2((size_t)nl);
-  for (int i = 0; i < nl; ++i) mine2[i] = {(uint64_t)reduced[i].R, (uint64_t)reduced[i].P};
+  for (int i = 0; i < nl; ++i) mine2[i] = {(uint64_t)reduced[i].R, (uint64_t)reduced[i].P, (uint64_t)reduced[i].nV};
   std::vector<uint64_t> cnt2;
-  if ((rc = all_gather_u64(cm, mine2, 2, &cnt2))) { cleanup(); return rc; }
+  if ((rc = all_gather_u64(cm, mine2, 3, &cnt2))) { cleanup(); return rc; }
   const bool own = cm->is_local(loop_owner);
   std::vector<Block> fin;
   {
@@ -359,32 +421,35 @@ int glia_hmt_rag_build_distributed(glia_hmt_ctx* c, glia_hmt_comm* cm, const gli
     for (int src = 0; src < world; ++src) {
       const int li = [&] { for (int i = 0; i < nl; ++i) if (cm->local[i] == src) return i; return -1; }();
       // interior records: the last destination class of the sorted arrays
-      uint64_t r0 = 0, p0 = 0;
-      for (int d = 0; d < world; ++d) { r0 += cR(src, d); p0 += cP(src, d); }
+      uint64_t r0 = 0, p0 = 0, v0 = 0;
+      for (int d = 0; d < world; ++d) { r0 += cR(src, d); p0 += cP(src, d); v0 += cV(src, d); }
       for (int piece = 0; piece < 2; ++piece) {
-        const uint64_t nR = piece ? cnt2[(size_t)src * 2] : cR(src, world), nP = piece ? cnt2[(size_t)src * 2 + 1] : cP(src, world);
+        const uint64_t nR = piece ? cnt2[(size_t)src * 3] : cR(src, world), nP = piece ? cnt2[(size_t)src * 3 + 1] : cP(src, world);
+        const uint64_t nV = piece ? cnt2[(size_t)src * 3 + 2] : cV(src, world);
         Block* to = nullptr;
         if (own) {
           Block& b = fin[(size_t)2 * src + piece];
-          b.R = nR; b.P = nP; b.K = K;
-          if (hipMalloc(&b.base, sizeof(uint32_t) * (Block::words(nR, nP, K) + 1)) != hipSuccess) { set_error("rag_build_distributed: out of memory"); cleanup(); return GLIA_HMT_ERR_HIP; }
+          b.R = nR; b.P = nP; b.V = nV; b.K = K;
+          if (hipMalloc(&b.base, sizeof(uint32_t) * (Block::words(nR, nP, K, nV) + 1)) != hipSuccess) { set_error("rag_build_distributed: out of memory"); cleanup(); return GLIA_HMT_ERR_HIP; }
           scratch.push_back(b.base);
           to = &b;
         }
         const RagArrays* from = li < 0 ? nullptr : (piece ? &reduced[li] : &sorted[li].arr);
-        add_record_transfers(&ts, src, loop_owner, from, piece ? 0 : r0, nR, piece ? 0 : p0, nP, to, K);
+        add_record_transfers(&ts, src, loop_owner, from, piece ? 0 : r0, nR, piece ? 0 : p0, nP, to, K, piece ? 0 : v0, nV);
       }
     }
     uint64_t sent = 0;
     if ((rc = run_transfers(cm, ts, &sent))) { cleanup(); return rc; }
     st.bytes_to_loop_owner = sent;
+    if (own && with_values)
+      for (Block& b : fin) if (b.P && (rc = block_value_offsets(&b, s, &scratch))) { cleanup(); return rc; }
   }
   if (own) {
     std::vector<RagArrays> parts;
     for (const Block& b : fin) if (b.R || b.P) parts.push_back(b.view(part[0]->arr));
     glia_hmt_rag* rag = new glia_hmt_rag(*part[0]);
     rag->arr = RagArrays(); rag->arr.K = K;
-    rag->d_folded = nullptr; rag->vol = VolumeRef();
+    rag->d_folded = nullptr; rag->vol = VolumeRef(); rag->slab = VolumeRef();
     rag->dims[2] = nz_global;
     rag->pass_ms = 0; rag->alg_bytes = 0;
     for (glia_hmt_rag* p : part) { rag->pass_ms += p->pass_ms; rag->alg_bytes += p->alg_bytes; }

@@ -391,7 +391,7 @@ def slab_range(nz, world, rank):
     return a.value, b.value, c.value, d.value
 
 
-def build_distributed(ctx, comm, slabs, nz_global, only_contour=False, loop_owner=0):
+def build_distributed(ctx, comm, slabs, nz_global, only_contour=False, loop_owner=0, with_values=False):
     """glia_hmt_rag_build_distributed.  slabs: one (labels, pb, first_plane, z_begin, z_end, cfg) per LOCAL rank of comm, in rank
     order (labels / pb: CUDA tensors of the planes handed in).  Returns (RegionMap of the whole volume | None, DistStats)."""
     arr = (Slab * len(slabs))()
@@ -407,7 +407,7 @@ def build_distributed(ctx, comm, slabs, nz_global, only_contour=False, loop_owne
         keep.append((lab, pb, cfg))
     h = C.c_void_p()
     st = DistStats()
-    _check(lib().glia_hmt_rag_build_distributed(ctx.h, comm.h, arr, C.c_int64(nz_global), C.c_int(int(only_contour)), C.c_int(loop_owner),
+    _check(lib().glia_hmt_rag_build_distributed(ctx.h, comm.h, arr, C.c_int64(nz_global), C.c_int(int(only_contour)), C.c_int(int(with_values)), C.c_int(loop_owner),
                                                 C.byref(h), C.byref(st)))
     rm = RegionMap(ctx, None, cfg=slabs[0][5], _handle=h) if h else None
     if rm is not None:

@@ -162,9 +162,12 @@ typedef struct {
   uint64_t bytes_cut_exchange, bytes_to_loop_owner;  /* bytes the local ranks sent to OTHER ranks in step 2 / step 3 */
 } glia_hmt_dist_stats;
 /* slabs[i] belongs to the i-th local rank of the communicator (rank order).  *out = the whole volume's map when loop_owner is a
- * local rank, NULL otherwise.  Collective: every process of the communicator calls it. */
+ * local rank, NULL otherwise.  Collective: every process of the communicator calls it.
+ * with_values != 0: the image value (d_pb) of every boundary voxel travels with its directed pair, so that the merged map can run
+ * the MEDIAN linkage (glia_hmt_merge_order_pb type 1, the reference tool's default, hmt/main_merge_order_pb.cxx:10; the reference
+ * keeps these value lists per edge, util/struct_merge.hxx:97-111) -- 4 bytes per boundary voxel on top of the records. */
 int glia_hmt_rag_build_distributed(glia_hmt_ctx* ctx, glia_hmt_comm* comm, const glia_hmt_slab* slabs, int64_t nz_global, int only_contour,
-                                   int loop_owner, glia_hmt_rag** out, glia_hmt_dist_stats* stats);
+                                   int with_values, int loop_owner, glia_hmt_rag** out, glia_hmt_dist_stats* stats);
 /* Which records of a slab's partial map may have a counterpart in another slab ("exchanging only the cross-slab boundary
  * regions"): d_region_cut[i] / d_pair_cut[i] (device, one byte per record, in the order of glia_hmt_rag_device_arrays) = 1 iff
  * the region's label / one of the pair's labels occurs on a plane next to a cut (first / last owned plane, halo plane).  Only

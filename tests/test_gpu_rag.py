@@ -257,6 +257,16 @@ def test_distributed_build_through_the_c_abi(ctx, shape, S, G, world, channels):
             a, b = whole.merge_order_bc(clf), merged.merge_order_bc(clf)
             assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
         merged.close()
+    # median linkage (the reference tool's default) on the merged map: the boundary values travel with their pairs
+    with pytest.raises(hmt.HmtError):
+        hmt.build_distributed(ctx, comm, slabs, nz)[0].merge_order_pb(type=1)           # without them: refused, as before
+    merged, st2 = hmt.build_distributed(ctx, comm, slabs, nz, loop_owner=world // 2, with_values=True)
+    assert st2.bytes_to_loop_owner > st.bytes_to_loop_owner
+    for typ in (1, 3, 2):
+        o1, s1 = whole.merge_order_pb(type=typ)
+        o2, s2 = merged.merge_order_pb(type=typ)
+        assert (o1 == o2).all() and (s1 == s2).all(), typ
+    merged.close()
     comm.close()
 
 
