@@ -29,6 +29,7 @@ inline void hipCheck(hipError_t e) { if (e != hipSuccess) perr(std::string("Erro
 struct Volume {
   int dim = 0;
   int64_t dims[3] = {1, 1, 1};
+  int64_t full_nz = 1;             // planes of the FILE (dims[2] = planes read, when only a z range was asked for)
   std::vector<uint32_t> u32;
   std::vector<float> f32;
   size_t size() const { return (size_t)dims[0] * dims[1] * dims[2]; }
@@ -36,7 +37,8 @@ struct Volume {
 
 // MetaImage reader: ObjectType = Image, NDims 2|3, ElementType MET_{UCHAR,USHORT,UINT,ULONG,SHORT,INT,FLOAT,DOUBLE},
 // CompressedData = False, ElementDataFile = LOCAL | <file>
-inline Volume readMetaImage(const std::string& file, bool wantFloat) {
+// zFirst / zCount (3D only, zCount >= 0): read only those planes -- a rank of the slab route reads its own z range
+inline Volume readMetaImage(const std::string& file, bool wantFloat, int64_t zFirst = 0, int64_t zCount = -1) {
   std::ifstream is(file, std::ios::binary);
   if (!is) perr("Error: cannot open file " + file);
   std::map<std::string, std::string> kv;
@@ -61,13 +63,21 @@ inline Volume readMetaImage(const std::string& file, bool wantFloat) {
   size_t es = et == "MET_UCHAR" ? 1 : (et == "MET_USHORT" || et == "MET_SHORT") ? 2 : (et == "MET_UINT" || et == "MET_INT" || et == "MET_FLOAT") ? 4
               : (et == "MET_ULONG" || et == "MET_DOUBLE" || et == "MET_ULONG_LONG") ? 8 : 0;
   if (!es) perr("Error: unsupported MetaImage element type " + et);
+  vol.full_nz = vol.dims[2];
+  std::streamoff skip = 0;
+  if (zCount >= 0) {
+    if (vol.dim != 3 || zFirst < 0 || zFirst + zCount > vol.dims[2]) perr("Error: plane range outside the image " + file);
+    skip = (std::streamoff)((size_t)zFirst * vol.dims[0] * vol.dims[1] * es);
+    vol.dims[2] = zCount;
+  }
   const size_t n = vol.size();
   std::vector<char> raw(n * es);
-  if (kv["ElementDataFile"] == "LOCAL") { is.seekg(dataPos); is.read(raw.data(), raw.size()); }
+  if (kv["ElementDataFile"] == "LOCAL") { is.seekg(dataPos + skip); is.read(raw.data(), raw.size()); if (!is) perr("Error: truncated image data in " + file); }
   else {
     std::string dir = file.substr(0, file.find_last_of('/') == std::string::npos ? 0 : file.find_last_of('/') + 1);
     std::ifstream rs(dir + kv["ElementDataFile"], std::ios::binary);
     if (!rs) perr("Error: cannot open file " + dir + kv["ElementDataFile"]);
+    rs.seekg(skip);
     rs.read(raw.data(), raw.size());
     if (!rs) perr("Error: truncated image data in " + file);
   }

@@ -376,7 +376,8 @@ static int rag_build_impl(glia_hmt_ctx* c, int dim, const int64_t dims[3], int64
   if (zb == 0 && ze == nz && gz0 == 0 && gnz == nz) {
     rag->vol.lab = lab_c; rag->vol.lab_nb = lab_nb; rag->vol.pb = d_pb ? d_pb : img; rag->vol.dim = dim;
     rag->vol.nx = nx; rag->vol.ny = ny; rag->vol.nz = nz;
-  } else if (!d_mask && dim == 3) {
+  }
+  if (!d_mask && dim == 3) {
     // a slab: the planes handed in, of which [zb, ze) are owned -- what collect_pair_values walks for the median linkage of the
     // slab route (the caller keeps the planes alive until glia_hmt_rag_build_distributed returns)
     rag->slab.lab = lab_c; rag->slab.lab_nb = lab_nb; rag->slab.pb = d_pb ? d_pb : img; rag->slab.dim = 3;

@@ -53,6 +53,42 @@ def test_merge_order_pb_cli(tools, tmp_path, shape, local):
     assert lines[-1] == "" and lines[:-1] == [_g(s) for s in s_ref]       # default ostream precision
 
 
+@pytest.mark.parametrize("slabs,typ,local", [(3, 1, True), (4, 2, False), (2, 1, False)])
+def test_merge_order_pb_cli_slab_route(tools, tmp_path, slabs, typ, local):
+    """merge_order_pb --slabs N: every slab read from the MetaImage by its own plane range, the records (and, for the median
+    linkage, the boundary values) through glia_hmt_rag_build_distributed; the same files as the single-pass tool writes"""
+    from oracle import pyoracle as O
+    shape = (48, 36, 40)
+    labels, pb = O.synth(shape, 6, 12)
+    seg, pbf = str(tmp_path / "seg.mha"), str(tmp_path / ("pb.mha" if local else "pb.mhd"))
+    write_mha(seg, labels, True)
+    write_mha(pbf, pb, local)
+    outs = []
+    for extra in ([], ["--slabs", str(slabs)]):
+        order_f, sal_f = str(tmp_path / ("order%d.txt" % len(outs))), str(tmp_path / ("sal%d.txt" % len(outs)))
+        subprocess.check_call([os.path.join(tools, "merge_order_pb"), "-s", seg, "-p", pbf, "-t", str(typ), "-o", order_f, "-y", sal_f] + extra)
+        outs.append((open(order_f, "rb").read(), open(sal_f, "rb").read()))
+    assert outs[0] == outs[1] and len(outs[0][0]) > 0
+    o_ref, _ = O.Rag(labels, only_contour=True).merge_order_pb(pb, type=typ)
+    assert (np.loadtxt(str(tmp_path / "order1.txt"), dtype=np.int64).reshape(-1, 3) == o_ref).all()
+
+
+def test_merge_order_pb_cli_slab_route_one_rccl_rank(tools, tmp_path):
+    """the one-process-per-slab form with the one rank a one-GPU box allows: unique id through the file, RCCL communicator"""
+    from oracle import pyoracle as O
+    labels, pb = O.synth((32, 32, 32), 8, 16)
+    seg, pbf = str(tmp_path / "seg.mha"), str(tmp_path / "pb.mha")
+    write_mha(seg, labels, True)
+    write_mha(pbf, pb, True)
+    order_f = str(tmp_path / "order.txt")
+    subprocess.check_call([os.path.join(tools, "merge_order_pb"), "-s", seg, "-p", pbf, "-o", order_f, "--slabs", "1", "--rank", "0",
+                           "--commId", str(tmp_path / "id.bin")])
+    o_ref, _ = O.Rag(labels, only_contour=True).merge_order_pb(pb, type=1)
+    assert (np.loadtxt(order_f, dtype=np.int64).reshape(-1, 3) == o_ref).all()
+    r = subprocess.run([os.path.join(tools, "merge_order_pb"), "-s", seg, "-p", pbf, "--slabs", "2", "-m", seg], capture_output=True)
+    assert r.returncode == 1 and b"mask" in r.stderr
+
+
 def test_merge_order_pb_cli_errors(tools, tmp_path):
     r = subprocess.run([os.path.join(tools, "merge_order_pb"), "-s", str(tmp_path / "missing.mha"), "-p", "x.mha"], capture_output=True)
     assert r.returncode == 1 and b"Error" in r.stderr
