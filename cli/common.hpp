@@ -15,6 +15,7 @@
 #include <map>
 #include <set>
 #include <sstream>
+#include <unistd.h>
 #include <string>
 #include <vector>
 
@@ -180,6 +181,37 @@ inline uint32_t* loadMask(const Args& a, const char* key, size_t expect) {
   return upload(m.u32);
 }
 
+// --slabs N [--rank r --commId file [--device d]]: the context and the communicator of the slab route (include/glia_hmt.h).  Without
+// --rank all N ranks live in this process; with it this process is rank r of N over RCCL and rank 0 hands RCCL's unique id to the
+// others through the file.
+inline glia_hmt_comm* makeSlabComm(const Args& a, int slabs, glia_hmt_ctx** ctx) {
+  const bool multi = a.has("rank");
+  const int rank = atoi(a.str("rank", "0").c_str());
+  if (multi && (!a.has("commId") || rank < 0 || rank >= slabs)) perr("Error: --rank needs --commId and 0 <= rank < slabs...");
+  int ndev = 0;
+  hipCheck(hipGetDeviceCount(&ndev));
+  const int device = a.has("device") ? atoi(a.str("device").c_str()) : (multi && ndev > 0 ? rank % ndev : 0);
+  check(glia_hmt_ctx_create(device, nullptr, ctx));
+  glia_hmt_comm* comm = nullptr;
+  if (!multi) { check(glia_hmt_comm_create_local(*ctx, slabs, &comm)); return comm; }
+  char id[128];
+  const std::string f = a.str("commId");
+  if (rank == 0) {
+    check(glia_hmt_comm_unique_id(id));
+    { std::ofstream os(f + ".tmp", std::ios::binary); os.write(id, sizeof(id)); }
+    if (rename((f + ".tmp").c_str(), f.c_str())) perr("Error: cannot create file " + f);
+  } else {
+    for (int tries = 0;; ++tries) {
+      std::ifstream is(f, std::ios::binary);
+      if (is && is.read(id, sizeof(id))) break;
+      if (tries > 1200) perr("Error: cannot open file " + f);
+      usleep(100000);
+    }
+  }
+  check(glia_hmt_comm_create_rccl(*ctx, slabs, rank, id, &comm));
+  return comm;
+}
+
 inline bool flagOf(const Args& a, const char* k) { std::string v = a.str(k, "0"); return v == "1" || v == "true"; }
 
 // prepareImages (hmt/hmt_util.hxx:17-56) + the shape normalisers of hmt/main_merge_order_bc.cxx:36-39 / main_bc_feat.cxx:43-46
@@ -190,10 +222,11 @@ struct FeatInputs {
   std::map<std::string, float*> volumes;      // every distinct image file is read and uploaded once
   glia_hmt_feat_config cfg;
 };
-inline void loadFeatInputs(const Args& a, FeatInputs& f) {
+// zFirst / zCount: only those planes of every volume (a slab of the slab route); the shape normalisers stay the whole volume's
+inline void loadFeatInputs(const Args& a, FeatInputs& f, int64_t zFirst = 0, int64_t zCount = -1) {
   const std::string pbFile = a.str("pb");
-  f.seg = readMetaImage(a.str("segImage"), false);
-  f.pb = readMetaImage(pbFile, true);
+  f.seg = readMetaImage(a.str("segImage"), false, zFirst, zCount);
+  f.pb = readMetaImage(pbFile, true, zFirst, zCount);
   if (f.seg.dim != f.pb.dim || f.seg.size() != f.pb.size()) perr("Error: image sizes do not match...");
   f.dLab = upload(f.seg.u32);
   f.dPb = upload(f.pb.f32);
@@ -201,7 +234,7 @@ inline void loadFeatInputs(const Args& a, FeatInputs& f) {
   auto volume = [&](const std::string& file) -> float* {
     auto it = f.volumes.find(file);
     if (it != f.volumes.end()) return it->second;
-    Volume v = readMetaImage(file, true);
+    Volume v = readMetaImage(file, true, zFirst, zCount);
     if (v.size() != f.seg.size()) perr("Error: image sizes do not match...");
     float* d = upload(v.f32);
     f.volumes[file] = d;
@@ -228,7 +261,7 @@ inline void loadFeatInputs(const Args& a, FeatInputs& f) {
   f.cfg.n_thresholds = (int)bt.size();
   for (size_t i = 0; i < bt.size(); ++i) f.cfg.thresholds[i] = atof(bt[i].c_str());
   double vol = 1.0, diag = 0.0;
-  for (int i = 0; i < f.seg.dim; ++i) { vol *= (double)f.seg.dims[i]; diag += (double)f.seg.dims[i] * (double)f.seg.dims[i]; }
+  for (int i = 0; i < f.seg.dim; ++i) { const double e = (double)(i == 2 ? f.seg.full_nz : f.seg.dims[i]); vol *= e; diag += e * e; }
   f.cfg.normalizing_area = flagOf(a, "ns") ? vol : 1.0;
   f.cfg.normalizing_length = flagOf(a, "ns") ? std::sqrt(diag) : 1.0;
   f.cfg.use_log_shape = flagOf(a, "logs");

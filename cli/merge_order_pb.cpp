@@ -10,9 +10,6 @@
 //                                  GPUs unless --device is given): rank 0 writes RCCL's unique id to file f, the others wait for it;
 //                                  the records travel over RCCL, rank 0 runs the merge loop and writes the outputs.
 // Median linkage (-t 1, the default) makes the boundary values travel with their pairs.  No mask in this mode.
-#include <chrono>
-#include <thread>
-
 #include "common.hpp"
 
 using namespace cli;
@@ -34,31 +31,7 @@ int main(int argc, char* argv[]) {
   std::vector<void*> dev;
   if (slabs > 0) {
     if (a.has("maskImage")) perr("Error: the slab route takes no mask...");
-    const bool multi = a.has("rank");
-    const int rank = atoi(a.str("rank", "0").c_str());
-    if (multi && (!a.has("commId") || rank < 0 || rank >= slabs)) perr("Error: --rank needs --commId and 0 <= rank < slabs...");
-    int ndev = 0;
-    hipCheck(hipGetDeviceCount(&ndev));
-    const int device = a.has("device") ? atoi(a.str("device").c_str()) : (multi && ndev > 0 ? rank % ndev : 0);
-    check(glia_hmt_ctx_create(device, nullptr, &ctx));
-    glia_hmt_comm* comm = nullptr;
-    if (multi) {
-      char id[128];
-      const std::string f = a.str("commId");
-      if (rank == 0) {
-        check(glia_hmt_comm_unique_id(id));
-        { std::ofstream os(f + ".tmp", std::ios::binary); os.write(id, sizeof(id)); }
-        if (rename((f + ".tmp").c_str(), f.c_str())) perr("Error: cannot create file " + f);
-      } else {
-        for (int tries = 0;; ++tries) {
-          std::ifstream is(f, std::ios::binary);
-          if (is && is.read(id, sizeof(id))) break;
-          if (tries > 1200) perr("Error: cannot open file " + f);
-          std::this_thread::sleep_for(std::chrono::milliseconds(100));
-        }
-      }
-      check(glia_hmt_comm_create_rccl(ctx, slabs, rank, id, &comm));
-    } else check(glia_hmt_comm_create_local(ctx, slabs, &comm));
+    glia_hmt_comm* comm = makeSlabComm(a, slabs, &ctx);
     int ranks[256];
     const int nl = glia_hmt_comm_local_ranks(comm, ranks, 256);
     // every local rank's planes straight from the files (owned planes + one halo plane per cut)

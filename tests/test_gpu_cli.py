@@ -89,6 +89,30 @@ def test_merge_order_pb_cli_slab_route_one_rccl_rank(tools, tmp_path):
     assert r.returncode == 1 and b"mask" in r.stderr
 
 
+def test_merge_order_bc_cli_slab_route(tools, tmp_path):
+    """merge_order_bc --slabs 3 (two image volumes, --ns: the normalisers stay the whole volume's): byte-identical output files"""
+    from oracle import pyoracle as O
+    import _rf
+    shape = (36, 32, 40)
+    labels, pb = O.synth(shape, 6, 12)
+    rng = np.random.default_rng(4)
+    raw = (np.round(rng.random(shape) * 255) / 256.0).astype(np.float32)
+    cfg = O.make_cfg(pb, rb=[(raw, 8, 0.0, 1.0), (pb, 8, 0.0, 1.0)], norm_area=float(np.prod(shape)), norm_len=float(np.sqrt(sum(d * d for d in shape))))
+    _, _, f0 = O.Rag(labels).merge_order_bc(cfg, None, stub_index=31, want_feats=True)
+    model = str(tmp_path / "model.bin")
+    _rf.write_model(model, _rf.random_forest(np.random.default_rng(3), 31, 6, f0))
+    seg, pbf, rawf = str(tmp_path / "seg.mha"), str(tmp_path / "pb.mha"), str(tmp_path / "raw.mha")
+    write_mha(seg, labels); write_mha(pbf, pb); write_mha(rawf, raw)
+    outs = []
+    for extra in ([], ["--slabs", "3"]):
+        files = [str(tmp_path / ("%s%d.txt" % (n, len(outs)))) for n in ("order", "sal", "bfeat")]
+        subprocess.check_call([os.path.join(tools, "merge_order_bc"), "--bct", "1", "--bcm", model, "-s", seg, "--pb", pbf,
+                               "--rbi", rawf, "--rbb", "8", "--rbl", "0.0", "--rbu", "1.0", "--rbi", pbf, "--rbb", "8", "--rbl", "0.0", "--rbu", "1.0",
+                               "--bt", "0.2", "0.5", "0.8", "-n", "1", "-l", "0", "-o", files[0], "--sal", files[1], "-b", files[2]] + extra)
+        outs.append([open(f_, "rb").read() for f_ in files])
+    assert outs[0] == outs[1] and len(outs[0][0]) > 0
+
+
 def test_merge_order_pb_cli_errors(tools, tmp_path):
     r = subprocess.run([os.path.join(tools, "merge_order_pb"), "-s", str(tmp_path / "missing.mha"), "-p", "x.mha"], capture_output=True)
     assert r.returncode == 1 and b"Error" in r.stderr
