@@ -267,6 +267,7 @@ def main():
         rm.close()
         t_e = time.time()
         info["host_ms"] = dict(build=(t_b - t_a) * 1e3, score=(t_c - t_b) * 1e3, merge_order=(t_d - t_c) * 1e3, close=(t_e - t_d) * 1e3)
+        info["_result"] = (order, sal)          # hashed after the timed region (the `verify` field)
         return info
 
     for _ in range(args.warmup):
@@ -288,6 +289,23 @@ def main():
         merges = float(sum(i["merges"] for i in infos))
         edges = float(sum(i["n_edges"] for i in infos))
 
+    # `verify`: digests of the LAST timed step's whole merge order / saliency arrays, computed outside the timed region, against the
+    # digests tests/test_gpu_headline.py gates (recorded from kernels that were bit-identical to the oracle wherever it finishes)
+    import hashlib
+    sha = lambda a: hashlib.sha1(__import__("numpy").ascontiguousarray(a).tobytes()).hexdigest()
+    known_pb = {(512, 16): ("652c84e7efe781bacc9df8c0a16675ca7e34cf17", "d78663710b1699d331a62c40471ba2d90ffc6515"),
+                (1024, 16): ("977022085e1a37a4d143841a51ea8834b6f53c59", "7923436b47d4484f1e95962ac87ff409d4f2c617")}
+    known_bc = {(256, 16): ("51b7b5316e0d8fd648ab2b444527633d8eaf65c5", "5eadbd683d6a042f7bf950aa2352ef93bdc12956"),
+                (512, 16): ("8e620b69eab2cc31991eaca662446f52ad2231df", "8e30e7ba92d7b89dc09c413260a0841df1cbf886")}
+    verify = None
+    if rank == 0:
+        o_, s_ = infos[-1]["_result"]
+        got = (sha(o_), sha(s_))
+        exp = known_pb.get((args.size, args.S))
+        verify = {"pb_mean_order_sha1": got[0], "pb_mean_saliency_sha1": got[1], "expected": list(exp) if exp else None,
+                  "ok": (got == exp) if exp else None}
+    for i_ in infos:
+        i_.pop("_result", None)
     bc_loop = None
     if rank == 0 and not args.no_bc:
         # the north-star linkage: the classifier-driven merge tree (util/struct_merge_bc.hxx:10-58) of the SAME volume, every
@@ -301,6 +319,9 @@ def main():
         bc_loop = {"linkage": "boundary classifier (random forest, 255 trees, D_f=%d)" % rm.feat_dim(), "merges": len(order),
                    "seconds": t1 - t0, "merges_per_sec": len(order) / (t1 - t0), "edges_scored": tm["n_edges_scored"],
                    "edge_features_per_sec": tm["n_edges_scored"] / (t1 - t0), "ms_init": tm["ms_init"], "ms_loop": tm["ms_loop"]}
+        got = (sha(order), sha(sal))
+        exp = known_bc.get((args.size, args.S))
+        bc_loop["verify"] = {"order_sha1": got[0], "saliency_sha1": got[1], "expected": list(exp) if exp else None, "ok": (got == exp) if exp else None}
         rm.close()
     out = None
     if rank == 0:
@@ -331,6 +352,7 @@ def main():
                        "initial_edges": infos[0]["n_edges"], "merges_per_step": infos[0]["merges"],
                        "parallelism": "replica x%d (the merge loop does not shard)" % world},
             "edge_features_per_sec": edges / dt,
+            "verify": verify,
             "phases_ms": {"accumulate": acc_ms, "edge_features_and_scores": score_ms,
                           "edge_table": sum(i["ms_table"] for i in infos) / len(infos), "merge_loop": loop_ms},
             "host_call_ms": {k: sum(i["host_ms"][k] for i in infos) / len(infos) for k in infos[0]["host_ms"]},
@@ -338,6 +360,7 @@ def main():
             "edge_feature_kernel_per_sec": infos[0]["n_edges"] / (score_ms * 1e-3) if score_ms else None,
             "roofline": {"bound": "hbm", "kernel": "rag_accumulate_kernel", "achieved": achieved, "peak": 8000.0,
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                         "traffic_source": "profiles/acc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of tools/acc_bench.py, separate passes; not measured in this run)",
                          "algorithmic_bytes_per_launch": infos[0]["acc_bytes"], "avg_launch_ms": acc_ms},
         }
         if bc_loop is not None:
