@@ -13,11 +13,17 @@
 //      L = the highest f on the path (the flood level), d = steps walked since the level last rose (distance on the plateau);
 //      equal costs: the smaller label.  Markers keep their label.  (Rounds 1-2 flooded on g: where g > f -- filled shallow
 //      minima -- basins were then split by plateau distance on g instead of by f's relief.)
-// Each step is a fixed point of a local rule, computed by whole-volume sweeps until nothing changes (HBM-streaming passes:
-// 4..28 B per voxel and sweep); the sweeps of step 3 are double-buffered (a voxel's state is three words).
+// Steps 1 and 3 are fixed points of local rules.  Rounds 1-2 computed them by whole-volume Jacobi sweeps (one launch moves
+// information by one voxel: 240 sweeps at 512^3, ~300x the algorithmic bytes); round 3: a workgroup iterates a 16^3 tile (2D:
+// 64^2) in LDS until it is stable before it writes it back, so a launch moves information by a tile, and the plateaus of step 2
+// are components of a union-find forest (one uniting pass, one flattening pass) instead of a min-index propagation.
 #include <rocprim/device/device_scan.hpp>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <utility>
 
+#include "greedy_common.hpp"
 #include "hmt_internal.hpp"
 
 namespace glia {
@@ -46,29 +52,135 @@ __global__ void ws_iota(unsigned long long* c, long long n) {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p < n) c[p] = (unsigned long long)p;
 }
-// one sweep of the reconstruction by erosion: g <- max(f, min over the voxel and its neighbours of g)
-__global__ void ws_hmin_sweep(WsGrid G, const float* f, const float* gin, float* gout, uint32_t* changed) {
-  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= G.n) return;
-  float m = gin[p];
-  ws_neighbours(G, p, [&](long long q) { const float v = gin[q]; m = v < m ? v : m; });
-  const float fp = f[p];
-  m = m > fp ? m : fp;
-  gout[p] = m;
-  if (m != gin[p]) *changed = 1u;
+
+// ---- tiles --------------------------------------------------------------------------------------------------------------------
+// Both fixed points below propagate one voxel per whole-volume sweep when every sweep is a launch (rounds 1-2: 240 sweeps at
+// 512^3).  Here a workgroup loads a tile and its one-voxel halo into LDS, iterates the local rule THERE until the tile is stable,
+// and writes the tile back: information crosses a tile per launch instead of a voxel, and the global rounds drop to about
+// (longest flood path) / (tile edge).  3D tiles are 16^3 (+ halo 18^3), 2D tiles 64 x 64 (+ halo 66 x 66).
+constexpr int kWsThreads = 512;
+constexpr int kWsCells = 18 * 18 * 18;       // >= 66 * 66
+struct WsTile {
+  int tx, ty, tz;                            // interior extent
+  int hx, hy, hz;                            // extent with halo
+  long long x0, y0, z0;                      // volume coordinates of the interior's first voxel
+};
+__device__ __forceinline__ WsTile ws_tile(const WsGrid& G) {
+  WsTile T;
+  if (G.dim == 3) { T.tx = T.ty = T.tz = 16; } else { T.tx = T.ty = 64; T.tz = 1; }
+  T.hx = T.tx + 2; T.hy = T.ty + 2; T.hz = G.dim == 3 ? T.tz + 2 : 1;
+  const long long nbx = (G.nx + T.tx - 1) / T.tx, nby = (G.ny + T.ty - 1) / T.ty;
+  const long long b = blockIdx.x;
+  T.x0 = (b % nbx) * T.tx; T.y0 = ((b / nbx) % nby) * T.ty; T.z0 = (b / (nbx * nby)) * T.tz;
+  return T;
 }
-// plateau components: comp(p) -> the smallest linear index of p's face-connected set of equal g.  In place: the rule is a
-// monotone minimum, so any interleaving reaches the same fixed point; one pointer jump per sweep shortens the chains.
-__global__ void ws_comp_sweep(WsGrid G, const float* g, unsigned long long* comp, uint32_t* changed) {
+// halo cell index -> volume index (or -1 outside the volume)
+__device__ __forceinline__ long long ws_cell_voxel(const WsGrid& G, const WsTile& T, int c, int& cx, int& cy, int& cz) {
+  cx = c % T.hx; cy = (c / T.hx) % T.hy; cz = c / (T.hx * T.hy);
+  const long long x = T.x0 + cx - 1, y = T.y0 + cy - 1, z = G.dim == 3 ? T.z0 + cz - 1 : 0;
+  if (x < 0 || y < 0 || z < 0 || x >= G.nx || y >= G.ny || z >= G.nz) return -1;
+  return (z * G.ny + y) * G.nx + x;
+}
+__device__ __forceinline__ bool ws_interior(const WsGrid& G, const WsTile& T, int cx, int cy, int cz) {
+  return cx >= 1 && cx <= T.tx && cy >= 1 && cy <= T.ty && (G.dim != 3 || (cz >= 1 && cz <= T.tz));
+}
+
+// Work list: a tile runs in a round only if it or one of its face neighbours changed in the round before (dirty[round parity]);
+// a tile that changes marks itself and its six neighbours for the next round.  After the first rounds nearly every launch is a
+// flag test.
+__device__ __forceinline__ bool ws_tile_take(const uint8_t* dirty_now) { return dirty_now[blockIdx.x] != 0; }
+__device__ __forceinline__ void ws_tile_mark(const WsGrid& G, const WsTile& T, uint8_t* dirty_next) {
+  const long long nbx = (G.nx + T.tx - 1) / T.tx, nby = (G.ny + T.ty - 1) / T.ty, nbz = (G.nz + T.tz - 1) / T.tz;
+  const long long b = blockIdx.x, bx = b % nbx, by = (b / nbx) % nby, bz = b / (nbx * nby);
+  dirty_next[b] = 1;
+  if (bx > 0) dirty_next[b - 1] = 1;
+  if (bx + 1 < nbx) dirty_next[b + 1] = 1;
+  if (by > 0) dirty_next[b - nbx] = 1;
+  if (by + 1 < nby) dirty_next[b + nbx] = 1;
+  if (bz > 0) dirty_next[b - nbx * nby] = 1;
+  if (bz + 1 < nbz) dirty_next[b + nbx * nby] = 1;
+}
+
+// reconstruction by erosion, one tile: g <- max(f, min over the voxel and its neighbours of g) until the tile is stable.  The
+// rule is a monotone decrease towards the greatest fixed point below the start, so any order of updates -- in place in LDS, halo
+// values of neighbouring tiles from any earlier moment -- reaches the same limit.
+__global__ __launch_bounds__(kWsThreads) void ws_hmin_tile(WsGrid G, const float* f, float* g, uint32_t* changed, uint8_t* dirty_now, uint8_t* dirty_next) {
+  __shared__ float sg[kWsCells];
+  __shared__ float sf[kWsCells];
+  __shared__ int any;
+  if (!ws_tile_take(dirty_now)) return;
+  __syncthreads();
+  if (threadIdx.x == 0) dirty_now[blockIdx.x] = 0;      // (this buffer is the round after next's "next")
+  const WsTile T = ws_tile(G);
+  const int ncell = T.hx * T.hy * T.hz;
+  for (int c = threadIdx.x; c < ncell; c += kWsThreads) {
+    int cx, cy, cz;
+    const long long v = ws_cell_voxel(G, T, c, cx, cy, cz);
+    sg[c] = v >= 0 ? g[v] : __builtin_inff();       // outside the volume: never the minimum
+    sf[c] = v >= 0 ? f[v] : __builtin_inff();
+  }
+  __syncthreads();
+  const int sy = T.hx, sz = T.hx * T.hy;
+  bool mine = false;
+  for (int it = 0; it < 96; ++it) {
+    bool ch = false;
+    for (int c = threadIdx.x; c < ncell; c += kWsThreads) {
+      const int cx = c % T.hx, cy = (c / T.hx) % T.hy, cz = c / (T.hx * T.hy);
+      if (!ws_interior(G, T, cx, cy, cz)) continue;
+      float m = sg[c];
+      const float g0 = m;
+      m = fminf(m, sg[c - 1]); m = fminf(m, sg[c + 1]); m = fminf(m, sg[c - sy]); m = fminf(m, sg[c + sy]);
+      if (G.dim == 3) { m = fminf(m, sg[c - sz]); m = fminf(m, sg[c + sz]); }
+      m = fmaxf(m, sf[c]);
+      if (m != g0) { sg[c] = m; ch = true; }
+    }
+    mine = mine || ch;
+    if (!__syncthreads_or(ch ? 1 : 0)) break;
+  }
+  if (threadIdx.x == 0) any = 0;
+  __syncthreads();
+  if (mine) any = 1;
+  for (int c = threadIdx.x; c < ncell; c += kWsThreads) {
+    int cx, cy, cz;
+    const long long v = ws_cell_voxel(G, T, c, cx, cy, cz);
+    if (v >= 0 && ws_interior(G, T, cx, cy, cz)) g[v] = sg[c];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && any) { *changed = 1u; ws_tile_mark(G, T, dirty_next); }
+}
+
+// plateau components by union-find: comp(p) -> the smallest linear index of p's face-connected set of equal g.  One pass unites
+// every voxel with its +x / +y / +z neighbour of equal value (the larger root is linked under the smaller with atomicMin), one
+// pass flattens.
+__device__ __forceinline__ unsigned long long ws_root(const unsigned long long* comp, unsigned long long x) {
+  for (;;) {
+    const unsigned long long p = __hip_atomic_load(&comp[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p == x) return x;
+    x = p;
+  }
+}
+__device__ __forceinline__ void ws_unite(unsigned long long* comp, unsigned long long a, unsigned long long b) {
+  for (;;) {
+    a = ws_root(comp, a); b = ws_root(comp, b);
+    if (a == b) return;
+    if (a > b) { const unsigned long long t = a; a = b; b = t; }
+    const unsigned long long old = atomicMin(&comp[b], a);       // b was a root: now it points at the smaller root a
+    if (old == b) return;
+    b = old;                                                     // somebody linked b meanwhile: go on from there
+  }
+}
+__global__ void ws_comp_unite(WsGrid G, const float* g, unsigned long long* comp) {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= G.n) return;
+  const long long x = p % G.nx, y = (p / G.nx) % G.ny, z = p / (G.nx * G.ny);
   const float gp = g[p];
-  unsigned long long c = comp[p];
-  const unsigned long long c0 = c;
-  ws_neighbours(G, p, [&](long long q) { if (g[q] == gp) { const unsigned long long cq = comp[q]; c = cq < c ? cq : c; } });
-  const unsigned long long cc = comp[c];
-  c = cc < c ? cc : c;
-  if (c < c0) { atomicMin(&comp[p], c); *changed = 1u; }
+  if (x + 1 < G.nx && g[p + 1] == gp) ws_unite(comp, (unsigned long long)p, (unsigned long long)(p + 1));
+  if (y + 1 < G.ny && g[p + G.nx] == gp) ws_unite(comp, (unsigned long long)p, (unsigned long long)(p + G.nx));
+  if (G.dim == 3 && z + 1 < G.nz && g[p + G.nx * G.ny] == gp) ws_unite(comp, (unsigned long long)p, (unsigned long long)(p + G.nx * G.ny));
+}
+__global__ void ws_comp_flatten(WsGrid G, unsigned long long* comp) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < G.n) comp[p] = ws_root(comp, (unsigned long long)p);
 }
 __global__ void ws_lower_flag(WsGrid G, const float* g, const unsigned long long* comp, uint32_t* haslower) {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -82,43 +194,89 @@ __global__ void ws_root_flag(WsGrid G, const unsigned long long* comp, const uin
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p < G.n) root[p] = (comp[p] == (unsigned long long)p && !haslower[p]) ? 1u : 0u;
 }
+// flooding in two fixed points.  A voxel's final state is the lexicographic minimum over its neighbours q of
+// (max(L_q, f_p), L unchanged ? d_q + 1 : 0, label_q), markers fixed.  Its first component alone obeys L_p = max(f_p, min_q L_q)
+// -- the erosion rule again (markers start at f, the rest at +inf, and a marker keeps its level because its own value takes part in
+// the minimum): ws_hmin_tile computes it in place.  With the levels final, only neighbours that reach p AT its level count:
+// L_q == L_p continues the plateau (d_q + 1), L_q < L_p with f_p == L_p is a rise (distance 0); (d, label) is ONE 64-bit word and
+// its rule a monotone decrease, so it is updated in place -- in LDS and in the volume -- in any order.
 __global__ void ws_init_flood(WsGrid G, const float* f, const unsigned long long* comp, const uint32_t* haslower, const uint32_t* rank, float* L,
-                              uint32_t* d, uint32_t* lab, uint32_t* marker) {
+                              unsigned long long* st) {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= G.n) return;
   const unsigned long long c = comp[p];
   const bool m = !haslower[c];
-  marker[p] = m ? 1u : 0u;
   L[p] = m ? f[p] : __builtin_inff();
-  d[p] = m ? 0u : 0xFFFFFFFFu;
-  lab[p] = m ? rank[c] + 1u : 0u;
+  st[p] = m ? (unsigned long long)(rank[c] + 1u) : ~0ull;       // marker: distance 0, its label; else unreached
 }
-// one sweep of the flooding: a voxel's state (L, d, label) = the lexicographic minimum over its labelled neighbours q of
-// (max(L_q, f_p), L unchanged ? d_q + 1 : 0, label_q); markers are fixed sources
-__global__ void ws_flood_sweep(WsGrid G, const float* f, const uint32_t* marker, const float* Li, const uint32_t* di, const uint32_t* li,
-                               float* Lo, uint32_t* dout, uint32_t* lo, uint32_t* changed) {
-  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= G.n) return;
-  float bL = Li[p]; uint32_t bd = di[p], bl = li[p];
-  if (!marker[p]) {
-    // recomputed from the neighbours alone, never from the voxel's own previous state: a neighbour whose cost improves may pass on
-    // a LARGER label at an unchanged cost for this voxel (the cost does not always rise strictly with the predecessor's), and a state
-    // kept from before would then rest on nothing.  Costs settle first (their rule is monotone), then labels along the acyclic
-    // relation "best predecessor".
-    bL = __builtin_inff(); bd = 0xFFFFFFFFu; bl = 0u;
-    const float gp = f[p];
-    ws_neighbours(G, p, [&](long long q) {
-      const uint32_t lq = li[q];
-      if (lq == 0u) return;
-      const float Lq = Li[q];
-      const float Lc = Lq > gp ? Lq : gp;
-      const uint32_t dc = Lc == Lq ? di[q] + 1u : 0u;
-      const bool better = bl == 0u || Lc < bL || (Lc == bL && (dc < bd || (dc == bd && lq < bl)));
-      if (better) { bL = Lc; bd = dc; bl = lq; }
-    });
-    if (bl != li[p] || bd != di[p] || bL != Li[p]) *changed = 1u;
+__global__ __launch_bounds__(kWsThreads) void ws_label_tile(WsGrid G, const float* f, const float* L, const uint32_t* haslower, const unsigned long long* comp,
+                                                            unsigned long long* st, uint32_t* changed, uint8_t* dirty_now, uint8_t* dirty_next) {
+  if (!ws_tile_take(dirty_now)) return;
+  __shared__ float sL[kWsCells];
+  __shared__ unsigned long long ss[kWsCells];
+  __shared__ int any;
+  __syncthreads();
+  if (threadIdx.x == 0) dirty_now[blockIdx.x] = 0;
+  const WsTile T = ws_tile(G);
+  const int ncell = T.hx * T.hy * T.hz;
+  constexpr int kPer = (kWsCells + kWsThreads - 1) / kWsThreads;
+  // per own cell: 0 = fixed, 1 = free, 3 = free and a rise may enter it (f_p == L_p)
+  uint32_t kind[kPer];
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const int c = threadIdx.x + k * kWsThreads;
+    kind[k] = 0;
+    if (c >= ncell) continue;
+    int cx, cy, cz;
+    const long long v = ws_cell_voxel(G, T, c, cx, cy, cz);
+    sL[c] = v >= 0 ? L[v] : __builtin_inff();
+    ss[c] = v >= 0 ? st[v] : ~0ull;          // outside the volume: unreached for ever
+    if (v >= 0 && ws_interior(G, T, cx, cy, cz) && haslower[comp[v]]) kind[k] = (f[v] == L[v]) ? 3u : 1u;
   }
-  Lo[p] = bL; dout[p] = bd; lo[p] = bl;
+  __syncthreads();
+  const int sy = T.hx, sz = T.hx * T.hy;
+  bool mine = false;
+  for (int it = 0; it < 128; ++it) {
+    bool ch = false;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int c = threadIdx.x + k * kWsThreads;
+      if (!kind[k]) continue;
+      const float Lp = sL[c];
+      unsigned long long best = ~0ull;
+      auto relax = [&](int q) {
+        const unsigned long long sq = ss[q];
+        if (sq == ~0ull) return;
+        const float Lq = sL[q];
+        unsigned long long cand = ~0ull;
+        if (Lq == Lp) cand = sq + (1ull << 32);                        // the plateau goes on: one step further
+        else if (Lq < Lp && kind[k] == 3u) cand = sq & 0xFFFFFFFFull;    // the level rises here: distance 0
+        best = cand < best ? cand : best;
+      };
+      relax(c - 1); relax(c + 1); relax(c - sy); relax(c + sy);
+      if (G.dim == 3) { relax(c - sz); relax(c + sz); }
+      if (best != ss[c]) { ss[c] = best; ch = true; }
+    }
+    mine = mine || ch;
+    if (!__syncthreads_or(ch ? 1 : 0)) break;
+  }
+  if (threadIdx.x == 0) any = 0;
+  __syncthreads();
+  if (mine) any = 1;
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const int c = threadIdx.x + k * kWsThreads;
+    if (!kind[k]) continue;
+    int cx, cy, cz;
+    const long long v = ws_cell_voxel(G, T, c, cx, cy, cz);
+    st[v] = ss[c];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && any) { *changed = 1u; ws_tile_mark(G, T, dirty_next); }
+}
+__global__ void ws_labels_out(const unsigned long long* st, long long n, uint32_t* out) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) out[p] = (uint32_t)st[p];
 }
 
 }  // namespace
@@ -130,45 +288,51 @@ int watershed_labels(int dim, const int64_t dims[3], const float* d_img, double 
   const long long n = G.n;
   if (n <= 0 || n >= (1ll << 32)) { set_error("watershed: between 1 and 2^32 - 1 voxels"); return GLIA_HMT_ERR_ARG; }
   const unsigned blocks = (unsigned)((n + 255) / 256);
-  float *g0 = nullptr, *g1 = nullptr, *L0 = nullptr, *L1 = nullptr;
-  uint32_t *d0 = nullptr, *d1 = nullptr, *l1 = nullptr, *haslower = nullptr, *root = nullptr, *rank = nullptr, *marker = nullptr, *changed = nullptr;
+  const long long tx = dim == 3 ? 16 : 64, tz = dim == 3 ? 16 : 1;
+  const unsigned tiles = (unsigned)(((G.nx + tx - 1) / tx) * ((G.ny + tx - 1) / tx) * ((G.nz + tz - 1) / tz));
+  float *g0 = nullptr, *L0 = nullptr;
+  uint32_t *haslower = nullptr, *root = nullptr, *rank = nullptr, *changed = nullptr;
   unsigned long long* comp = nullptr;
-  void* tmp = nullptr;
+  char* tmp = nullptr;
   int total_sweeps = 0;
-  auto fail = [&](int rc) {
-    for (void* p : {(void*)g0, (void*)g1, (void*)L0, (void*)L1, (void*)d0, (void*)d1, (void*)l1, (void*)haslower, (void*)root, (void*)rank, (void*)marker,
-                    (void*)changed, (void*)comp, tmp}) if (p) (void)hipFree(p);
-    return rc;
-  };
+  // the scratch volumes (28 bytes per voxel in all) come from the process-wide block cache (greedy_common.hpp): hipMalloc / hipFree
+  // of gigabyte blocks cost more than the kernels (measured: 160 ms of a 215 ms call at 512^3)
+  DeviceBuffers buf;
+  auto fail = [&](int rc) { return rc; };
 #define WS_TRY(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_error(std::string("watershed: ") + hipGetErrorString(_e)); return fail(GLIA_HMT_ERR_HIP); } } while (0)
-  WS_TRY(hipMalloc(&g0, 4 * n)); WS_TRY(hipMalloc(&g1, 4 * n)); WS_TRY(hipMalloc(&changed, 4));
-  // 1. h-minima transform
+#define WS_GET(ptr, count) do { int _rc = buf.get(&(ptr), (size_t)(count), false, stream); if (_rc) return _rc; } while (0)
+  const bool trace = getenv("GLIA_HMT_TRACE") != nullptr;
+  const auto tr0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    (void)hipStreamSynchronize(stream);
+    fprintf(stderr, "[trace] watershed: %s at %.2f ms (%d launches so far)\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count(), total_sweeps);
+  };
+  WS_GET(g0, n); WS_GET(changed, 4);
+  uint8_t* dirty[2] = {nullptr, nullptr};
+  WS_GET(dirty[0], tiles); WS_GET(dirty[1], tiles);
+  WS_TRY(hipMemsetAsync(dirty[0], 1, tiles, stream)); WS_TRY(hipMemsetAsync(dirty[1], 0, tiles, stream));
+  // 1. h-minima transform: tile rounds (in place: the rule is monotone) until no tile changes
   hipLaunchKernelGGL(ws_shift, dim3(blocks), dim3(256), 0, stream, d_img, g0, n, level);
   for (;;) {
     uint32_t h = 0;
     WS_TRY(hipMemsetAsync(changed, 0, 4, stream));
-    for (int rep = 0; rep < 8; ++rep) {        // a few sweeps per host round trip
-      hipLaunchKernelGGL(ws_hmin_sweep, dim3(blocks), dim3(256), 0, stream, G, d_img, g0, g1, changed);
-      std::swap(g0, g1);
+    for (int rep = 0; rep < 2; ++rep) {        // two rounds per host round trip
+      hipLaunchKernelGGL(ws_hmin_tile, dim3(tiles), dim3(kWsThreads), 0, stream, G, d_img, g0, changed, dirty[rep], dirty[rep ^ 1]);
       ++total_sweeps;
     }
     WS_TRY(hipMemcpyAsync(&h, changed, 4, hipMemcpyDeviceToHost, stream));
     WS_TRY(hipStreamSynchronize(stream));
     if (!h) break;
   }
-  (void)hipFree(g1); g1 = nullptr;
+  lap("h-minima done");
   const float* g = g0;
   // 2. plateaus, regional minima, raster-order numbering
-  WS_TRY(hipMalloc(&comp, 8 * n)); WS_TRY(hipMalloc(&haslower, 4 * n)); WS_TRY(hipMalloc(&root, 4 * (n + 1))); WS_TRY(hipMalloc(&rank, 4 * (n + 1)));
+  WS_GET(comp, n); WS_GET(haslower, n); WS_GET(root, n + 1); WS_GET(rank, n + 1);
   hipLaunchKernelGGL(ws_iota, dim3(blocks), dim3(256), 0, stream, comp, n);
-  for (;;) {
-    uint32_t h = 0;
-    WS_TRY(hipMemsetAsync(changed, 0, 4, stream));
-    for (int rep = 0; rep < 8; ++rep) { hipLaunchKernelGGL(ws_comp_sweep, dim3(blocks), dim3(256), 0, stream, G, g, comp, changed); ++total_sweeps; }
-    WS_TRY(hipMemcpyAsync(&h, changed, 4, hipMemcpyDeviceToHost, stream));
-    WS_TRY(hipStreamSynchronize(stream));
-    if (!h) break;
-  }
+  hipLaunchKernelGGL(ws_comp_unite, dim3(blocks), dim3(256), 0, stream, G, g, comp);
+  hipLaunchKernelGGL(ws_comp_flatten, dim3(blocks), dim3(256), 0, stream, G, comp);
+  total_sweeps += 2;
   WS_TRY(hipMemsetAsync(haslower, 0, 4 * n, stream));
   hipLaunchKernelGGL(ws_lower_flag, dim3(blocks), dim3(256), 0, stream, G, g, comp, haslower);
   hipLaunchKernelGGL(ws_root_flag, dim3(blocks), dim3(256), 0, stream, G, comp, haslower, root);
@@ -176,31 +340,48 @@ int watershed_labels(int dim, const int64_t dims[3], const float* d_img, double 
   {
     size_t bytes = 0;
     WS_TRY(rocprim::exclusive_scan(nullptr, bytes, root, rank, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), stream));
-    WS_TRY(hipMalloc(&tmp, bytes ? bytes : 16));
+    WS_GET(tmp, bytes ? bytes : 16);
     WS_TRY(rocprim::exclusive_scan(tmp, bytes, root, rank, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), stream));
   }
   uint32_t nlab = 0;
   WS_TRY(hipMemcpyAsync(&nlab, rank + n, 4, hipMemcpyDeviceToHost, stream));
-  // 3. flooding (double-buffered; the output volume is one of the two label planes)
-  WS_TRY(hipMalloc(&L0, 4 * n)); WS_TRY(hipMalloc(&L1, 4 * n)); WS_TRY(hipMalloc(&d0, 4 * n)); WS_TRY(hipMalloc(&d1, 4 * n));
-  WS_TRY(hipMalloc(&l1, 4 * n)); WS_TRY(hipMalloc(&marker, 4 * n));
-  uint32_t* l0 = d_out;
-  hipLaunchKernelGGL(ws_init_flood, dim3(blocks), dim3(256), 0, stream, G, d_img, comp, haslower, rank, L0, d0, l0, marker);
+  lap("plateaus + markers done");
+  // 3. flooding: levels (the erosion kernel again, in place), then (distance, label) in place
+  unsigned long long* stw = nullptr;
+  WS_GET(L0, n); WS_GET(stw, n);
+  hipLaunchKernelGGL(ws_init_flood, dim3(blocks), dim3(256), 0, stream, G, d_img, comp, haslower, rank, L0, stw);
+  WS_TRY(hipMemsetAsync(dirty[0], 1, tiles, stream)); WS_TRY(hipMemsetAsync(dirty[1], 0, tiles, stream));
   for (;;) {
     uint32_t h = 0;
-    WS_TRY(hipMemsetAsync(changed, 0, 4, stream));
-    for (int rep = 0; rep < 4; ++rep) {        // an even number of sweeps: the current state ends in (L0, d0, d_out)
-      hipLaunchKernelGGL(ws_flood_sweep, dim3(blocks), dim3(256), 0, stream, G, d_img, marker, L0, d0, l0, L1, d1, l1, changed);
-      hipLaunchKernelGGL(ws_flood_sweep, dim3(blocks), dim3(256), 0, stream, G, d_img, marker, L1, d1, l1, L0, d0, l0, changed);
-      total_sweeps += 2;
+    WS_TRY(hipMemsetAsync(changed, 0, 16, stream));
+    for (int rep = 0; rep < 2; ++rep) {
+      hipLaunchKernelGGL(ws_hmin_tile, dim3(tiles), dim3(kWsThreads), 0, stream, G, d_img, L0, changed, dirty[rep], dirty[rep ^ 1]);
+      ++total_sweeps;
     }
     WS_TRY(hipMemcpyAsync(&h, changed, 4, hipMemcpyDeviceToHost, stream));
     WS_TRY(hipStreamSynchronize(stream));
     if (!h) break;
   }
+  lap("flood levels done");
+  WS_TRY(hipMemsetAsync(dirty[0], 1, tiles, stream)); WS_TRY(hipMemsetAsync(dirty[1], 0, tiles, stream));
+  for (;;) {
+    uint32_t h = 0;
+    WS_TRY(hipMemsetAsync(changed, 0, 16, stream));
+    for (int rep = 0; rep < 2; ++rep) {
+      hipLaunchKernelGGL(ws_label_tile, dim3(tiles), dim3(kWsThreads), 0, stream, G, d_img, L0, haslower, comp, stw, changed, dirty[rep], dirty[rep ^ 1]);
+      ++total_sweeps;
+    }
+    WS_TRY(hipMemcpyAsync(&h, changed, 4, hipMemcpyDeviceToHost, stream));
+    WS_TRY(hipStreamSynchronize(stream));
+    if (!h) break;
+  }
+  hipLaunchKernelGGL(ws_labels_out, dim3(blocks), dim3(256), 0, stream, stw, n, d_out);
   WS_TRY(hipGetLastError());
+  lap("flooding done");
   if (n_labels) *n_labels = nlab;
   if (sweeps) *sweeps = total_sweeps;
+  WS_TRY(hipStreamSynchronize(stream));      // the blocks go back to the cache when buf dies: nothing may still use them
+#undef WS_GET
 #undef WS_TRY
   return fail(GLIA_HMT_OK);
 }
