@@ -1,6 +1,6 @@
 # the GPU measurements a round's profiles/ are built from: bash tools/closing_set.sh <tag>   (on the GPU box, via gpurun)
 set -e
-TAG=${1:-r02a}
+TAG=${1:-r03z}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -13,7 +13,10 @@ timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv 
 echo pmc done
 GLIA_PB_HASH=1 timeout -k 10 200 python tools/pb_bench.py 1024 16 2 > $OUT/pb1024_hash.txt 2>&1
 GLIA_PB_HASH=1 timeout -k 10 200 python tools/pb_bench.py 512 16 2 > $OUT/pb512_hash.txt 2>&1
-timeout -k 10 200 python tools/bc_bench.py 512 16 > $OUT/bc512.txt 2>&1
+GLIA_BC_HASH=1 timeout -k 10 200 python tools/bc_bench.py 512 16 > $OUT/bc512.txt 2>&1
+GLIA_BC_HASH=1 timeout -k 10 200 python tools/bc_bench.py 256 16 > $OUT/bc256.txt 2>&1
+GLIA_HMT_LIB=$PWD/glia_amd/libglia_hmt_prof.so timeout -k 10 200 python tools/bc_bench.py 512 16 > $OUT/bc512_prof.txt 2>&1 || true
 echo loops done
 timeout -k 10 300 python tools/e2e_bench.py > $OUT/e2e_2048x2048x512.txt 2>&1
+timeout -k 10 300 python tools/ws_bench.py 256 512 1024 > $OUT/watershed.txt 2>&1
 echo e2e done
