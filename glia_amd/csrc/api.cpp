@@ -166,8 +166,8 @@ int glia_hmt_ctx_create(int device, void* hip_stream, glia_hmt_ctx** out) {
   c->device = device;
   if (hip_stream) c->stream = (hipStream_t)hip_stream;
   else { GLIA_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
-  GLIA_HIP_TRY(hipMalloc(&c->flags, 64));
-  GLIA_HIP_TRY(hipMemsetAsync(c->flags, 0, 64, c->stream));
+  GLIA_HIP_TRY(hipMalloc(&c->flags, 256));      // 8 status words + profiling counters of the accumulation pass (profiling builds)
+  GLIA_HIP_TRY(hipMemsetAsync(c->flags, 0, 256, c->stream));
   GLIA_HIP_TRY(hipEventCreate(&c->ev0));
   GLIA_HIP_TRY(hipEventCreate(&c->ev1));
   static const LibmSel sel = probe_host_libm();
@@ -421,8 +421,11 @@ static int rag_build_impl(glia_hmt_ctx* c, int dim, const int64_t dims[3], int64
     pass_ms_total += ms;
     rag->pass_ms = pass_ms_total;
     if (p.debug & 32) {
-      fprintf(stderr, "[glia_hmt debug] region runs %u (lds-miss %u), pair runs %u (lds-miss %u), drains %u\n", flags[2], flags[4], flags[3], flags[5], flags[6]);
-      (void)hipMemsetAsync(c->flags, 0, 64, c->stream);
+      unsigned long long pc[8];
+      (void)hipMemcpy(pc, c->flags + 16, sizeof(pc), hipMemcpyDeviceToHost);
+      fprintf(stderr, "[glia_hmt debug] drainers: region batches %llu entries %llu cycles %llu | pair batches %llu entries %llu cycles %llu | idle polls %llu, drainer cycles %llu\n",
+              pc[0], pc[1], pc[2], pc[3], pc[4], pc[5], pc[6], pc[7]);
+      (void)hipMemsetAsync(c->flags, 0, 256, c->stream);
     }
     rag->alg_bytes = (double)(nx * ny * (ze - zb)) * 8.0 * (double)chans.size();
     // runs that found the tile's LDS tables full went to the global tables one by one (exact, slow): with more than one

@@ -20,17 +20,9 @@ void set_error(const std::string& msg);
   } while (0)
 
 // ---- accumulation tile geometry -------------------------------------------------------------
-constexpr int kVX = 4;             // voxels per lane along x (one 16-byte load)
-#ifndef GLIA_LANES_PER_ROW
-#define GLIA_LANES_PER_ROW 16
-#endif
-constexpr int kLanesPerRow = GLIA_LANES_PER_ROW;       // 16: wave = 4 rows x 64 voxels; 64: wave = 1 row x 256 voxels
-constexpr int kRowsPerWave = 64 / kLanesPerRow;
-constexpr int kTileWaves = 8;
-constexpr int kTileX = kLanesPerRow * kVX;
-constexpr int kTileY = kTileWaves * kRowsPerWave;
-constexpr int kThreads = kTileWaves * 64;
-constexpr int kTZ = 32;            // planes a workgroup marches through; kTZ*kVX <= 255 (8-bit run counters)
+constexpr int kTileX = 64;         // one wave = one row of 64 voxels, one voxel per lane
+constexpr int kTileY = 24;         // rows of a tile: 12 marching waves x 2 rows (8-bin records) or 6 x 4 (16-bin records)
+constexpr int kTZ = 32;            // planes a workgroup marches through (a run of a lane has at most kTZ voxels: 8-bit counters)
 
 // ---- record layouts (32-bit words).  All zero == "empty": minima / lower bounds are stored
 // complemented so that every reduction is an add or an unsigned max and tables initialise by memset.

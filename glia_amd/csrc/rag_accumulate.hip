@@ -11,19 +11,22 @@
 //   * per directed pair: the same moments/histogram over its boundary voxels plus the thresholded
 //     counts of type/feat.hxx:493-501,574-588.
 //
-// MI355X mapping.  HBM-bound: 8 algorithmic bytes per voxel (4 label + 4 image).
-//   * Tile = 64(x) x 32(y) x 32(z) voxels per 512-thread workgroup; a wave covers 4 rows of 64 voxels
-//     (16 lanes x one 16-byte load per row) and marches the 32 planes, keeping the z-1 / z / z+1 label rows
-//     in registers; y+-1 rows are re-read through L1/L2.  Tiles are dealt to XCDs in contiguous runs so halo
-//     rows of neighbouring tiles hit the same L2.
-//   * Supervoxels are spatially coherent, so a lane sees long RUNS of one label / one directed pair.  It
-//     reduces a run in registers (f64 sums, 8-bit packed histogram / threshold counters; planes are walked
-//     in serpentine x order so a lane that straddles a wall changes key once per plane, not twice).
-//   * A finished run is not flushed by its (single, divergent) lane: it is appended to a per-wave LDS ring
-//     (three 16-byte stores).  When the ring cannot take the next batch, the whole wave DRAINS it -- lane j
-//     owns entry j -- into the workgroup's LDS hash tables (find-or-insert + LDS atomics) at near-full lane
-//     utilisation.  After the march the workgroup folds its LDS tables into the global hash tables.
-//   * All reductions are integer adds, unsigned max, or f64 adds: exact, hence order-independent and
+// MI355X mapping (round 3 rewrite).  HBM-bound by bytes -- 8 algorithmic bytes per voxel (4 label + 4 image) --, but
+// instruction-issue bound in practice, so the design minimises wave instructions per voxel and keeps four waves per SIMD:
+//   * Tile = 64(x) x 32(y) x 32(z) voxels per 1024-thread workgroup (one per CU, it owns the 160 KiB of LDS).  A wave is
+//     one ROW of 64 voxels (lane = x, one 256-byte load per row), it marches the z COLUMN of its row through the tile's
+//     planes, then the column of a second row.  z-1 / z / z+1 labels of a column roll through registers, y+-1 rows are
+//     re-read through L1/L2, x+-1 come from the neighbouring lanes with one DPP move each (wave_shr / wave_shl, the halo
+//     label of lanes 0 / 63 rides in the `old` operand).  Loads run four planes ahead of the arithmetic.
+//   * Supervoxels are spatially coherent, so a lane sees long RUNS of one label / one directed pair down its column.  It
+//     reduces a run in registers (f64 sums with the square folded into an FMA -- v*v is exact in f64 --, float min / max,
+//     8-bit packed histogram counters in one 64-bit register, 8-bit packed threshold counters).  Everything positional
+//     (bounding box, first voxel, voxel count) follows from the run's first and last plane and costs nothing per voxel.
+//   * A finished run is appended to a per-wave LDS ring (three 16-byte stores, regions and pairs in one batch).  When the
+//     ring cannot take the next batch the whole wave DRAINS it -- lane j owns entry j -- into the workgroup's LDS hash
+//     tables (find-or-insert + LDS atomics; two 32-bit counters per 64-bit atomic, bounding boxes as OR-ed occupancy
+//     masks).  After the march the workgroup folds its LDS tables into the global hash tables.
+//   * All reductions are integer adds, ORs, unsigned max, or f64 adds: exact, hence order-independent and
 //     bit-reproducible, whenever the image is a multiple of 2^-k (Q8 pb); otherwise within ~1e-15 relative.
 #include <type_traits>
 
@@ -42,48 +45,73 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
   return x;
 }
 
-// ---- LDS layout ------------------------------------------------------------------------------------
-// region slot (words): 0 cnt | 1 border | 2..7 bbox (tile-relative, max-encoded: 63-xlo, xhi+1, 31-ylo, yhi+1,
-// 31-zlo, zhi+1; 63/31 stand for kTileX-1 / kTileY-1) | 8 sum(f64) | 10 sq(f64) | 12 ~ord(min) | 13 ord(max) | 14 0xFFFFF - first(tile-rel) | 16.. hist
-// pair slot (words):   0 cnt | 1 ~ord(min) | 2 ord(max) | 4..7 thr | 8 sum | 10 sq | 12.. hist
-constexpr int LR_CNT = 0, LR_BORDER = 1, LR_BOX = 2, LR_SUM = 8, LR_SQ = 10, LR_MIN = 12, LR_MAX = 13, LR_FIRST = 14,
-              LR_HIST = 16;
-constexpr int LP_CNT = 0, LP_MIN = 1, LP_MAX = 2, LP_THR = 4, LP_SUM = 8, LP_SQ = 10, LP_HIST = 12;
-constexpr int kXB = kTileX == 64 ? 6 : 8;      // bits of a tile-relative x
-constexpr int kYB = 11 - kXB;                  // bits of a tile-relative y (kTileX * kTileY == 2048)
-static_assert((1 << kXB) == kTileX && (1 << kYB) == kTileY && kTZ == 32, "tile-relative packing");
-constexpr uint32_t kXM = kTileX - 1, kYM = kTileY - 1;
-// LDS table sizes (one workgroup per CU owns the whole 160 KiB): 8-bin records allow 1024 pair slots, 16-bin 768
-template <int BINS> struct Slots { static constexpr int kReg = 256; static constexpr int kPair = BINS <= 8 ? 1024 : 768; };
-constexpr int kRingEntries = 64;
+static_assert(kTileX == 64 && kTileY == 24 && kTZ == 32, "the pass assumes 64 x 24 x 32 tiles");
+
+// ---- geometry ----------------------------------------------------------------------------------------
+template <int BINS> struct Geo {
+  static constexpr int kWaves = BINS <= 8 ? 16 : 8;         // 16-bin records need the LDS for tables: half the waves
+  static constexpr int kThreadsT = kWaves * 64;
+  static constexpr int kDrainers = BINS <= 8 ? 4 : 2;       // waves that only empty the rings of the others
+  static constexpr int kMarchers = kWaves - kDrainers;      // waves that march columns: 12 / 6
+  static constexpr int kPasses = kTileY / kMarchers;        // rows a wave marches one after the other: 2 / 4
+  static constexpr int kRegSlots = 256;
+  static constexpr int kPairSlots = 1024;
+  static constexpr int kEntryWords = BINS <= 8 ? 12 : 16;   // ring entry
+  static_assert(kPasses * kMarchers == kTileY, "rows of a tile = marching waves x passes");
+};
+#ifndef GLIA_ACC_DRAINAT
+#define GLIA_ACC_DRAINAT 32
+#endif
+constexpr int kDrainAt = GLIA_ACC_DRAINAT;            // a drainer gathers at least this many entries unless a wave of its waits or is done
 constexpr int kLdsProbes = 32;
 constexpr int kGlobalProbes = 512;
+constexpr int kAhead = 4;             // planes the loads run ahead of the arithmetic (= buffers per stream)
 
-// what drain_ring needs from the kernel arguments; copied to LDS once so that the non-inlined drain never forces
-// the by-value kernel argument onto the stack
+// ---- LDS record layouts (words); all-zero = empty.  Histogram / threshold counters are 16 bits wide, two per word: a tile
+// has fewer than 65536 voxels, and a 64-bit LDS atomic then adds four of them at once.
+// region: 0 cnt | 1 border | 2,3 x occupancy (u64, tile-relative) | 4 y occupancy | 5 z occupancy | 6 ~ord(min) | 7 ord(max) |
+//         8 sum(f64) | 10 sq(f64) | 12 0xFFFFF - first(tile-rel z<<11|y<<6|x) | 14.. hist
+// pair:   0 cnt | 1 ~ord(min) | 2,3 thr | 4 ord(max) | 6 sum | 8 sq | 10.. hist
+constexpr int LR_CNT = 0, LR_BORDER = 1, LR_XMASK = 2, LR_YMASK = 4, LR_ZMASK = 5, LR_MIN = 6, LR_MAX = 7, LR_SUM = 8, LR_SQ = 10,
+              LR_FIRST = 12, LR_HIST = 14;
+constexpr int LP_CNT = 0, LP_MIN = 1, LP_THR = 2, LP_MAX = 4, LP_SUM = 6, LP_SQ = 8, LP_HIST = 10;
+static_assert(kTileX * kTileY * kTZ < 65536, "16-bit counters in the LDS records");
+constexpr int kRingR = 64, kRingP = 64;      // entries of a marching wave's region / pair ring (powers of two)
+
+// what the drain and the fold need from the kernel arguments; copied to LDS once: read back from there they do not occupy
+// scalar registers during the march
 struct TableParams {
   uint32_t* rkeys; uint32_t* rrec; unsigned long long* pkeys; uint32_t* prec; uint32_t* flags;
   uint32_t rmask, pmask;
   int64_t nx, ny;
-  int64_t x0, y0, z0;     // tile origin
+  int64_t x0, y0, z0;     // tile origin (global coordinates)
 };
+
+// control words of a marching wave's rings
+constexpr int C_TAIL_R = 0, C_TAIL_P = 1, C_HEAD_R = 2, C_HEAD_P = 3, C_STATE = 4;
+constexpr uint32_t kRingWaiting = 1u, kRingDone = 2u;
 
 template <int BINS>
 struct Lds {
-  static constexpr int kRegWords = LR_HIST + BINS;        // 24 / 32
-  static constexpr int kPairWordsL = LP_HIST + BINS;      // 20 / 28
-  static constexpr int kEntryWords = BINS <= 8 ? 12 : 16; // ring entry
-  static constexpr int kRegSlots = Slots<BINS>::kReg, kPairSlots = Slots<BINS>::kPair;
-  unsigned long long rkey[kRegSlots];
-  unsigned long long pkey[kPairSlots];
-  uint32_t rrec[kRegSlots * kRegWords];
-  uint32_t prec[kPairSlots * kPairWordsL];
-  uint32_t ring[kTileWaves][kRingEntries * kEntryWords];   // reused as gslot[] by the final fold
+  using G = Geo<BINS>;
+  static constexpr int kRegWords = LR_HIST + BINS / 2;      // 18 / 22
+  static constexpr int kPairWordsL = LP_HIST + BINS / 2;    // 14 / 18
+  unsigned long long rkey[G::kRegSlots];
+  unsigned long long pkey[G::kPairSlots];
+  uint32_t rrec[G::kRegSlots * kRegWords];
+  uint32_t prec[G::kPairSlots * kPairWordsL];
+  uint32_t ringR[G::kMarchers][kRingR * G::kEntryWords];   // circular, per marching wave; reused as gslot[] by the final fold
+  uint32_t ringP[G::kMarchers][kRingP * G::kEntryWords];
+  uint32_t ctl[G::kMarchers][8];
   TableParams tp;
 };
+static_assert(sizeof(Lds<8>) <= 160 * 1024 && sizeof(Lds<16>) <= 160 * 1024, "LDS budget of one CU");
 
+// find-or-insert in an LDS key table.  The hash costs two quarter-rate multiplies; the slot index comes from a 24-bit multiply.
 __device__ __forceinline__ int lds_slot(unsigned long long* keys, int nslots, unsigned long long key) {
-  uint32_t h = (uint32_t)(((unsigned long long)hash64(key) * (unsigned long long)nslots) >> 32);
+  uint32_t m = (uint32_t)key ^ ((uint32_t)(key >> 32) * 0x9E3779B1u);
+  m ^= m >> 16; m *= 0x7feb352dU; m ^= m >> 15;
+  uint32_t h = __umul24(m >> 16, (uint32_t)nslots) >> 16;      // 16 bits x 10 bits: no overflow
   for (int i = 0; i < kLdsProbes; ++i) {
     unsigned long long cur = keys[h];
     if (cur == key) return (int)h;
@@ -128,144 +156,276 @@ __device__ __forceinline__ int global_pair_slot(const P& p, unsigned long long k
 
 // ---- ring entry (dwords) ---------------------------------------------------------------------------
 //  0 key lo (region: label+1; pair: b+1)     1 key hi (region: 0; pair: a+1)
-//  2 region: cnt | border<<8 | first_rel<<16     pair: cnt
-//  3 region: (63-xlo) | xhi<<6 | yrel<<12 | zhi<<17   pair: 4 x 8-bit threshold counters
-//  4,5 sum (f64)   6,7 sq (f64)   8 ord(min)   9 ord(max)   10,11 hist bins 0-7 (8-bit packed)  [12,13 bins 8-15]
-struct Tile { int64_t x0, y0, z0; };
+//  2 region: x | y<<6 | zfirst<<11 | zlast<<16 | border<<21 (tile-relative)     pair: cnt
+//  3 region: cnt (only read with a mask: without one cnt = zlast - zfirst + 1)  pair: 4 x 8-bit threshold counters
+//  4,5 sum (f64)   6,7 sq (f64)   8 min (float)   9 max (float)   10,11 hist bins 0-7 (8-bit packed)  [12,13 bins 8-15]
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 __attribute__((address_space(3))) lds_u32x4;
+typedef lds_u32x4* lds_u4_ptr;
 
-// Deliberately NOT inlined: it is called from every enqueue site but runs rarely; inlining sixteen copies
-// blows the register budget of the streaming loop.
-template <int BINS>
-__device__ __attribute__((noinline)) void drain_ring(Lds<BINS>& s, uint32_t* ring, int count, int lane) {
-  constexpr int EW = Lds<BINS>::kEntryWords;
-  if (lane >= count) return;
-  const TableParams& p = s.tp;
-  Tile t; t.x0 = p.x0; t.y0 = p.y0; t.z0 = p.z0;
-  const uint4* e = reinterpret_cast<const uint4*>(ring + lane * EW);
-  const uint4 a = e[0], b = e[1], c = e[2];
-  uint4 d = {0, 0, 0, 0};
+// control words of the rings: plain LDS loads / stores the compiler may neither cache nor move.  The LDS executes the
+// operations of a wave in order, so entries written before the tail are visible to whoever reads the new tail.
+__device__ __forceinline__ uint32_t ctl_load(const uint32_t* w) {
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+__device__ __forceinline__ void ctl_store(uint32_t* w, uint32_t v) {
+  asm volatile("" ::: "memory");
+  __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+}
+// four 8-bit counters -> two words of two 16-bit counters
+__device__ __forceinline__ unsigned long long widen4(uint32_t w) {
+  return (unsigned long long)__builtin_amdgcn_perm(w, w, 0x0c010c00u) | ((unsigned long long)__builtin_amdgcn_perm(w, w, 0x0c030c02u) << 32);
+}
+__device__ __forceinline__ uint32_t hist_byte(const u32x4& c, const u32x4& d, int k) {
+  const uint32_t w = (k < 4) ? c.z : (k < 8) ? c.w : (k < 12) ? d.x : d.y;
+  return (w >> ((k & 3) * 8)) & 0xFF;
+}
+
+// One batch of finished REGION runs (lane = entry) goes into the workgroup's tables
+template <int BINS, bool MASK>
+__device__ __forceinline__ void drain_regions(Lds<BINS>& s, const uint32_t entryAddr, const bool act) {
+  using G = Geo<BINS>;
+  if (!act) return;
+  const lds_u4_ptr e = (lds_u4_ptr)(uintptr_t)entryAddr;
+  const u32x4 a = e[0], b = e[1], c = e[2];
+  u32x4 d = {0, 0, 0, 0};
   if (BINS > 8) d = e[3];
-  const bool isRegion = a.y == 0;
-  const unsigned long long key = ((unsigned long long)a.y << 32) | a.x;
-  const uint32_t cnt = a.z & 0xFF;
-  double sum = __hiloint2double((int)b.y, (int)b.x), sq = __hiloint2double((int)b.w, (int)b.z);
-  const uint32_t omin = ~c.x, omax = c.y;
-  int slot = isRegion ? lds_slot(s.rkey, Lds<BINS>::kRegSlots, key) : lds_slot(s.pkey, Lds<BINS>::kPairSlots, key);
-#ifdef GLIA_HMT_PROFILE
-  atomicAdd(&p.flags[isRegion ? 2 : 3], 1u); if (slot < 0) atomicAdd(&p.flags[isRegion ? 4 : 5], 1u);
+  const double sum = __hiloint2double((int)b.y, (int)b.x), sq = __hiloint2double((int)b.w, (int)b.z);
+  const uint32_t cmn = c.x, cmx = c.y;      // (__builtin_bit_cast of a vector ELEMENT reads element 0 whatever the index)
+  const uint32_t omin = ~float_ord(__builtin_bit_cast(float, cmn)), omax = float_ord(__builtin_bit_cast(float, cmx));
+  const uint32_t meta = a.z;
+  const uint32_t rx = meta & 63, ry = (meta >> 6) & 31, zs = (meta >> 11) & 31, zl = (meta >> 16) & 31, border = (meta >> 21) & 63;
+  const uint32_t rcnt = MASK ? a.w : zl - zs + 1u;
+  const uint32_t zmask = (2u << zl) - (1u << zs);      // planes zs..zl (2u << 31 wraps to 0: the subtraction still gives the bits)
+  int slot = lds_slot(s.rkey, G::kRegSlots, (unsigned long long)a.x);
+#ifdef GLIA_ACC_NOCONFLICT
+  if (slot >= 0) slot = (int)((entryAddr / 48u) % (uint32_t)G::kRegSlots);
 #endif
   if (slot >= 0) {
-    uint32_t* rec = isRegion ? &s.rrec[slot * Lds<BINS>::kRegWords] : &s.prec[slot * Lds<BINS>::kPairWordsL];
-    const int oCnt = isRegion ? LR_CNT : LP_CNT, oSum = isRegion ? LR_SUM : LP_SUM, oSq = isRegion ? LR_SQ : LP_SQ;
-    const int oMin = isRegion ? LR_MIN : LP_MIN, oMax = isRegion ? LR_MAX : LP_MAX, oHist = isRegion ? LR_HIST : LP_HIST;
-    atomicAdd(&rec[oCnt], cnt);
-    atomicAdd((double*)&rec[oSum], sum);
-    atomicAdd((double*)&rec[oSq], sq);
-    atomicMax(&rec[oMin], omin);
-    atomicMax(&rec[oMax], omax);
-#pragma unroll
-    for (int k = 0; k < BINS; ++k) {
-      uint32_t w = (k < 4) ? c.z : (k < 8) ? c.w : (k < 12) ? d.x : d.y;
-      uint32_t h = (w >> ((k & 3) * 8)) & 0xFF;
-      if (h) atomicAdd(&rec[oHist + k], h);
+    uint32_t* rec = &s.rrec[slot * Lds<BINS>::kRegWords];
+    atomicAdd((unsigned long long*)&rec[LR_CNT], (unsigned long long)rcnt | ((unsigned long long)border << 32));
+    atomicAdd((double*)&rec[LR_SUM], sum);
+    atomicAdd((double*)&rec[LR_SQ], sq);
+    atomicMax(&rec[LR_MIN], omin);
+    atomicMax(&rec[LR_MAX], omax);
+    atomicAdd((unsigned long long*)&rec[LR_HIST], widen4(c.z));
+    atomicAdd((unsigned long long*)&rec[LR_HIST + 2], widen4(c.w));
+    if (BINS > 8) {
+      atomicAdd((unsigned long long*)&rec[LR_HIST + 4], widen4(d.x));
+      atomicAdd((unsigned long long*)&rec[LR_HIST + 6], widen4(d.y));
     }
-    if (isRegion) {
-      const uint32_t border = (a.z >> 8) & 0xFF, first = a.z >> 16;
-      const uint32_t xlo_c = a.w & kXM, xhi = (a.w >> kXB) & kXM, yrel = (a.w >> (2 * kXB)) & kYM, zhi = (a.w >> (2 * kXB + kYB)) & 31;
-      const uint32_t zlo = first >> 11;
-      if (border) atomicAdd(&rec[LR_BORDER], border);
-      atomicMax(&rec[LR_BOX + 0], xlo_c);
-      atomicMax(&rec[LR_BOX + 1], xhi + 1);
-      atomicMax(&rec[LR_BOX + 2], kYM - yrel);
-      atomicMax(&rec[LR_BOX + 3], yrel + 1);
-      atomicMax(&rec[LR_BOX + 4], 31 - zlo);
-      atomicMax(&rec[LR_BOX + 5], zhi + 1);
-      atomicMax(&rec[LR_FIRST], 0xFFFFFu - first);
-    } else {
-#pragma unroll
-      for (int k = 0; k < GLIA_HMT_MAX_THRESH; ++k) {
-        uint32_t h = (a.w >> (8 * k)) & 0xFF;
-        if (h) atomicAdd(&rec[LP_THR + k], h);
-      }
-    }
+    atomicOr((unsigned long long*)&rec[LR_XMASK], 1ull << rx);
+    atomicOr((unsigned long long*)&rec[LR_YMASK], (unsigned long long)(1u << ry) | ((unsigned long long)zmask << 32));
+    atomicMax(&rec[LR_FIRST], 0xFFFFFu - ((zs << 11) | (meta & 0x7FFu)));
     return;
   }
   // LDS table saturated (tile with very many tiny supervoxels): straight to the global tables (slow, exact).  The host
   // watches the count and gives the next pass shallower tiles.
+  const TableParams& p = s.tp;
   atomicAdd(&p.flags[7], 1u);
-  if (isRegion) {
-    int g = global_region_slot(p, a.x);
-    if (g < 0) return;
-    uint32_t* r = &p.rrec[(size_t)g * kRegionWords];
-    const uint32_t border = (a.z >> 8) & 0xFF, first = a.z >> 16;
-    const uint32_t xlo = kXM - (a.w & kXM), xhi = (a.w >> kXB) & kXM, yrel = (a.w >> (2 * kXB)) & kYM, zhi = (a.w >> (2 * kXB + kYB)) & 31;
-    const uint32_t zlo = first >> 11, fy = (first >> kXB) & kYM, fx = first & kXM;
-    atomicAdd(&r[R_CNT], cnt);
-    if (border) atomicAdd(&r[R_BORDER], border);
-    atomicAdd((double*)&r[R_SUM], sum); atomicAdd((double*)&r[R_SQ], sq);
-    atomicMax(&r[R_MIN], omin); atomicMax(&r[R_MAX], omax);
-    atomicMax(&r[R_LO + 0], 0x7fffffffu - (uint32_t)(t.x0 + xlo)); atomicMax(&r[R_HI + 0], (uint32_t)(t.x0 + xhi) + 1u);
-    atomicMax(&r[R_LO + 1], 0x7fffffffu - (uint32_t)(t.y0 + yrel)); atomicMax(&r[R_HI + 1], (uint32_t)(t.y0 + yrel) + 1u);
-    atomicMax(&r[R_LO + 2], 0x7fffffffu - (uint32_t)(t.z0 + zlo)); atomicMax(&r[R_HI + 2], (uint32_t)(t.z0 + zhi) + 1u);
-    unsigned long long fidx = (unsigned long long)((t.z0 + zlo) * p.ny * p.nx + (t.y0 + fy) * p.nx + (t.x0 + fx));
-    atomicMax((unsigned long long*)&r[R_FIRST], ~fidx);
+  const int g = global_region_slot(p, a.x);
+  if (g < 0) return;
+  uint32_t* r = &p.rrec[(size_t)g * kRegionWords];
+  atomicAdd(&r[R_CNT], rcnt);
+  if (border) atomicAdd(&r[R_BORDER], border);
+  atomicAdd((double*)&r[R_SUM], sum); atomicAdd((double*)&r[R_SQ], sq);
+  atomicMax(&r[R_MIN], omin); atomicMax(&r[R_MAX], omax);
+  const uint32_t gx = (uint32_t)p.x0 + rx, gy = (uint32_t)p.y0 + ry;
+  atomicMax(&r[R_LO + 0], 0x7fffffffu - gx); atomicMax(&r[R_HI + 0], gx + 1u);
+  atomicMax(&r[R_LO + 1], 0x7fffffffu - gy); atomicMax(&r[R_HI + 1], gy + 1u);
+  atomicMax(&r[R_LO + 2], 0x7fffffffu - ((uint32_t)p.z0 + zs)); atomicMax(&r[R_HI + 2], (uint32_t)p.z0 + zl + 1u);
+  const unsigned long long fidx = (unsigned long long)((p.z0 + zs) * p.ny * p.nx + (p.y0 + ry) * p.nx + (p.x0 + rx));
+  atomicMax((unsigned long long*)&r[R_FIRST], ~fidx);
 #pragma unroll
-    for (int k = 0; k < BINS; ++k) {
-      uint32_t w = (k < 4) ? c.z : (k < 8) ? c.w : (k < 12) ? d.x : d.y;
-      uint32_t h = (w >> ((k & 3) * 8)) & 0xFF;
-      if (h) atomicAdd(&r[R_HIST + k], h);
-    }
-  } else {
-    int g = global_pair_slot(p, key);
-    if (g < 0) return;
-    uint32_t* r = &p.prec[(size_t)g * kPairWords];
-    atomicAdd(&r[P_CNT], cnt);
-    atomicAdd((double*)&r[P_SUM], sum); atomicAdd((double*)&r[P_SQ], sq);
-    atomicMax(&r[P_MIN], omin); atomicMax(&r[P_MAX], omax);
-#pragma unroll
-    for (int k = 0; k < GLIA_HMT_MAX_THRESH; ++k) {
-      uint32_t h = (a.w >> (8 * k)) & 0xFF;
-      if (h) atomicAdd(&r[P_THR + k], h);
-    }
-#pragma unroll
-    for (int k = 0; k < BINS; ++k) {
-      uint32_t w = (k < 4) ? c.z : (k < 8) ? c.w : (k < 12) ? d.x : d.y;
-      uint32_t h = (w >> ((k & 3) * 8)) & 0xFF;
-      if (h) atomicAdd(&r[P_HIST + k], h);
-    }
+  for (int k = 0; k < BINS; ++k) {
+    const uint32_t h = hist_byte(c, d, k);
+    if (h) atomicAdd(&r[R_HIST + k], h);
   }
 }
 
+// One batch of finished PAIR runs
+template <int BINS>
+__device__ __forceinline__ void drain_pairs(Lds<BINS>& s, const uint32_t entryAddr, const bool act) {
+  using G = Geo<BINS>;
+  if (!act) return;
+  const lds_u4_ptr e = (lds_u4_ptr)(uintptr_t)entryAddr;
+  const u32x4 a = e[0], b = e[1], c = e[2];
+  u32x4 d = {0, 0, 0, 0};
+  if (BINS > 8) d = e[3];
+  const double sum = __hiloint2double((int)b.y, (int)b.x), sq = __hiloint2double((int)b.w, (int)b.z);
+  const uint32_t cmn = c.x, cmx = c.y;      // (__builtin_bit_cast of a vector ELEMENT reads element 0 whatever the index)
+  const uint32_t omin = ~float_ord(__builtin_bit_cast(float, cmn)), omax = float_ord(__builtin_bit_cast(float, cmx));
+  const unsigned long long key = ((unsigned long long)a.y << 32) | a.x;
+  int slot = lds_slot(s.pkey, G::kPairSlots, key);
+#ifdef GLIA_ACC_NOCONFLICT
+  if (slot >= 0) slot = (int)((entryAddr / 48u) % (uint32_t)G::kPairSlots);
+#endif
+  if (slot >= 0) {
+    uint32_t* rec = &s.prec[slot * Lds<BINS>::kPairWordsL];
+    atomicAdd(&rec[LP_CNT], a.z);
+    atomicAdd((unsigned long long*)&rec[LP_THR], widen4(a.w));
+    atomicAdd((double*)&rec[LP_SUM], sum);
+    atomicAdd((double*)&rec[LP_SQ], sq);
+    atomicMax(&rec[LP_MIN], omin);
+    atomicMax(&rec[LP_MAX], omax);
+    atomicAdd((unsigned long long*)&rec[LP_HIST], widen4(c.z));
+    atomicAdd((unsigned long long*)&rec[LP_HIST + 2], widen4(c.w));
+    if (BINS > 8) {
+      atomicAdd((unsigned long long*)&rec[LP_HIST + 4], widen4(d.x));
+      atomicAdd((unsigned long long*)&rec[LP_HIST + 6], widen4(d.y));
+    }
+    return;
+  }
+  const TableParams& p = s.tp;
+  atomicAdd(&p.flags[7], 1u);
+  const int g = global_pair_slot(p, key);
+  if (g < 0) return;
+  uint32_t* r = &p.prec[(size_t)g * kPairWords];
+  atomicAdd(&r[P_CNT], a.z);
+  atomicAdd((double*)&r[P_SUM], sum); atomicAdd((double*)&r[P_SQ], sq);
+  atomicMax(&r[P_MIN], omin); atomicMax(&r[P_MAX], omax);
+#pragma unroll
+  for (int k = 0; k < GLIA_HMT_MAX_THRESH; ++k) {
+    const uint32_t h = (a.w >> (8 * k)) & 0xFF;
+    if (h) atomicAdd(&r[P_THR + k], h);
+  }
+#pragma unroll
+  for (int k = 0; k < BINS; ++k) {
+    const uint32_t h = hist_byte(c, d, k);
+    if (h) atomicAdd(&r[P_HIST + k], h);
+  }
+}
+
+// a drainer wave: empties the rings of the marching waves d, d + kDrainers, d + 2 kDrainers until they are done.  A batch
+// gathers up to 64 entries of ONE kind from the three rings (lane = entry): full lanes, no region / pair divergence.
+template <int BINS, bool MASK>
+__device__ __forceinline__ void drainer_loop(Lds<BINS>& s, const int d, const int lane) {
+  using G = Geo<BINS>;
+  static_assert(G::kMarchers == 3 * G::kDrainers, "three marching waves per drainer");
+  constexpr uint32_t EB = G::kEntryWords * 4;
+  const int w0 = d, w1 = d + G::kDrainers, w2 = d + 2 * G::kDrainers;
+  const uint32_t bR0 = (uint32_t)(uintptr_t)s.ringR[w0], bR1 = (uint32_t)(uintptr_t)s.ringR[w1], bR2 = (uint32_t)(uintptr_t)s.ringR[w2];
+  const uint32_t bP0 = (uint32_t)(uintptr_t)s.ringP[w0], bP1 = (uint32_t)(uintptr_t)s.ringP[w1], bP2 = (uint32_t)(uintptr_t)s.ringP[w2];
+  uint32_t hR0 = 0, hR1 = 0, hR2 = 0, hP0 = 0, hP1 = 0, hP2 = 0;      // entries consumed (wave-uniform)
+  __builtin_amdgcn_s_setprio(3);     // the marching waves of this SIMD always have work: without priority the drainer starves
+#ifdef GLIA_HMT_PROFILE
+  unsigned long long pc[6] = {0, 0, 0, 0, 0, 0};     // region batches, entries, cycles; pair batches, entries, cycles
+  uint32_t polls = 0;
+  const unsigned long long tstart = __builtin_readcyclecounter();
+#define DPROF(x) x
+#else
+#define DPROF(x)
+#endif
+  for (;;) {
+    // states before tails: "done" is stored after the last entries
+    const uint32_t st0 = ctl_load(&s.ctl[w0][C_STATE]), st1 = ctl_load(&s.ctl[w1][C_STATE]), st2 = ctl_load(&s.ctl[w2][C_STATE]);
+    const bool urgent = (st0 | st1 | st2) != 0u;
+    bool any = false;
+    uint32_t left;
+    {
+      const uint32_t a0 = ctl_load(&s.ctl[w0][C_TAIL_R]) - hR0, a1 = ctl_load(&s.ctl[w1][C_TAIL_R]) - hR1, a2 = ctl_load(&s.ctl[w2][C_TAIL_R]) - hR2;
+      const uint32_t total = a0 + a1 + a2;
+      left = total;
+      if (total >= (uint32_t)kDrainAt || (urgent && total)) {
+        const uint32_t c0 = a0 < 64u ? a0 : 64u, c1 = a1 < 64u - c0 ? a1 : 64u - c0, c2 = a2 < 64u - c0 - c1 ? a2 : 64u - c0 - c1;
+        const uint32_t j = (uint32_t)lane;
+        const bool in0 = j < c0, in1 = j < c0 + c1;
+        const uint32_t base = in0 ? bR0 : in1 ? bR1 : bR2;
+        const uint32_t idx = in0 ? hR0 + j : in1 ? hR1 + (j - c0) : hR2 + (j - c0 - c1);
+        DPROF(const unsigned long long tq = __builtin_readcyclecounter();)
+        drain_regions<BINS, MASK>(s, base + (idx & (uint32_t)(kRingR - 1)) * EB, j < c0 + c1 + c2);
+        DPROF(asm volatile("s_waitcnt lgkmcnt(0)"); pc[0] += 1; pc[1] += c0 + c1 + c2; pc[2] += __builtin_readcyclecounter() - tq;)
+        hR0 += c0; hR1 += c1; hR2 += c2;
+        if (c0) ctl_store(&s.ctl[w0][C_HEAD_R], hR0);
+        if (c1) ctl_store(&s.ctl[w1][C_HEAD_R], hR1);
+        if (c2) ctl_store(&s.ctl[w2][C_HEAD_R], hR2);
+        left = total - (c0 + c1 + c2);
+        any = true;
+      }
+    }
+    {
+      const uint32_t a0 = ctl_load(&s.ctl[w0][C_TAIL_P]) - hP0, a1 = ctl_load(&s.ctl[w1][C_TAIL_P]) - hP1, a2 = ctl_load(&s.ctl[w2][C_TAIL_P]) - hP2;
+      const uint32_t total = a0 + a1 + a2;
+      left += total;
+      if (total >= (uint32_t)kDrainAt || (urgent && total)) {
+        const uint32_t c0 = a0 < 64u ? a0 : 64u, c1 = a1 < 64u - c0 ? a1 : 64u - c0, c2 = a2 < 64u - c0 - c1 ? a2 : 64u - c0 - c1;
+        const uint32_t j = (uint32_t)lane;
+        const bool in0 = j < c0, in1 = j < c0 + c1;
+        const uint32_t base = in0 ? bP0 : in1 ? bP1 : bP2;
+        const uint32_t idx = in0 ? hP0 + j : in1 ? hP1 + (j - c0) : hP2 + (j - c0 - c1);
+        DPROF(const unsigned long long tq = __builtin_readcyclecounter();)
+        drain_pairs<BINS>(s, base + (idx & (uint32_t)(kRingP - 1)) * EB, j < c0 + c1 + c2);
+        DPROF(asm volatile("s_waitcnt lgkmcnt(0)"); pc[3] += 1; pc[4] += c0 + c1 + c2; pc[5] += __builtin_readcyclecounter() - tq;)
+        hP0 += c0; hP1 += c1; hP2 += c2;
+        if (c0) ctl_store(&s.ctl[w0][C_HEAD_P], hP0);
+        if (c1) ctl_store(&s.ctl[w1][C_HEAD_P], hP1);
+        if (c2) ctl_store(&s.ctl[w2][C_HEAD_P], hP2);
+        left -= c0 + c1 + c2;
+        any = true;
+      }
+    }
+    if (st0 == kRingDone && st1 == kRingDone && st2 == kRingDone && left == 0u) break;
+    DPROF(polls += any ? 0u : 1u;)
+    if (!any) __builtin_amdgcn_s_sleep(2);
+  }
+#ifdef GLIA_HMT_PROFILE
+  if (lane == 0) {
+    unsigned long long* g = reinterpret_cast<unsigned long long*>(s.tp.flags + 16);
+    for (int k = 0; k < 6; ++k) atomicAdd(&g[k], pc[k]);
+    atomicAdd(&g[6], (unsigned long long)polls);
+    atomicAdd(&g[7], __builtin_readcyclecounter() - tstart);
+  }
+#endif
+}
+
+struct Tile { int64_t x0, y0, z0; };
+
 // per-lane run accumulators (registers)
+template <int BINS>
 struct Run {
-  uint32_t klo, khi;        // key; klo == 0 -> empty
-  uint32_t cnt;             // voxels
-  uint32_t aux;             // region: border count; pair: 4 x 8-bit threshold counters
+  uint32_t k0, k1;              // region: label, -      pair: own label a, neighbour label b
+  uint32_t pos;                 // region: x | y<<6 | zfirst<<11 (tile-relative)
+  uint32_t cnt;                 // region: voxels (kept only with a mask)   pair: voxels
+  uint32_t aux;                 // region: border voxels                    pair: 4 x 8-bit threshold counters
+  uint32_t last;                // region, with a mask: plane of the most recent voxel
   double sum, sq;
-  uint32_t omin, omax;      // order-preserving uint images of the float min / max
-  uint32_t h0, h1, h2, h3;  // 8-bit packed histogram counters
-  uint32_t first;           // region: tile-relative index of the first voxel
-  uint32_t last;            // region: tile-relative index of the most recent voxel (its plane = zhi)
-  uint32_t xbox;            // region: (63-xlo) | xhi << 16, packed-max
+  float mn, mx;
+  unsigned long long h[BINS / 8];   // 8-bit packed histogram counters (a run has at most 32 voxels)
 };
 
-struct U4 { uint32_t v[4]; };
-struct F4 { float v[4]; };
-typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
+// x-1 / x+1 labels of a row held one voxel per lane: DPP shifts over the whole wave; the lane without a source keeps `edge`
+__device__ __forceinline__ uint32_t from_left(uint32_t edge, uint32_t v) { return __builtin_amdgcn_update_dpp(edge, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t from_right(uint32_t edge, uint32_t v) { return __builtin_amdgcn_update_dpp(edge, v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
 
-template <int BINS, bool VEC, bool MASK>
-__global__ __launch_bounds__(kThreads, 2) void rag_accumulate_kernel(const AccParams p) {
+// float min / max as the bare instructions (fminf / fmaxf canonicalise both operands first: three instructions each)
+__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// rows are fetched with buffer loads: a wave-uniform base (resource, scalar registers) + a wave-uniform byte offset (scalar) + the
+// lane's constant byte offset -- no per-lane address arithmetic at all
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)0xFFFFFFFF, 0x00020000);
+}
+__device__ __forceinline__ uint32_t bload(rsrc_t r, uint32_t voff, uint32_t soff) { return __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0); }
+template <int BINS, bool MASK>
+__global__ __launch_bounds__(Geo<BINS>::kThreadsT) void rag_accumulate_kernel(const AccParams p) {
+  using G = Geo<BINS>;
   __shared__ __attribute__((aligned(16))) Lds<BINS> s;
-  constexpr int EW = Lds<BINS>::kEntryWords;
+  constexpr int EW = G::kEntryWords;
+  constexpr int kThreadsT = G::kThreadsT;
   const int tid = threadIdx.x;
   {
     uint4* w = reinterpret_cast<uint4*>(&s);
     const uint4 z4 = {0, 0, 0, 0};
     // keys + records only; the rings need no initialisation
     constexpr int n16 = (int)((sizeof(s.rkey) + sizeof(s.pkey) + sizeof(s.rrec) + sizeof(s.prec)) / 16);
-    for (int i = tid; i < n16; i += kThreads) w[i] = z4;
+    for (int i = tid; i < n16; i += kThreadsT) w[i] = z4;
+    if (tid < G::kMarchers * 8) (&s.ctl[0][0])[tid] = 0u;
   }
-  __syncthreads();
 
   // tile coordinates: blocks that share blockIdx % 8 share an XCD (L2); give each XCD a contiguous
   // run of tiles so y/z halo rows of neighbouring tiles are served by the same L2.
@@ -276,22 +436,22 @@ __global__ __launch_bounds__(kThreads, 2) void rag_accumulate_kernel(const AccPa
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
   }
   const int bx = bid % p.nbx, by = (bid / p.nbx) % p.nby, bz = bid / (p.nbx * p.nby);
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // the wave index as a scalar
   const int64_t nx = p.nx, ny = p.ny, nz = p.nz;
   Tile tile;
   tile.x0 = (int64_t)bx * kTileX; tile.y0 = (int64_t)by * kTileY; tile.z0 = p.zb + (int64_t)bz * p.tz;
-  const int xrel0 = (lane % kLanesPerRow) * kVX;
-  const int yrel = wave * kRowsPerWave + (lane / kLanesPerRow);
-  const int64_t x0 = tile.x0 + xrel0;
-  const int64_t y = tile.y0 + yrel;
+  const int64_t x = tile.x0 + lane;
   const int64_t z1 = (tile.z0 + p.tz < p.ze) ? tile.z0 + p.tz : p.ze;
+  const int n = (int)(z1 - tile.z0);            // planes of this tile
   const int64_t gz0 = p.gz0, gnz = p.gnz;
-  const bool rowOk = (y < ny) && (x0 < nx);
-  const int64_t sy = nx, sz = nx * ny;
+  const int64_t sz = nx * ny;
   const bool is3d = p.dim == 3;
   const int nfull = 2 * p.dim;
-  uint32_t* ring = s.ring[wave];
-  int ringCount = 0;   // wave-uniform
+  const bool marcher = wave < G::kMarchers;
+  uint32_t* ctl = s.ctl[marcher ? wave : 0];
+  // LDS byte addresses of the wave's rings (the low half of the generic pointers)
+  const uint32_t ringAddrR = (uint32_t)(uintptr_t)s.ringR[marcher ? wave : 0], ringAddrP = (uint32_t)(uintptr_t)s.ringP[marcher ? wave : 0];
+  uint32_t tailR = 0, seenR = 0, tailP = 0, seenP = 0;     // wave-uniform: entries written / entries known to be consumed
 #ifdef GLIA_HMT_PROFILE
   const uint32_t dbg = p.debug;       // ablation switches (GLIA_HMT_DEBUG), profiling builds only
 #else
@@ -306,305 +466,355 @@ __global__ __launch_bounds__(kThreads, 2) void rag_accumulate_kernel(const AccPa
   }
   __syncthreads();
 
-  auto loadLabFrom = [&](const uint32_t* base, int64_t yy, int64_t zz, bool ok) __attribute__((always_inline)) -> U4 {
-    U4 r;
-    r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0;
-    if (ok && rowOk) {
-      const uint32_t* q = base + zz * sz + yy * sy + x0;
-      if (VEC) {
-        uint4 t = *reinterpret_cast<const uint4*>(q);
-        r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
-      } else {
-#pragma unroll
-        for (int i = 0; i < kVX; ++i) if (x0 + i < nx) r.v[i] = q[i];
-      }
-    }
-    return r;
-  };
-  auto loadLab = [&](int64_t yy, int64_t zz, bool ok) __attribute__((always_inline)) -> U4 { return loadLabFrom(p.lab, yy, zz, ok); };
   const bool sepCentre = MASK && p.lab_c != p.lab;     // contour-only mode: the centre keeps its label under the mask
-  auto loadImg = [&](int64_t yy, int64_t zz) __attribute__((always_inline)) -> F4 {
-    F4 r;
-    r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0.f;
-    if (rowOk) {
-      const float* q = p.img + zz * sz + yy * sy + x0;
-      if (VEC) {
-        float4 t = *reinterpret_cast<const float4*>(q);
-        r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
-      } else {
-#pragma unroll
-        for (int i = 0; i < kVX; ++i) if (x0 + i < nx) r.v[i] = q[i];
-      }
-    }
-    return r;
-  };
 
-  Run rr, pr;
-  rr.klo = rr.khi = 0; rr.cnt = 0; rr.aux = 0; rr.sum = 0.0; rr.sq = 0.0; rr.omin = 0xFFFFFFFFu; rr.omax = 0;
-  rr.h0 = rr.h1 = rr.h2 = rr.h3 = 0; rr.first = 0; rr.last = 0; rr.xbox = 0;
-  pr = rr;
-
-  // append finished runs of the lanes in `ev` to the wave's ring (draining it first when it cannot take them)
-  auto enqueue = [&](bool ev, const Run& r, bool isRegion) __attribute__((always_inline)) {
-    const unsigned long long m = __ballot(ev);
-    if (m == 0) return;
-    const int n = __popcll(m);
-    if (ringCount + n > kRingEntries) {
-      drain_ring<BINS>(s, ring, ringCount, lane);
-      ringCount = 0;
-    }
-    if (ev) {
-      const int pos = ringCount + (int)__popcll(m & ((1ull << lane) - 1ull));
-      uint4* e = reinterpret_cast<uint4*>(ring + pos * EW);
-      uint4 a, b, c;
-      a.x = r.klo; a.y = r.khi;
-      if (isRegion) {
-        a.z = r.cnt | (r.aux << 8) | (r.first << 16);
-        a.w = (r.xbox & kXM) | ((r.xbox >> 16) << kXB) | ((uint32_t)yrel << (2 * kXB)) | ((r.last >> 11) << (2 * kXB + kYB));
-      } else { a.z = r.cnt; a.w = r.aux; }
-      b.x = (uint32_t)__double2loint(r.sum); b.y = (uint32_t)__double2hiint(r.sum);
-      b.z = (uint32_t)__double2loint(r.sq); b.w = (uint32_t)__double2hiint(r.sq);
-      c.x = r.omin; c.y = r.omax; c.z = r.h0; c.w = r.h1;
-      e[0] = a; e[1] = b; e[2] = c;
-      if (BINS > 8) { uint4 d; d.x = r.h2; d.y = r.h3; d.z = 0; d.w = 0; e[3] = d; }
-    }
-    ringCount += n;
-  };
-
-  // thresholds to registers
+  // thresholds: wave-uniform, kept in vector registers (scalar registers are the scarcer kind in the march)
   float fb[BINS];
 #pragma unroll
-  for (int k = 0; k < BINS; ++k) fb[k] = p.hist.fb[k];
-  const float lo_f = p.hist.lo_f, hi_f = p.hist.hi_f;
+  for (int k = 0; k < BINS; ++k) { fb[k] = p.hist.fb[k]; asm volatile("" : "+v"(fb[k])); }
+  float lo_f = p.hist.lo_f, hi_f = p.hist.hi_f;
+  asm volatile("" : "+v"(lo_f), "+v"(hi_f));
   const int nbins = p.hist.bins;
-  const float t0 = p.thr_f[0], t1 = p.thr_f[1], t2 = p.thr_f[2], t3 = p.thr_f[3];   // +inf beyond nthr
+  float t0 = p.thr_f[0], t1 = p.thr_f[1], t2 = p.thr_f[2], t3 = p.thr_f[3];   // +inf beyond nthr
+  asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
 
-  // one voxel: neighbour rule, run bookkeeping, accumulation
-  // INNER (a workgroup-uniform compile-time tag): the tile and its one-voxel halo lie inside the volume and there is no mask,
-  // so every voxel is valid, every neighbour exists and no voxel is a border voxel -- the validity logic (six flags, their
-  // count, the border test) folds away: ~25 of ~220 vector instructions per voxel.
-  auto voxel = [&](auto INNER_T, auto I, const U4& Lp, const U4& Lc, const U4& Cc, const U4& Ln, const U4& Up, const U4& Dn, const F4& V,
-                   uint32_t left, uint32_t right, int zrel, bool zmv, bool zpv, bool ymv, bool ypv)
-                   __attribute__((always_inline)) {
-    constexpr int i = decltype(I)::value;
-    constexpr bool INNER = decltype(INNER_T)::value;
-    const int64_t x = x0 + i;
-    const uint32_t L = MASK ? Cc.v[i] : Lc.v[i];
-    const bool ok = INNER || (rowOk && (VEC || x < nx) && !(dbg & 4) && (!MASK || L != kMaskedLabel));
-    const uint32_t xm = (i == 0) ? left : Lc.v[i > 0 ? i - 1 : 0];
-    const uint32_t xp = (i == kVX - 1) ? right : Lc.v[i < kVX - 1 ? i + 1 : kVX - 1];
-    bool xmv = INNER || x > 0, xpv = INNER || x + 1 < nx;
-    if (INNER) { zmv = zpv = ymv = ypv = true; }
-    if (MASK) {
-      xmv = xmv && xm != kMaskedLabel; xpv = xpv && xp != kMaskedLabel;
-      ymv = ymv && Up.v[i] != kMaskedLabel; ypv = ypv && Dn.v[i] != kMaskedLabel;
-      zmv = zmv && Lp.v[i] != kMaskedLabel; zpv = zpv && Ln.v[i] != kMaskedLabel;
-    }
-    uint32_t b = L;
-    b = (zpv && Ln.v[i] != L) ? Ln.v[i] : b;
-    b = (zmv && Lp.v[i] != L) ? Lp.v[i] : b;
-    b = (ypv && Dn.v[i] != L) ? Dn.v[i] : b;
-    b = (ymv && Up.v[i] != L) ? Up.v[i] : b;
-    b = (xpv && xp != L) ? xp : b;
-    b = (xmv && xm != L) ? xm : b;
-    const int nvalid = INNER ? 0 : (int)xmv + (int)xpv + (int)ymv + (int)ypv + (int)zmv + (int)zpv;
-    const bool boundary = ok && (b != L);
-    const bool border = !INNER && ok && !boundary && nvalid < nfull;
-    const float v = V.v[i];
-    // reference bin rule (util/image_stats.hxx:24-35) with float-exact thresholds
-    int c = 0;
+  Run<BINS> rr;
+  rr.k0 = rr.k1 = 0u; rr.pos = 0u; rr.cnt = 0u; rr.aux = 0u; rr.last = 0u; rr.sum = 0.0; rr.sq = 0.0; rr.mn = 0.f; rr.mx = 0.f;
 #pragma unroll
-    for (int k = 0; k < BINS; ++k) c += (v >= fb[k]) ? 1 : 0;
-    const bool inside = (v > lo_f) && (v < hi_f);
-    const int bin = inside ? c : ((v <= lo_f) ? 0 : nbins - 1);
-    const bool drop = inside && c >= nbins;
-    const uint32_t hinc = drop ? 0u : (1u << ((bin & 3) * 8));
-    const int hw = bin >> 2;
-    const double dv = (double)v;
-    const double dv2 = dv * dv;                       // exact: 24-bit x 24-bit significands
-    const uint32_t ov = float_ord(v);
+  for (int k = 0; k < BINS / 8; ++k) rr.h[k] = 0ull;
+  Run<BINS> pr = rr;
+  bool rhas = false, phas = false;     // the lane holds an unfinished region / pair run
 
-    // ---- region run ----
-    {
-      const uint32_t rkey = L + 1u;
-      const bool fresh = ok && (rkey != rr.klo);
-      const bool ev = fresh && rr.klo != 0;
-      if (!(dbg & 1)) enqueue(ev, rr, true);
-      const uint32_t xr = (uint32_t)(xrel0 + i);
-      const uint32_t rel = ((uint32_t)zrel << 11) | ((uint32_t)yrel << kXB) | xr;
-      const uint32_t xb = (kXM - xr) | (xr << 16);
-      if (fresh) {
-        rr.klo = rkey; rr.cnt = 0; rr.aux = 0; rr.sum = 0.0; rr.sq = 0.0; rr.omin = 0xFFFFFFFFu; rr.omax = 0;
-        rr.h0 = rr.h1 = rr.h2 = rr.h3 = 0; rr.first = rel; rr.xbox = xb;
-      }
-      if (ok) {
-        rr.cnt += 1; rr.aux += border ? 1u : 0u;
-        rr.sum += dv; rr.sq += dv2;
-        rr.omin = min(rr.omin, ov); rr.omax = max(rr.omax, ov);
-        rr.h0 += (hw == 0) ? hinc : 0u; rr.h1 += (hw == 1) ? hinc : 0u;
-        if (BINS > 8) { rr.h2 += (hw == 2) ? hinc : 0u; rr.h3 += (hw == 3) ? hinc : 0u; }
-        rr.first = min(rr.first, rel); rr.last = rel;
-        rr.xbox = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(ushort2_t, rr.xbox),
-                                                                        __builtin_bit_cast(ushort2_t, xb)));
+  auto put = [&](const uint32_t entryAddr, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, const Run<BINS>& r) __attribute__((always_inline)) {
+    lds_u4_ptr e = (lds_u4_ptr)(uintptr_t)entryAddr;
+    u32x4 a, b, c;
+    a.x = w0; a.y = w1; a.z = w2; a.w = w3;
+    b.x = (uint32_t)__double2loint(r.sum); b.y = (uint32_t)__double2hiint(r.sum);
+    b.z = (uint32_t)__double2loint(r.sq); b.w = (uint32_t)__double2hiint(r.sq);
+    c.x = __builtin_bit_cast(uint32_t, r.mn); c.y = __builtin_bit_cast(uint32_t, r.mx);
+    c.z = (uint32_t)r.h[0]; c.w = (uint32_t)(r.h[0] >> 32);
+    e[0] = a; e[1] = b; e[2] = c;
+    if (BINS > 8) { u32x4 d; d.x = (uint32_t)r.h[BINS / 8 - 1]; d.y = (uint32_t)(r.h[BINS / 8 - 1] >> 32); d.z = 0; d.w = 0; e[3] = d; }
+  };
+  // room for n more entries in a ring of the wave (waits for its drainer when there is none)
+  auto reserve = [&](const uint32_t tail, uint32_t& seen, const int n, const int cap, const int headWord) __attribute__((always_inline)) {
+#ifdef GLIA_ACC_NODRAIN
+    return;
+#endif
+    if (__builtin_expect(tail - seen + (uint32_t)n > (uint32_t)cap, 0)) {
+      seen = ctl_load(&ctl[headWord]);
+      if (tail - seen + (uint32_t)n > (uint32_t)cap) {
+        ctl_store(&ctl[C_STATE], kRingWaiting);
+        do {
+          __builtin_amdgcn_s_sleep(1);
+          seen = ctl_load(&ctl[headWord]);
+        } while (tail - seen + (uint32_t)n > (uint32_t)cap);
+        ctl_store(&ctl[C_STATE], 0u);
       }
     }
-    // ---- directed pair run ----
+  };
+  // append the finished runs of the lanes in evR / evP to the wave's rings.
+  // zlast: plane of the last voxel of a finished region run (wave-uniform without a mask)
+  auto enqueue = [&](bool evR, bool evP, uint32_t zlast) __attribute__((always_inline)) {
+    const unsigned long long mR = __ballot(evR), mP = __ballot(evP);
+    const int nR = __popcll(mR), nP = __popcll(mP);
+    if (nR) {
+      const uint32_t zl = MASK ? rr.last : zlast;
+      const uint32_t rmeta = rr.pos | (zl << 16) | (rr.aux << 21);
+      reserve(tailR, seenR, nR, kRingR, C_HEAD_R);
+      if (evR) put(ringAddrR + ((tailR + lanes_below(mR)) & (uint32_t)(kRingR - 1)) * (uint32_t)(EW * 4), rr.k0 + 1u, 0u, rmeta, rr.cnt, rr);
+      tailR += (uint32_t)nR;
+      ctl_store(&ctl[C_TAIL_R], tailR);
+    }
+    if (nP) {
+      const uint32_t rank = lanes_below(mP);
+      if (__builtin_expect(nP > kRingP, 0)) {      // more finished pair runs in one plane than their ring holds: two batches
+        reserve(tailP, seenP, kRingP, kRingP, C_HEAD_P);
+        if (evP && rank < (uint32_t)kRingP)
+          put(ringAddrP + ((tailP + rank) & (uint32_t)(kRingP - 1)) * (uint32_t)(EW * 4), pr.k1 + 1u, pr.k0 + 1u, pr.cnt, pr.aux, pr);
+        tailP += (uint32_t)kRingP;
+        ctl_store(&ctl[C_TAIL_P], tailP);
+        reserve(tailP, seenP, nP - kRingP, kRingP, C_HEAD_P);
+        if (evP && rank >= (uint32_t)kRingP)
+          put(ringAddrP + ((tailP + rank - (uint32_t)kRingP) & (uint32_t)(kRingP - 1)) * (uint32_t)(EW * 4), pr.k1 + 1u, pr.k0 + 1u, pr.cnt, pr.aux, pr);
+        tailP += (uint32_t)(nP - kRingP);
+        ctl_store(&ctl[C_TAIL_P], tailP);
+      } else {
+        reserve(tailP, seenP, nP, kRingP, C_HEAD_P);
+        if (evP) put(ringAddrP + ((tailP + rank) & (uint32_t)(kRingP - 1)) * (uint32_t)(EW * 4), pr.k1 + 1u, pr.k0 + 1u, pr.cnt, pr.aux, pr);
+        tailP += (uint32_t)nP;
+        ctl_store(&ctl[C_TAIL_P], tailP);
+      }
+    }
+  };
+
+  // INNER (a workgroup-uniform compile-time tag): the tile and its one-voxel halo lie inside the volume and there is no mask,
+  // so every voxel is valid, every neighbour exists and no voxel is a border voxel -- the validity logic folds away.
+  const bool inner_tile = !MASK && is3d && dbg == 0 && tile.x0 > 0 && tile.x0 + kTileX < nx && tile.y0 > 0 && tile.y0 + kTileY < ny &&
+                          tile.z0 + gz0 > 0 && z1 + gz0 < gnz && tile.z0 > 0 && z1 < nz;
+
+  // one column: the row yrel of the tile, planes tile.z0 .. z1-1, one voxel per lane and plane
+  auto column = [&](auto INNER_T, const int yrel) __attribute__((always_inline)) {
+    constexpr bool INNER = decltype(INNER_T)::value;
+    const int64_t y = tile.y0 + yrel;
+    if (!INNER && y >= ny) return;                                  // wave-uniform
+    const bool laneOk = INNER || x < nx;
+    const bool ymv = INNER || y > 0, ypv = INNER || y + 1 < ny;    // wave-uniform
+    const bool xmv = INNER || x > 0, xpv = INNER || x + 1 < nx;
+    const int nv_lane = (int)xmv + (int)xpv;
+    // wave-uniform element offset of (x0-1, y-1, z0-1): every row the column needs lies at a non-negative offset from it
+    const int64_t rowoff = (tile.z0 * ny + y) * nx + tile.x0 - (sz + nx + 1);
+    const uint32_t szb = (uint32_t)sz * 4u, nxb = (uint32_t)nx * 4u;     // the host keeps 11 planes below 4 GiB
+    const uint32_t oc0 = szb + nxb + 4u;                                    // byte offset of (x0, y, plane 0 of the current base)
+    // per-lane byte offsets.  The halo load reads relative to x0-1: lane 0 fetches x0-1, lane 63 fetches x0+64, the others
+    // their own voxel again (the same cache lines).
+    const uint32_t lx4 = (uint32_t)lane * 4u;
+    uint32_t hx4 = (uint32_t)lane * 4u + 4u;
+    if (lane == 0 && xmv) hx4 = 0u;
+    if (lane == 63 && xpv) hx4 = 65u * 4u;
+    const uint32_t yx = ((uint32_t)yrel << 6) | (uint32_t)lane;
+
+    uint32_t bLn[kAhead], bUp[kAhead], bDn[kAhead], bH[kAhead], bC[kAhead];
+    float bV[kAhead];
+    // request the rows of plane index t; oc = byte offset of its centre row from the resources' base.  (oc passes through an
+    // empty asm so that the offsets of the five rows are formed from it with one scalar add each: left to itself the compiler
+    // hoists twenty loop-invariant offset constants into scalar registers it does not have.)
+    auto issue = [&](const int t, uint32_t oc, const rsrc_t rL, const rsrc_t rV, const rsrc_t rC, auto J) __attribute__((always_inline)) {
+      constexpr int j = decltype(J)::value;
+      asm volatile("" : "+s"(oc));
+      if (INNER) {
+        bLn[j] = bload(rL, lx4, oc + szb); bUp[j] = bload(rL, lx4, oc - nxb); bDn[j] = bload(rL, lx4, oc + nxb);
+        bH[j] = bload(rL, hx4, oc - 4u);
+        bV[j] = __builtin_bit_cast(float, bload(rV, lx4, oc));
+      } else {
+        bLn[j] = 0u; bUp[j] = 0u; bDn[j] = 0u; bH[j] = 0u; bV[j] = 0.f;
+        if (MASK) bC[j] = 0u;
+        if (laneOk) {
+          if (tile.z0 + t + 1 < nz) bLn[j] = bload(rL, lx4, oc + szb);
+          if (ymv) bUp[j] = bload(rL, lx4, oc - nxb);
+          if (ypv) bDn[j] = bload(rL, lx4, oc + nxb);
+          bH[j] = bload(rL, hx4, oc - 4u);
+          bV[j] = __builtin_bit_cast(float, bload(rV, lx4, oc));
+          if (MASK && sepCentre) bC[j] = bload(rC, lx4, oc);
+        }
+      }
+    };
+    uint32_t Lp = 0u, Lc = 0u;
     {
-      const uint32_t klo = b + 1u, khi = L + 1u;
-      const bool diff = boundary && (klo != pr.klo || khi != pr.khi);
-      const bool ev = diff && pr.klo != 0;
-      if (!(dbg & 2)) enqueue(ev, pr, false);
+      const rsrc_t rL = make_rsrc(p.lab + rowoff), rV = make_rsrc(p.img + rowoff), rC = make_rsrc(p.lab_c + rowoff);
+      if (laneOk) {
+        if (INNER || tile.z0 > 0) Lp = bload(rL, lx4, oc0 - szb);
+        Lc = bload(rL, lx4, oc0);
+      }
+      issue(0, oc0, rL, rV, rC, std::integral_constant<int, 0>{});
+      if (1 < n) issue(1, oc0 + szb, rL, rV, rC, std::integral_constant<int, 1>{});
+      if (2 < n) issue(2, oc0 + 2u * szb, rL, rV, rC, std::integral_constant<int, 2>{});
+      if (3 < n) issue(3, oc0 + 3u * szb, rL, rV, rC, std::integral_constant<int, 3>{});
+    }
+    if (INNER) {     // every voxel is valid: the region run of the column's first voxel starts here, `rhas` is constant
+      rr.k0 = Lc; rr.pos = yx; rr.cnt = 0; rr.aux = 0; rr.sum = 0.0; rr.sq = 0.0; rr.mn = __builtin_inff(); rr.mx = -__builtin_inff();
+#pragma unroll
+      for (int k = 0; k < BINS / 8; ++k) rr.h[k] = 0ull;
+      rhas = true;
+    }
+
+    // one voxel per lane: neighbour rule, run bookkeeping, accumulation
+    auto step = [&](const int t, const int tb, const rsrc_t rL, const rsrc_t rV, const rsrc_t rC, auto J) __attribute__((always_inline)) {
+      constexpr int j = decltype(J)::value;
+      const uint32_t Ln = bLn[j], Up = bUp[j], Dn = bDn[j], Hh = bH[j];
+      const float v = bV[j];
+      const uint32_t xm = from_left(Hh, Lc), xp = from_right(Hh, Lc);
+      const uint32_t L = (MASK && sepCentre) ? bC[j] : Lc;
+      const int64_t zg = tile.z0 + t + gz0;
+      bool zmv = INNER || (is3d && zg > 0), zpv = INNER || (is3d && zg + 1 < gnz);     // wave-uniform
+      bool vxm = xmv, vxp = xpv, vym = ymv, vyp = ypv;
+      const bool ok = INNER || (laneOk && !(dbg & 4) && (!MASK || L != kMaskedLabel));
+      int nvalid = 0;
+      if (MASK) {
+        vxm = vxm && xm != kMaskedLabel; vxp = vxp && xp != kMaskedLabel;
+        vym = vym && Up != kMaskedLabel; vyp = vyp && Dn != kMaskedLabel;
+        zmv = zmv && Lp != kMaskedLabel; zpv = zpv && Ln != kMaskedLabel;
+        nvalid = (int)vxm + (int)vxp + (int)vym + (int)vyp + (int)zmv + (int)zpv;
+      } else if (!INNER) {
+        nvalid = nv_lane + (int)ymv + (int)ypv + (int)zmv + (int)zpv;
+      }
+      uint32_t b = L;
+      b = ((INNER || zpv) && Ln != L) ? Ln : b;
+      b = ((INNER || zmv) && Lp != L) ? Lp : b;
+      b = ((INNER || vyp) && Dn != L) ? Dn : b;
+      b = ((INNER || vym) && Up != L) ? Up : b;
+      b = ((INNER || vxp) && xp != L) ? xp : b;
+      b = ((INNER || vxm) && xm != L) ? xm : b;
+      const bool boundary = ok && (b != L);
+      const bool border = !INNER && ok && !boundary && nvalid < nfull;
+      // reference bin rule (util/image_stats.hxx:24-35) with float-exact thresholds
+      int c = 0;
+#pragma unroll
+      for (int k = 0; k < BINS; ++k) c += (v >= fb[k]) ? 1 : 0;
+      const bool inside = (v > lo_f) && (v < hi_f);
+      const int edge = (v <= lo_f) ? 0 : nbins - 1;
+      const int bin = inside ? c : edge;
+      const bool keep = !inside || c < nbins;
+      const unsigned long long hinc = (unsigned long long)(keep ? 1u : 0u) << ((bin & 7) * 8);
+      const double dv = (double)v;
+
+      // ---- finished runs ----
+      const bool fresh = INNER ? (L != rr.k0) : (ok && (!rhas || L != rr.k0));
+      const bool diff = boundary && (!phas || b != pr.k1 || L != pr.k0);
+      enqueue((dbg & 1) ? false : (INNER ? fresh : (fresh && rhas)), (dbg & 2) ? false : (diff && phas), (uint32_t)(t - 1));
+      if (fresh) {
+        rr.k0 = L; rr.pos = ((uint32_t)t << 11) | yx; rr.cnt = 0; rr.aux = 0; rr.sum = 0.0; rr.sq = 0.0;
+        rr.mn = __builtin_inff(); rr.mx = -__builtin_inff();
+#pragma unroll
+        for (int k = 0; k < BINS / 8; ++k) rr.h[k] = 0ull;
+      }
+      if (!INNER) rhas = rhas || fresh;
       if (diff) {
-        pr.klo = klo; pr.khi = khi; pr.cnt = 0; pr.aux = 0; pr.sum = 0.0; pr.sq = 0.0; pr.omin = 0xFFFFFFFFu; pr.omax = 0;
-        pr.h0 = pr.h1 = pr.h2 = pr.h3 = 0;
+        pr.k0 = L; pr.k1 = b; pr.cnt = 0; pr.aux = 0; pr.sum = 0.0; pr.sq = 0.0;
+        pr.mn = __builtin_inff(); pr.mx = -__builtin_inff();
+#pragma unroll
+        for (int k = 0; k < BINS / 8; ++k) pr.h[k] = 0ull;
+      }
+      phas = phas || diff;
+      // ---- accumulation ----
+      if (ok) {
+        if (MASK) { rr.cnt += 1; rr.last = (uint32_t)t; }
+        if (!INNER) rr.aux += border ? 1u : 0u;
+        rr.sum += dv; rr.sq = __builtin_fma(dv, dv, rr.sq);         // dv*dv is exact (24-bit x 24-bit significands)
+        rr.mn = vmin(rr.mn, v); rr.mx = vmax(rr.mx, v);
+        if (BINS <= 8) rr.h[0] += hinc;
+        else { rr.h[0] += (bin < 8) ? hinc : 0ull; rr.h[BINS / 8 - 1] += (bin < 8) ? 0ull : hinc; }
       }
       if (boundary) {
         pr.cnt += 1;
         pr.aux += ((v >= t0) ? 1u : 0u) | ((v >= t1) ? 0x100u : 0u) | ((v >= t2) ? 0x10000u : 0u) | ((v >= t3) ? 0x1000000u : 0u);
-        pr.sum += dv; pr.sq += dv2;
-        pr.omin = min(pr.omin, ov); pr.omax = max(pr.omax, ov);
-        pr.h0 += (hw == 0) ? hinc : 0u; pr.h1 += (hw == 1) ? hinc : 0u;
-        if (BINS > 8) { pr.h2 += (hw == 2) ? hinc : 0u; pr.h3 += (hw == 3) ? hinc : 0u; }
+        pr.sum += dv; pr.sq = __builtin_fma(dv, dv, pr.sq);
+        pr.mn = vmin(pr.mn, v); pr.mx = vmax(pr.mx, v);
+        if (BINS <= 8) pr.h[0] += hinc;
+        else { pr.h[0] += (bin < 8) ? hinc : 0ull; pr.h[BINS / 8 - 1] += (bin < 8) ? 0ull : hinc; }
       }
+      Lp = Lc; Lc = Ln;
+      if (t + kAhead < n) issue(t + kAhead, oc0 + (uint32_t)(t + kAhead - tb) * szb, rL, rV, rC, J);
+    };
+
+    for (int tb = 0; tb < n; tb += kAhead) {
+      const int64_t off = rowoff + (int64_t)tb * sz;
+      const rsrc_t rL = make_rsrc(p.lab + off), rV = make_rsrc(p.img + off), rC = make_rsrc(p.lab_c + off);
+      step(tb, tb, rL, rV, rC, std::integral_constant<int, 0>{});
+      if (tb + 1 < n) step(tb + 1, tb, rL, rV, rC, std::integral_constant<int, 1>{});
+      if (tb + 2 < n) step(tb + 2, tb, rL, rV, rC, std::integral_constant<int, 2>{});
+      if (tb + 3 < n) step(tb + 3, tb, rL, rV, rC, std::integral_constant<int, 3>{});
     }
+    // the column ends: every lane hands in what it holds
+    enqueue((dbg & 1) ? false : rhas, (dbg & 2) ? false : phas, (uint32_t)(n - 1));
+    rhas = false; phas = false;
   };
 
-  // software pipeline: the rows of plane z+1 (and the centre row of z+2) are requested before plane z is
-  // processed -- with one workgroup per CU (8 waves) memory latency is not hidden by other waves alone
-  auto halo = [&](int64_t z, uint32_t& left, uint32_t& right) __attribute__((always_inline)) {
-    left = 0u; right = 0u;
-    if ((lane % kLanesPerRow) == 0) left = (rowOk && x0 > 0 && z < z1) ? p.lab[z * sz + y * sy + x0 - 1] : 0u;
-    if ((lane % kLanesPerRow) == kLanesPerRow - 1) right = (rowOk && x0 + kVX < nx && z < z1) ? p.lab[z * sz + y * sy + x0 + kVX] : 0u;
-  };
-  U4 Lp = loadLab(y, tile.z0 - 1, tile.z0 > 0);
-  U4 Lc = loadLab(y, tile.z0, true);
-  U4 Ln = loadLab(y, tile.z0 + 1, tile.z0 + 1 < nz);
-  U4 Up = loadLab(y - 1, tile.z0, y > 0);
-  U4 Dn = loadLab(y + 1, tile.z0, y + 1 < ny);
-  F4 V = loadImg(y, tile.z0);
-  uint32_t hl, hr;
-  halo(tile.z0, hl, hr);
-  // is this an inner tile?  (full tile, not masked, 3D, one voxel away from every face of the -- global -- volume)
-  const bool inner_tile = !MASK && VEC && is3d && dbg == 0 && tile.x0 > 0 && tile.x0 + kTileX < nx && tile.y0 > 0 && tile.y0 + kTileY < ny &&
-                          tile.z0 + gz0 > 0 && z1 + gz0 < gnz && tile.z0 > 0 && z1 < nz;
-  auto march = [&](auto INNER_T) __attribute__((always_inline)) {
-  for (int64_t z = tile.z0; z < z1; ++z) {
-    const int zrel = (int)(z - tile.z0);
-    // requests for the next plane
-    const bool more = z + 1 < z1;
-    U4 Ln2 = loadLab(y, z + 2, more && z + 2 < nz);
-    U4 Up2 = loadLab(y - 1, z + 1, more && y > 0);
-    U4 Dn2 = loadLab(y + 1, z + 1, more && y + 1 < ny);
-    F4 V2 = V;
-    if (more) V2 = loadImg(y, z + 1);
-    uint32_t hl2, hr2;
-    halo(more ? z + 1 : z1, hl2, hr2);
-    uint32_t left = __shfl_up(Lc.v[3], 1, kLanesPerRow);
-    uint32_t right = __shfl_down(Lc.v[0], 1, kLanesPerRow);
-    if ((lane % kLanesPerRow) == 0) left = hl;
-    if ((lane % kLanesPerRow) == kLanesPerRow - 1) right = hr;
-    const bool zmv = is3d && (z + gz0) > 0, zpv = is3d && (z + gz0) + 1 < gnz;
-    const bool ymv = y > 0, ypv = y + 1 < ny;
-    U4 Cc = Lc;
-    if (MASK && sepCentre) Cc = loadLabFrom(p.lab_c, y, z, true);
-    // a run lasts at most kTZ planes x 4 voxels = 128 voxels, so the 8-bit packed counters cannot overflow.
-    // Serpentine x order: a lane that straddles a wall changes key once per plane instead of twice.
-    if ((zrel & 1) == 0) {
-      voxel(INNER_T, std::integral_constant<int, 0>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
-      voxel(INNER_T, std::integral_constant<int, 1>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
-      voxel(INNER_T, std::integral_constant<int, 2>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
-      voxel(INNER_T, std::integral_constant<int, 3>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
+  if (!marcher) {
+#ifndef GLIA_ACC_NODRAIN
+    drainer_loop<BINS, MASK>(s, wave - G::kMarchers, lane);
+#endif
+  } else {
+    if (inner_tile) {
+#pragma unroll 1
+      for (int pass = 0; pass < G::kPasses; ++pass) column(std::true_type{}, wave + pass * G::kMarchers);
     } else {
-      voxel(INNER_T, std::integral_constant<int, 3>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
-      voxel(INNER_T, std::integral_constant<int, 2>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
-      voxel(INNER_T, std::integral_constant<int, 1>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
-      voxel(INNER_T, std::integral_constant<int, 0>{}, Lp, Lc, Cc, Ln, Up, Dn, V, left, right, zrel, zmv, zpv, ymv, ypv);
+#pragma unroll 1
+      for (int pass = 0; pass < G::kPasses; ++pass) column(std::false_type{}, wave + pass * G::kMarchers);
     }
-    Lp = Lc; Lc = Ln; Ln = Ln2; Up = Up2; Dn = Dn2; V = V2; hl = hl2; hr = hr2;
-  }
-  };
-  if (inner_tile) march(std::true_type{}); else march(std::false_type{});
-  {
-    if (!(dbg & 1)) enqueue(rr.klo != 0, rr, true);
-    if (!(dbg & 2)) enqueue(pr.klo != 0, pr, false);
-    drain_ring<BINS>(s, ring, ringCount, lane);
+    ctl_store(&ctl[C_STATE], kRingDone);
   }
   __syncthreads();
   if (dbg & 8) return;
 
   // ---- fold the workgroup's LDS tables into the global tables ----
-  constexpr int kRegSlots = Lds<BINS>::kRegSlots, kPairSlots = Lds<BINS>::kPairSlots;
-  int* gslot = reinterpret_cast<int*>(&s.ring[0][0]);      // rings are idle now
-  static_assert(sizeof(s.ring) >= (kRegSlots + kPairSlots) * sizeof(int), "gslot does not fit in the rings");
-  for (int i = tid; i < kRegSlots + kPairSlots; i += kThreads) {
+  // (the table pointers come back from LDS: holding them in scalar registers through the march costs spills there)
+  const TableParams& gp = s.tp;
+  constexpr int kRegSlots = G::kRegSlots, kPairSlots = G::kPairSlots;
+  int* gslot = reinterpret_cast<int*>(&s.ringR[0][0]);      // rings are idle now
+  static_assert(sizeof(s.ringR) >= (kRegSlots + kPairSlots) * sizeof(int), "gslot does not fit in the rings");
+  for (int i = tid; i < kRegSlots + kPairSlots; i += kThreadsT) {
     int g = -1;
-    if (i < kRegSlots) { unsigned long long k = s.rkey[i]; if (k) g = global_region_slot(p, (uint32_t)k); }
-    else { unsigned long long k = s.pkey[i - kRegSlots]; if (k) g = global_pair_slot(p, k); }
+    if (i < kRegSlots) { unsigned long long k = s.rkey[i]; if (k) g = global_region_slot(gp, (uint32_t)k); }
+    else { unsigned long long k = s.pkey[i - kRegSlots]; if (k) g = global_pair_slot(gp, k); }
     gslot[i] = g;
   }
   __syncthreads();
   constexpr int RW = Lds<BINS>::kRegWords, PW = Lds<BINS>::kPairWordsL;
-  const uint32_t tx = (uint32_t)tile.x0, ty = (uint32_t)tile.y0, tz = (uint32_t)(tile.z0 + gz0);
-  for (int it = tid; it < kRegSlots * RW; it += kThreads) {
+  const uint32_t tx = (uint32_t)gp.x0, ty = (uint32_t)gp.y0, tz = (uint32_t)gp.z0;
+  uint32_t* const g_rrec = gp.rrec; uint32_t* const g_prec = gp.prec;
+  const int64_t fsy = gp.nx, fsz = gp.nx * gp.ny;
+  for (int it = tid; it < kRegSlots * RW; it += kThreadsT) {
     const int slot = it / RW, w = it % RW;
     const int g = gslot[slot];
     if (g < 0) continue;
-    uint32_t* dst = &p.rrec[(size_t)g * kRegionWords];
+    uint32_t* dst = &g_rrec[(size_t)g * kRegionWords];
     const uint32_t* src = &s.rrec[slot * RW];
     const uint32_t val = src[w];
     if (w == LR_SUM || w == LR_SQ) {
       double dd = *reinterpret_cast<const double*>(&src[w]);
       if (dd != 0.0) atomicAdd(reinterpret_cast<double*>(&dst[w == LR_SUM ? R_SUM : R_SQ]), dd);
-    } else if (w == LR_SUM + 1 || w == LR_SQ + 1 || w == 15) {
     } else if (w == LR_CNT) { atomicAdd(&dst[R_CNT], val); }
     else if (w == LR_BORDER) { if (val) atomicAdd(&dst[R_BORDER], val); }
-    else if (w == LR_BOX + 0) { atomicMax(&dst[R_LO + 0], 0x7fffffffu - (tx + (kXM - val))); }
-    else if (w == LR_BOX + 1) { atomicMax(&dst[R_HI + 0], tx + val); }
-    else if (w == LR_BOX + 2) { atomicMax(&dst[R_LO + 1], 0x7fffffffu - (ty + (kYM - val))); }
-    else if (w == LR_BOX + 3) { atomicMax(&dst[R_HI + 1], ty + val); }
-    else if (w == LR_BOX + 4) { atomicMax(&dst[R_LO + 2], 0x7fffffffu - (tz + (31u - val))); }
-    else if (w == LR_BOX + 5) { atomicMax(&dst[R_HI + 2], tz + val); }
-    else if (w == LR_MIN) { atomicMax(&dst[R_MIN], val); }
+    else if (w == LR_XMASK) {
+      const unsigned long long m = *reinterpret_cast<const unsigned long long*>(&src[LR_XMASK]);
+      atomicMax(&dst[R_LO + 0], 0x7fffffffu - (tx + (uint32_t)__builtin_ctzll(m)));
+      atomicMax(&dst[R_HI + 0], tx + 64u - (uint32_t)__builtin_clzll(m));
+    } else if (w == LR_YMASK) {
+      atomicMax(&dst[R_LO + 1], 0x7fffffffu - (ty + (uint32_t)__builtin_ctz(val)));
+      atomicMax(&dst[R_HI + 1], ty + 32u - (uint32_t)__builtin_clz(val));
+    } else if (w == LR_ZMASK) {
+      atomicMax(&dst[R_LO + 2], 0x7fffffffu - (tz + (uint32_t)__builtin_ctz(val)));
+      atomicMax(&dst[R_HI + 2], tz + 32u - (uint32_t)__builtin_clz(val));
+    } else if (w == LR_MIN) { atomicMax(&dst[R_MIN], val); }
     else if (w == LR_MAX) { atomicMax(&dst[R_MAX], val); }
     else if (w == LR_FIRST) {
       const uint32_t first = 0xFFFFFu - val;
-      const unsigned long long fidx = (unsigned long long)((tile.z0 + gz0 + (first >> 11)) * sz + (tile.y0 + ((first >> kXB) & kYM)) * sy +
-                                                           (tile.x0 + (first & kXM)));
+      const unsigned long long fidx = (unsigned long long)(((int64_t)tz + (first >> 11)) * fsz + ((int64_t)ty + ((first >> 6) & 31)) * fsy +
+                                                           ((int64_t)tx + (first & 63)));
       atomicMax(reinterpret_cast<unsigned long long*>(&dst[R_FIRST]), ~fidx);
-    } else if (w >= LR_HIST) { if (val) atomicAdd(&dst[R_HIST + (w - LR_HIST)], val); }
+    } else if (w >= LR_HIST) {     // two 16-bit counters
+      const int k = 2 * (w - LR_HIST);
+      if (val & 0xFFFFu) atomicAdd(&dst[R_HIST + k], val & 0xFFFFu);
+      if (val >> 16) atomicAdd(&dst[R_HIST + k + 1], val >> 16);
+    }
   }
-  for (int it = tid; it < kPairSlots * PW; it += kThreads) {
+  for (int it = tid; it < kPairSlots * PW; it += kThreadsT) {
     const int slot = it / PW, w = it % PW;
     const int g = gslot[kRegSlots + slot];
     if (g < 0) continue;
-    uint32_t* dst = &p.prec[(size_t)g * kPairWords];
+    uint32_t* dst = &g_prec[(size_t)g * kPairWords];
     const uint32_t* src = &s.prec[slot * PW];
     const uint32_t val = src[w];
     if (w == LP_SUM || w == LP_SQ) {
       double dd = *reinterpret_cast<const double*>(&src[w]);
       if (dd != 0.0) atomicAdd(reinterpret_cast<double*>(&dst[w == LP_SUM ? P_SUM : P_SQ]), dd);
-    } else if (w == LP_SUM + 1 || w == LP_SQ + 1 || w == 3) {
     } else if (w == LP_CNT) { atomicAdd(&dst[P_CNT], val); }
     else if (w == LP_MIN) { atomicMax(&dst[P_MIN], val); }
     else if (w == LP_MAX) { atomicMax(&dst[P_MAX], val); }
-    else if (w >= LP_THR && w < LP_THR + 4) { if (val) atomicAdd(&dst[P_THR + (w - LP_THR)], val); }
-    else if (w >= LP_HIST) { if (val) atomicAdd(&dst[P_HIST + (w - LP_HIST)], val); }
+    else if (w == LP_THR || w == LP_THR + 1) {
+      const int k = 2 * (w - LP_THR);
+      if (val & 0xFFFFu) atomicAdd(&dst[P_THR + k], val & 0xFFFFu);
+      if (val >> 16) atomicAdd(&dst[P_THR + k + 1], val >> 16);
+    } else if (w >= LP_HIST) {
+      const int k = 2 * (w - LP_HIST);
+      if (val & 0xFFFFu) atomicAdd(&dst[P_HIST + k], val & 0xFFFFu);
+      if (val >> 16) atomicAdd(&dst[P_HIST + k + 1], val >> 16);
+    }
   }
 }
 
 }  // namespace
 
-template <int BINS, bool VEC>
-static void launch_bv(const AccParams& p, uint32_t nb, hipStream_t stream) {
-  if (p.masked) hipLaunchKernelGGL((rag_accumulate_kernel<BINS, VEC, true>), dim3(nb), dim3(kThreads), 0, stream, p);
-  else hipLaunchKernelGGL((rag_accumulate_kernel<BINS, VEC, false>), dim3(nb), dim3(kThreads), 0, stream, p);
+template <int BINS>
+static void launch_b(const AccParams& p, uint32_t nb, hipStream_t stream) {
+  if (p.masked) hipLaunchKernelGGL((rag_accumulate_kernel<BINS, true>), dim3(nb), dim3(Geo<BINS>::kThreadsT), 0, stream, p);
+  else hipLaunchKernelGGL((rag_accumulate_kernel<BINS, false>), dim3(nb), dim3(Geo<BINS>::kThreadsT), 0, stream, p);
 }
 
 int launch_accumulate(const AccParams& p, hipStream_t stream) {
   const uint32_t nb = (uint32_t)p.nbx * p.nby * p.nbz;
-  const bool vec = (p.nx % kTileX) == 0;
-  if (p.hist.bins <= 8) { if (vec) launch_bv<8, true>(p, nb, stream); else launch_bv<8, false>(p, nb, stream); }
-  else { if (vec) launch_bv<16, true>(p, nb, stream); else launch_bv<16, false>(p, nb, stream); }
+  if (p.hist.bins <= 8) launch_b<8>(p, nb, stream); else launch_b<16>(p, nb, stream);
   GLIA_HIP_TRY(hipGetLastError());
   return GLIA_HMT_OK;
 }
