@@ -408,6 +408,8 @@ static int rag_build_impl(glia_hmt_ctx* c, int dim, const int64_t dims[3], int64
     p.flags = c->flags;
     { const char* dbg = getenv("GLIA_HMT_DEBUG"); p.debug = dbg ? (uint32_t)strtoul(dbg, nullptr, 0) : 0u; }
     if ((int64_t)p.nbx * p.nby * p.nbz >= (1ll << 31)) { glia_hmt_rag_free(rag); set_error("rag_build: volume too large"); return GLIA_HMT_ERR_ARG; }
+    // the pass addresses a column's rows with 32-bit byte offsets from a base that moves every four planes (rag_accumulate.hip)
+    if (nx * ny * 4 * 11 >= (1ll << 32)) { glia_hmt_rag_free(rag); set_error("rag_build: planes of more than 97 M voxels are not supported"); return GLIA_HMT_ERR_ARG; }
     hipError_t e = hipEventRecord(c->ev0, c->stream);
     if (e == hipSuccess) { rc = launch_accumulate(p, c->stream); e = hipEventRecord(c->ev1, c->stream); }
     if (e != hipSuccess) { glia_hmt_rag_free(rag); set_error(hipGetErrorString(e)); return GLIA_HMT_ERR_HIP; }

@@ -104,6 +104,65 @@ def test_rag_matches_oracle(ctx, shape, S, G, variant, bins):
     rm.close()
 
 
+def _check_against_oracle(rm, labels, pb, bins, thr):
+    ref = _oracle_rag(labels, pb, bins, 0.0, 1.0, thr)
+    reg, par = rm.regions(), rm.pairs()
+    assert (reg["label"] == ref["lab"]).all() and (reg["count"] == ref["npts"]).all() and (reg["border"] == ref["nborder"]).all()
+    assert (reg["lo"] == ref["lo"]).all() and (reg["hi"] == ref["hi"]).all()
+    assert (reg["min"] == ref["rmin"]).all() and (reg["max"] == ref["rmax"]).all()
+    assert (reg["sum"] == ref["rsum"]).all() and (reg["sumsq"] == ref["rsq"]).all()
+    assert (par["a"] == ref["a"]).all() and (par["b"] == ref["b"]).all() and (par["count"] == ref["n"]).all()
+    assert (par["min"] == ref["pmin"]).all() and (par["max"] == ref["pmax"]).all()
+    assert (par["sum"] == ref["psum"]).all() and (par["sumsq"] == ref["psq"]).all()
+    order = np.argsort(labels.ravel(), kind="stable")
+    starts = np.searchsorted(labels.ravel()[order], reg["label"])
+    assert (reg["first"] == order[starts]).all()
+    for i in range(0, len(reg["label"]), max(1, len(reg["label"]) // 40)):
+        assert (reg["hist"][i] == _np_hist(pb[labels == reg["label"][i]], bins, 0.0, 1.0)).all()
+    assert (reg["hist"].sum(1) == reg["count"]).all() and (par["hist"].sum(1) == par["count"]).all()
+
+
+def _cubes(nz, ny, nx, c, seed):
+    z, y, x = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    labels = (((z // c) * (ny // c) + (y // c)) * (nx // c) + (x // c) + 1).astype(np.uint32)
+    pb = (np.random.default_rng(seed).integers(0, 256, labels.shape) / 256.0).astype(np.float32)
+    return labels, pb
+
+
+def test_cubic_supervoxels_every_lane_ends_its_runs_in_the_same_plane(ctx):
+    """Walls perpendicular to the march: all 64 lanes of a wave finish a region run AND a pair run in one plane -- more entries
+    than a ring takes in one batch (the split hand-over of the pass)."""
+    torch = _torch()
+    from glia_amd import hmt
+    labels, pb = _cubes(48, 56, 128, 8, 5)
+    d_lab = torch.from_numpy(labels.view(np.int32)).cuda()
+    d_pb = torch.from_numpy(pb).cuda()
+    thr = (0.2, 0.5, 0.8)
+    cfg = hmt.make_config(d_pb, rb=[(d_pb, 8, 0.0, 1.0)], thresholds=thr)
+    rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, cfg=cfg)
+    _check_against_oracle(rm, labels, pb, 8, thr)
+    rm.close()
+
+
+def test_tiny_supervoxels_overflow_the_tile_tables():
+    """2 x 2 x 2 cells: thousands of regions per tile, far more than the workgroup's LDS tables hold -- the finished runs that find
+    them full go straight to the global tables, and the context answers with shallower tiles on the next build (own context: the
+    tile depth is remembered)."""
+    torch = _torch()
+    from glia_amd import hmt
+    own = hmt.Context(0)
+    labels, pb = _cubes(32, 48, 64, 2, 6)
+    d_lab = torch.from_numpy(labels.view(np.int32)).cuda()
+    d_pb = torch.from_numpy(pb).cuda()
+    thr = (0.2, 0.5, 0.8)
+    cfg = hmt.make_config(d_pb, rb=[(d_pb, 8, 0.0, 1.0)], thresholds=thr)
+    for _ in range(3):      # 32, then 16, then 8 planes per tile
+        rm = hmt.RegionMap(own, d_lab, pb=d_pb, cfg=cfg)
+        _check_against_oracle(rm, labels, pb, 8, thr)
+        rm.close()
+    own.close()
+
+
 @pytest.mark.parametrize("shape,S,G,variant,nslab", [((64, 40, 64), 8, 16, 0, 2), ((70, 36, 28), 6, 12, 1, 3),
                                                     ((33, 64, 128), 8, 32, 0, 4)])
 def test_slab_partials_merge_to_the_whole(ctx, shape, S, G, variant, nslab):
