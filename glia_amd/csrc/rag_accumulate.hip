@@ -328,7 +328,15 @@ __device__ __forceinline__ void drainer_loop(Lds<BINS>& s, const int d, const in
       const uint32_t total = a0 + a1 + a2;
       left = total;
       if (total >= (uint32_t)kDrainAt || (urgent && total)) {
-        const uint32_t c0 = a0 < 64u ? a0 : 64u, c1 = a1 < 64u - c0 ? a1 : 64u - c0, c2 = a2 < 64u - c0 - c1 ? a2 : 64u - c0 - c1;
+        // a balanced take: entries of one wave repeat few keys (LDS atomics on one address serialise), those of three waves
+        // rows apart do not
+        uint32_t c0 = a0 < 21u ? a0 : 21u, c1 = a1 < 21u ? a1 : 21u, c2 = a2 < 21u ? a2 : 21u;
+        {
+          uint32_t room = 64u - (c0 + c1 + c2);
+          const uint32_t e0 = a0 - c0 < room ? a0 - c0 : room; c0 += e0; room -= e0;
+          const uint32_t e1 = a1 - c1 < room ? a1 - c1 : room; c1 += e1; room -= e1;
+          const uint32_t e2 = a2 - c2 < room ? a2 - c2 : room; c2 += e2;
+        }
         const uint32_t j = (uint32_t)lane;
         const bool in0 = j < c0, in1 = j < c0 + c1;
         const uint32_t base = in0 ? bR0 : in1 ? bR1 : bR2;
@@ -349,7 +357,15 @@ __device__ __forceinline__ void drainer_loop(Lds<BINS>& s, const int d, const in
       const uint32_t total = a0 + a1 + a2;
       left += total;
       if (total >= (uint32_t)kDrainAt || (urgent && total)) {
-        const uint32_t c0 = a0 < 64u ? a0 : 64u, c1 = a1 < 64u - c0 ? a1 : 64u - c0, c2 = a2 < 64u - c0 - c1 ? a2 : 64u - c0 - c1;
+        // a balanced take: entries of one wave repeat few keys (LDS atomics on one address serialise), those of three waves
+        // rows apart do not
+        uint32_t c0 = a0 < 21u ? a0 : 21u, c1 = a1 < 21u ? a1 : 21u, c2 = a2 < 21u ? a2 : 21u;
+        {
+          uint32_t room = 64u - (c0 + c1 + c2);
+          const uint32_t e0 = a0 - c0 < room ? a0 - c0 : room; c0 += e0; room -= e0;
+          const uint32_t e1 = a1 - c1 < room ? a1 - c1 : room; c1 += e1; room -= e1;
+          const uint32_t e2 = a2 - c2 < room ? a2 - c2 : room; c2 += e2;
+        }
         const uint32_t j = (uint32_t)lane;
         const bool in0 = j < c0, in1 = j < c0 + c1;
         const uint32_t base = in0 ? bP0 : in1 ? bP1 : bP2;
@@ -697,9 +713,14 @@ __global__ __launch_bounds__(Geo<BINS>::kThreadsT) void rag_accumulate_kernel(co
       if (t + kAhead < n) issue(t + kAhead, oc0 + (uint32_t)(t + kAhead - tb) * szb, rL, rV, rC, J);
     };
 
+    const uint32_t* baseL = p.lab + rowoff; const float* baseV = p.img + rowoff; const uint32_t* baseC = p.lab_c + rowoff;
+    const int64_t stride4 = (int64_t)kAhead * sz;
     for (int tb = 0; tb < n; tb += kAhead) {
-      const int64_t off = rowoff + (int64_t)tb * sz;
-      const rsrc_t rL = make_rsrc(p.lab + off), rV = make_rsrc(p.img + off), rC = make_rsrc(p.lab_c + off);
+      // (through an empty asm: otherwise the 64-bit products that form the bases are recomputed in every plane)
+      asm volatile("" : "+s"(baseL), "+s"(baseV));
+      if (MASK) asm volatile("" : "+s"(baseC));
+      const rsrc_t rL = make_rsrc(baseL), rV = make_rsrc(baseV), rC = make_rsrc(baseC);
+      baseL += stride4; baseV += stride4; baseC += stride4;
       step(tb, tb, rL, rV, rC, std::integral_constant<int, 0>{});
       if (tb + 1 < n) step(tb + 1, tb, rL, rV, rC, std::integral_constant<int, 1>{});
       if (tb + 2 < n) step(tb + 2, tb, rL, rV, rC, std::integral_constant<int, 2>{});
