@@ -180,4 +180,49 @@ int pack_forest(const HostForest& hf, std::vector<PackedNode>* nodes, std::vecto
   return GLIA_HMT_OK;
 }
 
+// two levels per 64-byte line (forest.hpp): breadth-first over the nodes of even depth
+int pack_forest_pairs(const HostForest& hf, std::vector<PackedPair>* lines, std::vector<int>* roots) {
+  lines->clear();
+  roots->assign(hf.ntree, 0);
+  std::vector<int> queue;          // original node index of the line with the same position (relative to the tree's first line)
+  auto plain = [&](size_t base, int k) {
+    PackedNode n;
+    const int* m = &hf.meta[(base + k) * 4];
+    n.split = hf.split[base + k];
+    if (m[3] >= 0) { n.var = -1 - m[3]; n.left = 0; } else { n.var = m[0]; n.left = 0; }
+    return n;
+  };
+  for (int j = 0; j < hf.ntree; ++j) {
+    const size_t base = (size_t)j * hf.nrnodes;
+    const int first = (int)lines->size();
+    (*roots)[j] = first;
+    queue.assign(1, 0);
+    lines->push_back(PackedPair());
+    for (size_t q = 0; q < queue.size(); ++q) {
+      if ((int)queue.size() > hf.nrnodes) { set_error("forest: tree has a cycle"); return GLIA_HMT_ERR_IO; }
+      const int k = queue[q];
+      const int* m = &hf.meta[(base + k) * 4];
+      PackedPair L;
+      memset(&L, 0, sizeof(L));
+      L.n[0] = plain(base, k);
+      L.n[1] = L.n[0]; L.n[2] = L.n[0];
+      if (m[3] < 0) {
+        for (int side = 0; side < 2; ++side) {
+          const int c = m[1 + side];
+          PackedNode cn = plain(base, c);
+          const int* cm = &hf.meta[(base + c) * 4];
+          if (cm[3] < 0) {                       // internal daughter: the lines of its two daughters follow each other
+            cn.left = (int)lines->size();
+            queue.push_back(cm[1]); queue.push_back(cm[2]);
+            lines->push_back(PackedPair()); lines->push_back(PackedPair());
+          }
+          L.n[1 + side] = cn;
+        }
+      }
+      (*lines)[first + q] = L;
+    }
+  }
+  return GLIA_HMT_OK;
+}
+
 }  // namespace glia

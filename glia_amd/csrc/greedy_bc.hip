@@ -378,6 +378,24 @@ __device__ __forceinline__ int forest_vote(const DeviceForest& f, int tree, cons
   }
   return 0;
 }
+// the same walk over the two-levels-per-line layout (forest.hpp): half the trips to the L2, for walks that wait on each of them
+__device__ __forceinline__ int forest_vote_pairs(const DeviceForest& f, int tree, const double* x) {
+  int k = f.proot[tree];
+  for (int step = 0; step < f.nrnodes; step += 2) {
+    const uint4* q = reinterpret_cast<const uint4*>(&f.pairs[k]);
+    const uint4 a = q[0], b = q[1], c = q[2];                       // one line, three 16-byte loads in flight together
+    const int var0 = (int)a.z;
+    if (var0 < 0) return -1 - var0;
+    const double s0 = __hiloint2double((int)a.y, (int)a.x);
+    const bool right = !(x[var0] <= s0);
+    const uint4 d = right ? c : b;
+    const int var1 = (int)d.z;
+    if (var1 < 0) return -1 - var1;
+    const double s1 = __hiloint2double((int)d.y, (int)d.x);
+    k = (int)d.w + ((x[var1] <= s1) ? 0 : 1);
+  }
+  return 0;
+}
 __device__ __forceinline__ int pick_model(const DeviceClassifier& c, const double* x) {
   if (c.n_models == 1) return 0;
   if (x[c.dim1] < c.threshold) return 0;                // type/function.hxx:80-84
@@ -914,7 +932,7 @@ __device__ __forceinline__ void forest_chunk(const BcState& st, BcShared& s, con
     const uint32_t j = i / (uint32_t)ntree, t = i % (uint32_t)ntree;
     const int m = W.hdr[j].model;
     if (m < 0 || (int)t >= st.clf.f[m].ntree) continue;
-    if (forest_vote(st.clf.f[m], (int)t, &W.feat[j * W.fstride])) atomicAdd(&s.votes[j], 1);
+    if (forest_vote_pairs(st.clf.f[m], (int)t, &W.feat[j * W.fstride])) atomicAdd(&s.votes[j], 1);
   }
   __syncthreads();
 }

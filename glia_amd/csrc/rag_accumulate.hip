@@ -88,7 +88,7 @@ struct TableParams {
 };
 
 // control words of a marching wave's rings
-constexpr int C_TAIL_R = 0, C_TAIL_P = 1, C_HEAD_R = 2, C_HEAD_P = 3, C_STATE = 4;
+constexpr int C_TAIL_R = 0, C_TAIL_P = 1, C_STATE = 2, C_HEAD_R = 4, C_HEAD_P = 5;     // 0..3: written by the marching wave (one 16-byte read for the drainer)
 constexpr uint32_t kRingWaiting = 1u, kRingDone = 2u;
 
 template <int BINS>
@@ -102,7 +102,7 @@ struct Lds {
   uint32_t prec[G::kPairSlots * kPairWordsL];
   uint32_t ringR[G::kMarchers][kRingR * G::kEntryWords];   // circular, per marching wave; reused as gslot[] by the final fold
   uint32_t ringP[G::kMarchers][kRingP * G::kEntryWords];
-  uint32_t ctl[G::kMarchers][8];
+  alignas(16) uint32_t ctl[G::kMarchers][8];
   TableParams tp;
 };
 static_assert(sizeof(Lds<8>) <= 160 * 1024 && sizeof(Lds<16>) <= 160 * 1024, "LDS budget of one CU");
@@ -318,13 +318,21 @@ __device__ __forceinline__ void drainer_loop(Lds<BINS>& s, const int d, const in
 #define DPROF(x)
 #endif
   for (;;) {
-    // states before tails: "done" is stored after the last entries
-    const uint32_t st0 = ctl_load(&s.ctl[w0][C_STATE]), st1 = ctl_load(&s.ctl[w1][C_STATE]), st2 = ctl_load(&s.ctl[w2][C_STATE]);
+    // tails and state of a wave in one 16-byte read ("done" is stored after the last tails, and the LDS keeps a wave's order)
+    u32x4 q0 = *(const volatile lds_u32x4*)(uintptr_t)(uint32_t)(uintptr_t)&s.ctl[w0][0];
+    u32x4 q1 = *(const volatile lds_u32x4*)(uintptr_t)(uint32_t)(uintptr_t)&s.ctl[w1][0];
+    u32x4 q2 = *(const volatile lds_u32x4*)(uintptr_t)(uint32_t)(uintptr_t)&s.ctl[w2][0];
+    const uint32_t st0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q0.z), st1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q1.z),
+                   st2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q2.z);
+    const uint32_t tR0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q0.x), tR1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q1.x),
+                   tR2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q2.x);
+    const uint32_t tP0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q0.y), tP1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q1.y),
+                   tP2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q2.y);
     const bool urgent = (st0 | st1 | st2) != 0u;
     bool any = false;
     uint32_t left;
     {
-      const uint32_t a0 = ctl_load(&s.ctl[w0][C_TAIL_R]) - hR0, a1 = ctl_load(&s.ctl[w1][C_TAIL_R]) - hR1, a2 = ctl_load(&s.ctl[w2][C_TAIL_R]) - hR2;
+      const uint32_t a0 = tR0 - hR0, a1 = tR1 - hR1, a2 = tR2 - hR2;
       const uint32_t total = a0 + a1 + a2;
       left = total;
       if (total >= (uint32_t)kDrainAt || (urgent && total)) {
@@ -353,7 +361,7 @@ __device__ __forceinline__ void drainer_loop(Lds<BINS>& s, const int d, const in
       }
     }
     {
-      const uint32_t a0 = ctl_load(&s.ctl[w0][C_TAIL_P]) - hP0, a1 = ctl_load(&s.ctl[w1][C_TAIL_P]) - hP1, a2 = ctl_load(&s.ctl[w2][C_TAIL_P]) - hP2;
+      const uint32_t a0 = tP0 - hP0, a1 = tP1 - hP1, a2 = tP2 - hP2;
       const uint32_t total = a0 + a1 + a2;
       left += total;
       if (total >= (uint32_t)kDrainAt || (urgent && total)) {
@@ -512,6 +520,13 @@ __global__ __launch_bounds__(Geo<BINS>::kThreadsT) void rag_accumulate_kernel(co
     e[0] = a; e[1] = b; e[2] = c;
     if (BINS > 8) { u32x4 d; d.x = (uint32_t)r.h[BINS / 8 - 1]; d.y = (uint32_t)(r.h[BINS / 8 - 1] >> 32); d.z = 0; d.w = 0; e[3] = d; }
   };
+  // both tails in one 8-byte store (every few planes, and before the wave waits or ends)
+  auto publish = [&]() __attribute__((always_inline)) {
+    asm volatile("" ::: "memory");
+    *(volatile unsigned long long __attribute__((address_space(3)))*)(uintptr_t)(uint32_t)(uintptr_t)&ctl[C_TAIL_R] =
+        (unsigned long long)tailR | ((unsigned long long)tailP << 32);
+    asm volatile("" ::: "memory");
+  };
   // room for n more entries in a ring of the wave (waits for its drainer when there is none)
   auto reserve = [&](const uint32_t tail, uint32_t& seen, const int n, const int cap, const int headWord) __attribute__((always_inline)) {
 #ifdef GLIA_ACC_NODRAIN
@@ -520,6 +535,7 @@ __global__ __launch_bounds__(Geo<BINS>::kThreadsT) void rag_accumulate_kernel(co
     if (__builtin_expect(tail - seen + (uint32_t)n > (uint32_t)cap, 0)) {
       seen = ctl_load(&ctl[headWord]);
       if (tail - seen + (uint32_t)n > (uint32_t)cap) {
+        publish();                                  // what is written must be seen, or nobody makes room
         ctl_store(&ctl[C_STATE], kRingWaiting);
         do {
           __builtin_amdgcn_s_sleep(1);
@@ -540,7 +556,6 @@ __global__ __launch_bounds__(Geo<BINS>::kThreadsT) void rag_accumulate_kernel(co
       reserve(tailR, seenR, nR, kRingR, C_HEAD_R);
       if (evR) put(ringAddrR + ((tailR + lanes_below(mR)) & (uint32_t)(kRingR - 1)) * (uint32_t)(EW * 4), rr.k0 + 1u, 0u, rmeta, rr.cnt, rr);
       tailR += (uint32_t)nR;
-      ctl_store(&ctl[C_TAIL_R], tailR);
     }
     if (nP) {
       const uint32_t rank = lanes_below(mP);
@@ -549,19 +564,17 @@ __global__ __launch_bounds__(Geo<BINS>::kThreadsT) void rag_accumulate_kernel(co
         if (evP && rank < (uint32_t)kRingP)
           put(ringAddrP + ((tailP + rank) & (uint32_t)(kRingP - 1)) * (uint32_t)(EW * 4), pr.k1 + 1u, pr.k0 + 1u, pr.cnt, pr.aux, pr);
         tailP += (uint32_t)kRingP;
-        ctl_store(&ctl[C_TAIL_P], tailP);
         reserve(tailP, seenP, nP - kRingP, kRingP, C_HEAD_P);
         if (evP && rank >= (uint32_t)kRingP)
           put(ringAddrP + ((tailP + rank - (uint32_t)kRingP) & (uint32_t)(kRingP - 1)) * (uint32_t)(EW * 4), pr.k1 + 1u, pr.k0 + 1u, pr.cnt, pr.aux, pr);
         tailP += (uint32_t)(nP - kRingP);
-        ctl_store(&ctl[C_TAIL_P], tailP);
       } else {
         reserve(tailP, seenP, nP, kRingP, C_HEAD_P);
         if (evP) put(ringAddrP + ((tailP + rank) & (uint32_t)(kRingP - 1)) * (uint32_t)(EW * 4), pr.k1 + 1u, pr.k0 + 1u, pr.cnt, pr.aux, pr);
         tailP += (uint32_t)nP;
-        ctl_store(&ctl[C_TAIL_P], tailP);
       }
     }
+    if (nR | nP) publish();
   };
 
   // INNER (a workgroup-uniform compile-time tag): the tile and its one-voxel halo lie inside the volume and there is no mask,
@@ -728,6 +741,7 @@ __global__ __launch_bounds__(Geo<BINS>::kThreadsT) void rag_accumulate_kernel(co
     }
     // the column ends: every lane hands in what it holds
     enqueue((dbg & 1) ? false : rhas, (dbg & 2) ? false : phas, (uint32_t)(n - 1));
+    publish();
     rhas = false; phas = false;
   };
 
