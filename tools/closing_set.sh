@@ -10,6 +10,8 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p
 echo stats done
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o acc -- python3 tools/acc_bench.py 1024 16 1 > $OUT/pmc_fetch.log 2>&1
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o acc -- python3 tools/acc_bench.py 1024 16 1 > $OUT/pmc_write.log 2>&1
+timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/pmc_sq -o acc -- python3 tools/acc_bench.py 1024 16 1 > $OUT/pmc_sq.log 2>&1
+GLIA_HMT_DEBUG=32 GLIA_HMT_LIB=$PWD/glia_amd/libglia_hmt_prof.so timeout -k 10 120 python tools/acc_bench.py 1024 16 1 > $OUT/acc_drainers.txt 2>&1 || true
 echo pmc done
 GLIA_PB_HASH=1 timeout -k 10 200 python tools/pb_bench.py 1024 16 2 > $OUT/pb1024_hash.txt 2>&1
 GLIA_PB_HASH=1 timeout -k 10 200 python tools/pb_bench.py 512 16 2 > $OUT/pb512_hash.txt 2>&1
