@@ -423,8 +423,9 @@ static int rag_build_impl(glia_hmt_ctx* c, int dim, const int64_t dims[3], int64
     pass_ms_total += ms;
     rag->pass_ms = pass_ms_total;
     if (p.debug & 32) {
-      unsigned long long pc[8];
+      unsigned long long pc[12];
       (void)hipMemcpy(pc, c->flags + 16, sizeof(pc), hipMemcpyDeviceToHost);
+      fprintf(stderr, "[glia_hmt debug] marching waves: %llu waits for room in a ring, %llu cycles waiting of %llu cycles marching\n", pc[9], pc[8], pc[10]);
       fprintf(stderr, "[glia_hmt debug] drainers: region batches %llu entries %llu cycles %llu | pair batches %llu entries %llu cycles %llu | idle polls %llu, drainer cycles %llu\n",
               pc[0], pc[1], pc[2], pc[3], pc[4], pc[5], pc[6], pc[7]);
       (void)hipMemsetAsync(c->flags, 0, 256, c->stream);

@@ -559,6 +559,9 @@ struct WinState {
   // scattered store per dying edge less in the contraction's store stream): no reload can reach it before the next baseline,
   // and the baseline's collection pass recognises it by its dead region.
   uint8_t* rdead;
+  // tests (GLIA_HMT_FORCE_TREE=k): hand the queue over to the tournament-tree kernel at the first empty window after k merges --
+  // the path of ST_NEED_TREE, which no data set reaches by itself any more (oversized cells are split)
+  unsigned long long force_tree;
 };
 constexpr uint32_t kWinCap = 1536;          // window slots (live items + holes)
 constexpr uint32_t kWinBudget = 768;        // a reload stops before exceeding this many items ...
@@ -637,7 +640,7 @@ __device__ __forceinline__ void win_put(WinShared& w, uint32_t slot, double sal,
 __device__ __forceinline__ void win_take(const WinState& st, WinShared& w, uint32_t e, const EdgeRec& r) {
   if (r.seq != 0) {
     const uint32_t slot = atomicAdd(&w.n, 1u);
-    if (slot < kWinCap) win_put(w, slot, r.sal, r.seq, e, r.u, r.v, r.hu, r.hv); else w.err = 1;
+    if (slot < st.wcap) win_put(w, slot, r.sal, r.seq, e, r.u, r.v, r.hu, r.hv); else w.err = 1;
   }
 }
 
@@ -934,6 +937,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(WinState 
     const Key root = win_root(w, lane);
     if (root.seq == 0) {
       WPH(5);
+      if (st.force_tree && k >= st.force_tree) { status = ST_NEED_TREE; break; }
       const int r = win_reload(st, w, tid, reinterpret_cast<double*>(&s.stage[0]), reinterpret_cast<unsigned long long*>(&s.stage[0]) + kSelMax);
 #ifdef GLIA_HMT_PROFILE
       wreloads += 1; wloaded += w.n;
@@ -1016,22 +1020,22 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(WinState 
     __syncthreads();     // full: a wave that loaded has waited for its loads anyway, so its older stores are done for free
     WPH(1);
     // room for every new edge that may land in the window (total bounds their number)
-    if (wn_now + total > kWinCap) {
+    if (wn_now + total > st.wcap) {
 #ifdef GLIA_HMT_PROFILE
       wcompacts += 1;
 #endif
-      win_compact(w, tid);
-      if (w.n + total > kWinCap) {
+      win_compact(w, tid, st.wcap);
+      if (w.n + total > st.wcap) {
         win_flush(st, w, tid);
-        if (total > kWinCap) {             // a contraction wider than the window: nothing of it goes there
+        if (total > st.wcap) {             // a contraction wider than the window: nothing of it goes there
           if (tid == 0) { w.cthr = (int)st.wB; w.tsal = __builtin_inf(); w.tseq = ~0ull; }
           __syncthreads();
         }
       }
     }
-    const int cthr2 = (wn_now + total > kWinCap) ? w.cthr : cthr;
-    const double tsal2 = (wn_now + total > kWinCap) ? w.tsal : tsal;
-    const unsigned long long tseq2 = (wn_now + total > kWinCap) ? w.tseq : tseq;
+    const int cthr2 = (wn_now + total > st.wcap) ? w.cthr : cthr;
+    const double tsal2 = (wn_now + total > st.wcap) ? w.tsal : tsal;
+    const unsigned long long tseq2 = (wn_now + total > st.wcap) ? w.tseq : tseq;
     const uint32_t nwork = small ? s.nitems : total;
     WPH(2);
 
@@ -1497,6 +1501,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
       // no live item in the window
       BPH(5);
       if (pend_e != kNone) { st.er[pend_e].next = pend_old; pend_e = kNone; }
+      if (st.force_tree && k >= st.force_tree) { status = ST_NEED_TREE; break; }
       const int r = win_reload(st, w, tid, reinterpret_cast<double*>(&s.stage[0]), reinterpret_cast<unsigned long long*>(&s.stage[0]) + kSelMax);
       BPH(6);
       if (r == 1) { status = ST_DONE; break; }
@@ -2133,6 +2138,8 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
     while (B < E0 / 4 && B < (1u << 22)) B <<= 1;
     ws.wB = B; ws.R0 = R;
     ws.wcap = kWinCap; ws.wbudget = kWinBudget;
+    ws.force_tree = 0;
+    if (const char* fenv = getenv("GLIA_HMT_FORCE_TREE")) ws.force_tree = strtoull(fenv, nullptr, 10);
     if (const char* cenv = getenv("GLIA_HMT_WINCAP")) {                  // tests: a tiny window makes spills, evictions and cell splits routine
       const uint32_t c = (uint32_t)strtoul(cenv, nullptr, 10);
       if (c >= 16 && c <= kWinCap) { ws.wcap = c; ws.wbudget = c / 2; }

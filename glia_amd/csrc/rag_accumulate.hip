@@ -520,6 +520,10 @@ __global__ __launch_bounds__(Geo<BINS>::kThreadsT) void rag_accumulate_kernel(co
     e[0] = a; e[1] = b; e[2] = c;
     if (BINS > 8) { u32x4 d; d.x = (uint32_t)r.h[BINS / 8 - 1]; d.y = (uint32_t)(r.h[BINS / 8 - 1] >> 32); d.z = 0; d.w = 0; e[3] = d; }
   };
+#ifdef GLIA_HMT_PROFILE
+  unsigned long long waitCycles = 0; uint32_t waits = 0;
+  const unsigned long long tmarch0 = __builtin_readcyclecounter();
+#endif
   // both tails in one 8-byte store (every few planes, and before the wave waits or ends)
   auto publish = [&]() __attribute__((always_inline)) {
     asm volatile("" ::: "memory");
@@ -537,10 +541,16 @@ __global__ __launch_bounds__(Geo<BINS>::kThreadsT) void rag_accumulate_kernel(co
       if (tail - seen + (uint32_t)n > (uint32_t)cap) {
         publish();                                  // what is written must be seen, or nobody makes room
         ctl_store(&ctl[C_STATE], kRingWaiting);
+#ifdef GLIA_HMT_PROFILE
+        const unsigned long long tw0 = __builtin_readcyclecounter();
+#endif
         do {
           __builtin_amdgcn_s_sleep(1);
           seen = ctl_load(&ctl[headWord]);
         } while (tail - seen + (uint32_t)n > (uint32_t)cap);
+#ifdef GLIA_HMT_PROFILE
+        waitCycles += __builtin_readcyclecounter() - tw0; waits += 1;
+#endif
         ctl_store(&ctl[C_STATE], 0u);
       }
     }
@@ -758,6 +768,12 @@ __global__ __launch_bounds__(Geo<BINS>::kThreadsT) void rag_accumulate_kernel(co
       for (int pass = 0; pass < G::kPasses; ++pass) column(std::false_type{}, wave + pass * G::kMarchers);
     }
     ctl_store(&ctl[C_STATE], kRingDone);
+#ifdef GLIA_HMT_PROFILE
+    if (lane == 0) {
+      unsigned long long* g = reinterpret_cast<unsigned long long*>(s.tp.flags + 16);
+      atomicAdd(&g[8], waitCycles); atomicAdd(&g[9], (unsigned long long)waits); atomicAdd(&g[10], __builtin_readcyclecounter() - tmarch0);
+    }
+#endif
   }
   __syncthreads();
   if (dbg & 8) return;

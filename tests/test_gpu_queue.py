@@ -85,6 +85,19 @@ def test_horizon_placements(ctx, env):
     assert o.shape == tree[0].shape and (o == tree[0]).all() and (s == tree[1]).all()
 
 
+@pytest.mark.parametrize("env", [dict(GLIA_HMT_FORCE_TREE=1), dict(GLIA_HMT_FORCE_TREE=1500), dict(GLIA_HMT_FORCE_TREE=700, GLIA_HMT_PB_BATCH=0),
+                                 dict(GLIA_HMT_FORCE_TREE=2500, GLIA_HMT_WINCAP=64, GLIA_HMT_REBASE=400)])
+def test_hand_over_to_the_tree_kernel_in_mid_run(ctx, env):
+    """ST_NEED_TREE: the window kernels stop at an empty window and the tournament-tree kernel continues from the same state (edge
+    records unpacked into its arrays, thin list entries).  No data set reaches that exit by itself any more -- oversized saliency
+    cells are split -- so the test forces it after k merges."""
+    d_lab, d_pb = _volume(ctx, (128, 128, 128), 8, 0, None)
+    tree = _order(ctx, d_lab, d_pb, GLIA_HMT_PB_WINDOW=0)
+    assert len(tree[0]) == 4095
+    o, s = _order(ctx, d_lab, d_pb, **env)
+    assert o.shape == tree[0].shape and (o == tree[0]).all() and (s == tree[1]).all()
+
+
 def test_constant_pb_on_every_queue(ctx):
     """every saliency equal: one saliency cell holds the whole queue, the order is the tie rule alone"""
     import torch
