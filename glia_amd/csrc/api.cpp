@@ -1,6 +1,7 @@
 // glia_amd/csrc/api.cpp -- C ABI of libglia_hmt.so (see include/glia_hmt.h for the reference
 // operators each entry point replaces).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -114,6 +115,8 @@ using namespace glia;
 
 #include "api_types.hpp"
 
+static std::atomic<int> g_live_contexts{0};
+
 static int free_tables(glia_hmt_ctx* c) {
   if (c->rkeys) GLIA_HIP_TRY(hipFree(c->rkeys));
   if (c->rrec) GLIA_HIP_TRY(hipFree(c->rrec));
@@ -173,6 +176,7 @@ int glia_hmt_ctx_create(int device, void* hip_stream, glia_hmt_ctx** out) {
   static const LibmSel sel = probe_host_libm();
   c->libm = sel;
   *out = c;
+  ++g_live_contexts;
   // The call succeeds either way; a host libm none of the restatements reproduces is reported through glia_hmt_last_error()
   // (and glia_hmt_ctx_libm_status): entropy, --logs and compactness columns are then within 1 ulp of the host's, not pinned.
   if (sel.log2_variant == 0 || sel.log_variant == 0 || sel.pow_variant == 0)
@@ -242,6 +246,8 @@ int glia_hmt_libm_eval(glia_hmt_ctx* c, int function, int variant, const double*
   return launch_libm_eval(function, variant, d_in, d_out, n, c->stream);
 }
 
+unsigned long long glia_hmt_release_cached_memory(void) { return (unsigned long long)glia::BlockCache::get().trim(); }
+
 void glia_hmt_ctx_destroy(glia_hmt_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
@@ -252,6 +258,7 @@ void glia_hmt_ctx_destroy(glia_hmt_ctx* c) {
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
+  if (--g_live_contexts <= 0) (void)glia::BlockCache::get().trim();      // nobody left to reuse the parked blocks
 }
 
 int glia_hmt_ctx_sync(glia_hmt_ctx* c) {

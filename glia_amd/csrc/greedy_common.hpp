@@ -434,7 +434,7 @@ struct BlockCache {
   std::vector<Block> free_blocks;
   std::mutex mu;
   size_t cached = 0;
-  static constexpr size_t kMaxCached = 24ull << 30;
+  static constexpr size_t kMaxCached = 12ull << 30;      // parked at most; glia_hmt_release_cached_memory() / the last context's end return all of it
   static BlockCache& get() { static BlockCache c; return c; }
   void* take(size_t bytes, int device) {
     std::lock_guard<std::mutex> lock(mu);
@@ -448,6 +448,14 @@ struct BlockCache {
     cached -= free_blocks[best].bytes;
     free_blocks.erase(free_blocks.begin() + (long)best);
     return p;
+  }
+  size_t trim() {                                        // every parked block back to the driver; returns the bytes released
+    std::lock_guard<std::mutex> lock(mu);
+    const size_t was = cached;
+    for (const Block& b : free_blocks) (void)hipFree(b.p);
+    free_blocks.clear();
+    cached = 0;
+    return was;
   }
   void give(void* p, size_t bytes, int device) {
     std::lock_guard<std::mutex> lock(mu);

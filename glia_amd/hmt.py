@@ -115,6 +115,13 @@ class Context:
         _check(lib().glia_hmt_ctx_libm(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    @staticmethod
+    def release_cached_memory():
+        """Scratch blocks the library parks for reuse go back to the driver (glia_hmt_release_cached_memory); returns the bytes released."""
+        f = lib().glia_hmt_release_cached_memory
+        f.restype = C.c_ulonglong
+        return int(f())
+
     def libm_pinned(self):
         """True when log2, log and pow of the host libm are all reproduced bit for bit (glia_hmt_ctx_libm_status)."""
         return lib().glia_hmt_ctx_libm_status(self.h) == 1

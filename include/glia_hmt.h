@@ -46,6 +46,10 @@ const char* glia_hmt_version(void);
  * hipStream_t the caller owns (e.g. torch.cuda.current_stream().cuda_stream). */
 int glia_hmt_ctx_create(int device, void* hip_stream, glia_hmt_ctx** out);
 void glia_hmt_ctx_destroy(glia_hmt_ctx* ctx);
+/* The library parks scratch blocks of finished calls for reuse (at most 12 GiB per process; a hipMalloc / hipFree pair is a
+ * device-wide synchronisation).  This returns them to the driver -- for callers that share the device with another allocator
+ * (torch, a second library).  Returns the number of bytes released.  Destroying the last context of a process does the same. */
+unsigned long long glia_hmt_release_cached_memory(void);
 int glia_hmt_ctx_sync(glia_hmt_ctx* ctx);
 /* Logarithms of the feature vector.  The reference computes histogram entropies with std::log2 (util/stats.hxx:145-152)
  * and the --logs features with std::log (glia_base.hxx:80-81), the compactness with std::pow (type/feat.hxx:78-79), i.e.
