@@ -308,7 +308,10 @@ __device__ __forceinline__ void drainer_loop(Lds<BINS>& s, const int d, const in
   const uint32_t bR0 = (uint32_t)(uintptr_t)s.ringR[w0], bR1 = (uint32_t)(uintptr_t)s.ringR[w1], bR2 = (uint32_t)(uintptr_t)s.ringR[w2];
   const uint32_t bP0 = (uint32_t)(uintptr_t)s.ringP[w0], bP1 = (uint32_t)(uintptr_t)s.ringP[w1], bP2 = (uint32_t)(uintptr_t)s.ringP[w2];
   uint32_t hR0 = 0, hR1 = 0, hR2 = 0, hP0 = 0, hP1 = 0, hP2 = 0;      // entries consumed (wave-uniform)
-  __builtin_amdgcn_s_setprio(3);     // the marching waves of this SIMD always have work: without priority the drainer starves
+#ifndef GLIA_ACC_DPRIO
+#define GLIA_ACC_DPRIO 3
+#endif
+  __builtin_amdgcn_s_setprio(GLIA_ACC_DPRIO);     // the marching waves of this SIMD always have work: without priority the drainer starves
 #ifdef GLIA_HMT_PROFILE
   unsigned long long pc[6] = {0, 0, 0, 0, 0, 0};     // region batches, entries, cycles; pair batches, entries, cycles
   uint32_t polls = 0;
@@ -780,77 +783,88 @@ __global__ __launch_bounds__(Geo<BINS>::kThreadsT) void rag_accumulate_kernel(co
 
   // ---- fold the workgroup's LDS tables into the global tables ----
   // (the table pointers come back from LDS: holding them in scalar registers through the march costs spills there)
+  // 1. the used slots into a dense list (the rings are idle now: their space holds it); 2. one probe of the global table per
+  // key, all in one round; 3. the records word by word -- consecutive lanes add to DIFFERENT records, i.e. different cache
+  // lines: the L2 applies the atomics of one line one after the other.
   const TableParams& gp = s.tp;
   constexpr int kRegSlots = G::kRegSlots, kPairSlots = G::kPairSlots;
-  int* gslot = reinterpret_cast<int*>(&s.ringR[0][0]);      // rings are idle now
-  static_assert(sizeof(s.ringR) >= (kRegSlots + kPairSlots) * sizeof(int), "gslot does not fit in the rings");
+  uint32_t* const fold = &s.ringR[0][0];
+  uint32_t* const nused = fold;                      // [0]
+  unsigned short* const used = reinterpret_cast<unsigned short*>(fold + 4);            // slot ids, regions first come first
+  int* const gslot = reinterpret_cast<int*>(fold + 4 + (kRegSlots + kPairSlots) / 2);  // global slot of used[j]
+  static_assert(sizeof(s.ringR) >= (4 + (kRegSlots + kPairSlots) / 2 + (kRegSlots + kPairSlots)) * sizeof(uint32_t), "the fold's lists do not fit in the rings");
+  if (tid == 0) *nused = 0u;
+  __syncthreads();
   for (int i = tid; i < kRegSlots + kPairSlots; i += kThreadsT) {
-    int g = -1;
-    if (i < kRegSlots) { unsigned long long k = s.rkey[i]; if (k) g = global_region_slot(gp, (uint32_t)k); }
-    else { unsigned long long k = s.pkey[i - kRegSlots]; if (k) g = global_pair_slot(gp, k); }
-    gslot[i] = g;
+    const unsigned long long k = i < kRegSlots ? s.rkey[i] : s.pkey[i - kRegSlots];
+    if (k) used[atomicAdd(nused, 1u)] = (unsigned short)i;
   }
   __syncthreads();
+  const int nu = (int)*nused;
+  for (int j = tid; j < nu; j += kThreadsT) {
+    const int i = used[j];
+    gslot[j] = i < kRegSlots ? global_region_slot(gp, (uint32_t)s.rkey[i]) : global_pair_slot(gp, s.pkey[i - kRegSlots]);
+  }
+  __syncthreads();
+  if (dbg & 64) return;      // (ablation: the global slots are resolved, nothing is added)
   constexpr int RW = Lds<BINS>::kRegWords, PW = Lds<BINS>::kPairWordsL;
+  static_assert(RW >= PW, "the word loop runs over the longer record");
   const uint32_t tx = (uint32_t)gp.x0, ty = (uint32_t)gp.y0, tz = (uint32_t)gp.z0;
   uint32_t* const g_rrec = gp.rrec; uint32_t* const g_prec = gp.prec;
   const int64_t fsy = gp.nx, fsz = gp.nx * gp.ny;
-  for (int it = tid; it < kRegSlots * RW; it += kThreadsT) {
-    const int slot = it / RW, w = it % RW;
-    const int g = gslot[slot];
-    if (g < 0) continue;
-    uint32_t* dst = &g_rrec[(size_t)g * kRegionWords];
-    const uint32_t* src = &s.rrec[slot * RW];
-    const uint32_t val = src[w];
-    if (w == LR_SUM || w == LR_SQ) {
-      double dd = *reinterpret_cast<const double*>(&src[w]);
-      if (dd != 0.0) atomicAdd(reinterpret_cast<double*>(&dst[w == LR_SUM ? R_SUM : R_SQ]), dd);
-    } else if (w == LR_CNT) { atomicAdd(&dst[R_CNT], val); }
-    else if (w == LR_BORDER) { if (val) atomicAdd(&dst[R_BORDER], val); }
-    else if (w == LR_XMASK) {
-      const unsigned long long m = *reinterpret_cast<const unsigned long long*>(&src[LR_XMASK]);
-      atomicMax(&dst[R_LO + 0], 0x7fffffffu - (tx + (uint32_t)__builtin_ctzll(m)));
-      atomicMax(&dst[R_HI + 0], tx + 64u - (uint32_t)__builtin_clzll(m));
-    } else if (w == LR_YMASK) {
-      atomicMax(&dst[R_LO + 1], 0x7fffffffu - (ty + (uint32_t)__builtin_ctz(val)));
-      atomicMax(&dst[R_HI + 1], ty + 32u - (uint32_t)__builtin_clz(val));
-    } else if (w == LR_ZMASK) {
-      atomicMax(&dst[R_LO + 2], 0x7fffffffu - (tz + (uint32_t)__builtin_ctz(val)));
-      atomicMax(&dst[R_HI + 2], tz + 32u - (uint32_t)__builtin_clz(val));
-    } else if (w == LR_MIN) { atomicMax(&dst[R_MIN], val); }
-    else if (w == LR_MAX) { atomicMax(&dst[R_MAX], val); }
-    else if (w == LR_FIRST) {
-      const uint32_t first = 0xFFFFFu - val;
-      const unsigned long long fidx = (unsigned long long)(((int64_t)tz + (first >> 11)) * fsz + ((int64_t)ty + ((first >> 6) & 31)) * fsy +
-                                                           ((int64_t)tx + (first & 63)));
-      atomicMax(reinterpret_cast<unsigned long long*>(&dst[R_FIRST]), ~fidx);
-    } else if (w >= LR_HIST) {     // two 16-bit counters
-      const int k = 2 * (w - LR_HIST);
-      if (val & 0xFFFFu) atomicAdd(&dst[R_HIST + k], val & 0xFFFFu);
-      if (val >> 16) atomicAdd(&dst[R_HIST + k + 1], val >> 16);
-    }
-  }
-  for (int it = tid; it < kPairSlots * PW; it += kThreadsT) {
-    const int slot = it / PW, w = it % PW;
-    const int g = gslot[kRegSlots + slot];
-    if (g < 0) continue;
-    uint32_t* dst = &g_prec[(size_t)g * kPairWords];
-    const uint32_t* src = &s.prec[slot * PW];
-    const uint32_t val = src[w];
-    if (w == LP_SUM || w == LP_SQ) {
-      double dd = *reinterpret_cast<const double*>(&src[w]);
-      if (dd != 0.0) atomicAdd(reinterpret_cast<double*>(&dst[w == LP_SUM ? P_SUM : P_SQ]), dd);
-    } else if (w == LP_CNT) { atomicAdd(&dst[P_CNT], val); }
-    else if (w == LP_MIN) { atomicMax(&dst[P_MIN], val); }
-    else if (w == LP_MAX) { atomicMax(&dst[P_MAX], val); }
-    else if (w == LP_THR || w == LP_THR + 1) {
-      const int k = 2 * (w - LP_THR);
-      if (val & 0xFFFFu) atomicAdd(&dst[P_THR + k], val & 0xFFFFu);
-      if (val >> 16) atomicAdd(&dst[P_THR + k + 1], val >> 16);
-    } else if (w >= LP_HIST) {
-      const int k = 2 * (w - LP_HIST);
-      if (val & 0xFFFFu) atomicAdd(&dst[P_HIST + k], val & 0xFFFFu);
-      if (val >> 16) atomicAdd(&dst[P_HIST + k + 1], val >> 16);
+#pragma unroll 1
+  for (int w = 0; w < RW; ++w) {
+    for (int j = tid; j < nu; j += kThreadsT) {
+      const int i = used[j], g = gslot[j];
+      if (g < 0 || (dbg & 128)) continue;
+      if (i < kRegSlots) {
+        uint32_t* dst = &g_rrec[(size_t)g * kRegionWords];
+        const uint32_t* src = &s.rrec[i * RW];
+        const uint32_t val = src[w];
+        if (w == LR_SUM || w == LR_SQ) {
+          double dd = *reinterpret_cast<const double*>(&src[w]);
+          if (dd != 0.0) atomicAdd(reinterpret_cast<double*>(&dst[w == LR_SUM ? R_SUM : R_SQ]), dd);
+        } else if (w == LR_CNT) {      // count and border count: adjacent in both records
+          atomicAdd(reinterpret_cast<unsigned long long*>(&dst[R_CNT]), (unsigned long long)val | ((unsigned long long)src[LR_BORDER] << 32));
+        } else if (w == LR_XMASK) {
+          const unsigned long long m = *reinterpret_cast<const unsigned long long*>(&src[LR_XMASK]);
+          atomicMax(&dst[R_LO + 0], 0x7fffffffu - (tx + (uint32_t)__builtin_ctzll(m)));
+          atomicMax(&dst[R_HI + 0], tx + 64u - (uint32_t)__builtin_clzll(m));
+        } else if (w == LR_YMASK) {
+          atomicMax(&dst[R_LO + 1], 0x7fffffffu - (ty + (uint32_t)__builtin_ctz(val)));
+          atomicMax(&dst[R_HI + 1], ty + 32u - (uint32_t)__builtin_clz(val));
+        } else if (w == LR_ZMASK) {
+          atomicMax(&dst[R_LO + 2], 0x7fffffffu - (tz + (uint32_t)__builtin_ctz(val)));
+          atomicMax(&dst[R_HI + 2], tz + 32u - (uint32_t)__builtin_clz(val));
+        } else if (w == LR_MIN) { atomicMax(&dst[R_MIN], val); }
+        else if (w == LR_MAX) { atomicMax(&dst[R_MAX], val); }
+        else if (w == LR_FIRST) {
+          const uint32_t first = 0xFFFFFu - val;
+          const unsigned long long fidx = (unsigned long long)(((int64_t)tz + (first >> 11)) * fsz + ((int64_t)ty + ((first >> 6) & 31)) * fsy +
+                                                               ((int64_t)tx + (first & 63)));
+          atomicMax(reinterpret_cast<unsigned long long*>(&dst[R_FIRST]), ~fidx);
+        } else if (w >= LR_HIST) {     // two 16-bit counters -> two adjacent 32-bit counters of the record, one 64-bit add
+          const int k = 2 * (w - LR_HIST);
+          if (val) atomicAdd(reinterpret_cast<unsigned long long*>(&dst[R_HIST + k]), (unsigned long long)(val & 0xFFFFu) | ((unsigned long long)(val >> 16) << 32));
+        }
+      } else if (w < PW) {
+        uint32_t* dst = &g_prec[(size_t)g * kPairWords];
+        const uint32_t* src = &s.prec[(i - kRegSlots) * PW];
+        const uint32_t val = src[w];
+        if (w == LP_SUM || w == LP_SQ) {
+          double dd = *reinterpret_cast<const double*>(&src[w]);
+          if (dd != 0.0) atomicAdd(reinterpret_cast<double*>(&dst[w == LP_SUM ? P_SUM : P_SQ]), dd);
+        } else if (w == LP_CNT) { atomicAdd(&dst[P_CNT], val); }
+        else if (w == LP_MIN) { atomicMax(&dst[P_MIN], val); }
+        else if (w == LP_MAX) { atomicMax(&dst[P_MAX], val); }
+        else if (w == LP_THR || w == LP_THR + 1) {
+          const int k = 2 * (w - LP_THR);
+          if (val) atomicAdd(reinterpret_cast<unsigned long long*>(&dst[P_THR + k]), (unsigned long long)(val & 0xFFFFu) | ((unsigned long long)(val >> 16) << 32));
+        } else if (w >= LP_HIST) {
+          const int k = 2 * (w - LP_HIST);
+          if (val) atomicAdd(reinterpret_cast<unsigned long long*>(&dst[P_HIST + k]), (unsigned long long)(val & 0xFFFFu) | ((unsigned long long)(val >> 16) << 32));
+        }
+      }
     }
   }
 }
