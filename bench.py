@@ -50,7 +50,7 @@ def cpu_baseline(size, S, bc_size, curve_sizes=(), target_regions=0):
                     t3 = time.time()
                     res = subprocess.run([ref], stdin=f, capture_output=True, text=True, check=True, timeout=600)
                     t4 = time.time()
-            n_ref = len([l for l in res.stdout.split("\n") if l.strip()])
+            n_ref = len([l for l in res.stdout.split("\n") if l.strip() and not l.startswith("K ")])     # ("K a b" lines: its transformKeys)
             eng = [l for l in res.stderr.split("\n") if l.startswith("engine_seconds")]
             if eng:
                 t4 = t3 + float(eng[-1].split()[1])     # the engine's own clock around genMergeOrderGreedy (no dump parsing)
@@ -71,6 +71,8 @@ def cpu_baseline(size, S, bc_size, curve_sizes=(), target_regions=0):
     t1 = time.time()
     out["edge_features_per_sec"] = rag.n_feat_evals / (t1 - t0)
     out["bc_merges_per_sec"] = len(order) / (t1 - t0)
+    out["bc_note"] = ("classifier path: the oracle port only (the reference's bc tools need ITK and its third-party forest code, absent here: "
+                      "no reference-engine leg, no curve)")
     if curve_sizes and os.path.exists(ref):
         out["curve"] = reference_curve(curve_sizes, S, ref, target_regions)
     return out
@@ -98,7 +100,7 @@ def reference_curve(sizes, S, ref, target_regions):
         eng = [l for l in res.stderr.split("\n") if l.startswith("engine_seconds")]
         if eng:
             dt = float(eng[-1].split()[1])
-        n = len([l for l in res.stdout.split("\n") if l.strip()])
+        n = len([l for l in res.stdout.split("\n") if l.strip() and not l.startswith("K ")])
         pts.append({"size": size, "regions": n + 1, "merges": n, "engine_seconds": dt, "merges_per_sec": n / dt})
     xs = [math.log(p["regions"]) for p in pts]; ys = [math.log(p["merges_per_sec"]) for p in pts]
     mx, my = sum(xs) / len(xs), sum(ys) / len(ys)
