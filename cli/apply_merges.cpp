@@ -12,7 +12,6 @@ int main(int argc, char* argv[]) {
                  {"inputImage", "mask", "merge", "relabel", "write16", "compress", "outputImage"}, usage);
   for (const char* req : {"inputImage", "merge", "outputImage"})
     if (!a.has(req)) { std::cerr << "Error: the option '--" << req << "' is required but missing\n" << usage; return EXIT_FAILURE; }
-  if (flagOf(a, "compress")) perr("Error: compressed output is not supported...");
   struct T3 { uint32_t x0, x1, x2; };
   std::vector<T3> merges;
   for (auto& file : a.all("merge")) {
@@ -40,7 +39,7 @@ int main(int argc, char* argv[]) {
   uint32_t nl = 0;
   if (flagOf(a, "relabel")) check(glia_hmt_relabel_image(ctx, dLab, (int64_t)img.size(), 0, &nl));
   hipCheck(hipMemcpy(img.u32.data(), dLab, img.size() * 4, hipMemcpyDeviceToHost));
-  writeMetaImage(a.str("outputImage"), img.dim, img.dims, img.u32, flagOf(a, "write16"));
+  writeMetaImage(a.str("outputImage"), img.dim, img.dims, img.u32, flagOf(a, "write16"), flagOf(a, "compress"));
   glia_hmt_ctx_destroy(ctx);
   (void)hipFree(dLab);
   if (dMask) (void)hipFree(dMask);

@@ -1,6 +1,6 @@
 // cli/common.hpp -- shared pieces of the drop-in command line tools (hmt/main_merge_order_pb.cxx,
 // hmt/main_merge_order_bc.cxx).  GLIA reads images through ITK, which this image does not have; the tools here
-// read MetaImage files (.mha / .mhd + raw, uncompressed; ITK writes them natively) and keep GLIA's flags,
+// read MetaImage files (.mha / .mhd + raw, plain or zlib-compressed -- what ITK writes natively --) and keep GLIA's flags,
 // output formats (util/text_io.hxx:103-133) and error behaviour (message on stderr, exit status 1).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -13,6 +13,7 @@
 #include <fstream>
 #include <iostream>
 #include <map>
+#include <zlib.h>
 #include <set>
 #include <sstream>
 #include <unistd.h>
@@ -37,7 +38,7 @@ struct Volume {
 };
 
 // MetaImage reader: ObjectType = Image, NDims 2|3, ElementType MET_{UCHAR,USHORT,UINT,ULONG,SHORT,INT,FLOAT,DOUBLE},
-// CompressedData = False, ElementDataFile = LOCAL | <file>
+// CompressedData = False | True (one zlib stream, itk::MetaImageIO), ElementDataFile = LOCAL | <file>
 // zFirst / zCount (3D only, zCount >= 0): read only those planes -- a rank of the slab route reads its own z range
 inline Volume readMetaImage(const std::string& file, bool wantFloat, int64_t zFirst = 0, int64_t zCount = -1) {
   std::ifstream is(file, std::ios::binary);
@@ -53,8 +54,7 @@ inline Volume readMetaImage(const std::string& file, bool wantFloat, int64_t zFi
     kv[k] = v;
     if (k == "ElementDataFile") { dataPos = is.tellg(); break; }
   }
-  if (kv.count("CompressedData") && (kv["CompressedData"] == "True" || kv["CompressedData"] == "true"))
-    perr("Error: compressed MetaImage files are not supported: " + file);
+  const bool compressed = kv.count("CompressedData") && (kv["CompressedData"] == "True" || kv["CompressedData"] == "true");
   Volume vol;
   vol.dim = atoi(kv["NDims"].c_str());
   if (vol.dim != 2 && vol.dim != 3) perr("Error: unsupported image dimension in " + file);
@@ -73,9 +73,41 @@ inline Volume readMetaImage(const std::string& file, bool wantFloat, int64_t zFi
   }
   const size_t n = vol.size();
   std::vector<char> raw(n * es);
-  if (kv["ElementDataFile"] == "LOCAL") { is.seekg(dataPos + skip); is.read(raw.data(), raw.size()); if (!is) perr("Error: truncated image data in " + file); }
+  const std::string dir = file.substr(0, file.find_last_of('/') == std::string::npos ? 0 : file.find_last_of('/') + 1);
+  if (compressed) {
+    // one zlib stream over the whole image: inflate it, keep the bytes of the wanted planes
+    std::vector<char> packed;
+    if (kv["ElementDataFile"] == "LOCAL") { is.seekg(dataPos); packed.assign(std::istreambuf_iterator<char>(is), std::istreambuf_iterator<char>()); }
+    else {
+      std::ifstream rs(dir + kv["ElementDataFile"], std::ios::binary);
+      if (!rs) perr("Error: cannot open file " + dir + kv["ElementDataFile"]);
+      packed.assign(std::istreambuf_iterator<char>(rs), std::istreambuf_iterator<char>());
+    }
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (inflateInit(&zs) != Z_OK) perr("Error: zlib initialisation failed");
+    std::vector<char> chunk(1 << 22);
+    size_t inPos = 0, outPos = 0;                 // outPos: bytes of the whole image produced so far
+    const size_t want0 = (size_t)skip, want1 = (size_t)skip + raw.size();
+    int zr = Z_OK;
+    while (zr != Z_STREAM_END && outPos < want1) {
+      if (zs.avail_in == 0 && inPos < packed.size()) {
+        const size_t take = std::min<size_t>(packed.size() - inPos, (size_t)1 << 30);
+        zs.next_in = (Bytef*)(packed.data() + inPos); zs.avail_in = (uInt)take; inPos += take;
+      }
+      zs.next_out = (Bytef*)chunk.data(); zs.avail_out = (uInt)chunk.size();
+      zr = inflate(&zs, Z_NO_FLUSH);
+      if (zr != Z_OK && zr != Z_STREAM_END) { inflateEnd(&zs); perr("Error: corrupt compressed image data in " + file); }
+      const size_t got = chunk.size() - zs.avail_out;
+      const size_t a = std::max(outPos, want0), b = std::min(outPos + got, want1);
+      if (a < b) memcpy(raw.data() + (a - want0), chunk.data() + (a - outPos), b - a);
+      outPos += got;
+      if (got == 0 && zs.avail_in == 0 && inPos >= packed.size()) break;
+    }
+    inflateEnd(&zs);
+    if (outPos < want1) perr("Error: truncated image data in " + file);
+  } else if (kv["ElementDataFile"] == "LOCAL") { is.seekg(dataPos + skip); is.read(raw.data(), raw.size()); if (!is) perr("Error: truncated image data in " + file); }
   else {
-    std::string dir = file.substr(0, file.find_last_of('/') == std::string::npos ? 0 : file.find_last_of('/') + 1);
     std::ifstream rs(dir + kv["ElementDataFile"], std::ios::binary);
     if (!rs) perr("Error: cannot open file " + dir + kv["ElementDataFile"]);
     rs.seekg(skip);
@@ -139,27 +171,48 @@ inline Args parse(int argc, char** argv, const std::map<std::string, std::string
   return a;
 }
 
-// MetaImage writer (single .mha file, uncompressed); 16-bit output for --write16 (castWriteImage<UInt16Image>)
-inline void writeMetaImage(const std::string& file, int dim, const int64_t dims[3], const std::vector<uint32_t>& v, bool as16) {
+// MetaImage writer (single .mha file); 16-bit output for --write16 (castWriteImage<UInt16Image>); compress = the tools'
+// --compress / -z (itk::ImageFileWriter::SetUseCompression, util/image_io.hxx:46-52): one zlib stream, CompressedDataSize in the header
+inline void writeMetaImageBytes(const std::string& file, int dim, const int64_t dims[3], const char* elementType, const void* data, size_t bytes, bool compress) {
   std::ofstream os(file, std::ios::binary);
   if (!os) perr("Error: cannot create file " + file);
-  os << "ObjectType = Image\nNDims = " << dim << "\nBinaryData = True\nBinaryDataByteOrderMSB = False\nCompressedData = False\nDimSize =";
+  std::vector<char> packed;
+  if (compress) {
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (deflateInit(&zs, 2) != Z_OK) perr("Error: zlib initialisation failed");
+    std::vector<char> chunk(1 << 22);
+    size_t inPos = 0;
+    int zr = Z_OK;
+    while (zr != Z_STREAM_END) {
+      if (zs.avail_in == 0 && inPos < bytes) {
+        const size_t take = std::min<size_t>(bytes - inPos, (size_t)1 << 30);
+        zs.next_in = (Bytef*)((const char*)data + inPos); zs.avail_in = (uInt)take; inPos += take;
+      }
+      zs.next_out = (Bytef*)chunk.data(); zs.avail_out = (uInt)chunk.size();
+      zr = deflate(&zs, inPos >= bytes ? Z_FINISH : Z_NO_FLUSH);
+      if (zr == Z_STREAM_ERROR) { deflateEnd(&zs); perr("Error: compression failed for " + file); }
+      packed.insert(packed.end(), chunk.data(), chunk.data() + (chunk.size() - zs.avail_out));
+    }
+    deflateEnd(&zs);
+  }
+  os << "ObjectType = Image\nNDims = " << dim << "\nBinaryData = True\nBinaryDataByteOrderMSB = False\nCompressedData = " << (compress ? "True" : "False");
+  if (compress) os << "\nCompressedDataSize = " << packed.size();
+  os << "\nDimSize =";
   for (int i = 0; i < dim; ++i) os << " " << dims[i];
-  os << "\nElementType = " << (as16 ? "MET_USHORT" : "MET_UINT") << "\nElementDataFile = LOCAL\n";
+  os << "\nElementType = " << elementType << "\nElementDataFile = LOCAL\n";
+  if (compress) os.write(packed.data(), packed.size()); else os.write((const char*)data, bytes);
+}
+inline void writeMetaImage(const std::string& file, int dim, const int64_t dims[3], const std::vector<uint32_t>& v, bool as16, bool compress = false) {
   if (as16) {
     std::vector<uint16_t> w(v.size());
     for (size_t i = 0; i < v.size(); ++i) w[i] = (uint16_t)v[i];
-    os.write((const char*)w.data(), w.size() * 2);
-  } else os.write((const char*)v.data(), v.size() * 4);
+    writeMetaImageBytes(file, dim, dims, "MET_USHORT", w.data(), w.size() * 2, compress);
+  } else writeMetaImageBytes(file, dim, dims, "MET_UINT", v.data(), v.size() * 4, compress);
 }
 
-inline void writeMetaImageFloat(const std::string& file, int dim, const int64_t dims[3], const std::vector<float>& v) {
-  std::ofstream os(file, std::ios::binary);
-  if (!os) perr("Error: cannot create file " + file);
-  os << "ObjectType = Image\nNDims = " << dim << "\nBinaryData = True\nBinaryDataByteOrderMSB = False\nCompressedData = False\nDimSize =";
-  for (int i = 0; i < dim; ++i) os << " " << dims[i];
-  os << "\nElementType = MET_FLOAT\nElementDataFile = LOCAL\n";
-  os.write((const char*)v.data(), v.size() * 4);
+inline void writeMetaImageFloat(const std::string& file, int dim, const int64_t dims[3], const std::vector<float>& v, bool compress = false) {
+  writeMetaImageBytes(file, dim, dims, "MET_FLOAT", v.data(), v.size() * 4, compress);
 }
 
 // readData(order, file, true) of util/text_io.hxx:193-213 for TTriple<Label> (type/tuple.hxx:26-28)

@@ -13,7 +13,6 @@ int main(int argc, char* argv[]) {
                  {"segImage", "pbImage", "maskImage", "sizeThreshold", "rpbThreshold", "relabel", "write16", "compress", "outputImage"}, usage);
   for (const char* req : {"segImage", "pbImage", "sizeThreshold", "outputImage"})
     if (!a.has(req)) { std::cerr << "Error: the option '--" << req << "' is required but missing\n" << usage; return EXIT_FAILURE; }
-  if (flagOf(a, "compress")) perr("Error: compressed output is not supported...");
   auto ts = a.all("sizeThreshold");
   if (ts.empty() || ts.size() > 2) perr("Error: one or two size thresholds expected...");
   int sizes[2] = {atoi(ts[0].c_str()), ts.size() > 1 ? atoi(ts[1].c_str()) : 0};
@@ -36,7 +35,7 @@ int main(int argc, char* argv[]) {
   uint32_t nl = 0;
   if (flagOf(a, "relabel")) check(glia_hmt_relabel_image(ctx, dLab, (int64_t)seg.size(), 0, &nl));           // :80
   hipCheck(hipMemcpy(seg.u32.data(), dLab, seg.size() * 4, hipMemcpyDeviceToHost));
-  writeMetaImage(a.str("outputImage"), seg.dim, seg.dims, seg.u32, flagOf(a, "write16"));
+  writeMetaImage(a.str("outputImage"), seg.dim, seg.dims, seg.u32, flagOf(a, "write16"), flagOf(a, "compress"));
   glia_hmt_rag_free(rag); glia_hmt_ctx_destroy(ctx);
   (void)hipFree(dLab); (void)hipFree(dPb);
   return EXIT_SUCCESS;

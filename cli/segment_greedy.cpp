@@ -23,7 +23,6 @@ int main(int argc, char* argv[]) {
                  {"segImage", "mergeOrders", "mergeProbs", "regionProbs", "maskImage", "ignore", "relabel", "write16", "compress", "finalSegImage", "bcImage"}, usage);
   for (const char* req : {"segImage", "mergeOrders"})
     if (!a.has(req)) { std::cerr << "Error: the option '--" << req << "' is required but missing\n" << usage; return EXIT_FAILURE; }
-  if (flagOf(a, "compress")) perr("Error: compressed output is not supported...");
   // one tree per merge order file (main_segment_greedy.cxx:33-60)
   const auto orderFiles = a.all("mergeOrders"), probFiles = a.all("mergeProbs"), rprobFiles = a.all("regionProbs");
   const int nTree = (int)orderFiles.size();
@@ -64,7 +63,7 @@ int main(int argc, char* argv[]) {
     check(glia_hmt_rag_build(cx, segb.dim, segb.dims, dL, dM, /*only_contour=*/1, dZ, nullptr, &rag));
     check(glia_hmt_boundary_confidence(cx, rag, nTree, nn.data(), pl.data(), pp.data(), p0.data(), pq.data(), dOut));
     hipCheck(hipMemcpy(zeros.data(), dOut, zeros.size() * 4, hipMemcpyDeviceToHost));
-    writeMetaImageFloat(a.str("bcImage"), segb.dim, segb.dims, zeros);
+    writeMetaImageFloat(a.str("bcImage"), segb.dim, segb.dims, zeros, flagOf(a, "compress"));
     glia_hmt_rag_free(rag); glia_hmt_ctx_destroy(cx);
     (void)hipFree(dL); (void)hipFree(dZ); (void)hipFree(dOut);
     if (dM) (void)hipFree(dM);
@@ -94,7 +93,7 @@ int main(int argc, char* argv[]) {
   uint32_t nl = 0;
   if (flagOf(a, "relabel")) check(glia_hmt_relabel_image(ctx, dLab, (int64_t)seg.size(), 0, &nl));
   hipCheck(hipMemcpy(seg.u32.data(), dLab, seg.size() * 4, hipMemcpyDeviceToHost));
-  writeMetaImage(a.str("finalSegImage"), seg.dim, seg.dims, seg.u32, flagOf(a, "write16"));
+  writeMetaImage(a.str("finalSegImage"), seg.dim, seg.dims, seg.u32, flagOf(a, "write16"), flagOf(a, "compress"));
   glia_hmt_ctx_destroy(ctx);
   (void)hipFree(dLab);
   if (dMask) (void)hipFree(dMask);

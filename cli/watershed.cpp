@@ -11,7 +11,6 @@ int main(int argc, char* argv[]) {
                  {"inputImage", "level", "relabel", "write16", "compress", "outputImage"}, usage);
   for (const char* req : {"inputImage", "level", "outputImage"})
     if (!a.has(req)) { std::cerr << "Error: the option '--" << req << "' is required but missing\n" << usage; return EXIT_FAILURE; }
-  if (flagOf(a, "compress")) perr("Error: compressed output is not supported...");
   Volume img = readMetaImage(a.str("inputImage"), true);
   float* dImg = upload(img.f32);
   uint32_t* dLab;
@@ -23,7 +22,7 @@ int main(int argc, char* argv[]) {
   if (flagOf(a, "relabel")) check(glia_hmt_relabel_image(ctx, dLab, (int64_t)img.size(), 0, &nl));                // :11
   std::vector<uint32_t> out(img.size());
   hipCheck(hipMemcpy(out.data(), dLab, img.size() * 4, hipMemcpyDeviceToHost));
-  writeMetaImage(a.str("outputImage"), img.dim, img.dims, out, flagOf(a, "write16"));                               // :12-16
+  writeMetaImage(a.str("outputImage"), img.dim, img.dims, out, flagOf(a, "write16"), flagOf(a, "compress"));                               // :12-16
   glia_hmt_ctx_destroy(ctx);
   (void)hipFree(dLab); (void)hipFree(dImg);
   return EXIT_SUCCESS;

@@ -11,18 +11,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "cli")
 
 
-def write_mha(path, arr, local=True):
+def write_mha(path, arr, local=True, compress=False):
     et = {np.dtype(np.uint32): "MET_UINT", np.dtype(np.float32): "MET_FLOAT", np.dtype(np.uint16): "MET_USHORT",
           np.dtype(np.uint8): "MET_UCHAR"}[arr.dtype]
     dims = " ".join(str(d) for d in arr.shape[::-1])
-    hdr = ("ObjectType = Image\nNDims = %d\nBinaryData = True\nBinaryDataByteOrderMSB = False\nCompressedData = False\n"
-           "DimSize = %s\nElementType = %s\nElementDataFile = %s\n") % (arr.ndim, dims, et, "LOCAL" if local else os.path.basename(path) + ".raw")
+    data = np.ascontiguousarray(arr).tobytes()
+    if compress:
+        import zlib
+        data = zlib.compress(data, 6)
+    hdr = ("ObjectType = Image\nNDims = %d\nBinaryData = True\nBinaryDataByteOrderMSB = False\nCompressedData = %s\n%s"
+           "DimSize = %s\nElementType = %s\nElementDataFile = %s\n") % (arr.ndim, "True" if compress else "False",
+                                                                      "CompressedDataSize = %d\n" % len(data) if compress else "", dims, et,
+                                                                      "LOCAL" if local else os.path.basename(path) + ".raw")
     with open(path, "wb") as f:
         f.write(hdr.encode())
         if local:
-            f.write(np.ascontiguousarray(arr).tobytes())
+            f.write(data)
     if not local:
-        np.ascontiguousarray(arr).tofile(path + ".raw")
+        with open(path + ".raw", "wb") as f:
+            f.write(data)
 
 
 @pytest.fixture(scope="module")
@@ -182,8 +189,37 @@ def read_mha(path):
     i = raw.index(b"ElementDataFile = LOCAL\n") + len(b"ElementDataFile = LOCAL\n")
     hdr = dict(ln.split(" = ") for ln in raw[:i].decode().strip().split("\n"))
     dims = [int(x) for x in hdr["DimSize"].split()][::-1]
-    dt = {"MET_UINT": np.uint32, "MET_USHORT": np.uint16}[hdr["ElementType"]]
-    return np.frombuffer(raw[i:], dtype=dt).reshape(dims)
+    dt = {"MET_UINT": np.uint32, "MET_USHORT": np.uint16, "MET_FLOAT": np.float32}[hdr["ElementType"]]
+    body = raw[i:]
+    if hdr.get("CompressedData") == "True":
+        import zlib
+        assert int(hdr["CompressedDataSize"]) == len(body)
+        body = zlib.decompress(body)
+    return np.frombuffer(body, dtype=dt).reshape(dims)
+
+
+@pytest.mark.parametrize("local", [True, False])
+def test_compressed_metaimage_in_and_out(tools, tmp_path, local):
+    """--compress / -z (itk::ImageFileWriter::SetUseCompression, util/image_io.hxx:46-52): the tools read zlib-compressed MetaImage
+    files (data in the .mha or beside it) and write them"""
+    from oracle import pyoracle as O
+    labels, pb = O.synth((40, 36, 28), 6, 12)
+    seg, pbf, out = (str(tmp_path / n) for n in ("seg.mha", "pb.mha", "out.mha"))
+    write_mha(seg, labels, local=local, compress=True)
+    write_mha(pbf, pb, local=local, compress=True)
+    subprocess.check_call([os.path.join(tools, "pre_merge"), "-s", seg, "-p", pbf, "-t", "100", "500", "-b", "0.28", "-r", "1", "-z", "1", "-o", out])
+    assert b"CompressedData = True" in open(out, "rb").read(300)
+    o_ref, _ = O.Rag(labels).pre_merge(pb, [100, 500], 0.28)
+    ref, _ = O.relabel_image(O.transform_image(labels, *O.transform_keys(o_ref)))
+    assert (read_mha(out) == ref).all()
+    # the next tool: compressed in, compressed out
+    order_f, out2 = str(tmp_path / "order.txt"), str(tmp_path / "out2.mha")
+    with open(order_f, "w") as f:
+        for r in o_ref:
+            f.write("%d %d %d\n" % tuple(r))
+    subprocess.check_call([os.path.join(tools, "apply_merges"), "-i", seg, "-g", order_f, "-z", "1", "-o", out2])
+    ref = O.transform_image(labels, *O.transform_keys(o_ref))
+    assert (read_mha(out2) == ref).all()
 
 
 def test_bc_feat_cli(tools, tmp_path):
