@@ -9,6 +9,9 @@
 #include <unordered_map>
 #include <vector>
 
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_run_length_encode.hpp>
+
 #include "hmt_internal.hpp"
 
 namespace glia {
@@ -220,7 +223,40 @@ int relabel_image(uint32_t* d_lab, int64_t n, int64_t min_size, uint32_t* n_labe
   GLIA_HIP_TRY(hipMemcpyAsync(&maxl, d_max, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   GLIA_HIP_TRY(hipStreamSynchronize(stream));
   (void)hipFree(d_max);
-  if (maxl >= kDenseLimit) { set_error("relabel_image: labels above 2^28 are not supported"); return GLIA_HMT_ERR_UNSUPPORTED; }
+  std::vector<uint32_t> labs;                   // labels present (not 0), and their voxel counts
+  std::vector<unsigned long long> cntOf;
+  if (maxl >= kDenseLimit) {
+    // sparse labels: no count array over the label range -- sort a copy of the labels, run lengths of the sorted copy
+    uint32_t *d_a = nullptr, *d_b = nullptr, *d_u = nullptr, *d_c = nullptr, *d_nr = nullptr;
+    void* d_tmp = nullptr;
+    auto freeAll = [&]() { for (void* q : {(void*)d_a, (void*)d_b, (void*)d_u, (void*)d_c, (void*)d_nr, d_tmp}) if (q) (void)hipFree(q); };
+    auto fail = [&](hipError_t e) { freeAll(); set_error(std::string("relabel_image: ") + hipGetErrorString(e)); return GLIA_HMT_ERR_HIP; };
+    hipError_t e;
+    if ((e = hipMalloc(&d_a, sizeof(uint32_t) * (size_t)n)) != hipSuccess || (e = hipMalloc(&d_b, sizeof(uint32_t) * (size_t)n)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpyAsync(d_a, d_lab, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, stream)) != hipSuccess) return fail(e);
+    size_t tmp_bytes = 0;
+    if ((e = rocprim::radix_sort_keys(nullptr, tmp_bytes, d_a, d_b, (size_t)n, 0, 32, stream)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16)) != hipSuccess) return fail(e);
+    if ((e = rocprim::radix_sort_keys(d_tmp, tmp_bytes, d_a, d_b, (size_t)n, 0, 32, stream)) != hipSuccess) return fail(e);
+    (void)hipFree(d_tmp); d_tmp = nullptr;
+    // run lengths: unique labels into d_a (reused), counts into d_c; a run has at most n <= 2^32 - 1... counts are 32-bit in
+    // rocPRIM's interface: volumes beyond 2^32 voxels of ONE label are out of reach of this path
+    if ((e = hipMalloc(&d_c, sizeof(uint32_t) * (size_t)n)) != hipSuccess || (e = hipMalloc(&d_nr, sizeof(uint32_t))) != hipSuccess) return fail(e);
+    d_u = d_a; d_a = nullptr;
+    tmp_bytes = 0;
+    if ((e = rocprim::run_length_encode(nullptr, tmp_bytes, d_b, (unsigned int)n, d_u, d_c, d_nr, stream)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16)) != hipSuccess) return fail(e);
+    if ((e = rocprim::run_length_encode(d_tmp, tmp_bytes, d_b, (unsigned int)n, d_u, d_c, d_nr, stream)) != hipSuccess) return fail(e);
+    uint32_t nr = 0;
+    if ((e = hipMemcpyAsync(&nr, d_nr, sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess || (e = hipStreamSynchronize(stream)) != hipSuccess) return fail(e);
+    std::vector<uint32_t> u(nr), c32(nr);
+    if (nr) {
+      if ((e = hipMemcpy(u.data(), d_u, sizeof(uint32_t) * nr, hipMemcpyDeviceToHost)) != hipSuccess) return fail(e);
+      if ((e = hipMemcpy(c32.data(), d_c, sizeof(uint32_t) * nr, hipMemcpyDeviceToHost)) != hipSuccess) return fail(e);
+    }
+    freeAll();
+    for (uint32_t i = 0; i < nr; ++i) if (u[i] != 0u) { labs.push_back(u[i]); cntOf.push_back(c32[i]); }
+  } else {
   unsigned long long* d_cnt;
   GLIA_HIP_TRY(hipMalloc(&d_cnt, sizeof(unsigned long long) * ((size_t)maxl + 1)));
   GLIA_HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long) * ((size_t)maxl + 1), stream));
@@ -230,16 +266,18 @@ int relabel_image(uint32_t* d_lab, int64_t n, int64_t min_size, uint32_t* n_labe
   GLIA_HIP_TRY(hipMemcpyAsync(cnt.data(), d_cnt, sizeof(unsigned long long) * cnt.size(), hipMemcpyDeviceToHost, stream));
   GLIA_HIP_TRY(hipStreamSynchronize(stream));
   (void)hipFree(d_cnt);
+  for (uint32_t l = 1; l <= maxl; ++l) if (cnt[l]) { labs.push_back(l); cntOf.push_back(cnt[l]); }
+  }
   // RelabelComponentImageFilter: objects (label != 0) sorted by size, largest first, ties by the smaller original
   // label; objects below the minimum size become background
-  std::vector<uint32_t> labs;
-  for (uint32_t l = 1; l <= maxl; ++l) if (cnt[l]) labs.push_back(l);
-  std::sort(labs.begin(), labs.end(), [&](uint32_t a, uint32_t b) { return cnt[a] != cnt[b] ? cnt[a] > cnt[b] : a < b; });
+  std::vector<uint32_t> idx(labs.size());
+  for (size_t i = 0; i < idx.size(); ++i) idx[i] = (uint32_t)i;
+  std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return cntOf[a] != cntOf[b] ? cntOf[a] > cntOf[b] : labs[a] < labs[b]; });
   std::vector<uint32_t> src, dst;
   uint32_t next = 1;
-  for (uint32_t l : labs) {
-    src.push_back(l);
-    dst.push_back((min_size > 0 && cnt[l] < (unsigned long long)min_size) ? 0u : next++);
+  for (uint32_t i : idx) {
+    src.push_back(labs[i]);
+    dst.push_back((min_size > 0 && cntOf[i] < (unsigned long long)min_size) ? 0u : next++);
   }
   *n_labels = next - 1;
   return transform_image(d_lab, n, src.data(), dst.data(), (int64_t)src.size(), nullptr, 0, stream, nullptr);

@@ -66,6 +66,22 @@ def test_relabel_image(ctx, min_size):
     assert (np.diff(sizes.astype(np.int64)) <= 0).all() and (got[:3] == 0).all()
 
 
+@pytest.mark.parametrize("min_size", [0, 40])
+def test_relabel_image_with_labels_above_2_28(ctx, min_size):
+    """sparse label values (hashes, 2^31 offsets): no count array over the label range -- sort + run lengths on the device"""
+    from glia_amd import hmt
+    from oracle import pyoracle as O
+    labels, _ = O.synth((40, 36, 28), 6, 12)
+    big = (labels.astype(np.uint64) * 2654435761 % (2 ** 32 - 7) + 3).astype(np.uint32)      # injective enough: checked below
+    assert len(np.unique(big)) == len(np.unique(labels)) and big.max() >= 2 ** 28
+    big[:3] = 0
+    d = _dev(big)
+    n = hmt.relabel_image(ctx, d, min_size=min_size)
+    ref, n_ref = O.relabel_image(big, min_size=min_size)
+    got = d.cpu().numpy().view(np.uint32)
+    assert n == n_ref and (got == ref).all()
+
+
 @pytest.mark.parametrize("sizes,rpb", [((150,), 0.0), ((100, 500), 0.28)])
 def test_pre_merge_pipeline(ctx, sizes, rpb):
     """gadget/main_pre_merge.cxx end to end: order under the size condition -> transformKeys -> transformImage"""
