@@ -318,7 +318,7 @@ int glia_hmt_transform_image(glia_hmt_ctx* ctx, uint32_t* d_labels, int64_t n_vo
 
 /* relabelImage (util/image.hxx:992-1001) = itk::RelabelComponentImageFilter, in place: objects (labels != 0) get the
  * consecutive labels 1..n by decreasing voxel count (ties: smaller original label first), objects smaller than
- * min_size (> 0) become 0.  ITK is not available to pin this against; labels must be < 2^28. */
+ * min_size (> 0) become 0.  ITK is not available to pin this against. */
 int glia_hmt_relabel_image(glia_hmt_ctx* ctx, uint32_t* d_labels, int64_t n_voxels, int64_t min_size, uint32_t* n_labels);
 
 /* milliseconds of the last glia_hmt_transform_image kernel on this context (HIP events) */
