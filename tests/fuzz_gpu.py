@@ -49,7 +49,19 @@ while time.time() < t_end:
         rpb = float(rng.uniform(0.1, 0.5))
         o, s = rm.pre_merge(sizes, rpb); rm.close()
         ro, rs = O.Rag(labels, mask=mask).pre_merge(pb, sizes, rpb)
-        assert o.shape == ro.shape and (o == ro).all(), "pre_merge %s %g" % (sizes, rpb)
+        if not (o.shape == ro.shape and (o == ro).all()):
+            # diagnosis: does a fresh build of the same map give the same answer?
+            again = []
+            for _ in range(3):
+                rm2 = hmt.RegionMap(ctx, d_lab, pb=d_pb, mask=d_mask, only_contour=False)
+                o2, _ = rm2.pre_merge(sizes, rpb); rm2.close()
+                again.append(bool(o2.shape == ro.shape and (o2 == ro).all()))
+            k = 0
+            while k < min(len(o), len(ro)) and (o[k] == ro[k]).all(): k += 1
+            np.savez_compressed(os.path.join(ROOT, "gpurun_out", "fuzz_fail_premerge.npz"), labels=labels, pb=pb, mask=mask if mask is not None else np.zeros(0),
+                                sizes=np.asarray(sizes), rpb=np.asarray([rpb]), got=o, want=ro)
+            raise AssertionError("pre_merge %s %r: first difference at merge %d of %d / %d, got %s want %s; three fresh builds agree with the oracle: %s"
+                                 % (sizes, rpb, k, len(o), len(ro), o[k].tolist() if k < len(o) else None, ro[k].tolist() if k < len(ro) else None, again))
         # classifier linkage, random image lists (the oracle re-walks voxels per edge: keep it to a few hundred regions)
         if len(np.unique(labels)) > 300:
             n += 1
