@@ -66,6 +66,10 @@ int pq_setup(DeviceBuffers& buf, PqTree& t, hipStream_t stream) {
   return GLIA_HMT_OK;
 }
 
+// A barrier behind which every global store and atomic of the workgroup has been performed.  (__syncthreads() is NOT that on
+// gfx950: the workgroup-scope fence of a workgroup that is not split over CUs waits for lgkmcnt only -- found in round 3, when
+// a merge order differed once in ~30 000 runs; the comments of rounds 1-2 that say "vmcnt(0) inside" were wishful.)
+__device__ __forceinline__ void full_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 struct GreedyState {
   uint32_t R0;
   uint32_t* adj_off;   // [2*R0] start of a region's incident-edge list in pool
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
   __shared__ Key s_topk[kTopLds];
   Key* topk = (!MEDIAN && pq.nlevels >= 2 && pq.lv[pq.nlevels - 1].size <= kTopLds) ? s_topk : nullptr;
   if (topk) pq_top_load<kGreedyThreads>(pq, topk, tid);
-  __syncthreads();
+  full_barrier();
   pq_top<kGreedyThreads>(pq, s.pq, tid, topk);      // the root lives in LDS: rebuilt at every launch
 
 #ifdef GLIA_HMT_PROFILE
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
         }
       }
     }
-    __syncthreads();
+    full_barrier();
     PH(0);
     if (s.stop != ST_RUN) { status = s.stop; break; }
     if (s.reject) { pq_propagate<kGreedyThreads>(pq, s.pq, tid, topk); continue; }
@@ -268,14 +272,14 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
         (side1 ? s.mv1 : s.mv0)[h] = eid + 1u;
       } else (side1 ? st.mark1 : st.mark0)[rs] = eid + 1u;
     }
-    __syncthreads();
+    full_barrier();
     PH(1);
 
     // ---- phase B: one new edge (rs, r2) per distinct neighbour (TBoundaryTable::update) ----
     bool bad = false;
     const uint32_t nwork = small ? s.nitems : total;
     for (uint32_t base = 0; base < nwork; base += kGreedyThreads) {
-      if (MEDIAN) { if (tid == 0) jobs.n = 0; __syncthreads(); }
+      if (MEDIAN) { if (tid == 0) jobs.n = 0; full_barrier(); }
       const uint32_t i = base + tid;
       do {
         if (i >= nwork) break;
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
         if (seq1) { pq.leaf_seq[e1s] = 0; if (top1 == e1s) pq_touch(pq, s.pq, 0, 0, e1s); }
       } while (false);
       if (MEDIAN) {
-        __syncthreads();
+        full_barrier();
         const uint32_t J = jobs.n;
         if (J) {
           if (tid == 0) {
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
             }
             jobs.off[J] = o; jobs.toff[J] = to;
           }
-          __syncthreads();
+          full_barrier();
           const unsigned long long tot = jobs.off[J];
           const uint32_t ntiles = jobs.toff[J];
           // stable merge of the two sorted runs (ties: the (r0,rs) run first).  Merge-path splits cut every job into
@@ -387,7 +391,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
               jobs.ta0[tid] = d0 == 0 ? 0u : merge_split(A, na, B, nb, d0);
               jobs.ta1[tid] = d1 == n ? na : merge_split(A, na, B, nb, d1);
             }
-            __syncthreads();
+            full_barrier();
             const uint32_t cnt = ntiles - round0 < (uint32_t)kGreedyThreads ? ntiles - round0 : (uint32_t)kGreedyThreads;
             float* in = jobs.buf[wave];
             float* ob = in + kMergeTile;
@@ -441,9 +445,9 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
               if (lane == 0 && mi >= d0 && mi < d1) jobs.med[j] = ob[(mi - d0) + ((mi - d0) >> 4)];
               wave_lds_sync();
             }
-            __syncthreads();
+            full_barrier();
           }
-          __syncthreads();
+          full_barrier();
           if ((uint32_t)tid < J) {
             const uint32_t newE = jobs.newE[tid];
             const unsigned long long off = vals_used + jobs.off[tid];
@@ -452,7 +456,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
             pq.leaf_sal[newE] = st.size_weight ? -med * (double)min(st.rsz[st.e_u[newE]], st.rsz[r2]) : -med;
           }
           vals_used += tot;
-          __syncthreads();
+          full_barrier();
         }
       }
         }
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
 #endif
     k += 1; ne += newcount; pool_used += total;
   }
-  __syncthreads();
+  full_barrier();
   if (topk) pq_top_store<kGreedyThreads>(pq, topk, tid);      // the next launch (or the host's rebuild) starts from global memory
   if (tid == 0) { st.ctrl[0] = k; st.ctrl[1] = ne; st.ctrl[2] = pool_used; st.ctrl[3] = status; st.ctrl[4] = vals_used; }
 #ifdef GLIA_HMT_PROFILE
@@ -623,9 +627,9 @@ __device__ __forceinline__ uint32_t block_scan_incl(uint32_t v, uint32_t* wsum, 
   uint32_t x = v;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, d); if (lane >= d) x += y; }
-  __syncthreads();
+  full_barrier();
   if (lane == 63) wsum[wave] = x;
-  __syncthreads();
+  full_barrier();
   uint32_t base = 0, tot = 0;
 #pragma unroll
   for (int i = 0; i < kNW; ++i) { const uint32_t s = wsum[i]; if (i < wave) base += s; tot += s; }
@@ -713,7 +717,7 @@ __device__ __forceinline__ void win_compact(WinShared& w, int tid, uint32_t cap 
 #pragma unroll
   for (int j = 0; j < kWinPer; ++j) if (seq[j] != 0) { win_put(w, o, sal[j], seq[j], e[j], u[j], v[j], hu[j], hv[j]); ++o; }
   if (tid == 0) w.n = total;
-  __syncthreads();
+  full_barrier();
 }
 
 __device__ __forceinline__ void win_push_global(const WinState& st, uint32_t e, uint32_t cell) {
@@ -727,7 +731,7 @@ __device__ __forceinline__ void win_push_global(const WinState& st, uint32_t e, 
 __device__ __forceinline__ void win_flush(const WinState& st, WinShared& w, int tid) {
   const double smin = st.wrange[0], scale = st.wrange[1];
   if (tid == 0) w.maxcell = 0;
-  __syncthreads();
+  full_barrier();
   const uint32_t n = w.n < st.wcap ? w.n : st.wcap;
   uint32_t mc = 0;
   for (uint32_t i = tid; i < n; i += kGreedyThreads) {
@@ -737,12 +741,12 @@ __device__ __forceinline__ void win_flush(const WinState& st, WinShared& w, int 
     mc = mc > c + 1u ? mc : c + 1u;
   }
   if (mc) atomicMax(&w.maxcell, mc);
-  __syncthreads();
+  full_barrier();
   if (tid == 0) {
     if (w.maxcell && (int)w.maxcell - 1 >= w.cthr) { w.cthr = (int)w.maxcell - 1; w.tsal = __builtin_inf(); w.tseq = ~0ull; }
     w.n = 0;
   }
-  __syncthreads();
+  full_barrier();
 }
 
 // Items above tau found the window full and went to their cells' lists: tau rises to the largest of their saliencies and
@@ -751,15 +755,15 @@ __device__ __forceinline__ void win_evict(const WinState& st, WinShared& w, int 
   const double smin = st.wrange[0], scale = st.wrange[1];
   const double lim = f64_unord(w.spill_ord);
   const uint32_t n = w.n < st.wcap ? w.n : st.wcap;
-  __syncthreads();
+  full_barrier();
   for (uint32_t i = tid; i < n; i += kGreedyThreads) {
     if (w.seq[i] == 0 || w.sal[i] > lim) continue;
     win_push_global(st, w.e[i], win_cell(w.sal[i], smin, scale, st.wB));
     w.seq[i] = 0;
   }
-  __syncthreads();
+  full_barrier();
   if (tid == 0) { w.n = n; w.cthr = (int)win_cell(lim, smin, scale, st.wB); w.tsal = lim; w.tseq = ~0ull; w.spill_ord = 0; }
-  __syncthreads();
+  full_barrier();
 }
 
 // initial entries [a, b) of the sorted array into the window (every thread calls; no barrier)
@@ -772,9 +776,9 @@ __device__ __forceinline__ void win_take_initial(const WinState& st, WinShared& 
 // contains barriers)
 constexpr uint32_t kSelMax = 384;           // list items a split cell hands over at most (bounded min-heap in LDS)
 __device__ __forceinline__ int win_reload(const WinState& st, WinShared& w, int tid, double* sel_sal, unsigned long long* sel_seq) {
-  __syncthreads();                       // (vmcnt(0) inside) this workgroup's list pushes and counter updates are done
+  full_barrier();                       // (vmcnt(0) inside) this workgroup's list pushes and counter updates are done
   if (tid == 0) { w.n = 0; w.need_tree = 0; }
-  __syncthreads();
+  full_barrier();
   uint32_t c_hi = (uint32_t)(w.cthr + 1) < st.wB ? (uint32_t)(w.cthr + 1) : st.wB, loaded = 0, iptr = w.iptr;
   int result = 1;
   const uint32_t c_floor = st.wch < st.wB ? st.wch : 0u;      // the horizon: cells below it are not loaded
@@ -801,7 +805,7 @@ __device__ __forceinline__ int win_reload(const WinState& st, WinShared& w, int 
         }
         if (cn != 0) st_l2(&st.wcnt[c], 0u);
       }
-      __syncthreads();
+      full_barrier();
       loaded += w.bcast;
       c_hi = c_lo;
       if (loaded) result = 0;
@@ -848,7 +852,7 @@ __device__ __forceinline__ int win_reload(const WinState& st, WinShared& w, int 
           // tau from the list: the heap's minimum if the list holds more than the heap
           w.psal = nlive > K ? sel_sal[0] : -__builtin_inf(); w.pseq = nlive > K ? sel_seq[0] : 0ull;
         }
-        __syncthreads();
+        full_barrier();
         double tsal = w.psal; unsigned long long tseq = w.pseq;
         const uint32_t iA = seg_end > iptr ? (seg_end - iptr < RA ? seg_end : iptr + RA) : iptr;
         if (iA < seg_end) {                                                     // array entries stay behind: their first one bounds tau
@@ -856,7 +860,7 @@ __device__ __forceinline__ int win_reload(const WinState& st, WinShared& w, int 
           if (as > tsal || (as == tsal && aq > tseq)) { tsal = as; tseq = aq; }
         }
         if (tid == 0) w.bcast = 0;
-        __syncthreads();
+        full_barrier();
         // array entries above tau (a prefix of [iptr, iA): the array is sorted)
         uint32_t mine = 0;
         for (uint32_t i = iptr + (uint32_t)tid; i < iA; i += kGreedyThreads) {
@@ -865,7 +869,7 @@ __device__ __forceinline__ int win_reload(const WinState& st, WinShared& w, int 
           if (r.sal > tsal || (r.sal == tsal && q > tseq)) { ++mine; win_take(st, w, e, r); }
         }
         if (mine) atomicAdd(&w.bcast, mine);
-        __syncthreads();
+        full_barrier();
         iptr += w.bcast;
         if (tid == 0) {
           // list nodes above tau move, the others stay linked
@@ -881,28 +885,28 @@ __device__ __forceinline__ int win_reload(const WinState& st, WinShared& w, int 
           if (keep_tail != kNone) st.er[keep_tail].next = kNone;
           st_l2(&st.whead[cs], keep_head);
         }
-        __syncthreads();
+        full_barrier();
         const uint32_t moved = w.n - before;
         if (moved == 0u && w.bcast == 0u) {
           // nothing above the new tau and no array entry passed: the cell is empty, its count was too high (counts are upper
           // bounds: the batch kernel does not discount an edge that dies with exactly tau's key) -- on to the cells below
-          __syncthreads();
+          full_barrier();
           if (tid == 0) st_l2(&st.wcnt[cs], 0u);
           c_hi = cs;
           continue;
         }
         if (tid == 0) { if (moved) atomicSub(&st.wcnt[cs], moved); w.cthr = (int)cs; w.tsal = tsal; w.tseq = tseq; w.iptr = iptr; }
         if (moved || w.bcast) result = 0;
-        __syncthreads();
+        full_barrier();
         return result;
       }
       break;
     }
     if (loaded >= (kWinMinLoad < st.wbudget / 4u ? kWinMinLoad : st.wbudget / 4u)) break;      // else: a whole block of (nearly) empty cells, go on below it
   }
-  __syncthreads();
+  full_barrier();
   if (tid == 0 && result != 2) { w.cthr = (int)c_hi - 1; w.tsal = __builtin_inf(); w.tseq = ~0ull; w.iptr = iptr; }
-  __syncthreads();
+  full_barrier();
   if (result == 1 && c_floor != 0u) result = 3;
   return result;
 }
@@ -922,7 +926,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(WinState 
   for (uint32_t i = tid; i < kWinCap; i += kGreedyThreads) { w.seq[i] = 0; w.e[i] = 0; w.v[i] = 0; w.sal[i] = 0.0; }
   if (tid < 128) w.touched[tid >> 6][tid & 63] = 0;
   if (tid < kNW) { w.part[tid].sal = -__builtin_inf(); w.part[tid].seq = 0; w.part[tid].arg = 0; }
-  __syncthreads();
+  full_barrier();
   const double smin = st.wrange[0], scale = st.wrange[1];
   uint32_t r2prev = kNone;
 #ifdef GLIA_HMT_PROFILE
@@ -964,7 +968,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(WinState 
     const uint32_t tb0 = w.touched[par ^ 1][(r0 >> 5) & 63u], tb1 = w.touched[par ^ 1][(r1 >> 5) & 63u];
     const bool dep = r2prev != kNone && (r1 == r2prev || r0 == r2prev || ((tb0 >> (r0 & 31u)) & 1u) || ((tb1 >> (r1 & 31u)) & 1u));
     if (dep) {
-      __syncthreads();                    // (vmcnt(0) inside) the previous contraction's stores are done
+      full_barrier();                    // (vmcnt(0) inside) the previous contraction's stores are done
 #ifdef GLIA_HMT_PROFILE
       wdeps += 1;
 #endif
@@ -981,9 +985,9 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(WinState 
         if (!ok && sz1 < st.cond_t1 && sdivide(su1, (double)sz1, 0.0) > st.cond_rpb) ok = true;
       }
       if (!ok) {
-        __syncthreads();                 // every thread has read the slot
+        full_barrier();                 // every thread has read the slot
         if (tid == 0) { w.seq[slot] = 0; st.er[e].seq = 0; }
-        __syncthreads();
+        full_barrier();
         win_scan(st, w, tid, kNone, 0);
         continue;
       }
@@ -1017,7 +1021,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(WinState 
         (side1 ? s.mv1 : s.mv0)[h] = i + 1u;
       } else (side1 ? st.mark1 : st.mark0)[fe.rs] = i + 1u;
     }
-    __syncthreads();     // full: a wave that loaded has waited for its loads anyway, so its older stores are done for free
+    full_barrier();     // full: a wave that loaded has waited for its loads anyway, so its older stores are done for free
     WPH(1);
     // room for every new edge that may land in the window (total bounds their number)
     if (wn_now + total > st.wcap) {
@@ -1029,7 +1033,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(WinState 
         win_flush(st, w, tid);
         if (total > st.wcap) {             // a contraction wider than the window: nothing of it goes there
           if (tid == 0) { w.cthr = (int)st.wB; w.tsal = __builtin_inf(); w.tseq = ~0ull; }
-          __syncthreads();
+          full_barrier();
         }
       }
     }
@@ -1127,7 +1131,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(WinState 
       }
     }
     if (bad) s.bad = 1;
-    if (small) lds_barrier(); else __syncthreads();         // the stores of this phase stay in flight
+    if (small) lds_barrier(); else full_barrier();         // the stores of this phase stay in flight
     if (s.bad) { if (pend_e != kNone) st.er[pend_e].next = pend_old; status = ST_BAD_SALIENCY; break; }
     WPH(3);
     const uint32_t newcount = s.newcount;
@@ -1143,7 +1147,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(WinState 
       }
     }
     if (tid == 0) { st.adj_off[r2] = r2off; st.adj_len[r2] = newcount; s.nitems = 0; s.newcount = 0; }
-    if (w.kovf) __syncthreads();       // the scan will ask the edge records which window items died: those stores must be done
+    if (w.kovf) full_barrier();       // the scan will ask the edge records which window items died: those stores must be done
     win_scan(st, w, tid, r2, newcount);
     if (pend_e != kNone) st.er[pend_e].next = pend_old;     // (the atomic has long returned; only a reload reads the link, behind a full barrier)
     r2prev = r2;
@@ -1164,7 +1168,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(WinState 
                        wnb[0], wnb[1], wnb[2], wnb[3], wnb[4], wtb[0], wtb[1], wtb[2], wtb[3], wtb[4], wdb[0], wdb[1], wdb[2], wdb[3], wdb[4]);
 #endif
   // leave through the global lists: the next launch (or the tree kernel) starts from them
-  __syncthreads();
+  full_barrier();
   win_flush(st, w, tid);
   if (tid == 0) {
     st.ctrl[0] = k; st.ctrl[1] = ne; st.ctrl[2] = pool_used; st.ctrl[3] = w.err ? (unsigned long long)ST_INTERNAL : status;
@@ -1276,7 +1280,7 @@ __device__ __forceinline__ void batch_scan(const WinState& st, WinShared& w, Bat
   const Key m2 = wave_max_sal_first(kk);
   SCAN_T(3);
   if ((tid & 63) == 0) { b.part1[tid >> 6] = m1; b.part2[tid >> 6] = m2; }
-  __syncthreads();
+  full_barrier();
   SCAN_T(4);
   if (tid == 0) { b.nkill = 0; b.kovf = 0; }
 }
@@ -1301,7 +1305,7 @@ __device__ __forceinline__ uint32_t batch_contract_wide(const WinState& st, WinS
 #ifdef GLIA_HMT_PROFILE
   unsigned long long wt_ = __builtin_readcyclecounter();
 #endif
-  __syncthreads();                                                       // every thread has read the slot
+  full_barrier();                                                       // every thread has read the slot
   WIDE_T(0);
   if (tid == 0) {
     w.seq[slot] = 0;
@@ -1327,7 +1331,7 @@ __device__ __forceinline__ uint32_t batch_contract_wide(const WinState& st, WinS
       (side1 ? s.mv1 : s.mv0)[h] = i + 1u;
     } else (side1 ? st.mark1 : st.mark0)[fe.rs] = i + 1u;
   }
-  __syncthreads();
+  full_barrier();
   WIDE_T(1);
   if (wn_now + total > st.wcap && wn_now > st.wcap / 2u) win_compact(w, tid, st.wcap);      // (holes out; a full window spills, see win_evict)
   WIDE_T(2);
@@ -1428,7 +1432,7 @@ __device__ __forceinline__ uint32_t batch_contract_wide(const WinState& st, WinS
   if (small) rounds(std::true_type{}); else rounds(std::false_type{});
   if (bad) b.bad = 1;
   WIDE_T(3);
-  __syncthreads();
+  full_barrier();
   WIDE_T(4);
   const uint32_t newcount = s.newcount;
   if (!small) {
@@ -1442,7 +1446,7 @@ __device__ __forceinline__ uint32_t batch_contract_wide(const WinState& st, WinS
   if (!small) for (uint32_t i = tid; i < (w.n < st.wcap ? w.n : st.wcap); i += kGreedyThreads) if (w.v[i] == r2) w.hv[i].y = newcount;      // window items of r2: its list length
   if (pend_e != kNone) st.er[pend_e].next = pend_old;
   if (tid == 0) { st.adj_off[r2] = r2off; st.adj_len[r2] = newcount; }
-  __syncthreads();
+  full_barrier();
   WIDE_T(5);
   if (tid == 0) { s.nitems = 0; s.newcount = 0; }
   *newcount_out = newcount;
@@ -1464,7 +1468,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
   for (uint32_t i = tid; i < kWinCap; i += kGreedyThreads) { w.seq[i] = 0; w.e[i] = 0; w.v[i] = 0; w.sal[i] = 0.0; }
   b.bitmap[wave][lane] = 0;
   if (tid < kNW) { Key z; z.sal = -__builtin_inf(); z.seq = 0; z.arg = 0; b.part1[tid] = z; b.part2[tid] = z; }
-  __syncthreads();
+  full_barrier();
   const double smin = st.wrange[0], scale = st.wrange[1];
   uint32_t pend_e = kNone, pend_old = kNone;          // (per lane) a list push whose link is stored a round later
   constexpr uint32_t kTab = kMarkSlots / kNW;         // private neighbour table of a wave
@@ -1617,7 +1621,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
     for (int d = 32; d >= 1; d >>= 1) { const double o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
     if (lane == 0) { b.m_newcount[wave] = narrow ? newcount : 0u; b.m_total[wave] = narrow ? total : 0xFFFFFFFFu; b.m_maxsal[wave] = mx; }
     if (bad) b.bad = 1;
-    __syncthreads();
+    full_barrier();
     BPH(1);
     if (b.bad) { status = ST_BAD_SALIENCY; break; }
     // ---- validate: the longest prefix of the batch whose order is certain (lane j checks member j) ----
@@ -1655,7 +1659,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
     if (w.n + ne_off > st.wcap && w.n > st.wcap / 2u) {                    // holes out (a full window spills, see win_evict)
       if ((uint32_t)wave < V && lane == 0) w.seq[slot] = 0;
       popped = true;                                                     // (slot numbers are void after a compaction)
-      __syncthreads();
+      full_barrier();
       win_compact(w, tid, st.wcap);
     }
     const int cthr = w.cthr; const double tsal = w.tsal; const unsigned long long tseq = w.tseq;
@@ -1726,7 +1730,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
         }
       }
     }
-    __syncthreads();
+    full_barrier();
     BPH(3);
 #ifdef GLIA_HMT_PROFILE
     brounds += 1; bmembers += M; bvalid += V;
@@ -1748,7 +1752,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
 #endif
   if (pend_e != kNone) st.er[pend_e].next = pend_old;
   // leave through the global lists: the next launch (or the tree kernel) starts from them
-  __syncthreads();
+  full_barrier();
   win_flush(st, w, tid);
   if (tid == 0) {
     st.ctrl[0] = k; st.ctrl[1] = ne; st.ctrl[2] = pool_used; st.ctrl[3] = w.err ? (unsigned long long)ST_INTERNAL : status;

@@ -494,6 +494,12 @@ struct DeviceBuffers {
     int rc = raw((void**)p, sizeof(T) * (n ? n : 1));
     if (rc) return rc;
     if (zero) GLIA_HIP_TRY(hipMemsetAsync(*p, 0, sizeof(T) * (n ? n : 1), s));
+    else {
+      // GLIA_HMT_POISON=<byte>: blocks handed out unzeroed are filled with that byte -- a block of the cache carries whatever the
+      // last call left in it, and a read before the first write would otherwise depend on the history of the process
+      static const int poison = [] { const char* e = getenv("GLIA_HMT_POISON"); return e ? (int)strtol(e, nullptr, 0) & 0xFF : -1; }();
+      if (poison >= 0) GLIA_HIP_TRY(hipMemsetAsync(*p, poison, sizeof(T) * (n ? n : 1), s));
+    }
     return GLIA_HMT_OK;
   }
   template <typename T> int grow(T** p, size_t old_n, size_t new_n, hipStream_t s) {

@@ -41,6 +41,25 @@ while time.time() < t_end:
             assert o.shape == ro.shape and (o == ro).all(), "pb order type %d" % typ
             assert (s == rs).all() if (variant == 0 or typ == 1) else np.allclose(s, rs, rtol=0, atol=1e-12), "pb saliency type %d" % typ
         rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, mask=d_mask, only_contour=False)
+        if os.environ.get("FUZZ_LIGHT"):      # the map itself, every integer of it, against the oracle's
+            orag = O.Rag(labels, mask=mask)
+            lab_o, npts_o, nb_o = orag.regions(); a_o, b_o, n_o = orag.pairs()
+            rst = orag.region_stats(pb); pst = orag.pair_stats(pb)
+            reg, par = rm.regions(), rm.pairs()
+            what = None
+            if len(reg["label"]) != len(lab_o) or not (reg["label"] == lab_o).all(): what = "region labels (%d vs %d)" % (len(reg["label"]), len(lab_o))
+            elif not (reg["count"] == npts_o).all(): what = "region counts"
+            elif not (reg["border"] == nb_o).all(): what = "border counts"
+            elif len(par["a"]) != len(a_o) or not ((par["a"] == a_o).all() and (par["b"] == b_o).all()): what = "pair keys (%d vs %d)" % (len(par["a"]), len(a_o))
+            elif not (par["count"] == n_o).all(): what = "pair counts"
+            elif not ((reg["min"] == rst[2]).all() and (reg["max"] == rst[3]).all() and (par["min"] == pst[2]).all() and (par["max"] == pst[3]).all()): what = "minima / maxima"
+            elif not ((reg["lo"] == rst[4]).all() and (reg["hi"] == rst[5]).all()): what = "bounding boxes"
+            elif not ((reg["hist"].sum(1) == npts_o).all() and (par["hist"].sum(1) == n_o).all()): what = "histogram totals"
+            elif not (np.allclose(reg["sum"], rst[0], rtol=1e-12, atol=0) and np.allclose(par["sum"], pst[0], rtol=1e-12, atol=0)): what = "sums"
+            if what:
+                np.savez_compressed(os.path.join(ROOT, "gpurun_out", "fuzz_fail_map.npz"), labels=labels, pb=pb, mask=mask if mask is not None else np.zeros(0),
+                                    **{"g_" + k: np.asarray(v) for k, v in reg.items()}, **{"gp_" + k: np.asarray(v) for k, v in par.items()})
+                raise AssertionError("region map: %s differ from the oracle's" % what)
         if rng.random() < 0.5:
             o, s = rm.merge_order_pb(type=3)
             ro, rs = O.Rag(labels, mask=mask).merge_order_pb(pb, type=3, update_region=True)
@@ -63,8 +82,9 @@ while time.time() < t_end:
             raise AssertionError("pre_merge %s %r: first difference at merge %d of %d / %d, got %s want %s; three fresh builds agree with the oracle: %s"
                                  % (sizes, rpb, k, len(o), len(ro), o[k].tolist() if k < len(o) else None, ro[k].tolist() if k < len(ro) else None, again))
         # classifier linkage, random image lists (the oracle re-walks voxels per edge: keep it to a few hundred regions)
-        if len(np.unique(labels)) > 300:
+        if len(np.unique(labels)) > 300 or os.environ.get("FUZZ_LIGHT"):      # FUZZ_LIGHT=1: maps, pb linkages and pre_merge only (ten times the cases)
             n += 1
+            if n % 200 == 0: print("%d cases ok (%.0f s left)" % (n, t_end - time.time()), flush=True)
             continue
         raw = (np.round(rng.random(shape) * 255) / 256.0).astype(np.float32)
         d_raw = torch.from_numpy(raw).cuda()
@@ -105,8 +125,8 @@ while time.time() < t_end:
             ro, rs = O.Rag(labels, mask=mask).merge_order_bc(ocfg, O.make_forest(forest, -1))
             assert o.shape == ro.shape and (o == ro).all() and (s == rs).all(), "bc forest"
         rm.close()
-    except AssertionError as e:
-        print("MISMATCH after %d cases: %s  config %s" % (n, e, cfgdesc), flush=True)
+    except (AssertionError, hmt.HmtError) as e:
+        print("MISMATCH after %d cases: %r  config %s" % (n, e, cfgdesc), flush=True)
         np.savez_compressed(os.path.join(ROOT, "gpurun_out", "fuzz_fail.npz"), labels=labels, pb=pb, mask=mask if mask is not None else np.zeros(0))
         sys.exit(1)
     n += 1
