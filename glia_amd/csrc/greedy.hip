@@ -961,6 +961,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(WinState 
     const int cthr = w.cthr; const double tsal = w.tsal; const unsigned long long tseq = w.tseq;
     const uint32_t off0 = h0r.x, len0 = h0r.y, off1 = h1r.x, len1 = h1r.y;
     const uint32_t total = len0 + len1;
+    if (k >= (unsigned long long)st.R0) { status = ST_INTERNAL; break; }      // more merges than regions: the state is corrupt, stop before writing past the outputs
     const uint32_t r2 = st.R0 + (uint32_t)k;
     const uint32_t r2off = (uint32_t)pool_used;
     const int par = (int)(k & 1ull);
@@ -1525,6 +1526,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
     const uint2 h0r = w.hu[slot], h1r = w.hv[slot];
     const uint32_t off0 = h0r.x, len0 = h0r.y, off1 = h1r.x, len1 = h1r.y;
     const uint32_t total = len0 + len1;
+    if (k >= (unsigned long long)st.R0) { status = ST_INTERNAL; break; }      // more merges than regions: the state is corrupt
     // the best candidate decides: wide -> the whole workgroup takes it alone
     const unsigned long long firstmask = __ballot(gi == 0 && cand_ok && rank == 0u);
     const Key top = b.part1[__builtin_ctzll(firstmask)];
@@ -2016,8 +2018,9 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
   hipLaunchKernelGGL(region_sizes, dim3((R + 255) / 256), dim3(256), 0, stream, rag.d_rrec, R, st.rsz, st.rsum);
   if ((rc = buf.get(&st.mark0, 2 * (size_t)R, true, stream))) return rc;
   if ((rc = buf.get(&st.mark1, 2 * (size_t)R, true, stream))) return rc;
-  if ((rc = buf.get(&st.order, 3 * (size_t)R, false, stream))) return rc;
-  if ((rc = buf.get(&st.sal_out, (size_t)R, false, stream))) return rc;
+  // (+ kNW entries: a loop whose state is corrupt is stopped when k reaches R, at most one round of the batch kernel later)
+  if ((rc = buf.get(&st.order, 3 * ((size_t)R + 16), false, stream))) return rc;
+  if ((rc = buf.get(&st.sal_out, (size_t)R + 16, false, stream))) return rc;
   if ((rc = buf.get(&st.ctrl, 16, true, stream))) return rc;
   uint32_t* cursor;
   if ((rc = buf.get(&cursor, 2 * (size_t)R, true, stream))) return rc;
@@ -2206,7 +2209,7 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
     if (ctrl[3] == ST_RUN && !window) continue;
     if (ctrl[3] == ST_DONE) break;
     if (ctrl[3] == ST_BAD_SALIENCY) { set_error("Error: invalid boundary saliency..."); return GLIA_HMT_ERR_SALIENCY; }
-    if (ctrl[3] == ST_INTERNAL) { set_error("greedy: window queue overflow (internal error)"); return GLIA_HMT_ERR_HIP; }
+    if (ctrl[3] == ST_INTERNAL) { set_error("greedy: window queue overflow or more merges than regions (internal error)"); return GLIA_HMT_ERR_HIP; }
     if (ctrl[3] == ST_NEED_TREE) {
       // a saliency cell with more live items than the window holds (massive exact ties): the tournament tree takes over
       // from the same state -- leaf keys are the ground truth of both queues, the lists get their thin entries
