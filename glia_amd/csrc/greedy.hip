@@ -1253,6 +1253,7 @@ __device__ __forceinline__ void batch_scan(const WinState& st, WinShared& w, Bat
       for (int j = 0; j < kWinPer; ++j) deadm[j] |= (uint32_t)(kt == e[j]);
     }
     if (kovf) {                                                          // more deaths than the list holds (rare): ask the edge records
+      full_barrier();                                                    // (the stores that mark them are performed)
 #pragma unroll
       for (int j = 0; j < kWinPer; ++j) {
         const uint32_t i = own + (uint32_t)j * kGreedyThreads;
@@ -1281,7 +1282,7 @@ __device__ __forceinline__ void batch_scan(const WinState& st, WinShared& w, Bat
   const Key m2 = wave_max_sal_first(kk);
   SCAN_T(3);
   if ((tid & 63) == 0) { b.part1[tid >> 6] = m1; b.part2[tid >> 6] = m2; }
-  full_barrier();
+  full_barrier();                  // ... and are performed here, before the next round loads the lists they rewrote
   SCAN_T(4);
   if (tid == 0) { b.nkill = 0; b.kovf = 0; }
 }
@@ -1306,7 +1307,7 @@ __device__ __forceinline__ uint32_t batch_contract_wide(const WinState& st, WinS
 #ifdef GLIA_HMT_PROFILE
   unsigned long long wt_ = __builtin_readcyclecounter();
 #endif
-  full_barrier();                                                       // every thread has read the slot
+  lds_barrier();                                                        // every thread has read the slot
   WIDE_T(0);
   if (tid == 0) {
     w.seq[slot] = 0;
@@ -1332,7 +1333,7 @@ __device__ __forceinline__ uint32_t batch_contract_wide(const WinState& st, WinS
       (side1 ? s.mv1 : s.mv0)[h] = i + 1u;
     } else (side1 ? st.mark1 : st.mark0)[fe.rs] = i + 1u;
   }
-  full_barrier();
+  if (small) lds_barrier(); else full_barrier();      // (the global mark arrays are read by other threads below)
   WIDE_T(1);
   if (wn_now + total > st.wcap && wn_now > st.wcap / 2u) win_compact(w, tid, st.wcap);      // (holes out; a full window spills, see win_evict)
   WIDE_T(2);
@@ -1433,7 +1434,7 @@ __device__ __forceinline__ uint32_t batch_contract_wide(const WinState& st, WinS
   if (small) rounds(std::true_type{}); else rounds(std::false_type{});
   if (bad) b.bad = 1;
   WIDE_T(3);
-  full_barrier();
+  if (small) lds_barrier(); else full_barrier();      // (wide case: r2's new list entries are read back below, by other threads than wrote them)
   WIDE_T(4);
   const uint32_t newcount = s.newcount;
   if (!small) {
@@ -1447,7 +1448,7 @@ __device__ __forceinline__ uint32_t batch_contract_wide(const WinState& st, WinS
   if (!small) for (uint32_t i = tid; i < (w.n < st.wcap ? w.n : st.wcap); i += kGreedyThreads) if (w.v[i] == r2) w.hv[i].y = newcount;      // window items of r2: its list length
   if (pend_e != kNone) st.er[pend_e].next = pend_old;
   if (tid == 0) { st.adj_off[r2] = r2off; st.adj_len[r2] = newcount; }
-  full_barrier();
+  lds_barrier();                   // (the scan that follows ends with the full barrier)
   WIDE_T(5);
   if (tid == 0) { s.nitems = 0; s.newcount = 0; }
   *newcount_out = newcount;
@@ -1623,7 +1624,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
     for (int d = 32; d >= 1; d >>= 1) { const double o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
     if (lane == 0) { b.m_newcount[wave] = narrow ? newcount : 0u; b.m_total[wave] = narrow ? total : 0xFFFFFFFFu; b.m_maxsal[wave] = mx; }
     if (bad) b.bad = 1;
-    full_barrier();
+    lds_barrier();                 // (LDS data only; the round's global stores are waited for at the END of the scan that follows the commit)
     BPH(1);
     if (b.bad) { status = ST_BAD_SALIENCY; break; }
     // ---- validate: the longest prefix of the batch whose order is certain (lane j checks member j) ----
@@ -1661,7 +1662,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
     if (w.n + ne_off > st.wcap && w.n > st.wcap / 2u) {                    // holes out (a full window spills, see win_evict)
       if ((uint32_t)wave < V && lane == 0) w.seq[slot] = 0;
       popped = true;                                                     // (slot numbers are void after a compaction)
-      full_barrier();
+      lds_barrier();
       win_compact(w, tid, st.wcap);
     }
     const int cthr = w.cthr; const double tsal = w.tsal; const unsigned long long tseq = w.tseq;
@@ -1732,7 +1733,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
         }
       }
     }
-    full_barrier();
+    lds_barrier();                   // the commit's global stores stay in flight through the scan ...
     BPH(3);
 #ifdef GLIA_HMT_PROFILE
     brounds += 1; bmembers += M; bvalid += V;
