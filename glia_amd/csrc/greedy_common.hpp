@@ -469,10 +469,27 @@ struct DeviceBuffers {
   std::vector<size_t> sizes;
   int device = -1;
   size_t misses = 0, miss_bytes = 0;         // allocations the block cache could not serve (GLIA_HMT_TRACE reports them)
-  ~DeviceBuffers() { for (size_t i = 0; i < all.size(); ++i) BlockCache::get().give(all[i], sizes[i], device); }
+  // GLIA_HMT_CANARY=1 (debugging): 256 bytes of a pattern behind every block's requested size, checked when the buffers go back --
+  // an overrun by a few elements otherwise lands in the slack of a cached block and shows only when two blocks happen to touch
+  static bool canary_mode() { static const bool on = getenv("GLIA_HMT_CANARY") != nullptr; return on; }
+  std::vector<size_t> asked;                 // requested bytes of each block (canary position)
+  ~DeviceBuffers() {
+    if (canary_mode()) {
+      (void)hipDeviceSynchronize();
+      unsigned char tail[256];
+      for (size_t i = 0; i < all.size(); ++i) {
+        if (hipMemcpy(tail, (const char*)all[i] + asked[i], 256, hipMemcpyDeviceToHost) != hipSuccess) continue;
+        for (int k = 0; k < 256; ++k)
+          if (tail[k] != 0xCB) { fprintf(stderr, "[glia_hmt canary] block %zu of %zu (%zu bytes asked): byte %d behind its end was overwritten (0x%02x)\n", i, all.size(), asked[i], k, tail[k]); break; }
+      }
+    }
+    for (size_t i = 0; i < all.size(); ++i) BlockCache::get().give(all[i], sizes[i], device);
+  }
   int raw(void** p, size_t bytes) {
     if (device < 0) GLIA_HIP_TRY(hipGetDevice(&device));
+    const size_t want = bytes;                 // (the canary starts at the first byte that was not asked for)
     bytes = (bytes + 255) & ~(size_t)255;
+    if (canary_mode()) bytes += 256;
     void* q = BlockCache::get().take(bytes, device);
     if (!q) {
       ++misses; miss_bytes += bytes;
@@ -487,7 +504,8 @@ struct DeviceBuffers {
       }
     }
     *p = q;
-    all.push_back(q); sizes.push_back(bytes);
+    all.push_back(q); sizes.push_back(bytes); asked.push_back(want);
+    if (canary_mode()) GLIA_HIP_TRY(hipMemset((char*)q + want, 0xCB, 256));
     return GLIA_HMT_OK;
   }
   template <typename T> int get(T** p, size_t n, bool zero, hipStream_t s) {
@@ -504,10 +522,11 @@ struct DeviceBuffers {
   }
   template <typename T> int grow(T** p, size_t old_n, size_t new_n, hipStream_t s) {
     T* q = nullptr;
-    GLIA_HIP_TRY(hipMalloc((void**)&q, sizeof(T) * (new_n ? new_n : 1)));
+    GLIA_HIP_TRY(hipMalloc((void**)&q, sizeof(T) * (new_n ? new_n : 1) + (canary_mode() ? 256 : 0)));
+    if (canary_mode()) GLIA_HIP_TRY(hipMemset((char*)q + sizeof(T) * (new_n ? new_n : 1), 0xCB, 256));
     GLIA_HIP_TRY(hipMemcpyAsync(q, *p, sizeof(T) * old_n, hipMemcpyDeviceToDevice, s));
     GLIA_HIP_TRY(hipStreamSynchronize(s));
-    for (size_t i = 0; i < all.size(); ++i) if (all[i] == (void*)*p) { (void)hipFree(all[i]); all[i] = q; sizes[i] = sizeof(T) * (new_n ? new_n : 1); }
+    for (size_t i = 0; i < all.size(); ++i) if (all[i] == (void*)*p) { (void)hipFree(all[i]); all[i] = q; sizes[i] = sizeof(T) * (new_n ? new_n : 1) + (canary_mode() ? 256 : 0); asked[i] = sizeof(T) * (new_n ? new_n : 1); }
     *p = q;
     return GLIA_HMT_OK;
   }
