@@ -566,6 +566,9 @@ struct WinState {
   // tests (GLIA_HMT_FORCE_TREE=k): hand the queue over to the tournament-tree kernel at the first empty window after k merges --
   // the path of ST_NEED_TREE, which no data set reaches by itself any more (oversized cells are split)
   unsigned long long force_tree;
+  // debugging (GLIA_HMT_LDS_POISON=1|2|3): the kernels' LDS starts as small random words / random words / all ones instead of
+  // whatever the last workgroup on the CU left there -- a field read before its first write shows at once
+  uint32_t lds_poison;
 };
 constexpr uint32_t kWinCap = 1536;          // window slots (live items + holes)
 constexpr uint32_t kWinBudget = 768;        // a reload stops before exceeding this many items ...
@@ -911,6 +914,15 @@ __device__ __forceinline__ int win_reload(const WinState& st, WinShared& w, int 
   return result;
 }
 
+// debugging: see WinState::lds_poison
+template <typename T>
+__device__ __forceinline__ void lds_poison_fill(T& obj, uint32_t mode, uint32_t salt, int tid) {
+  uint32_t* p = reinterpret_cast<uint32_t*>(&obj);
+  for (uint32_t i = (uint32_t)tid; i < sizeof(T) / 4; i += kGreedyThreads) {
+    uint32_t x = (i + salt) * 2654435761u; x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12;
+    p[i] = mode == 1 ? (x & 63u) : mode == 2 ? x : 0xFFFFFFFFu;
+  }
+}
 template <bool COND>
 __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(WinState st) {
   __shared__ WinShared w;
@@ -918,6 +930,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(WinState 
   const int tid = threadIdx.x, lane = tid & 63;
   unsigned long long k = st.ctrl[0], ne = st.ctrl[1], pool_used = st.ctrl[2];
   uint32_t status = ST_RUN;
+  if (st.lds_poison) { lds_poison_fill(w, st.lds_poison, (uint32_t)k, tid); lds_poison_fill(s, st.lds_poison, (uint32_t)k + 77u, tid); full_barrier(); }
   if (tid == 0) {
     w.n = 0; w.nk = 0; w.kovf = 0; w.err = 0; s.nitems = 0; s.newcount = 0; s.bad = 0;
     w.cthr = (int)(long long)st.ctrl[5]; w.tsal = __longlong_as_double((long long)st.ctrl[6]); w.tseq = st.ctrl[7]; w.iptr = (uint32_t)st.ctrl[8];
@@ -1172,7 +1185,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(WinState 
   full_barrier();
   win_flush(st, w, tid);
   if (tid == 0) {
-    st.ctrl[0] = k; st.ctrl[1] = ne; st.ctrl[2] = pool_used; st.ctrl[3] = w.err ? (unsigned long long)ST_INTERNAL : status;
+    st.ctrl[0] = k; st.ctrl[1] = ne; st.ctrl[2] = pool_used; st.ctrl[3] = w.err ? (unsigned long long)ST_INTERNAL : status; st.ctrl[9] = w.err; st.ctrl[10] = w.n;
     st.ctrl[5] = (unsigned long long)(long long)w.cthr; st.ctrl[6] = (unsigned long long)__double_as_longlong(w.tsal); st.ctrl[7] = w.tseq; st.ctrl[8] = w.iptr;
   }
 }
@@ -1462,6 +1475,10 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   unsigned long long k = st.ctrl[0], ne = st.ctrl[1], pool_used = st.ctrl[2];
   uint32_t status = ST_RUN;
+  if (st.lds_poison) {
+    lds_poison_fill(w, st.lds_poison, (uint32_t)k, tid); lds_poison_fill(s, st.lds_poison, (uint32_t)k + 77u, tid); lds_poison_fill(b, st.lds_poison, (uint32_t)k + 177u, tid);
+    full_barrier();
+  }
   if (tid == 0) {
     w.n = 0; w.nk = 0; w.kovf = 0; w.err = 0; w.spill_ord = 0; s.nitems = 0; s.newcount = 0; s.bad = 0; b.nkill = 0; b.kovf = 0; b.bad = 0;
     w.cthr = (int)(long long)st.ctrl[5]; w.tsal = __longlong_as_double((long long)st.ctrl[6]); w.tseq = st.ctrl[7]; w.iptr = (uint32_t)st.ctrl[8];
@@ -1758,7 +1775,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
   full_barrier();
   win_flush(st, w, tid);
   if (tid == 0) {
-    st.ctrl[0] = k; st.ctrl[1] = ne; st.ctrl[2] = pool_used; st.ctrl[3] = w.err ? (unsigned long long)ST_INTERNAL : status;
+    st.ctrl[0] = k; st.ctrl[1] = ne; st.ctrl[2] = pool_used; st.ctrl[3] = w.err ? (unsigned long long)ST_INTERNAL : status; st.ctrl[9] = w.err; st.ctrl[10] = w.n;
     st.ctrl[5] = (unsigned long long)(long long)w.cthr; st.ctrl[6] = (unsigned long long)__double_as_longlong(w.tsal); st.ctrl[7] = w.tseq; st.ctrl[8] = w.iptr;
   }
 }
@@ -1945,12 +1962,22 @@ __global__ void median_init(GreedyState st, uint32_t E0) {
   atomicAdd(&st.rbv[st.e_v[e]], (unsigned long long)n);
 }
 
+__global__ void poison_random_kernel(uint32_t* p, unsigned long long words, uint32_t salt) {
+  const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < words) { uint32_t x = (uint32_t)i * 2654435761u + salt; x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12; p[i] = x & 63u; }      // small values: plausible stale indices / counters, never a wild address
+}
 __global__ void fill_leaves_dead(PqTree t, uint32_t from) {
   uint32_t i = from + blockIdx.x * blockDim.x + threadIdx.x;
   if (i < t.nleaves) { t.leaf_seq[i] = 0; t.leaf_sal[i] = -__builtin_inf(); }
 }
 
 }  // namespace
+
+void poison_random(uint32_t* p, size_t words, hipStream_t s) {
+  static uint32_t salt = 12345u;
+  salt = salt * 1664525u + 1013904223u;
+  if (words) hipLaunchKernelGGL(poison_random_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, p, (unsigned long long)words, salt);
+}
 
 // Runs the pb-mean greedy merge on a compact RAG.  h_order receives dense ids (leaf i = i-th label ascending,
 // merged region R+k); the caller maps them to keys.
@@ -2083,7 +2110,7 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
     hipLaunchKernelGGL(median_init, dim3((E0 + 255) / 256), dim3(256), 0, stream, st, E0);
     GLIA_HIP_TRY(hipGetLastError());
   }
-  unsigned long long ctrl[9] = {0, E0, 2ull * E0, ST_RUN, n_values, 0, 0, 0, 0};
+  unsigned long long ctrl[11] = {0, E0, 2ull * E0, ST_RUN, n_values, 0, 0, 0, 0, 0, 0};      // [9], [10]: diagnostics of ST_INTERNAL
   // buffers of the window queue's baseline (see win_rebaseline below)
   unsigned long long *rb_kseq = nullptr, *rb_kseq2 = nullptr, *rb_ksal = nullptr, *rb_ksal2 = nullptr, *rb_iseq = nullptr;
   uint32_t *rb_vals = nullptr, *rb_vals2 = nullptr, *rb_isort = nullptr, *rb_ige = nullptr, *rb_counter = nullptr;
@@ -2148,6 +2175,7 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
     ws.wcap = kWinCap; ws.wbudget = kWinBudget;
     ws.force_tree = 0;
     if (const char* fenv = getenv("GLIA_HMT_FORCE_TREE")) ws.force_tree = strtoull(fenv, nullptr, 10);
+    if (const char* lenv = getenv("GLIA_HMT_LDS_POISON")) ws.lds_poison = (uint32_t)strtoul(lenv, nullptr, 10);
     if (const char* cenv = getenv("GLIA_HMT_WINCAP")) {                  // tests: a tiny window makes spills, evictions and cell splits routine
       const uint32_t c = (uint32_t)strtoul(cenv, nullptr, 10);
       if (c >= 16 && c <= kWinCap) { ws.wcap = c; ws.wbudget = c / 2; }
@@ -2210,7 +2238,12 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
     if (ctrl[3] == ST_RUN && !window) continue;
     if (ctrl[3] == ST_DONE) break;
     if (ctrl[3] == ST_BAD_SALIENCY) { set_error("Error: invalid boundary saliency..."); return GLIA_HMT_ERR_SALIENCY; }
-    if (ctrl[3] == ST_INTERNAL) { set_error("greedy: window queue overflow or more merges than regions (internal error)"); return GLIA_HMT_ERR_HIP; }
+    if (ctrl[3] == ST_INTERNAL) {
+      char msg[256];
+      snprintf(msg, sizeof(msg), "greedy: window queue overflow or more merges than regions (internal error: merges %llu of %u regions, %llu edges of %u initial, "
+               "window %llu%s, %s kernel)", ctrl[0], R, ctrl[1], E0, ctrl[10], ctrl[9] ? " overflowed" : "", !window ? "tree" : cond_n > 0 ? "window" : "batch");
+      set_error(msg); return GLIA_HMT_ERR_HIP;
+    }
     if (ctrl[3] == ST_NEED_TREE) {
       // a saliency cell with more live items than the window holds (massive exact ties): the tournament tree takes over
       // from the same state -- leaf keys are the ground truth of both queues, the lists get their thin entries

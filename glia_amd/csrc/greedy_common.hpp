@@ -464,6 +464,7 @@ struct BlockCache {
     cached += bytes;
   }
 };
+void poison_random(uint32_t* p, size_t words, hipStream_t s);      // greedy.hip
 struct DeviceBuffers {
   std::vector<void*> all;
   std::vector<size_t> sizes;
@@ -473,6 +474,11 @@ struct DeviceBuffers {
   // an overrun by a few elements otherwise lands in the slack of a cached block and shows only when two blocks happen to touch
   static bool canary_mode() { static const bool on = getenv("GLIA_HMT_CANARY") != nullptr; return on; }
   std::vector<size_t> asked;                 // requested bytes of each block (canary position)
+  // GLIA_HMT_REDZONE=1 (debugging): 4 KiB more behind every block, and everything behind the requested size is filled with small
+  // random words when the block is handed out -- a READ past the end then sees junk instead of the block's own quiet slack.
+  // GLIA_HMT_REDZONE_MASK=<hex>: bit k = only behind the k-th block of this set (bit 63: the 64th and later).
+  static bool redzone_mode() { static const bool on = getenv("GLIA_HMT_REDZONE") != nullptr; return on; }
+  int unzeroed = 0;                          // blocks handed out unzeroed so far (GLIA_HMT_POISON_MASK)
   ~DeviceBuffers() {
     if (canary_mode()) {
       (void)hipDeviceSynchronize();
@@ -490,6 +496,7 @@ struct DeviceBuffers {
     const size_t want = bytes;                 // (the canary starts at the first byte that was not asked for)
     bytes = (bytes + 255) & ~(size_t)255;
     if (canary_mode()) bytes += 256;
+    if (redzone_mode()) bytes += 4096;
     void* q = BlockCache::get().take(bytes, device);
     if (!q) {
       ++misses; miss_bytes += bytes;
@@ -511,12 +518,24 @@ struct DeviceBuffers {
   template <typename T> int get(T** p, size_t n, bool zero, hipStream_t s) {
     int rc = raw((void**)p, sizeof(T) * (n ? n : 1));
     if (rc) return rc;
+    if (redzone_mode()) {
+      static const unsigned long long rmask = [] { const char* e = getenv("GLIA_HMT_REDZONE_MASK"); return e ? strtoull(e, nullptr, 16) : ~0ull; }();
+      const size_t ord = all.size() - 1, from = (asked.back() + 3) & ~(size_t)3;
+      if ((rmask >> (ord < 63 ? ord : 63)) & 1ull) poison_random((uint32_t*)((char*)*p + from), (sizes.back() - from) / 4, s);
+    }
     if (zero) GLIA_HIP_TRY(hipMemsetAsync(*p, 0, sizeof(T) * (n ? n : 1), s));
     else {
       // GLIA_HMT_POISON=<byte>: blocks handed out unzeroed are filled with that byte -- a block of the cache carries whatever the
       // last call left in it, and a read before the first write would otherwise depend on the history of the process
-      static const int poison = [] { const char* e = getenv("GLIA_HMT_POISON"); return e ? (int)strtol(e, nullptr, 0) & 0xFF : -1; }();
-      if (poison >= 0) GLIA_HIP_TRY(hipMemsetAsync(*p, poison, sizeof(T) * (n ? n : 1), s));
+      static const int poison = [] { const char* e = getenv("GLIA_HMT_POISON"); return !e ? -1 : (e[0] == 'r' ? 256 : (int)strtol(e, nullptr, 0) & 0xFF); }();
+      // GLIA_HMT_POISON_MASK=<hex>: bit k = the k-th unzeroed block of this set of buffers is poisoned, the others are zeroed (to find
+      // WHICH block is read before it is written)
+      static const unsigned long long pmask = [] { const char* e = getenv("GLIA_HMT_POISON_MASK"); return e ? strtoull(e, nullptr, 16) : ~0ull; }();
+      const bool mine = poison >= 0 && ((pmask >> (unzeroed < 63 ? unzeroed : 63)) & 1ull);
+      if (poison >= 0) ++unzeroed;
+      if (mine && poison == 256) poison_random((uint32_t*)*p, (sizeof(T) * (n ? n : 1)) / 4, s);      // GLIA_HMT_POISON=rand: small pseudo-random words
+      else if (mine) GLIA_HIP_TRY(hipMemsetAsync(*p, poison, sizeof(T) * (n ? n : 1), s));
+      else if (poison >= 0) GLIA_HIP_TRY(hipMemsetAsync(*p, 0, sizeof(T) * (n ? n : 1), s));
     }
     return GLIA_HMT_OK;
   }

@@ -29,6 +29,7 @@ while time.time() < t_end:
     if rng.random() < 0.35:
         mask = (rng.random(shape) > rng.uniform(0.05, 0.4)).astype(np.uint32)
     cfgdesc = dict(shape=shape, S=S, G=G, variant=variant, masked=mask is not None)
+    stage = "region map"
     d_lab = torch.from_numpy(labels.view(np.int32)).cuda()
     d_pb = torch.from_numpy(pb).cuda()
     d_mask = torch.from_numpy(mask.view(np.int32)).cuda() if mask is not None else None
@@ -36,6 +37,7 @@ while time.time() < t_end:
         # pb linkages
         for typ in (1, 2):
             rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, mask=d_mask, only_contour=True)
+            stage = "merge_order_pb type %d" % typ
             o, s = rm.merge_order_pb(type=typ); rm.close()
             ro, rs = O.Rag(labels, mask=mask, only_contour=True).merge_order_pb(pb, type=typ)
             assert o.shape == ro.shape and (o == ro).all(), "pb order type %d" % typ
@@ -61,11 +63,13 @@ while time.time() < t_end:
                                     **{"g_" + k: np.asarray(v) for k, v in reg.items()}, **{"gp_" + k: np.asarray(v) for k, v in par.items()})
                 raise AssertionError("region map: %s differ from the oracle's" % what)
         if rng.random() < 0.5:
+            stage = "merge_order_pb type 3"
             o, s = rm.merge_order_pb(type=3)
             ro, rs = O.Rag(labels, mask=mask).merge_order_pb(pb, type=3, update_region=True)
             assert o.shape == ro.shape and (o == ro).all() and (s == rs).all(), "median x size"
         sizes = sorted(int(x) for x in rng.integers(2, 4 * S ** dim, size=int(rng.integers(1, 3))))
         rpb = float(rng.uniform(0.1, 0.5))
+        stage = "pre_merge"
         o, s = rm.pre_merge(sizes, rpb); rm.close()
         ro, rs = O.Rag(labels, mask=mask).pre_merge(pb, sizes, rpb)
         if not (o.shape == ro.shape and (o == ro).all()):
@@ -126,7 +130,7 @@ while time.time() < t_end:
             assert o.shape == ro.shape and (o == ro).all() and (s == rs).all(), "bc forest"
         rm.close()
     except (AssertionError, hmt.HmtError) as e:
-        print("MISMATCH after %d cases: %r  config %s" % (n, e, cfgdesc), flush=True)
+        print("MISMATCH after %d cases (last call: %s): %r  config %s" % (n, stage, e, cfgdesc), flush=True)
         np.savez_compressed(os.path.join(ROOT, "gpurun_out", "fuzz_fail.npz"), labels=labels, pb=pb, mask=mask if mask is not None else np.zeros(0))
         sys.exit(1)
     n += 1
