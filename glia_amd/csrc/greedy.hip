@@ -21,6 +21,8 @@
 // Dense region ids: leaves 0..R-1 ascending by label, merged regions R+k; the map id -> key is monotone,
 // so every key comparison of the reference is an id comparison here.
 #include <cstring>
+#include <unistd.h>
+#include <vector>
 #include <limits>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -2242,7 +2244,29 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
       char msg[256];
       snprintf(msg, sizeof(msg), "greedy: window queue overflow or more merges than regions (internal error: merges %llu of %u regions, %llu edges of %u initial, "
                "window %llu%s, %s kernel)", ctrl[0], R, ctrl[1], E0, ctrl[10], ctrl[9] ? " overflowed" : "", !window ? "tree" : cond_n > 0 ? "window" : "batch");
-      set_error(msg); return GLIA_HMT_ERR_HIP;
+      set_error(msg);
+      // GLIA_HMT_DUMP_DIR=<dir> (debugging): the loop's global state at the moment it gave up -- the order so far, every edge record,
+      // the list pool -- for a replay on the CPU (tools/internal_dump.py)
+      if (const char* ddir = getenv("GLIA_HMT_DUMP_DIR")) {
+        static int n_dumps = 0;
+        if (window && n_dumps < 4) {
+          const size_t nk = (size_t)std::min<unsigned long long>(ctrl[0], (unsigned long long)R + 16), nedges = (size_t)std::min<unsigned long long>(ctrl[1], st.Ecap);
+          const size_t npool = (size_t)std::min<unsigned long long>(ctrl[2], st.pool_cap);
+          std::vector<uint32_t> h_ord(3 * nk + 1); std::vector<EdgeRec> h_er(nedges + 1); std::vector<FatEntry> h_pool(npool + 1);
+          if (hipMemcpy(h_ord.data(), st.order, 12 * nk, hipMemcpyDeviceToHost) == hipSuccess &&
+              hipMemcpy(h_er.data(), ws.er, sizeof(EdgeRec) * nedges, hipMemcpyDeviceToHost) == hipSuccess &&
+              hipMemcpy(h_pool.data(), ws.fpool, sizeof(FatEntry) * npool, hipMemcpyDeviceToHost) == hipSuccess) {
+            char path[512];
+            snprintf(path, sizeof(path), "%s/internal_%d_%d.bin", ddir, (int)getpid(), n_dumps++);
+            if (FILE* f = fopen(path, "wb")) {
+              const unsigned long long hdr[8] = {R, E0, nk, nedges, npool, (unsigned long long)cond_n, ctrl[9], ctrl[10]};
+              fwrite(hdr, 8, 8, f); fwrite(h_ord.data(), 12, nk, f); fwrite(h_er.data(), sizeof(EdgeRec), nedges, f); fwrite(h_pool.data(), sizeof(FatEntry), npool, f);
+              fclose(f);
+            }
+          }
+        }
+      }
+      return GLIA_HMT_ERR_HIP;
     }
     if (ctrl[3] == ST_NEED_TREE) {
       // a saliency cell with more live items than the window holds (massive exact ties): the tournament tree takes over

@@ -148,7 +148,7 @@ class Rag:
                                                 C.c_int(int(only_contour))))
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:      # (module globals are gone at interpreter shutdown)
             lib().orc_rag_free(self.h)
             self.h = None
 
