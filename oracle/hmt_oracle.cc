@@ -427,16 +427,40 @@ double distX2(std::vector<double> const& a, std::vector<double> const& b) {   //
 // type/feat.hxx:594-639 + 674-738 + 815-852
 struct ImageFeats {
   std::vector<double> histogram;
-  double entropy = 0.0, mean = 0.0, stddev = 0.0, min = 0.0, max = 0.0;
+  double entropy = 0.0, mean = 0.0, stddev = 0.0, min = 0.0, max = 0.0, median = 0.0;
   bool hasReal = true;
   bool histAsFeats = false;     // GLIA_USE_HISTOGRAM_AS_FEATS (CMakeLists.txt:54-58): the histogram itself precedes its entropy (feat.hxx:608-621)
-  template <typename M> void generate(M const& points, const float* img, HistSpec const& hs, bool real, bool histFeats = false) {
-    hasReal = real; histAsFeats = histFeats;
+  // GLIA_USE_MEDIAN_AS_FEATS (CMakeLists.txt:59-63): a fifth real feature, the median, ahead of the mean -- and mean / standard
+  // deviation come from stats::mean / stats::var over the VECTOR of values (feat.hxx:710-722; util/stats.hxx:36-69): the mean is
+  // sum / n with a double accumulator, the variance the mean of (x - mean)^2 -- not E[x^2] - mean^2 as in the default build.
+  // The reference sums the vector in the order stats::amedian left it in, and amedian shuffles it with rand() first
+  // (stats.hxx:87): its own last bits of mean and stddev depend on the history of rand().  The restatement leaves the shuffle
+  // out (as everywhere: the order statistic does not depend on it) and sums in the order nth_element leaves; these two columns
+  // are therefore comparable to 1e-12 relative, every other column bit for bit.  PARITY UNPINNED (feat.hxx needs ITK).
+  bool medianAsFeats = false;
+  template <typename M> void generate(M const& points, const float* img, HistSpec const& hs, bool real, bool histFeats = false, bool medFeats = false) {
+    hasReal = real; histAsFeats = histFeats; medianAsFeats = medFeats;
     histOver(histogram, points, img, hs);
     entropy = ::entropy(histogram);
     if (!real) return;
     int n = (int)mapSize(points);
     if (n == 0) return;
+    if (medFeats) {
+      std::vector<float> vals;
+      vals.reserve(n);
+      traverse(points, [&](int64_t p) { vals.push_back(img[p]); });
+      median = amedian(vals);
+      double sum = 0.0;                                                   // stats::sum<TContainer, double> (stats.hxx:36-42)
+      for (float x : vals) sum += x;
+      mean = sdivide(sum, (double)vals.size(), 0.0);                      // stats::mean (:55-57)
+      double ret = 0.0;                                                   // stats::var (:60-69)
+      for (float x : vals) { double dx = x - mean; ret += dx * dx; }
+      stddev = ssqrt(sdivide(ret, (double)vals.size(), 0.0), 0.0);
+      float mn = vals.front(), mx = vals.front();                         // stats::min / stats::max (:18-33)
+      for (float x : vals) { if (x < mn) mn = x; if (x > mx) mx = x; }
+      min = mn; max = mx;
+      return;
+    }
     mean = 0.0; min = FMAX; max = -FMAX; stddev = 0.0;
     traverse(points, [&](int64_t p) {
       float val = img[p];
@@ -451,7 +475,7 @@ struct ImageFeats {
   void serialize(std::vector<double>& f) const {
     if (histAsFeats) for (double x : histogram) f.push_back(x);
     f.push_back(entropy);
-    if (hasReal) { f.push_back(mean); f.push_back(stddev); f.push_back(min); f.push_back(max); }
+    if (hasReal) { if (medianAsFeats) f.push_back(median); f.push_back(mean); f.push_back(stddev); f.push_back(min); f.push_back(max); }
   }
 };
 
@@ -513,11 +537,11 @@ struct RegionFeats {
     }
     // bc_feat.hxx:100-124
     region.resize(cfg.c.n_rimg);
-    for (int i = 0; i < cfg.c.n_rimg; ++i) region[i].generate(reg.pts, cfg.c.rimg[i], cfg.rh[i], true, cfg.c.hist_as_feats != 0);
+    for (int i = 0; i < cfg.c.n_rimg; ++i) region[i].generate(reg.pts, cfg.c.rimg[i], cfg.rh[i], true, cfg.c.hist_as_feats != 0, cfg.c.median_as_feats != 0);
     labelRegion.resize(cfg.c.n_rlimg);
     for (int i = 0; i < cfg.c.n_rlimg; ++i) labelRegion[i].generate(reg.pts, cfg.c.rlimg[i], cfg.rlh[i], false, cfg.c.hist_as_feats != 0);
     boundary.resize(cfg.c.n_bimg);
-    for (int i = 0; i < cfg.c.n_bimg; ++i) boundary[i].generate(reg.boundary, cfg.c.bimg[i], cfg.bh[i], true, cfg.c.hist_as_feats != 0);
+    for (int i = 0; i < cfg.c.n_bimg; ++i) boundary[i].generate(reg.boundary, cfg.c.bimg[i], cfg.bh[i], true, cfg.c.hist_as_feats != 0, cfg.c.median_as_feats != 0);
   }
   void log() {  // feat.hxx:46-52, 463-467
     area = slog(area, 0.0); perim = slog(perim, 0.0); bboxArea = slog(bboxArea, 0.0);
@@ -543,7 +567,7 @@ struct BoundaryFeats {
   double areaDiff = 0, rAreaDiff0 = 0, rAreaDiff1 = 0, perimDiff = 0, rPerimDiff0 = 0, rPerimDiff1 = 0;
   double boundaryLength = 0, rBLA0 = 0, rBLA1 = 0, rBLP0 = 0, rBLP1 = 0;
   std::vector<double> vbl, rvbl, rvblp0, rvblp1;
-  struct Diff { double l1, x2, ed, meanD, stdD, minD, maxD; bool real; };
+  struct Diff { double l1, x2, ed, meanD, stdD, minD, maxD; bool real; double medD = 0.0; bool med = false; };
   std::vector<Diff> region, labelRegion;
   std::vector<ImageFeats> boundary;
 
@@ -585,6 +609,7 @@ struct BoundaryFeats {
       d.ed = fabs(a.entropy - c.entropy);
       d.meanD = std::fabs(a.mean - c.mean); d.stdD = std::fabs(a.stddev - c.stddev);
       d.minD = std::fabs(a.min - c.min); d.maxD = std::fabs(a.max - c.max);
+      d.medD = std::fabs(a.median - c.median); d.med = a.medianAsFeats;       // feat.hxx:803-805
       d.real = true;
       region.push_back(d);
     }
@@ -599,7 +624,7 @@ struct BoundaryFeats {
       labelRegion.push_back(d);
     }
     boundary.resize(cfg.c.n_bimg);
-    for (int i = 0; i < cfg.c.n_bimg; ++i) boundary[i].generate(b, cfg.c.bimg[i], cfg.bh[i], true, cfg.c.hist_as_feats != 0);
+    for (int i = 0; i < cfg.c.n_bimg; ++i) boundary[i].generate(b, cfg.c.bimg[i], cfg.bh[i], true, cfg.c.hist_as_feats != 0, cfg.c.median_as_feats != 0);
   }
   void log() {  // feat.hxx:103-106, 148-155, 531-539
     areaDiff = slog(areaDiff, 0.0); perimDiff = slog(perimDiff, 0.0);
@@ -616,6 +641,7 @@ struct BoundaryFeats {
     for (double x : rvblp1) f.push_back(x);
     for (auto const& d : region) {
       f.push_back(d.l1); f.push_back(d.x2); f.push_back(d.ed);
+      if (d.med) f.push_back(d.medD);                                          // feat.hxx:784-786
       f.push_back(d.meanD); f.push_back(d.stdD); f.push_back(d.minD); f.push_back(d.maxD);
     }
     for (auto const& d : labelRegion) { f.push_back(d.l1); f.push_back(d.x2); f.push_back(d.ed); }
@@ -639,7 +665,7 @@ void selectFeatures(std::vector<double>& f, BoundaryFeats const& x0, RegionFeats
                     RegionFeats const& x2) {
   f.push_back(x1.area); f.push_back(x2.area); f.push_back(x1.perim); f.push_back(x2.perim);
   f.push_back(x0.boundaryLength);
-  for (auto const& bf : x0.boundary) f.push_back(bf.mean);
+  for (auto const& bf : x0.boundary) { f.push_back(bf.mean); if (bf.medianAsFeats) f.push_back(bf.median); }      // bc_feat.hxx:263-268
   for (auto const& rf : x0.region) { f.push_back(rf.meanD); f.push_back(rf.l1); f.push_back(rf.x2); f.push_back(rf.ed); }
   for (auto const& rlf : x0.labelRegion) { f.push_back(rlf.l1); f.push_back(rlf.x2); }
 }
@@ -999,10 +1025,11 @@ int64_t orc_merge_order_pb(orc_rag* h, const float* pb, int type, int update_reg
 }
 
 int orc_feat_dim(int dim, const orc_feat_cfg* c) {
-  if (c->use_simple) return 5 + c->n_bimg + 4 * c->n_rimg + 2 * c->n_rlimg;
+  const int med = c->median_as_feats ? 1 : 0;      // GLIA_USE_MEDIAN_AS_FEATS: one more column per real-feature block (feat.hxx:677-680, 772-775)
+  if (c->use_simple) return 5 + (1 + med) * c->n_bimg + 4 * c->n_rimg + 2 * c->n_rlimg;      // bc_feat.hxx:250-256
   int T = c->n_thr;
-  int rf = 4 + dim + 2 * T + 5 * c->n_rimg + c->n_rlimg + 5 * c->n_bimg;
-  int bf = 11 + 4 * T + 7 * c->n_rimg + 3 * c->n_rlimg + 5 * c->n_bimg;
+  int rf = 4 + dim + 2 * T + (5 + med) * c->n_rimg + c->n_rlimg + (5 + med) * c->n_bimg;
+  int bf = 11 + 4 * T + (7 + med) * c->n_rimg + 3 * c->n_rlimg + (5 + med) * c->n_bimg;
   if (c->hist_as_feats) {        // every ImageLabelFeats block carries its histogram (feat.hxx:608-621); the diff blocks do not
     int hb = 0;
     for (int i = 0; i < c->n_bimg; ++i) hb += c->bbins[i];

@@ -63,6 +63,7 @@ typedef struct {
   int use_log;                         // --logs
   int use_simple;                      // --simpf
   int hist_as_feats;                   // build option GLIA_HMT_HIST_FEAT -> GLIA_USE_HISTOGRAM_AS_FEATS (CMakeLists.txt:54-58, feat.hxx:608-621)
+  int median_as_feats;                 // build option GLIA_HMT_MEDIAN_FEAT -> GLIA_USE_MEDIAN_AS_FEATS (CMakeLists.txt:59-63, feat.hxx:677-722, 772-808; bc_feat.hxx:252-268)
 } orc_feat_cfg;
 
 // Random forest in the layout produced by rf_old::readModelFromBinaryFile after

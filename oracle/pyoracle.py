@@ -27,7 +27,7 @@ class FeatCfg(C.Structure):
         ("blo", C.c_double * MAX_IMAGES), ("bhi", C.c_double * MAX_IMAGES),
         ("pb", C.c_void_p), ("n_thr", C.c_int), ("thr", C.c_double * MAX_THRESH),
         ("norm_area", C.c_double), ("norm_len", C.c_double),
-        ("use_log", C.c_int), ("use_simple", C.c_int), ("hist_as_feats", C.c_int),
+        ("use_log", C.c_int), ("use_simple", C.c_int), ("hist_as_feats", C.c_int), ("median_as_feats", C.c_int),
     ]
 
 
@@ -92,7 +92,7 @@ def synth(shape, S, G, seed=0x9E3779B97F4A7C15, variant=0):
 
 
 def make_cfg(pb, rb=(), r=(), rl=(), b=(), thr=(0.2, 0.5, 0.8), norm_area=1.0, norm_len=1.0,
-             use_log=False, use_simple=False, hist_as_feats=False):
+             use_log=False, use_simple=False, hist_as_feats=False, median_as_feats=False):
     """rb/r/rl/b: lists of (image, bins, lo, hi).  Mirrors prepareImages (hmt_util.hxx:17-56)."""
     cfg = FeatCfg()
     keep = [pb]
@@ -114,6 +114,7 @@ def make_cfg(pb, rb=(), r=(), rl=(), b=(), thr=(0.2, 0.5, 0.8), norm_area=1.0, n
     cfg.norm_area, cfg.norm_len = norm_area, norm_len
     cfg.use_log, cfg.use_simple = int(use_log), int(use_simple)
     cfg.hist_as_feats = int(hist_as_feats)
+    cfg.median_as_feats = int(median_as_feats)
     cfg._keep = keep
     return cfg
 
