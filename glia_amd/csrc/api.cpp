@@ -19,6 +19,7 @@ namespace glia {
 
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
+bool last_error_is_internal() { return g_err.find("internal error") != std::string::npos; }
 
 static float ceil_f32(double d) {   // smallest float >= d
   if (std::isinf(d) || std::isnan(d)) return (float)d;
@@ -247,6 +248,7 @@ int glia_hmt_libm_eval(glia_hmt_ctx* c, int function, int variant, const double*
 }
 
 unsigned long long glia_hmt_release_cached_memory(void) { return (unsigned long long)glia::BlockCache::get().trim(); }
+unsigned long long glia_hmt_merge_loop_retries(void) { return glia::merge_loop_retries(); }
 
 void glia_hmt_ctx_destroy(glia_hmt_ctx* c) {
   if (!c) return;

@@ -20,6 +20,7 @@
 // insertions and deletions of one contraction are applied level by level from a dirty-node worklist.
 // Dense region ids: leaves 0..R-1 ascending by label, merged regions R+k; the map id -> key is monotone,
 // so every key comparison of the reference is an id comparison here.
+#include <atomic>
 #include <cstring>
 #include <unistd.h>
 #include <vector>
@@ -1983,9 +1984,9 @@ void poison_random(uint32_t* p, size_t words, hipStream_t s) {
 
 // Runs the pb-mean greedy merge on a compact RAG.  h_order receives dense ids (leaf i = i-th label ascending,
 // merged region R+k); the caller maps them to keys.
-int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, double* h_sal, int64_t capacity,
-                int64_t* n_merges, double* ms_table, double* ms_loop, int64_t* n_scored, int cond_n,
-                const long long* cond_sizes, double cond_rpb, const VolumeRef* median_of, bool size_weight) {
+static int greedy_mean_once(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, double* h_sal, int64_t capacity,
+                            int64_t* n_merges, double* ms_table, double* ms_loop, int64_t* n_scored, int cond_n,
+                            const long long* cond_sizes, double cond_rpb, const VolumeRef* median_of, bool size_weight) {
   const long long P = rag.P;
   const uint32_t R = (uint32_t)rag.R;
   *n_merges = 0;
@@ -2329,6 +2330,46 @@ int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, dou
   }
   *n_merges = n;
   return GLIA_HMT_OK;
+}
+
+
+// Every merge of a correct order joins two regions that still exist and creates region R + k.  An order that fails this O(R) replay
+// is the signature of the open defect of the window kernel (queue items that survive their death are popped again and
+// join a region that is gone; "more merges than regions" is its late stage).  The defect is a race: a second run of the same call
+// is right.  Until the race is found the call checks its result and runs again (at most twice), counts it
+// (glia_hmt_merge_loop_retries) and says so on stderr once per process.  A mitigation, not a fix: an order that is wrong without a
+// dead reference would pass.
+static std::atomic<unsigned long long> g_merge_retries{0};
+unsigned long long merge_loop_retries() { return g_merge_retries.load(); }
+static bool order_is_consistent(const uint32_t* o, int64_t n, uint32_t R) {
+  std::vector<uint8_t> gone(2 * (size_t)R + 1, 0);
+  for (int64_t k = 0; k < n; ++k) {
+    const uint32_t a = o[3 * k], b = o[3 * k + 1], c = o[3 * k + 2];
+    if (k >= (int64_t)R || c != R + (uint32_t)k || a >= c || b >= c || a == b || gone[a] || gone[b]) return false;
+    gone[a] = gone[b] = 1;
+  }
+  return true;
+}
+int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, double* h_sal, int64_t capacity,
+                int64_t* n_merges, double* ms_table, double* ms_loop, int64_t* n_scored, int cond_n,
+                const long long* cond_sizes, double cond_rpb, const VolumeRef* median_of, bool size_weight) {
+  const char* ienv = getenv("GLIA_HMT_FAULT_INJECT");                    // tests: spoil the first attempt(s) of a call
+  const long inject = ienv ? strtol(ienv, nullptr, 10) : 0L;
+  int rc = GLIA_HMT_OK;
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    rc = greedy_mean_once(rag, stream, h_order, h_sal, capacity, n_merges, ms_table, ms_loop, n_scored, cond_n, cond_sizes, cond_rpb, median_of, size_weight);
+    if (rc == GLIA_HMT_OK && inject > attempt && *n_merges > 1) h_order[3 * (*n_merges - 1)] = h_order[0];      // (a region that went at merge 0)
+    const bool internal = rc == GLIA_HMT_ERR_HIP && last_error_is_internal();
+    if (rc != GLIA_HMT_OK && !internal) return rc;
+    if (rc == GLIA_HMT_OK && order_is_consistent(h_order, *n_merges, (uint32_t)rag.R)) return rc;
+    g_merge_retries.fetch_add(1);
+    static std::atomic<bool> said{false};
+    if (!said.exchange(true)) fprintf(stderr, "[glia_hmt] a merge order failed its consistency check and the call was run again (DESIGN 3.3, the open defect of the "
+                                      "window kernel); glia_hmt_merge_loop_retries() counts these\n");
+    (void)hipStreamSynchronize(stream);
+  }
+  if (rc == GLIA_HMT_OK) { set_error("greedy: the merge order failed its consistency check three times (internal error)"); rc = GLIA_HMT_ERR_HIP; }
+  return rc;
 }
 
 }  // namespace glia

@@ -10,6 +10,8 @@
 namespace glia {
 
 void set_error(const std::string& msg);
+bool last_error_is_internal();                 // the last error of this thread is one of the merge loops' internal-error stops
+unsigned long long merge_loop_retries();        // greedy.hip: calls that were run again after a failed consistency check
 #define GLIA_HIP_TRY(expr)                                                                       \
   do {                                                                                           \
     hipError_t _e = (expr);                                                                      \

@@ -122,6 +122,13 @@ class Context:
         f.restype = C.c_ulonglong
         return int(f())
 
+    @staticmethod
+    def merge_loop_retries():
+        """Merge-order calls of this process that failed the library's consistency check and were run again (glia_hmt_merge_loop_retries)."""
+        f = lib().glia_hmt_merge_loop_retries
+        f.restype = C.c_ulonglong
+        return int(f())
+
     def libm_pinned(self):
         """True when log2, log and pow of the host libm are all reproduced bit for bit (glia_hmt_ctx_libm_status)."""
         return lib().glia_hmt_ctx_libm_status(self.h) == 1

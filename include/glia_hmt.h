@@ -50,6 +50,10 @@ void glia_hmt_ctx_destroy(glia_hmt_ctx* ctx);
  * device-wide synchronisation).  This returns them to the driver -- for callers that share the device with another allocator
  * (torch, a second library).  Returns the number of bytes released.  Destroying the last context of a process does the same. */
 unsigned long long glia_hmt_release_cached_memory(void);
+/* pb / pre_merge merge orders are replayed on the host before they are returned (every merge joins two regions that still exist and
+ * creates region R + k); a call whose order fails is run again, at most twice (the open defect of the window kernel,
+ * a race that shows about once in 10^4 .. 10^5 small volumes).  Number of such re-runs in this process so far; 0 is the normal answer. */
+unsigned long long glia_hmt_merge_loop_retries(void);
 int glia_hmt_ctx_sync(glia_hmt_ctx* ctx);
 /* Logarithms of the feature vector.  The reference computes histogram entropies with std::log2 (util/stats.hxx:145-152)
  * and the --logs features with std::log (glia_base.hxx:80-81), the compactness with std::pow (type/feat.hxx:78-79), i.e.

@@ -133,3 +133,34 @@ def test_pre_merge_on_a_tiny_window(ctx):
                 else:
                     os.environ[k] = v
         assert o.shape == ro.shape and (o == ro).all() and (s == rs).all(), env
+
+
+def test_an_inconsistent_order_is_caught_and_the_call_run_again(ctx):
+    """Every pb / pre_merge order is replayed on the host before it is returned (greedy.hip, greedy_mean): GLIA_HMT_FAULT_INJECT=n
+    spoils the first n attempts of a call (the last merge names a region that went at merge 0).  One spoiled attempt: the answer
+    is the oracle's and the retry counter moves; three: the call fails with the internal error instead of returning the order."""
+    import torch
+    from glia_amd import hmt
+    from oracle import pyoracle as O
+    labels, pb = O.synth((40, 40, 24), 5, 10)
+    d_lab, d_pb = torch.from_numpy(labels.view(np.int32)).cuda(), torch.from_numpy(pb).cuda()
+    ro, rs = O.Rag(labels, only_contour=True).merge_order_pb(pb, type=2)
+    po, ps = O.Rag(labels).pre_merge(pb, [100, 300], 0.3)
+    before = hmt.Context.merge_loop_retries()
+    o, s = _order(ctx, d_lab, d_pb)
+    assert (o == ro).all() and (s == rs).all() and hmt.Context.merge_loop_retries() == before
+    o, s = _order(ctx, d_lab, d_pb, GLIA_HMT_FAULT_INJECT=1)
+    assert (o == ro).all() and (s == rs).all() and hmt.Context.merge_loop_retries() == before + 1
+    os.environ["GLIA_HMT_FAULT_INJECT"] = "2"
+    try:
+        rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, only_contour=False)
+        o, s = rm.pre_merge([100, 300], 0.3)
+        rm.close()
+        assert o.shape == po.shape and (o == po).all() and (s == ps).all() and hmt.Context.merge_loop_retries() == before + 3
+        os.environ["GLIA_HMT_FAULT_INJECT"] = "3"
+        rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, only_contour=True)
+        with pytest.raises(hmt.HmtError, match="consistency check"):
+            rm.merge_order_pb(type=2)
+        rm.close()
+    finally:
+        del os.environ["GLIA_HMT_FAULT_INJECT"]
