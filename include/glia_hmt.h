@@ -52,7 +52,8 @@ void glia_hmt_ctx_destroy(glia_hmt_ctx* ctx);
 unsigned long long glia_hmt_release_cached_memory(void);
 /* pb / pre_merge merge orders are replayed on the host before they are returned (every merge joins two regions that still exist and
  * creates region R + k); a call whose order fails is run again, at most twice (the open defect of the window kernel,
- * a race that shows about once in 10^4 .. 10^5 small volumes).  Number of such re-runs in this process so far; 0 is the normal answer. */
+ * a race that shows about once in 10^4 .. 10^5 small volumes); glia_hmt_pre_merge runs its loop twice and returns when two runs agree.
+ * Number of re-runs (failed checks, disagreeing runs) in this process so far; 0 is the normal answer. */
 unsigned long long glia_hmt_merge_loop_retries(void);
 int glia_hmt_ctx_sync(glia_hmt_ctx* ctx);
 /* Logarithms of the feature vector.  The reference computes histogram entropies with std::log2 (util/stats.hxx:145-152)
