@@ -1163,8 +1163,13 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(WinState 
         st.mark0[fb.rs] = 0; st.mark1[fb.rs] = 0;
       }
     }
+    // Every wave has to have READ s.newcount (above) before thread 0 clears it for the next contraction.  Rounds 2-3 cleared it here
+    // without a barrier in between: a wave that came out of the last barrier a few hundred cycles late read 0, completed its headers
+    // with length 0 and -- worse -- went on with its private copy of `ne` short by this contraction's edges, so the edges it created
+    // later overwrote records of live ones (the rare pre_merge failure of round 3; the wide path of the batch kernel
+    // always had this barrier).  kovf: the scan will ask the edge records which window items died, those stores must be done as well.
+    if (w.kovf) full_barrier(); else lds_barrier();
     if (tid == 0) { st.adj_off[r2] = r2off; st.adj_len[r2] = newcount; s.nitems = 0; s.newcount = 0; }
-    if (w.kovf) full_barrier();       // the scan will ask the edge records which window items died: those stores must be done
     win_scan(st, w, tid, r2, newcount);
     if (pend_e != kNone) st.er[pend_e].next = pend_old;     // (the atomic has long returned; only a reload reads the link, behind a full barrier)
     r2prev = r2;
