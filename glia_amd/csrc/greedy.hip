@@ -1168,8 +1168,13 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(WinState 
     // with length 0 and -- worse -- went on with its private copy of `ne` short by this contraction's edges, so the edges it created
     // later overwrote records of live ones (the rare pre_merge failure of round 3; the wide path of the batch kernel
     // always had this barrier).  kovf: the scan will ask the edge records which window items died, those stores must be done as well.
+#ifdef GLIA_WINDOW_NO_RESET_BARRIER      // control build of the experiment that confirms the fix (make ctrl, tools/confirm_window_fix.sh): as it was
+    if (tid == 0) { st.adj_off[r2] = r2off; st.adj_len[r2] = newcount; s.nitems = 0; s.newcount = 0; }
+    if (w.kovf) full_barrier();
+#else
     if (w.kovf) full_barrier(); else lds_barrier();
     if (tid == 0) { st.adj_off[r2] = r2off; st.adj_len[r2] = newcount; s.nitems = 0; s.newcount = 0; }
+#endif
     win_scan(st, w, tid, r2, newcount);
     if (pend_e != kNone) st.er[pend_e].next = pend_old;     // (the atomic has long returned; only a reload reads the link, behind a full barrier)
     r2prev = r2;
