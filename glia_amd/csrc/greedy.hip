@@ -1654,6 +1654,9 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
     for (int d = 32; d >= 1; d >>= 1) { const double o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
     if (lane == 0) { b.m_newcount[wave] = narrow ? newcount : 0u; b.m_total[wave] = narrow ? total : 0xFFFFFFFFu; b.m_maxsal[wave] = mx; }
     if (bad) b.bad = 1;
+    // the window's fill, read by every wave BEFORE the barrier: behind it the committing waves raise w.n, and the "compact first?" test below
+    // has to come out the same in every wave (it guards barriers) -- on its own late read of w.n a slow wave could take the branch alone
+    const uint32_t wn_round = w.n;
     lds_barrier();                 // (LDS data only; the round's global stores are waited for at the END of the scan that follows the commit)
     BPH(1);
     if (b.bad) { status = ST_BAD_SALIENCY; break; }
@@ -1689,7 +1692,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
     if (pool_used + sum_tot > st.pool_cap) { status = ST_NEED_POOL; break; }
     // room in the window for everything the batch may insert (the popped items leave first: a flush must not see them)
     bool popped = false;
-    if (w.n + ne_off > st.wcap && w.n > st.wcap / 2u) {                    // holes out (a full window spills, see win_evict)
+    if (wn_round + ne_off > st.wcap && wn_round > st.wcap / 2u) {          // holes out (a full window spills, see win_evict)
       if ((uint32_t)wave < V && lane == 0) w.seq[slot] = 0;
       popped = true;                                                     // (slot numbers are void after a compaction)
       lds_barrier();
