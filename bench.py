@@ -298,7 +298,8 @@ def main():
     known_pb = {(512, 16): ("652c84e7efe781bacc9df8c0a16675ca7e34cf17", "d78663710b1699d331a62c40471ba2d90ffc6515"),
                 (1024, 16): ("977022085e1a37a4d143841a51ea8834b6f53c59", "7923436b47d4484f1e95962ac87ff409d4f2c617")}
     known_bc = {(256, 16): ("51b7b5316e0d8fd648ab2b444527633d8eaf65c5", "5eadbd683d6a042f7bf950aa2352ef93bdc12956"),
-                (512, 16): ("8e620b69eab2cc31991eaca662446f52ad2231df", "8e30e7ba92d7b89dc09c413260a0841df1cbf886")}
+                (512, 16): ("8e620b69eab2cc31991eaca662446f52ad2231df", "8e30e7ba92d7b89dc09c413260a0841df1cbf886"),
+                (1024, 16): ("6d930d8a816d75d194b20c5f4eb068a3bd362f3f", "1915075dc494d7c5b56baea947414d1890c2d8f8")}
     verify = None
     if rank == 0:
         o_, s_ = infos[-1]["_result"]
@@ -355,6 +356,9 @@ def main():
                        "parallelism": "replica x%d (the merge loop does not shard)" % world},
             "edge_features_per_sec": edges / dt,
             "verify": verify,
+            # calls that ended with GLIA_HMT_ERR_INTERNAL (a loop's own consistency stop, or an order that failed the O(R) replay of
+            # glia_hmt_check_merge_order); the library never runs a loop twice, so a healthy line carries 0 here
+            "internal_errors": hmt.Context.internal_errors(),
             "phases_ms": {"accumulate": acc_ms, "edge_features_and_scores": score_ms,
                           "edge_table": sum(i["ms_table"] for i in infos) / len(infos), "merge_loop": loop_ms},
             "host_call_ms": {k: sum(i["host_ms"][k] for i in infos) / len(infos) for k in infos[0]["host_ms"]},

@@ -247,21 +247,29 @@ inline glia_hmt_comm* makeSlabComm(const Args& a, int slabs, glia_hmt_ctx** ctx)
   check(glia_hmt_ctx_create(device, nullptr, ctx));
   glia_hmt_comm* comm = nullptr;
   if (!multi) { check(glia_hmt_comm_create_local(*ctx, slabs, &comm)); return comm; }
+  // The id file carries the launch's nonce (--commNonce, default: the parent process id -- one launcher script starts all ranks) in
+  // front of RCCL's 128-byte id: a file left over from an earlier launch does not carry it and is never taken for this launch's
+  // (a stale id would make ncclCommInitRank hang instead of fail).  Rank 0 removes an old file first, writes the new one atomically
+  // (rename) and removes it again once the communicator stands.
   char id[128];
   const std::string f = a.str("commId");
+  const unsigned long long nonce = a.has("commNonce") ? strtoull(a.str("commNonce").c_str(), nullptr, 0) : (unsigned long long)getppid();
   if (rank == 0) {
+    (void)remove(f.c_str());
     check(glia_hmt_comm_unique_id(id));
-    { std::ofstream os(f + ".tmp", std::ios::binary); os.write(id, sizeof(id)); }
+    { std::ofstream os(f + ".tmp", std::ios::binary); os.write(reinterpret_cast<const char*>(&nonce), sizeof(nonce)); os.write(id, sizeof(id)); }
     if (rename((f + ".tmp").c_str(), f.c_str())) perr("Error: cannot create file " + f);
   } else {
     for (int tries = 0;; ++tries) {
       std::ifstream is(f, std::ios::binary);
-      if (is && is.read(id, sizeof(id))) break;
-      if (tries > 1200) perr("Error: cannot open file " + f);
+      unsigned long long got = 0;
+      if (is && is.read(reinterpret_cast<char*>(&got), sizeof(got)) && got == nonce && is.read(id, sizeof(id))) break;
+      if (tries > 1200) perr("Error: cannot open file " + f + " (or it belongs to another launch: --commNonce)");
       usleep(100000);
     }
   }
   check(glia_hmt_comm_create_rccl(*ctx, slabs, rank, id, &comm));
+  if (rank == 0) (void)remove(f.c_str());      // (ncclCommInitRank returns when every rank has joined)
   return comm;
 }
 

@@ -14,7 +14,7 @@ int main(int argc, char* argv[]) {
                             "[-n b] [-l b] [--simpf b] -o <order> [--sal <file>] [-b <file>]   (flags as hmt/main_merge_order_bc.cxx:172-242)\n";
   std::vector<std::string> known = {"bct", "nn1", "nn2", "bcm", "bcfmm", "bcmd", "segImage", "rbi", "rbb", "rbl", "rbu", "rli", "rlb", "rll", "rlu",
                                     "ri", "rb", "rl", "ru", "bi", "bb", "bl", "bu", "pb", "maskImage", "bt", "ns", "logs", "simpf", "histf", "mergeOrder",
-                                    "sal", "bfeat", "slabs", "rank", "commId", "device"};
+                                    "sal", "bfeat", "slabs", "rank", "commId", "commNonce", "device"};
   Args a = parse(argc, argv, {{"s", "segImage"}, {"m", "maskImage"}, {"n", "ns"}, {"l", "logs"}, {"o", "mergeOrder"}, {"b", "bfeat"}}, known, usage);
   for (const char* req : {"bct", "bcm", "segImage", "pb", "mergeOrder"})
     if (!a.has(req)) { std::cerr << "Error: the option '--" << req << "' is required but missing\n" << usage; perr("Error: unable to parse input arguments"); }

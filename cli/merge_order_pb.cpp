@@ -22,7 +22,7 @@ int main(int argc, char* argv[]) {
       "  -o [ --mergeOrder ] arg Output merging order file name (optional)\n  -y [ --saliency ] arg  Output merging saliency file name (optional)\n"
       "  --slabs arg            z slabs of the slab route (optional); with --rank arg --commId arg: one process per slab over RCCL\n";
   Args a = parse(argc, argv, {{"s", "segImage"}, {"p", "pbImage"}, {"m", "maskImage"}, {"t", "type"}, {"o", "mergeOrder"}, {"y", "saliency"}},
-                 {"segImage", "pbImage", "maskImage", "type", "mergeOrder", "saliency", "slabs", "rank", "commId", "device"}, usage);
+                 {"segImage", "pbImage", "maskImage", "type", "mergeOrder", "saliency", "slabs", "rank", "commId", "commNonce", "device"}, usage);
   if (!a.has("segImage") || !a.has("pbImage")) { std::cerr << "Error: the option '--segImage'/'--pbImage' is required but missing\n" << usage; return EXIT_FAILURE; }
   const int type = atoi(a.str("type", "1").c_str());
   if (type != 1 && type != 2) perr("Error: unsupported boundary stats type...");          // :36

@@ -19,7 +19,38 @@ namespace glia {
 
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
-bool last_error_is_internal() { return g_err.find("internal error") != std::string::npos; }
+
+// ---- options ------------------------------------------------------------------------------------------------------------
+// Tuning and test switches of the loops (which queue, window size, baseline interval, helper count, instance tier ...).  One
+// process-wide table, set through glia_hmt_set_option(); it starts from the environment variables of the same names, read ONCE
+// when the table is first used -- no entry point calls getenv() per call.
+static const char* const kOptionKeys[] = {"GLIA_HMT_PB_WINDOW", "GLIA_HMT_PB_BATCH", "GLIA_HMT_WINCAP", "GLIA_HMT_REBASE", "GLIA_HMT_HORIZON",
+                                          "GLIA_HMT_FORCE_TREE", "GLIA_HMT_HELPERS", "GLIA_HMT_TRACE", "GLIA_HMT_LIBM", "GLIA_HMT_BC_NOCOMMON",
+                                          "GLIA_HMT_BC_GENERIC", "GLIA_HMT_DEBUG"};
+static std::mutex g_opt_mu;
+static std::unordered_map<std::string, std::string> g_opt;
+static bool g_opt_init = false;
+static void opt_init_locked() {
+  if (g_opt_init) return;
+  for (const char* k : kOptionKeys) if (const char* e = getenv(k)) g_opt[k] = e;
+  g_opt_init = true;
+}
+static bool opt_known(const char* key) { for (const char* k : kOptionKeys) if (!strcmp(k, key)) return true; return false; }
+bool option(const char* key, std::string* value) {
+  std::lock_guard<std::mutex> lock(g_opt_mu);
+  opt_init_locked();
+  auto it = g_opt.find(key);
+  if (it == g_opt.end()) return false;
+  if (value) *value = it->second;
+  return true;
+}
+int set_option(const char* key, const char* value) {
+  if (!key || !opt_known(key)) { set_error(std::string("set_option: unknown option ") + (key ? key : "(null)")); return GLIA_HMT_ERR_ARG; }
+  std::lock_guard<std::mutex> lock(g_opt_mu);
+  opt_init_locked();
+  if (value) g_opt[key] = value; else g_opt.erase(key);
+  return GLIA_HMT_OK;
+}
 
 static float ceil_f32(double d) {   // smallest float >= d
   if (std::isinf(d) || std::isnan(d)) return (float)d;
@@ -87,7 +118,9 @@ static LibmSel probe_host_libm() {
   if (l2) sel.log2_variant = kLibmSse2;
   if (lf) sel.log_variant = kLibmFma; else if (ls) sel.log_variant = kLibmSse2;
   if (pf) sel.pow_variant = kLibmFma; else if (ps) sel.pow_variant = kLibmSse2;
-  if (const char* e = getenv("GLIA_HMT_LIBM")) {
+  std::string ov;
+  if (option("GLIA_HMT_LIBM", &ov)) {
+    const char* e = ov.c_str();
     const int v = !strcmp(e, "sse2") ? kLibmSse2 : !strcmp(e, "fma") ? kLibmFma : kLibmDevice;
     sel.log_variant = v; sel.log2_variant = v == kLibmFma ? kLibmSse2 : v; sel.pow_variant = v;
   }
@@ -103,10 +136,10 @@ int greedy_bc(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier& cl
               int n_shards, double* h_scores) {
   auto* fn = &greedy_bc_generic;
   const bool common = cfg.K == 1 && cfg.n_region == 1 && cfg.n_rlabel == 0 && cfg.n_boundary == 1 && !cfg.use_hist && !cfg.use_log &&
-                      !cfg.use_simple && !getenv("GLIA_HMT_BC_NOCOMMON");
+                      !cfg.use_simple && !option("GLIA_HMT_BC_NOCOMMON");
   if (cfg.libm_log2 == kLibmSse2 && cfg.libm_log == kLibmFma && cfg.libm_pow == kLibmFma) fn = common ? &greedy_bc_fma_common : &greedy_bc_fma;
   else if (cfg.libm_log2 == kLibmSse2 && cfg.libm_log == kLibmSse2 && cfg.libm_pow == kLibmSse2) fn = common ? &greedy_bc_sse2_common : &greedy_bc_sse2;
-  if (getenv("GLIA_HMT_BC_GENERIC")) fn = &greedy_bc_generic;       // tests: the run-time-dispatch instance
+  if (option("GLIA_HMT_BC_GENERIC")) fn = &greedy_bc_generic;       // tests: the run-time-dispatch instance
   return fn(rag, cfg, clf, stream, h_order, h_sal, h_feats, capacity, n_merges, ms_table, ms_init, ms_loop, n_scored, init_only,
             h_forced, n_forced, shard, n_shards, h_scores);
 }
@@ -248,7 +281,16 @@ int glia_hmt_libm_eval(glia_hmt_ctx* c, int function, int variant, const double*
 }
 
 unsigned long long glia_hmt_release_cached_memory(void) { return (unsigned long long)glia::BlockCache::get().trim(); }
-unsigned long long glia_hmt_merge_loop_retries(void) { return glia::merge_loop_retries(); }
+unsigned long long glia_hmt_internal_errors(void) { return glia::internal_errors(); }
+int glia_hmt_set_option(const char* key, const char* value) { return glia::set_option(key, value); }
+int glia_hmt_check_merge_order(const uint32_t* h_order, int64_t n_merges, int64_t n_regions, int64_t* first_bad) {
+  if ((!h_order && n_merges) || n_merges < 0 || n_regions < 0 || n_regions > 0x7FFFFFFFll) { set_error("check_merge_order: invalid argument"); return GLIA_HMT_ERR_ARG; }
+  int64_t bad = -1;
+  if (glia::merge_order_is_consistent(h_order, n_merges, (uint32_t)n_regions, &bad)) { if (first_bad) *first_bad = -1; return GLIA_HMT_OK; }
+  if (first_bad) *first_bad = bad;
+  set_error("check_merge_order: merge " + std::to_string(bad) + " joins a region that does not exist (any more) or creates the wrong one");
+  return GLIA_HMT_ERR_ARG;
+}
 
 void glia_hmt_ctx_destroy(glia_hmt_ctx* c) {
   if (!c) return;
@@ -415,7 +457,7 @@ static int rag_build_impl(glia_hmt_ctx* c, int dim, const int64_t dims[3], int64
     p.rkeys = c->rkeys; p.rrec = c->rrec; p.rmask = c->rcap - 1;
     p.pkeys = c->pkeys; p.prec = c->prec; p.pmask = c->pcap - 1;
     p.flags = c->flags;
-    { const char* dbg = getenv("GLIA_HMT_DEBUG"); p.debug = dbg ? (uint32_t)strtoul(dbg, nullptr, 0) : 0u; }
+    { std::string dbg; p.debug = option("GLIA_HMT_DEBUG", &dbg) ? (uint32_t)strtoul(dbg.c_str(), nullptr, 0) : 0u; }
     if ((int64_t)p.nbx * p.nby * p.nbz >= (1ll << 31)) { glia_hmt_rag_free(rag); set_error("rag_build: volume too large"); return GLIA_HMT_ERR_ARG; }
     // the pass addresses a column's rows with 32-bit byte offsets from a base that moves every four planes (rag_accumulate.hip)
     if (nx * ny * 4 * 11 >= (1ll << 32)) { glia_hmt_rag_free(rag); set_error("rag_build: planes of more than 97 M voxels are not supported"); return GLIA_HMT_ERR_ARG; }

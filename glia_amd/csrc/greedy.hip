@@ -22,7 +22,6 @@
 // so every key comparison of the reference is an id comparison here.
 #include <atomic>
 #include <cstring>
-#include <unistd.h>
 #include <vector>
 #include <limits>
 #include <rocprim/device/device_scan.hpp>
@@ -72,7 +71,7 @@ int pq_setup(DeviceBuffers& buf, PqTree& t, hipStream_t stream) {
 // A barrier behind which every global store and atomic of the workgroup has been performed.  (__syncthreads() is NOT that on
 // gfx950: the workgroup-scope fence of a workgroup that is not split over CUs waits for lgkmcnt only -- found in round 3, when
 // a merge order differed once in ~30 000 runs; the comments of rounds 1-2 that say "vmcnt(0) inside" were wishful.)
-__device__ __forceinline__ void full_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void full_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); GLIA_SKEW_DELAY(); }
 struct GreedyState {
   uint32_t R0;
   uint32_t* adj_off;   // [2*R0] start of a region's incident-edge list in pool
@@ -463,8 +462,11 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_pb_kernel(GreedyState s
         }
       }
         }
-    if (tid == 0) { pq.leaf_seq[e] = 0; pq_touch(pq, s.pq, 0, 0, e);   /* the root is the maximum of its node: no need to look */ s.nitems = 0; }
+    if (tid == 0) { pq.leaf_seq[e] = 0; pq_touch(pq, s.pq, 0, 0, e);   /* the root is the maximum of its node: no need to look */ }
     if (__syncthreads_or(bad ? 1 : 0)) { status = ST_BAD_SALIENCY; break; }
+    // (round 4 audit, DESIGN 3.3: s.nitems used to be cleared in front of this barrier -- the mean linkage has no barrier inside
+    // phase B, so a wave that left the barrier behind phase A late could have read its item count after thread 0 had cleared it)
+    if (tid == 0) s.nitems = 0;
     PH(2);
 
     // ---- phase C: publish r2's list; the rare big contraction resets the global marks it used ----
@@ -569,9 +571,6 @@ struct WinState {
   // tests (GLIA_HMT_FORCE_TREE=k): hand the queue over to the tournament-tree kernel at the first empty window after k merges --
   // the path of ST_NEED_TREE, which no data set reaches by itself any more (oversized cells are split)
   unsigned long long force_tree;
-  // debugging (GLIA_HMT_LDS_POISON=1|2|3): the kernels' LDS starts as small random words / random words / all ones instead of
-  // whatever the last workgroup on the CU left there -- a field read before its first write shows at once
-  uint32_t lds_poison;
 };
 constexpr uint32_t kWinCap = 1536;          // window slots (live items + holes)
 constexpr uint32_t kWinBudget = 768;        // a reload stops before exceeding this many items ...
@@ -614,7 +613,7 @@ __host__ __device__ __forceinline__ double f64_unord(unsigned long long o) {
   o ^= (o >> 63) ? 0x8000000000000000ull : ~0ull;
   return __builtin_bit_cast(double, o);
 }
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }   // global stores stay in flight
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); GLIA_SKEW_DELAY(); }   // global stores stay in flight
 
 __host__ __device__ __forceinline__ uint32_t win_cell(double sal, double smin, double scale, uint32_t B) {
   double t = (sal - smin) * scale;          // monotone in sal (saliencies are never NaN: sdivide guards the division)
@@ -917,15 +916,6 @@ __device__ __forceinline__ int win_reload(const WinState& st, WinShared& w, int 
   return result;
 }
 
-// debugging: see WinState::lds_poison
-template <typename T>
-__device__ __forceinline__ void lds_poison_fill(T& obj, uint32_t mode, uint32_t salt, int tid) {
-  uint32_t* p = reinterpret_cast<uint32_t*>(&obj);
-  for (uint32_t i = (uint32_t)tid; i < sizeof(T) / 4; i += kGreedyThreads) {
-    uint32_t x = (i + salt) * 2654435761u; x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12;
-    p[i] = mode == 1 ? (x & 63u) : mode == 2 ? x : 0xFFFFFFFFu;
-  }
-}
 template <bool COND>
 __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(WinState st) {
   __shared__ WinShared w;
@@ -933,7 +923,6 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(WinState 
   const int tid = threadIdx.x, lane = tid & 63;
   unsigned long long k = st.ctrl[0], ne = st.ctrl[1], pool_used = st.ctrl[2];
   uint32_t status = ST_RUN;
-  if (st.lds_poison) { lds_poison_fill(w, st.lds_poison, (uint32_t)k, tid); lds_poison_fill(s, st.lds_poison, (uint32_t)k + 77u, tid); full_barrier(); }
   if (tid == 0) {
     w.n = 0; w.nk = 0; w.kovf = 0; w.err = 0; s.nitems = 0; s.newcount = 0; s.bad = 0;
     w.cthr = (int)(long long)st.ctrl[5]; w.tsal = __longlong_as_double((long long)st.ctrl[6]); w.tseq = st.ctrl[7]; w.iptr = (uint32_t)st.ctrl[8];
@@ -1168,13 +1157,8 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(WinState 
     // with length 0 and -- worse -- went on with its private copy of `ne` short by this contraction's edges, so the edges it created
     // later overwrote records of live ones (the rare pre_merge failure of round 3; the wide path of the batch kernel
     // always had this barrier).  kovf: the scan will ask the edge records which window items died, those stores must be done as well.
-#ifdef GLIA_WINDOW_NO_RESET_BARRIER      // control build of the experiment that confirms the fix (make ctrl, tools/confirm_window_fix.sh): as it was
-    if (tid == 0) { st.adj_off[r2] = r2off; st.adj_len[r2] = newcount; s.nitems = 0; s.newcount = 0; }
-    if (w.kovf) full_barrier();
-#else
     if (w.kovf) full_barrier(); else lds_barrier();
     if (tid == 0) { st.adj_off[r2] = r2off; st.adj_len[r2] = newcount; s.nitems = 0; s.newcount = 0; }
-#endif
     win_scan(st, w, tid, r2, newcount);
     if (pend_e != kNone) st.er[pend_e].next = pend_old;     // (the atomic has long returned; only a reload reads the link, behind a full barrier)
     r2prev = r2;
@@ -1488,10 +1472,6 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_batch_kernel(WinState s
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   unsigned long long k = st.ctrl[0], ne = st.ctrl[1], pool_used = st.ctrl[2];
   uint32_t status = ST_RUN;
-  if (st.lds_poison) {
-    lds_poison_fill(w, st.lds_poison, (uint32_t)k, tid); lds_poison_fill(s, st.lds_poison, (uint32_t)k + 77u, tid); lds_poison_fill(b, st.lds_poison, (uint32_t)k + 177u, tid);
-    full_barrier();
-  }
   if (tid == 0) {
     w.n = 0; w.nk = 0; w.kovf = 0; w.err = 0; w.spill_ord = 0; s.nitems = 0; s.newcount = 0; s.bad = 0; b.nkill = 0; b.kovf = 0; b.bad = 0;
     w.cthr = (int)(long long)st.ctrl[5]; w.tsal = __longlong_as_double((long long)st.ctrl[6]); w.tseq = st.ctrl[7]; w.iptr = (uint32_t)st.ctrl[8];
@@ -1978,22 +1958,12 @@ __global__ void median_init(GreedyState st, uint32_t E0) {
   atomicAdd(&st.rbv[st.e_v[e]], (unsigned long long)n);
 }
 
-__global__ void poison_random_kernel(uint32_t* p, unsigned long long words, uint32_t salt) {
-  const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < words) { uint32_t x = (uint32_t)i * 2654435761u + salt; x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12; p[i] = x & 63u; }      // small values: plausible stale indices / counters, never a wild address
-}
 __global__ void fill_leaves_dead(PqTree t, uint32_t from) {
   uint32_t i = from + blockIdx.x * blockDim.x + threadIdx.x;
   if (i < t.nleaves) { t.leaf_seq[i] = 0; t.leaf_sal[i] = -__builtin_inf(); }
 }
 
 }  // namespace
-
-void poison_random(uint32_t* p, size_t words, hipStream_t s) {
-  static uint32_t salt = 12345u;
-  salt = salt * 1664525u + 1013904223u;
-  if (words) hipLaunchKernelGGL(poison_random_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, p, (unsigned long long)words, salt);
-}
 
 // Runs the pb-mean greedy merge on a compact RAG.  h_order receives dense ids (leaf i = i-th label ascending,
 // merged region R+k); the caller maps them to keys.
@@ -2037,8 +2007,9 @@ static int greedy_mean_once(const RagArrays& rag, hipStream_t stream, uint32_t* 
   if ((rc = buf.get(&st.adj_len, 2 * (size_t)R + 1, true, stream))) return rc;
   // pb-mean linkage (with or without the pre_merge condition) runs on the window queue; GLIA_HMT_PB_WINDOW=0 keeps the
   // tournament tree (kernel experiments, parity gate: both must give byte-identical results)
-  const char* wenv = getenv("GLIA_HMT_PB_WINDOW");
-  bool window = !median_of && !size_weight && !(wenv && wenv[0] == '0');
+  std::string o_window, o_batch, o_txt;
+  const bool batch_off = option("GLIA_HMT_PB_BATCH", &o_batch) && o_batch[0] == '0';      // one contraction at a time on the window queue (same result)
+  bool window = !median_of && !size_weight && !(option("GLIA_HMT_PB_WINDOW", &o_window) && o_window[0] == '0');
   WinState ws;
   memset(&ws, 0, sizeof(ws));
   if (window) {
@@ -2145,7 +2116,7 @@ static int greedy_mean_once(const RagArrays& rag, hipStream_t stream, uint32_t* 
     uint32_t n = 0;
     GLIA_HIP_TRY(hipMemcpyAsync(&n, rb_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     GLIA_HIP_TRY(hipStreamSynchronize(stream));
-    if (n > E0) { set_error("greedy: more live edges than initial edges (internal error)"); return GLIA_HMT_ERR_HIP; }
+    if (n > E0) { set_error("greedy: more live edges than initial edges (internal error)"); return GLIA_HMT_ERR_INTERNAL; }
     if (n) {
       size_t tmp = rb_tmp_bytes;
       GLIA_HIP_TRY(rocprim::radix_sort_pairs_desc(rb_tmp, tmp, rb_kseq, rb_kseq2, rb_vals, rb_vals2, (size_t)n, 0, 64, stream));
@@ -2159,8 +2130,8 @@ static int greedy_mean_once(const RagArrays& rag, hipStream_t stream, uint32_t* 
     hipLaunchKernelGGL(win_segments_kernel, dim3((ws.wB + 1 + 255) / 256), dim3(256), 0, stream, ws, rb_isort, n, rb_ige);
     GLIA_HIP_TRY(hipGetLastError());
     ws.nsort = n;
-    const char* renv = getenv("GLIA_HMT_REBASE");                          // created edges between baselines (tuning)
-    ws.rebase_after = renv ? strtoull(renv, nullptr, 10) : std::max<unsigned long long>(800000ull, (unsigned long long)n / 2ull);
+    std::string renv;                                                      // created edges between baselines (tuning)
+    ws.rebase_after = option("GLIA_HMT_REBASE", &renv) ? strtoull(renv.c_str(), nullptr, 10) : std::max<unsigned long long>(800000ull, (unsigned long long)n / 2ull);
     // the horizon (WinState::wch): the top of the queue sank by d cells while the last interval's edges were created; the next
     // interval is given horizon_factor times that (scaled to its planned length; at least 1/512 of the cells) before a reload
     // would run into the horizon
@@ -2190,10 +2161,9 @@ static int greedy_mean_once(const RagArrays& rag, hipStream_t stream, uint32_t* 
     ws.wB = B; ws.R0 = R;
     ws.wcap = kWinCap; ws.wbudget = kWinBudget;
     ws.force_tree = 0;
-    if (const char* fenv = getenv("GLIA_HMT_FORCE_TREE")) ws.force_tree = strtoull(fenv, nullptr, 10);
-    if (const char* lenv = getenv("GLIA_HMT_LDS_POISON")) ws.lds_poison = (uint32_t)strtoul(lenv, nullptr, 10);
-    if (const char* cenv = getenv("GLIA_HMT_WINCAP")) {                  // tests: a tiny window makes spills, evictions and cell splits routine
-      const uint32_t c = (uint32_t)strtoul(cenv, nullptr, 10);
+    if (option("GLIA_HMT_FORCE_TREE", &o_txt)) ws.force_tree = strtoull(o_txt.c_str(), nullptr, 10);
+    if (option("GLIA_HMT_WINCAP", &o_txt)) {                             // tests: a tiny window makes spills, evictions and cell splits routine
+      const uint32_t c = (uint32_t)strtoul(o_txt.c_str(), nullptr, 10);
       if (c >= 16 && c <= kWinCap) { ws.wcap = c; ws.wbudget = c / 2; }
     }
     unsigned long long* mm; double* range;
@@ -2226,11 +2196,8 @@ static int greedy_mean_once(const RagArrays& rag, hipStream_t stream, uint32_t* 
     GLIA_HIP_TRY(hipGetLastError());
     GLIA_HIP_TRY(hipMemcpyAsync(h_range, range, sizeof(h_range), hipMemcpyDeviceToHost, stream));
     GLIA_HIP_TRY(hipStreamSynchronize(stream));
-    {
-      const char* benv = getenv("GLIA_HMT_PB_BATCH");
-      const char* henv = getenv("GLIA_HMT_HORIZON");                     // 0 = off; else the factor on the measured descent (default 0.5)
-      if (cond_n <= 0 && !(benv && benv[0] == '0')) horizon_factor = henv ? atof(henv) : 0.5;   // (swept 0.05 .. 8 at 1024^3: flat from 0.1 to 0.5, +1 % at 2, +2 % at 4)
-    }
+    // the horizon: 0 = off; else the factor on the measured descent (swept 0.05 .. 8 at 1024^3: flat from 0.1 to 0.5, +1 % at 2, +2 % at 4)
+    if (cond_n <= 0 && !batch_off) horizon_factor = option("GLIA_HMT_HORIZON", &o_txt) ? atof(o_txt.c_str()) : 0.5;
     if ((rc = win_rebaseline(E0))) return rc;
   } else if ((rc = pq_setup(buf, st.pq, stream))) return rc;
   GLIA_HIP_TRY(hipMemcpyAsync(st.ctrl, ctrl, sizeof(ctrl), hipMemcpyHostToDevice, stream));
@@ -2241,10 +2208,8 @@ static int greedy_mean_once(const RagArrays& rag, hipStream_t stream, uint32_t* 
   while (true) {
     if (window) {
       ws.max_iters = st.max_iters;
-      // GLIA_HMT_PB_BATCH=0: one contraction at a time on the window queue (kernel experiments; same result)
-      const char* benv = getenv("GLIA_HMT_PB_BATCH");
       if (cond_n > 0) hipLaunchKernelGGL(greedy_window_kernel<true>, dim3(1), dim3(kGreedyThreads), 0, stream, ws);
-      else if (benv && benv[0] == '0') hipLaunchKernelGGL(greedy_window_kernel<false>, dim3(1), dim3(kGreedyThreads), 0, stream, ws);
+      else if (batch_off) hipLaunchKernelGGL(greedy_window_kernel<false>, dim3(1), dim3(kGreedyThreads), 0, stream, ws);
       else hipLaunchKernelGGL(greedy_batch_kernel, dim3(1), dim3(kGreedyThreads), 0, stream, ws);
     } else if (median_of) hipLaunchKernelGGL(greedy_pb_kernel<true>, dim3(1), dim3(kGreedyThreads), 0, stream, st);
     else hipLaunchKernelGGL(greedy_pb_kernel<false>, dim3(1), dim3(kGreedyThreads), 0, stream, st);
@@ -2259,28 +2224,7 @@ static int greedy_mean_once(const RagArrays& rag, hipStream_t stream, uint32_t* 
       snprintf(msg, sizeof(msg), "greedy: window queue overflow or more merges than regions (internal error: merges %llu of %u regions, %llu edges of %u initial, "
                "window %llu%s, %s kernel)", ctrl[0], R, ctrl[1], E0, ctrl[10], ctrl[9] ? " overflowed" : "", !window ? "tree" : cond_n > 0 ? "window" : "batch");
       set_error(msg);
-      // GLIA_HMT_DUMP_DIR=<dir> (debugging): the loop's global state at the moment it gave up -- the order so far, every edge record,
-      // the list pool -- for a replay on the CPU (tools/internal_dump.py)
-      if (const char* ddir = getenv("GLIA_HMT_DUMP_DIR")) {
-        static int n_dumps = 0;
-        if (window && n_dumps < 4) {
-          const size_t nk = (size_t)std::min<unsigned long long>(ctrl[0], (unsigned long long)R + 16), nedges = (size_t)std::min<unsigned long long>(ctrl[1], st.Ecap);
-          const size_t npool = (size_t)std::min<unsigned long long>(ctrl[2], st.pool_cap);
-          std::vector<uint32_t> h_ord(3 * nk + 1); std::vector<EdgeRec> h_er(nedges + 1); std::vector<FatEntry> h_pool(npool + 1);
-          if (hipMemcpy(h_ord.data(), st.order, 12 * nk, hipMemcpyDeviceToHost) == hipSuccess &&
-              hipMemcpy(h_er.data(), ws.er, sizeof(EdgeRec) * nedges, hipMemcpyDeviceToHost) == hipSuccess &&
-              hipMemcpy(h_pool.data(), ws.fpool, sizeof(FatEntry) * npool, hipMemcpyDeviceToHost) == hipSuccess) {
-            char path[512];
-            snprintf(path, sizeof(path), "%s/internal_%d_%d.bin", ddir, (int)getpid(), n_dumps++);
-            if (FILE* f = fopen(path, "wb")) {
-              const unsigned long long hdr[8] = {R, E0, nk, nedges, npool, (unsigned long long)cond_n, ctrl[9], ctrl[10]};
-              fwrite(hdr, 8, 8, f); fwrite(h_ord.data(), 12, nk, f); fwrite(h_er.data(), sizeof(EdgeRec), nedges, f); fwrite(h_pool.data(), sizeof(FatEntry), npool, f);
-              fclose(f);
-            }
-          }
-        }
-      }
-      return GLIA_HMT_ERR_HIP;
+      return GLIA_HMT_ERR_INTERNAL;
     }
     if (ctrl[3] == ST_NEED_TREE) {
       // a saliency cell with more live items than the window holds (massive exact ties): the tournament tree takes over
@@ -2346,19 +2290,19 @@ static int greedy_mean_once(const RagArrays& rag, hipStream_t stream, uint32_t* 
 }
 
 
-// Every merge of a correct order joins two regions that still exist and creates region R + k.  An order that fails this O(R) replay
-// is the signature of the open defect of the window kernel (queue items that survive their death are popped again and
-// join a region that is gone; "more merges than regions" is its late stage).  The defect is a race: a second run of the same call
-// is right.  Until the race is found the call checks its result and runs again (at most twice), counts it
-// (glia_hmt_merge_loop_retries) and says so on stderr once per process.  A mitigation, not a fix: an order that is wrong without a
-// dead reference would pass.
-static std::atomic<unsigned long long> g_merge_retries{0};
-unsigned long long merge_loop_retries() { return g_merge_retries.load(); }
-static bool order_is_consistent(const uint32_t* o, int64_t n, uint32_t R) {
+// Every merge of a correct order joins two regions that still exist and creates region R + k (util/struct_merge.hxx:19-31: the loop
+// appends (r0, r1, key++) and erases both regions' items).  The pb / pre_merge loops replay their order against this rule on the host
+// before they return it -- an O(R) pass, ~1 ms at 262 144 regions -- and a violation is an ERROR (GLIA_HMT_ERR_INTERNAL), never a
+// silent second run: round 3 re-ran such calls (a net under the window kernel's race on its edge counter), which let a
+// kernel defect pass every test.  glia_hmt_internal_errors() counts the calls that ended this way.
+static std::atomic<unsigned long long> g_internal_errors{0};
+unsigned long long internal_errors() { return g_internal_errors.load(); }
+void count_internal_error() { g_internal_errors.fetch_add(1); }
+bool merge_order_is_consistent(const uint32_t* o, int64_t n, uint32_t R, int64_t* first_bad) {
   std::vector<uint8_t> gone(2 * (size_t)R + 1, 0);
   for (int64_t k = 0; k < n; ++k) {
     const uint32_t a = o[3 * k], b = o[3 * k + 1], c = o[3 * k + 2];
-    if (k >= (int64_t)R || c != R + (uint32_t)k || a >= c || b >= c || a == b || gone[a] || gone[b]) return false;
+    if (k >= (int64_t)R || c != R + (uint32_t)k || a >= c || b >= c || a == b || gone[a] || gone[b]) { if (first_bad) *first_bad = k; return false; }
     gone[a] = gone[b] = 1;
   }
   return true;
@@ -2366,37 +2310,13 @@ static bool order_is_consistent(const uint32_t* o, int64_t n, uint32_t R) {
 int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, double* h_sal, int64_t capacity,
                 int64_t* n_merges, double* ms_table, double* ms_loop, int64_t* n_scored, int cond_n,
                 const long long* cond_sizes, double cond_rpb, const VolumeRef* median_of, bool size_weight) {
-  const char* ienv = getenv("GLIA_HMT_FAULT_INJECT");                    // tests: spoil the first attempt(s) of a call
-  const long inject = ienv ? strtol(ienv, nullptr, 10) : 0L;
-  // The loop with the pre_merge condition (greedy_window_kernel<true>) is the one the open defect was seen in, and an order that is
-  // wrong without a dead reference passes the replay: such a call runs its loop TWICE and returns when two runs agree byte for byte
-  // (the defect is a race, two runs do not fail alike).  GLIA_HMT_PREMERGE_ONCE=1 switches that off (timing experiments).
-  const bool twice = cond_n > 0 && getenv("GLIA_HMT_PREMERGE_ONCE") == nullptr;
-  std::vector<std::vector<uint32_t>> seen_o;
-  std::vector<std::vector<double>> seen_s;
-  int rc = GLIA_HMT_OK;
-  const int max_runs = twice ? 5 : 3;
-  for (int attempt = 0; attempt < max_runs; ++attempt) {
-    rc = greedy_mean_once(rag, stream, h_order, h_sal, capacity, n_merges, ms_table, ms_loop, n_scored, cond_n, cond_sizes, cond_rpb, median_of, size_weight);
-    if (rc == GLIA_HMT_OK && inject > attempt && *n_merges > 1) h_order[3 * (*n_merges - 1)] = h_order[0];      // (a region that went at merge 0)
-    const bool internal = rc == GLIA_HMT_ERR_HIP && last_error_is_internal();
-    if (rc != GLIA_HMT_OK && !internal) return rc;
-    if (rc == GLIA_HMT_OK && order_is_consistent(h_order, *n_merges, (uint32_t)rag.R)) {
-      if (!twice) return rc;
-      const size_t n = (size_t)*n_merges;
-      for (size_t r = 0; r < seen_o.size(); ++r)
-        if (seen_o[r].size() == 3 * n && (n == 0 || (memcmp(seen_o[r].data(), h_order, 12 * n) == 0 && memcmp(seen_s[r].data(), h_sal, 8 * n) == 0))) return rc;
-      seen_o.emplace_back(h_order, h_order + 3 * n);
-      seen_s.emplace_back(h_sal, h_sal + n);
-      if (seen_o.size() == 1) continue;                                  // the first opinion: no retry to count yet
-    }
-    g_merge_retries.fetch_add(1);
-    static std::atomic<bool> said{false};
-    if (!said.exchange(true)) fprintf(stderr, "[glia_hmt] a merge order failed its consistency check (or two runs of a pre_merge disagreed) and the call was run again "
-                                      "(DESIGN 3.3, the open defect of the window kernel); glia_hmt_merge_loop_retries() counts these\n");
-    (void)hipStreamSynchronize(stream);
+  int rc = greedy_mean_once(rag, stream, h_order, h_sal, capacity, n_merges, ms_table, ms_loop, n_scored, cond_n, cond_sizes, cond_rpb, median_of, size_weight);
+  int64_t bad = -1;
+  if (rc == GLIA_HMT_OK && !merge_order_is_consistent(h_order, *n_merges, (uint32_t)rag.R, &bad)) {
+    set_error("greedy: merge " + std::to_string(bad) + " of " + std::to_string(*n_merges) + " joins a region that does not exist (any more) or creates the wrong one (internal error)");
+    rc = GLIA_HMT_ERR_INTERNAL;
   }
-  if (rc == GLIA_HMT_OK) { set_error("greedy: the merge order failed its consistency check (or no two runs agreed) in every attempt (internal error)"); rc = GLIA_HMT_ERR_HIP; }
+  if (rc == GLIA_HMT_ERR_INTERNAL) { count_internal_error(); (void)hipStreamSynchronize(stream); }
   return rc;
 }
 

@@ -1577,7 +1577,7 @@ int GLIA_BC_ENTRY(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier
     std::copy(h_stage, h_stage + R, by_first.begin());
     std::copy(h_stage + R, h_stage + 2 * (size_t)R, lab.begin());
   }
-  const bool trace = getenv("GLIA_HMT_TRACE") != nullptr;
+  const bool trace = option("GLIA_HMT_TRACE");
   const auto tr0 = std::chrono::steady_clock::now();
   auto tr_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count(); };
   rmap_ranks_ordered(lab, by_first, &rank);
@@ -1665,8 +1665,8 @@ int GLIA_BC_ENTRY(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier
   {
     // helper workgroups that score whole records (only a real forest in a scoring run needs them): one per compute unit
     // beside the loop's; GLIA_HMT_HELPERS overrides
-    const char* env = getenv("GLIA_HMT_HELPERS");
-    int nh = env ? atoi(env) : 255;
+    std::string env;
+    int nh = option("GLIA_HMT_HELPERS", &env) ? atoi(env.c_str()) : 255;
     if (nh < 0) nh = 0;
     if (nh > 1023) nh = 1023;
     // the loop's workgroup and its helpers talk through polled flags, so they must all be resident at once: never ask for

@@ -5,6 +5,7 @@
 #include <mutex>
 
 #include "hmt_internal.hpp"
+#include "skew.hpp"       // (after every library header: the skew build wraps the workgroup barriers of OUR kernels only)
 
 namespace glia {
 
@@ -464,88 +465,43 @@ struct BlockCache {
     cached += bytes;
   }
 };
-void poison_random(uint32_t* p, size_t words, hipStream_t s);      // greedy.hip
 struct DeviceBuffers {
   std::vector<void*> all;
   std::vector<size_t> sizes;
   int device = -1;
   size_t misses = 0, miss_bytes = 0;         // allocations the block cache could not serve (GLIA_HMT_TRACE reports them)
-  // GLIA_HMT_CANARY=1 (debugging): 256 bytes of a pattern behind every block's requested size, checked when the buffers go back --
-  // an overrun by a few elements otherwise lands in the slack of a cached block and shows only when two blocks happen to touch
-  static bool canary_mode() { static const bool on = getenv("GLIA_HMT_CANARY") != nullptr; return on; }
-  std::vector<size_t> asked;                 // requested bytes of each block (canary position)
-  // GLIA_HMT_REDZONE=1 (debugging): 4 KiB more behind every block, and everything behind the requested size is filled with small
-  // random words when the block is handed out -- a READ past the end then sees junk instead of the block's own quiet slack.
-  // GLIA_HMT_REDZONE_MASK=<hex>: bit k = only behind the k-th block of this set (bit 63: the 64th and later).
-  static bool redzone_mode() { static const bool on = getenv("GLIA_HMT_REDZONE") != nullptr; return on; }
-  int unzeroed = 0;                          // blocks handed out unzeroed so far (GLIA_HMT_POISON_MASK)
   ~DeviceBuffers() {
-    if (canary_mode()) {
-      (void)hipDeviceSynchronize();
-      unsigned char tail[256];
-      for (size_t i = 0; i < all.size(); ++i) {
-        if (hipMemcpy(tail, (const char*)all[i] + asked[i], 256, hipMemcpyDeviceToHost) != hipSuccess) continue;
-        for (int k = 0; k < 256; ++k)
-          if (tail[k] != 0xCB) { fprintf(stderr, "[glia_hmt canary] block %zu of %zu (%zu bytes asked): byte %d behind its end was overwritten (0x%02x)\n", i, all.size(), asked[i], k, tail[k]); break; }
-      }
-    }
     for (size_t i = 0; i < all.size(); ++i) BlockCache::get().give(all[i], sizes[i], device);
   }
   int raw(void** p, size_t bytes) {
     if (device < 0) GLIA_HIP_TRY(hipGetDevice(&device));
-    const size_t want = bytes;                 // (the canary starts at the first byte that was not asked for)
     bytes = (bytes + 255) & ~(size_t)255;
-    if (canary_mode()) bytes += 256;
-    if (redzone_mode()) bytes += 4096;
     void* q = BlockCache::get().take(bytes, device);
     if (!q) {
       ++misses; miss_bytes += bytes;
       hipError_t e = hipMalloc(&q, bytes);
       if (e != hipSuccess) {                     // out of memory with blocks parked in the cache: release them and retry
-        BlockCache& c = BlockCache::get();
-        std::lock_guard<std::mutex> lock(c.mu);
-        for (auto& b : c.free_blocks) (void)hipFree(b.p);
-        c.free_blocks.clear(); c.cached = 0;
+        (void)BlockCache::get().trim();
         (void)hipGetLastError();
         GLIA_HIP_TRY(hipMalloc(&q, bytes));
       }
     }
     *p = q;
-    all.push_back(q); sizes.push_back(bytes); asked.push_back(want);
-    if (canary_mode()) GLIA_HIP_TRY(hipMemset((char*)q + want, 0xCB, 256));
+    all.push_back(q); sizes.push_back(bytes);
     return GLIA_HMT_OK;
   }
   template <typename T> int get(T** p, size_t n, bool zero, hipStream_t s) {
     int rc = raw((void**)p, sizeof(T) * (n ? n : 1));
     if (rc) return rc;
-    if (redzone_mode()) {
-      static const unsigned long long rmask = [] { const char* e = getenv("GLIA_HMT_REDZONE_MASK"); return e ? strtoull(e, nullptr, 16) : ~0ull; }();
-      const size_t ord = all.size() - 1, from = (asked.back() + 3) & ~(size_t)3;
-      if ((rmask >> (ord < 63 ? ord : 63)) & 1ull) poison_random((uint32_t*)((char*)*p + from), (sizes.back() - from) / 4, s);
-    }
     if (zero) GLIA_HIP_TRY(hipMemsetAsync(*p, 0, sizeof(T) * (n ? n : 1), s));
-    else {
-      // GLIA_HMT_POISON=<byte>: blocks handed out unzeroed are filled with that byte -- a block of the cache carries whatever the
-      // last call left in it, and a read before the first write would otherwise depend on the history of the process
-      static const int poison = [] { const char* e = getenv("GLIA_HMT_POISON"); return !e ? -1 : (e[0] == 'r' ? 256 : (int)strtol(e, nullptr, 0) & 0xFF); }();
-      // GLIA_HMT_POISON_MASK=<hex>: bit k = the k-th unzeroed block of this set of buffers is poisoned, the others are zeroed (to find
-      // WHICH block is read before it is written)
-      static const unsigned long long pmask = [] { const char* e = getenv("GLIA_HMT_POISON_MASK"); return e ? strtoull(e, nullptr, 16) : ~0ull; }();
-      const bool mine = poison >= 0 && ((pmask >> (unzeroed < 63 ? unzeroed : 63)) & 1ull);
-      if (poison >= 0) ++unzeroed;
-      if (mine && poison == 256) poison_random((uint32_t*)*p, (sizeof(T) * (n ? n : 1)) / 4, s);      // GLIA_HMT_POISON=rand: small pseudo-random words
-      else if (mine) GLIA_HIP_TRY(hipMemsetAsync(*p, poison, sizeof(T) * (n ? n : 1), s));
-      else if (poison >= 0) GLIA_HIP_TRY(hipMemsetAsync(*p, 0, sizeof(T) * (n ? n : 1), s));
-    }
     return GLIA_HMT_OK;
   }
   template <typename T> int grow(T** p, size_t old_n, size_t new_n, hipStream_t s) {
     T* q = nullptr;
-    GLIA_HIP_TRY(hipMalloc((void**)&q, sizeof(T) * (new_n ? new_n : 1) + (canary_mode() ? 256 : 0)));
-    if (canary_mode()) GLIA_HIP_TRY(hipMemset((char*)q + sizeof(T) * (new_n ? new_n : 1), 0xCB, 256));
+    GLIA_HIP_TRY(hipMalloc((void**)&q, sizeof(T) * (new_n ? new_n : 1)));
     GLIA_HIP_TRY(hipMemcpyAsync(q, *p, sizeof(T) * old_n, hipMemcpyDeviceToDevice, s));
     GLIA_HIP_TRY(hipStreamSynchronize(s));
-    for (size_t i = 0; i < all.size(); ++i) if (all[i] == (void*)*p) { (void)hipFree(all[i]); all[i] = q; sizes[i] = sizeof(T) * (new_n ? new_n : 1) + (canary_mode() ? 256 : 0); asked[i] = sizeof(T) * (new_n ? new_n : 1); }
+    for (size_t i = 0; i < all.size(); ++i) if (all[i] == (void*)*p) { (void)hipFree(all[i]); all[i] = q; sizes[i] = sizeof(T) * (new_n ? new_n : 1); }
     *p = q;
     return GLIA_HMT_OK;
   }

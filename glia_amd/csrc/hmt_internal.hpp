@@ -10,8 +10,13 @@
 namespace glia {
 
 void set_error(const std::string& msg);
-bool last_error_is_internal();                 // the last error of this thread is one of the merge loops' internal-error stops
-unsigned long long merge_loop_retries();        // greedy.hip: calls that were run again after a failed consistency check
+// process-wide tuning / test switches (api.cpp; glia_hmt_set_option): true when `key` is set, its text in *value
+bool option(const char* key, std::string* value = nullptr);
+// merge loops: calls that ended with GLIA_HMT_ERR_INTERNAL (a kernel's own consistency stop, or an order that fails the replay)
+unsigned long long internal_errors();
+void count_internal_error();
+// dense ids: every merge k joins two regions that still exist and creates region R + k (util/struct_merge.hxx:19-31)
+bool merge_order_is_consistent(const uint32_t* dense_order, int64_t n, uint32_t R, int64_t* first_bad);
 #define GLIA_HIP_TRY(expr)                                                                       \
   do {                                                                                           \
     hipError_t _e = (expr);                                                                      \

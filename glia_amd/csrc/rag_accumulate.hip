@@ -31,6 +31,7 @@
 #include <type_traits>
 
 #include "hmt_internal.hpp"
+#include "skew.hpp"
 
 namespace glia {
 

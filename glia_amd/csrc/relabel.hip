@@ -226,7 +226,9 @@ int relabel_image(uint32_t* d_lab, int64_t n, int64_t min_size, uint32_t* n_labe
   std::vector<uint32_t> labs;                   // labels present (not 0), and their voxel counts
   std::vector<unsigned long long> cntOf;
   if (maxl >= kDenseLimit) {
-    // sparse labels: no count array over the label range -- sort a copy of the labels, run lengths of the sorted copy
+    // sparse labels: no count array over the label range -- sort a copy of the labels, run lengths of the sorted copy.  rocPRIM's
+    // run-length interface takes a 32-bit size and returns 32-bit counts: larger volumes are refused, not truncated
+    if (n > 0xFFFFFFFFll) { set_error("relabel_image: labels >= 2^28 in a volume of more than 2^32 - 1 voxels are not supported"); return GLIA_HMT_ERR_UNSUPPORTED; }
     uint32_t *d_a = nullptr, *d_b = nullptr, *d_u = nullptr, *d_c = nullptr, *d_nr = nullptr;
     void* d_tmp = nullptr;
     auto freeAll = [&]() { for (void* q : {(void*)d_a, (void*)d_b, (void*)d_u, (void*)d_c, (void*)d_nr, d_tmp}) if (q) (void)hipFree(q); };

@@ -1,0 +1,37 @@
+// glia_amd/csrc/skew.hpp -- the wave-skew build (make skew / make skew2; never shipped).
+//
+// Round 3 lost a week of GPU time to one shape of bug: an LDS word that every wave reads behind a barrier and ONE thread
+// rewrites before the next barrier; a wave that leaves the barrier a few hundred cycles late reads the new value
+// (greedy_window_kernel's edge counter).  Such a bug needs adverse timing to show.  This build makes the adverse
+// timing the rule: behind EVERY workgroup barrier of the loop kernels -- full_barrier / lds_barrier / __syncthreads and its
+// _or / _count forms -- every wave but wave 0 (GLIA_HMT_SKEW=1: the writer is early, the readers late) or wave 0 alone
+// (GLIA_HMT_SKEW=2: the writer late) sleeps for tens of thousands of cycles.  A kernel whose barriers separate every such
+// read from its rewrite gives the same bytes under both; the GPU tests are run once against each library
+// (tools/skew_tests.sh, record in profiles/).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#ifdef GLIA_HMT_SKEW
+#ifndef GLIA_HMT_SKEW_SLEEPS
+#define GLIA_HMT_SKEW_SLEEPS 4          // x s_sleep 127 (8128 cycles each)
+#endif
+namespace glia {
+__device__ __forceinline__ void skew_delay() {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const bool late = (GLIA_HMT_SKEW == 1) ? (wave != 0) : (wave == 0);
+  if (late) {
+#pragma unroll 1
+    for (int i = 0; i < GLIA_HMT_SKEW_SLEEPS; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+}
+__device__ __forceinline__ void skew_syncthreads() { __syncthreads(); skew_delay(); }
+__device__ __forceinline__ int skew_syncthreads_or(int p) { const int r = __syncthreads_or(p); skew_delay(); return r; }
+__device__ __forceinline__ int skew_syncthreads_count(int p) { const int r = __syncthreads_count(p); skew_delay(); return r; }
+}  // namespace glia
+#define __syncthreads() ::glia::skew_syncthreads()
+#define __syncthreads_or(p) ::glia::skew_syncthreads_or(p)
+#define __syncthreads_count(p) ::glia::skew_syncthreads_count(p)
+#define GLIA_SKEW_DELAY() ::glia::skew_delay()
+#else
+#define GLIA_SKEW_DELAY() do {} while (0)
+#endif

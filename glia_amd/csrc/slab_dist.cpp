@@ -74,15 +74,21 @@ struct Transfer { int src, dst; const void* from; void* to; size_t bytes; };
 int run_transfers(glia_hmt_comm* cm, const std::vector<Transfer>& ts, uint64_t* bytes_sent) {
   hipStream_t s = cm->ctx->stream;
   if (cm->nccl) GLIA_NCCL_TRY(g_rccl.GroupStart());
-  for (const Transfer& t : ts) {
-    if (!t.bytes) continue;
-    const bool ls = cm->is_local(t.src), ld = cm->is_local(t.dst);
-    if (ls && ld) { if (t.from != t.to) GLIA_HIP_TRY(hipMemcpyAsync(t.to, t.from, t.bytes, hipMemcpyDeviceToDevice, s)); }
-    else if (ls) GLIA_NCCL_TRY(g_rccl.Send(t.from, t.bytes, ncclUint8, t.dst, cm->nccl, s));
-    else if (ld) GLIA_NCCL_TRY(g_rccl.Recv(t.to, t.bytes, ncclUint8, t.src, cm->nccl, s));
-    if (ls && t.src != t.dst && bytes_sent) *bytes_sent += t.bytes;
-  }
-  if (cm->nccl) GLIA_NCCL_TRY(g_rccl.GroupEnd());
+  // an error between GroupStart and GroupEnd must not leave the group open (the communicator would be unusable): the loop runs
+  // inside a lambda and GroupEnd is called whatever it returns
+  const int rc = [&]() -> int {
+    for (const Transfer& t : ts) {
+      if (!t.bytes) continue;
+      const bool ls = cm->is_local(t.src), ld = cm->is_local(t.dst);
+      if (ls && ld) { if (t.from != t.to) GLIA_HIP_TRY(hipMemcpyAsync(t.to, t.from, t.bytes, hipMemcpyDeviceToDevice, s)); }
+      else if (ls) GLIA_NCCL_TRY(g_rccl.Send(t.from, t.bytes, ncclUint8, t.dst, cm->nccl, s));
+      else if (ld) GLIA_NCCL_TRY(g_rccl.Recv(t.to, t.bytes, ncclUint8, t.src, cm->nccl, s));
+      if (ls && t.src != t.dst && bytes_sent) *bytes_sent += t.bytes;
+    }
+    return GLIA_HMT_OK;
+  }();
+  if (cm->nccl) { if (rc) { (void)g_rccl.GroupEnd(); return rc; } GLIA_NCCL_TRY(g_rccl.GroupEnd()); }
+  if (rc) return rc;
   GLIA_HIP_TRY(hipStreamSynchronize(s));
   return GLIA_HMT_OK;
 }

@@ -25,6 +25,7 @@
 
 #include "greedy_common.hpp"
 #include "hmt_internal.hpp"
+#include "skew.hpp"
 
 namespace glia {
 namespace {
@@ -301,7 +302,7 @@ int watershed_labels(int dim, const int64_t dims[3], const float* d_img, double 
   auto fail = [&](int rc) { return rc; };
 #define WS_TRY(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_error(std::string("watershed: ") + hipGetErrorString(_e)); return fail(GLIA_HMT_ERR_HIP); } } while (0)
 #define WS_GET(ptr, count) do { int _rc = buf.get(&(ptr), (size_t)(count), false, stream); if (_rc) return _rc; } while (0)
-  const bool trace = getenv("GLIA_HMT_TRACE") != nullptr;
+  const bool trace = option("GLIA_HMT_TRACE");
   const auto tr0 = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
     if (!trace) return;

@@ -67,6 +67,43 @@ def _check(rc):
         raise HmtError(rc, lib().glia_hmt_last_error().decode())
 
 
+ERR_ARG, ERR_INTERNAL = -1, -7
+
+
+def set_option(key, value):
+    """glia_hmt_set_option: a process-wide tuning / test switch of the loops (value None unsets it)."""
+    _check(lib().glia_hmt_set_option(key.encode(), None if value is None else str(value).encode()))
+
+
+class options:
+    """with options(GLIA_HMT_WINCAP=32, ...): the switches are set inside the block and unset afterwards (no result depends on
+    them; the queue tests use them to drive the window queue through its rare paths)."""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.kv:
+            set_option(k, None)
+        return False
+
+
+def check_merge_order(dense_order, n_regions):
+    """glia_hmt_check_merge_order on a DENSE-id order ([n][3] uint32): -1 when every merge joins two regions that still exist and
+    creates region n_regions + k, else the first merge that does not."""
+    o = np.ascontiguousarray(dense_order, dtype=np.uint32).reshape(-1, 3)
+    bad = C.c_int64(-1)
+    rc = lib().glia_hmt_check_merge_order(o.ctypes.data_as(C.c_void_p), C.c_int64(len(o)), C.c_int64(int(n_regions)), C.byref(bad))
+    if rc not in (0, ERR_ARG):
+        _check(rc)
+    return int(bad.value)
+
+
 def _dims(shape):
     dim = len(shape)
     d = (C.c_int64 * 3)(1, 1, 1)
@@ -123,9 +160,10 @@ class Context:
         return int(f())
 
     @staticmethod
-    def merge_loop_retries():
-        """Merge-order calls of this process that failed the library's consistency check and were run again (glia_hmt_merge_loop_retries)."""
-        f = lib().glia_hmt_merge_loop_retries
+    def internal_errors():
+        """Calls of this process that ended with GLIA_HMT_ERR_INTERNAL -- a merge loop's own consistency stop or an order that
+        failed the replay of glia_hmt_check_merge_order (glia_hmt_internal_errors).  0 is the only healthy answer."""
+        f = lib().glia_hmt_internal_errors
         f.restype = C.c_ulonglong
         return int(f())
 

@@ -30,6 +30,7 @@ extern "C" {
 #define GLIA_HMT_ERR_CAPACITY (-4)     /* caller-provided output buffer too small */
 #define GLIA_HMT_ERR_SALIENCY (-5)     /* "Error: invalid boundary saliency..." (util/struct_merge.hxx:58-59) */
 #define GLIA_HMT_ERR_IO (-6)           /* file could not be read / malformed */
+#define GLIA_HMT_ERR_INTERNAL (-7)     /* a merge loop stopped on its own consistency check (see glia_hmt_internal_errors) */
 
 #define GLIA_HMT_MAX_IMAGES 8
 #define GLIA_HMT_MAX_BINS 16
@@ -50,11 +51,22 @@ void glia_hmt_ctx_destroy(glia_hmt_ctx* ctx);
  * device-wide synchronisation).  This returns them to the driver -- for callers that share the device with another allocator
  * (torch, a second library).  Returns the number of bytes released.  Destroying the last context of a process does the same. */
 unsigned long long glia_hmt_release_cached_memory(void);
-/* pb / pre_merge merge orders are replayed on the host before they are returned (every merge joins two regions that still exist and
- * creates region R + k); a call whose order fails is run again, at most twice (the open defect of the window kernel,
- * a race that shows about once in 10^4 .. 10^5 small volumes); glia_hmt_pre_merge runs its loop twice and returns when two runs agree.
- * Number of re-runs (failed checks, disagreeing runs) in this process so far; 0 is the normal answer. */
-unsigned long long glia_hmt_merge_loop_retries(void);
+/* The invariant of genMergeOrderGreedy's output (util/struct_merge.hxx:19-31: the loop appends (r0, r1, key++) and erases the two
+ * regions' items): merge k joins two regions that still exist and creates region n_regions + k.  h_order holds DENSE ids (leaf i =
+ * i-th label ascending, merged region n_regions + k).  Returns GLIA_HMT_OK, or GLIA_HMT_ERR_ARG with *first_bad = the first merge
+ * that breaks the rule.  The pb / pre_merge loops run this O(R) replay on every order before they return it; a violation ends the
+ * call with GLIA_HMT_ERR_INTERNAL -- it is never repaired by running the loop again. */
+int glia_hmt_check_merge_order(const uint32_t* h_order, int64_t n_merges, int64_t n_regions, int64_t* first_bad);
+/* Calls of this process that ended with GLIA_HMT_ERR_INTERNAL.  0 is the only healthy answer: bench.py prints it, the GPU test
+ * session and __graft_entry__.smoke() assert it. */
+unsigned long long glia_hmt_internal_errors(void);
+/* Tuning and test switches of the loops, process-wide: which queue the pb-mean loop runs on (GLIA_HMT_PB_WINDOW, GLIA_HMT_PB_BATCH,
+ * GLIA_HMT_FORCE_TREE), its window size / baseline interval / horizon (GLIA_HMT_WINCAP, GLIA_HMT_REBASE, GLIA_HMT_HORIZON), the
+ * classifier loop's helper workgroups and instance tier (GLIA_HMT_HELPERS, GLIA_HMT_BC_NOCOMMON, GLIA_HMT_BC_GENERIC), the libm
+ * variant (GLIA_HMT_LIBM, read when a context is created), GLIA_HMT_TRACE, GLIA_HMT_DEBUG (profiling build).  No setting changes a
+ * result.  value = NULL unsets.  The table starts from the environment variables of the same names, read once; nothing in the
+ * library calls getenv() per call.  Unknown key: GLIA_HMT_ERR_ARG. */
+int glia_hmt_set_option(const char* key, const char* value);
 int glia_hmt_ctx_sync(glia_hmt_ctx* ctx);
 /* Logarithms of the feature vector.  The reference computes histogram entropies with std::log2 (util/stats.hxx:145-152)
  * and the --logs features with std::log (glia_base.hxx:80-81), the compactness with std::pow (type/feat.hxx:78-79), i.e.

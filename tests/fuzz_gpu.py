@@ -130,11 +130,12 @@ while time.time() < t_end:
             assert o.shape == ro.shape and (o == ro).all() and (s == rs).all(), "bc forest"
         rm.close()
     except (AssertionError, hmt.HmtError) as e:
-        print("MISMATCH after %d cases (last call: %s; merge-loop re-runs so far: %d): %r  config %s" % (n, stage, hmt.Context.merge_loop_retries(), e, cfgdesc), flush=True)
+        print("MISMATCH after %d cases (last call: %s; internal errors so far: %d): %r  config %s" % (n, stage, hmt.Context.internal_errors(), e, cfgdesc), flush=True)
         np.savez_compressed(os.path.join(ROOT, "gpurun_out", "fuzz_fail.npz"), labels=labels, pb=pb, mask=mask if mask is not None else np.zeros(0))
         sys.exit(1)
     n += 1
     if n % 5 == 0:
         print("%d cases ok (%.0f s left)" % (n, t_end - time.time()), flush=True)
-print("fuzz: %d random configurations, all identical to the oracle (%d classifier runs diverged at a libm near-tie of an entropy score); merge-loop re-runs after a failed check: %d"
-      % (n, near_ties, hmt.Context.merge_loop_retries()))
+print("fuzz: %d random configurations, all identical to the oracle (%d classifier runs diverged at a libm near-tie of an entropy score); calls that ended with GLIA_HMT_ERR_INTERNAL: %d"
+      % (n, near_ties, hmt.Context.internal_errors()))
+sys.exit(1 if hmt.Context.internal_errors() else 0)

@@ -42,6 +42,26 @@ def test_errors_are_status_codes_not_exits():
     assert rc == -6 and b"model file" in lib.glia_hmt_last_error()
 
 
+def test_merge_order_invariant_and_options_are_host_code():
+    """glia_hmt_check_merge_order (the replay of util/struct_merge.hxx:19-31 every pb / pre_merge order passes before it is returned)
+    and glia_hmt_set_option need no GPU."""
+    lib = _lib()
+    lib.glia_hmt_internal_errors.restype = C.c_ulonglong
+    R = 6
+    good = np.array([[0, 1, 6], [2, 6, 7], [3, 4, 8], [7, 8, 9], [5, 9, 10]], np.uint32)
+    bad_at = C.c_int64(7)
+    assert lib.glia_hmt_check_merge_order(good.ctypes.data_as(C.c_void_p), C.c_int64(5), C.c_int64(R), C.byref(bad_at)) == 0 and bad_at.value == -1
+    for row, col, val, where in ((3, 0, 0, 3), (2, 2, 9, 2), (4, 1, 5, 4), (1, 1, 7, 1)):      # gone region, wrong key, a == b, not created yet
+        o = good.copy(); o[row, col] = val
+        assert lib.glia_hmt_check_merge_order(o.ctypes.data_as(C.c_void_p), C.c_int64(5), C.c_int64(R), C.byref(bad_at)) == -1
+        assert bad_at.value == where
+    six = np.array([[0, 1, 6]] * 6, np.uint32)
+    assert lib.glia_hmt_check_merge_order(six.ctypes.data_as(C.c_void_p), C.c_int64(6), C.c_int64(R), C.byref(bad_at)) == -1   # more merges than R - 1
+    assert lib.glia_hmt_internal_errors() == 0
+    assert lib.glia_hmt_set_option(b"GLIA_HMT_WINCAP", b"32") == 0 and lib.glia_hmt_set_option(b"GLIA_HMT_WINCAP", None) == 0
+    assert lib.glia_hmt_set_option(b"GLIA_HMT_NO_SUCH_SWITCH", b"1") == -1
+
+
 def _parse(lib, path, label=-1):
     nt, nn, nc = C.c_int(), C.c_int(), C.c_int()
     assert lib.glia_hmt_forest_file_parse(path.encode(), C.c_int(label), C.byref(nt), C.byref(nn), C.byref(nc), None, None,

@@ -94,11 +94,8 @@ def test_random_forest_matches_oracle(ctx, shape, S, G, ntree, depth):
     # the forest is walked by helper workgroups (63 by default); the result may not depend on how many there are:
     # 0 = the contraction workgroup walks the trees itself, 5 = every helper takes several records of a chunk
     for nh in ("0", "5"):
-        os.environ["GLIA_HMT_HELPERS"] = nh
-        try:
+        with hmt.options(GLIA_HMT_HELPERS=nh):
             o2, s2 = rm.merge_order_bc(clf)[:2]
-        finally:
-            del os.environ["GLIA_HMT_HELPERS"]
         assert (o2 == o_ref).all() and (s2 == s_ref).all(), "helpers=" + nh
 
 
@@ -137,11 +134,8 @@ def test_ensemble_random_forest_matches_oracle(ctx, shape, S, G, ntrees):
     assert (sal == s_ref).all()
     assert _feat_close(feats, f_ref)
     for nh in ("0", "5"):
-        os.environ["GLIA_HMT_HELPERS"] = nh
-        try:
+        with hmt.options(GLIA_HMT_HELPERS=nh):
             o2, s2 = rm.merge_order_bc(clf)[:2]
-        finally:
-            del os.environ["GLIA_HMT_HELPERS"]
         assert (o2 == o_ref).all() and (s2 == s_ref).all(), "helpers=" + nh
 
 
@@ -446,18 +440,10 @@ def test_loop_instances_agree(ctx, shape, S, G):
     stub = 11 + 4 * 3 + 7 + 1
     results = []
     for env in ({}, {"GLIA_HMT_BC_NOCOMMON": "1"}, {"GLIA_HMT_BC_GENERIC": "1"}):
-        old = {k: os.environ.get(k) for k in env}
-        os.environ.update(env)
-        try:
+        with hmt.options(**env):
             rm = _gpu_rm(ctx, labels, pb)
             results.append(rm.merge_order_bc(hmt.FeatureStubClassifier(ctx, stub), want_feats=True))
             rm.close()
-        finally:
-            for k, v in old.items():
-                if v is None:
-                    del os.environ[k]
-                else:
-                    os.environ[k] = v
     cfg = O.make_cfg(pb, rb=[(pb, 8, 0.0, 1.0)])
     o_ref, s_ref, f_ref = O.Rag(labels).merge_order_bc(cfg, None, stub_index=stub, want_feats=True)
     for o, s, f in results:

@@ -17,6 +17,9 @@ PB_1024 = ("977022085e1a37a4d143841a51ea8834b6f53c59", "7923436b47d4484f1e95962a
 PB_512 = ("652c84e7efe781bacc9df8c0a16675ca7e34cf17", "d78663710b1699d331a62c40471ba2d90ffc6515")
 BC_512 = ("8e620b69eab2cc31991eaca662446f52ad2231df", "8e30e7ba92d7b89dc09c413260a0841df1cbf886")
 BC_256 = ("51b7b5316e0d8fd648ab2b444527633d8eaf65c5", "5eadbd683d6a042f7bf950aa2352ef93bdc12956")
+# the classifier loop at 1024^3: the digest of bench.py's `bc_loop` leg, identical in profiles/r03x_bench1024.json, r03y, r03z and the
+# driver's BENCH_r03.json (four runs, three builds of the loop)
+BC_1024 = ("6d930d8a816d75d194b20c5f4eb068a3bd362f3f", "1915075dc494d7c5b56baea947414d1890c2d8f8")
 
 
 @pytest.fixture(scope="module")
@@ -52,17 +55,14 @@ def test_pb_mean_order_at_headline_size(ctx, size, expect):
     assert (_sha(order), _sha(sal)) == expect
 
 
-@pytest.mark.parametrize("size,expect", [(256, BC_256), (512, BC_512)])
+@pytest.mark.parametrize("size,expect", [(256, BC_256), (512, BC_512), (1024, BC_1024)])
 def test_classifier_order_at_headline_size(ctx, size, expect):
     """the north-star linkage (255-tree forest, D_f = 104) at 512^3: invariants + the recorded digest"""
     from glia_amd import hmt
     from glia_amd.synth_forest import synthetic_forest, write_model
     labels, pb = ctx.synth((size,) * 3, 16, 128)
     cfg = hmt.make_config(pb, rb=[(pb, 8, 0.0, 1.0)])
-    with tempfile.TemporaryDirectory() as d:
-        path = os.path.join(d, "m.bin")
-        write_model(path, synthetic_forest(ntree=255, dim=3))
-        clf = hmt.RandomForest(ctx, path)
+    clf = _forest(ctx)
     rm = hmt.RegionMap(ctx, labels, pb=pb, cfg=cfg)
     R = rm.num_regions
     order, sal = rm.merge_order_bc(clf)
@@ -71,3 +71,103 @@ def test_classifier_order_at_headline_size(ctx, size, expect):
     assert ((sal >= 0.0) & (sal <= 1.0)).all()                               # vote fractions
     assert np.all(np.abs(sal * 255.0 - np.round(sal * 255.0)) < 1e-9)        # k / ntree
     assert (_sha(order), _sha(sal)) == expect
+
+
+# ---- BASELINE config 5: 2048 x 2048 x 512, RF-scored, label volume -> final segmentation, on one MI355X ----------------------
+# recorded by this test's first run on the round-4 library (profiles/r04_config5.txt); the order / saliency digests of the same
+# volume were also printed by tools/e2e_bench.py
+C5_ORDER, C5_SAL = None, None
+C5_SEGMENTS, C5_SIZES_SHA, C5_CHECKSUM = None, None, None
+
+
+def _forest(ctx):
+    from glia_amd import hmt
+    from glia_amd.synth_forest import synthetic_forest, write_model
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "m.bin")
+        write_model(path, synthetic_forest(ntree=255, dim=3))
+        return hmt.RandomForest(ctx, path)
+
+
+def _position_checksum(torch, lab):
+    """sum over voxels of label * (1 + index mod 1000003), in wrapping int64, slab by slab on the device: depends on WHERE every
+    label sits, costs one pass"""
+    total = 0
+    flat = lab.reshape(-1)
+    step = 1 << 27
+    for a in range(0, flat.numel(), step):
+        part = flat[a:a + step].to(torch.int64)
+        w = (torch.arange(a, a + part.numel(), device=lab.device, dtype=torch.int64) % 1000003) + 1
+        total = (total + int((part * w).sum().item())) & 0xFFFFFFFFFFFFFFFF
+    return total
+
+
+def test_config5_end_to_end(ctx):
+    """BASELINE config 5 (2048 x 2048 x 512 voxels, S = 16: 524 288 supervoxels; 255-tree forest, D_f = 104): RAG + statistics ->
+    merge_order_bc -> genTreeWithNodePotentials -> resolveTreeGreedy -> genLabelTransform -> transformImage -> relabelImage.
+    The oracle cannot reach this size; what is checked is what the domain offers at any size --
+      * the merge order: invariants of util/struct_merge.hxx:19-31 (each merge joins two live regions and creates maxKey + 1 + k),
+        saliencies are vote fractions k / 255;
+      * the tree: 2R - 1 nodes, children before parents; the greedy picks are an antichain that covers every leaf exactly once
+        (hmt/tree_greedy.hxx:104-152), the label transform maps every leaf;
+      * the final volume: every voxel labelled 1..n, every label used, sizes non-increasing in the label (RelabelComponent),
+        voxel conservation: the size of every final segment = the summed sizes of the supervoxels the transform sends there;
+        relabelImage is idempotent;
+    -- plus recorded SHA-1 digests of the order, the saliencies, the segment sizes and a position-dependent checksum of the final volume."""
+    import time
+    import torch
+    from glia_amd import hmt
+    shape, S = (512, 2048, 2048), 16
+    labels, pb = ctx.synth(shape, S, 8 * S)
+    N = labels.numel()
+    cfg = hmt.make_config(pb, rb=[(pb, 8, 0.0, 1.0)])
+    clf = _forest(ctx)
+    t0 = time.time()
+    rm = hmt.RegionMap(ctx, labels, pb=pb, cfg=cfg)
+    R = rm.num_regions
+    reg = rm.regions()
+    order, sal = rm.merge_order_bc(clf)
+    t_tree = time.time() - t0
+    rm.close()
+    assert R == 524288
+    _invariants(order, R, R + 1)
+    assert ((sal >= 0.0) & (sal <= 1.0)).all() and np.all(np.abs(sal * 255.0 - np.round(sal * 255.0)) < 1e-9)
+    lab, par, c0, c1, pot = hmt.tree_potentials(order, sal)
+    n_nodes = len(lab)
+    assert n_nodes == 2 * R - 1 and par[-1] < 0 and (par[:-1] > np.arange(n_nodes - 1)).all()      # children before parents, root last
+    picks = hmt.resolve_tree_greedy(par, c0, c1, pot)
+    # every leaf has exactly one picked node among itself and its ancestors (pointer jumping over the parent array)
+    cover = np.zeros(n_nodes + 1, np.int64); cover[picks] = 1
+    assert cover.sum() == len(picks)
+    ptr = np.where(par < 0, n_nodes, par).astype(np.int64); ptr = np.concatenate([ptr, [n_nodes]])
+    for _ in range(22):
+        cover = cover + cover[ptr]; cover[n_nodes] = 0
+        ptr = ptr[ptr]
+    leaves = np.nonzero(c0 < 0)[0]
+    assert len(leaves) == R and (cover[leaves] == 1).all()
+    src, dst = hmt.label_transform(lab, c0, c1, picks, 1)
+    assert len(src) == R and (np.sort(src) == np.arange(1, R + 1)).all() and len(np.unique(dst)) == len(picks)
+    # supervoxel sizes from the region map, summed per destination
+    sizes_sv = np.zeros(R + 1, np.int64); sizes_sv[reg["label"]] = reg["count"]
+    assert sizes_sv.sum() == N
+    exp_sizes = np.bincount(dst, weights=sizes_sv[src].astype(np.float64)).astype(np.int64)
+    exp_sizes = np.sort(exp_sizes[exp_sizes > 0])[::-1]
+    ms = hmt.transform_image(ctx, labels, src, dst, fill_missing=True)
+    n_seg = hmt.relabel_image(ctx, labels)
+    assert n_seg == len(picks)
+    sizes = torch.bincount(labels.reshape(-1), minlength=n_seg + 1).cpu().numpy()
+    assert sizes[0] == 0 and sizes.sum() == N and (sizes[1:] > 0).all()                   # every voxel labelled, every label used
+    assert (np.diff(sizes[1:]) <= 0).all()                                                # by decreasing size
+    assert (sizes[1:] == exp_sizes).all()                                                 # voxel conservation through the whole chain
+    chk = _position_checksum(torch, labels)
+    before = labels.clone()
+    assert hmt.relabel_image(ctx, labels) == n_seg and torch.equal(before, labels)        # idempotent
+    del before
+    got = dict(order=_sha(order), sal=_sha(sal), segments=int(n_seg), sizes=_sha(sizes.astype(np.int64)), checksum=chk)
+    print("config 5: %d merges in %.2f s (RAG + merge tree), %d segments, transform kernel %.3f ms; digests %r" % (len(order), t_tree, n_seg, ms, got))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "config5_digests.txt"), "w") as f:
+            f.write(repr(got) + "\n")
+    if C5_ORDER is not None:
+        assert got == dict(order=C5_ORDER, sal=C5_SAL, segments=C5_SEGMENTS, sizes=C5_SIZES_SHA, checksum=C5_CHECKSUM)

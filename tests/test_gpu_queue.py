@@ -3,10 +3,10 @@
   tournament tree (greedy_pb_kernel, round 1)  ==  window queue, one contraction at a time (greedy_window_kernel)
                                                ==  window queue, batched contractions (greedy_batch_kernel, the default)
 under conditions that force every rare path of the window queue: a tiny window (spills, evictions, cells split by the bounded
-heap), frequent re-baselines, massive exact ties, launches that end early.  The switches are environment variables read per call
-(glia_amd/csrc/greedy.hip): GLIA_HMT_PB_WINDOW=0 (tree), GLIA_HMT_PB_BATCH=0 (sequential window), GLIA_HMT_WINCAP, GLIA_HMT_REBASE."""
-import os
-
+heap), frequent re-baselines, massive exact ties, launches that end early.  The switches are library options (glia_hmt_set_option,
+hmt.options): GLIA_HMT_PB_WINDOW=0 (tree), GLIA_HMT_PB_BATCH=0 (sequential window), GLIA_HMT_WINCAP, GLIA_HMT_REBASE, ...
+No loop is ever run twice: an order that breaks the invariant of glia_hmt_check_merge_order is GLIA_HMT_ERR_INTERNAL, and the
+session ends with a check that glia_hmt_internal_errors() stayed 0 (tests/conftest.py)."""
 import numpy as np
 import pytest
 
@@ -25,18 +25,10 @@ def ctx():
 
 def _order(ctx, d_lab, d_pb, **env):
     from glia_amd import hmt
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update({k: str(v) for k, v in env.items()})
-    try:
+    with hmt.options(**env):
         rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, only_contour=True)
         o, s = rm.merge_order_pb(type=2)
         rm.close()
-    finally:
-        for k, v in old.items():
-            if v is None:
-                del os.environ[k]
-            else:
-                os.environ[k] = v
     return o, s
 
 
@@ -120,47 +112,43 @@ def test_pre_merge_on_a_tiny_window(ctx):
     d_lab, d_pb = torch.from_numpy(labels.view(np.int32)).cuda(), torch.from_numpy(pb).cuda()
     ro, rs = O.Rag(labels).pre_merge(pb, [150, 400], 0.3)
     for env in (dict(), dict(GLIA_HMT_WINCAP=32), dict(GLIA_HMT_REBASE=200)):
-        old = {k: os.environ.get(k) for k in env}
-        os.environ.update({k: str(v) for k, v in env.items()})
-        try:
+        with hmt.options(**env):
             rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, only_contour=False)
             o, s = rm.pre_merge([150, 400], 0.3)
             rm.close()
-        finally:
-            for k, v in old.items():
-                if v is None:
-                    del os.environ[k]
-                else:
-                    os.environ[k] = v
         assert o.shape == ro.shape and (o == ro).all() and (s == rs).all(), env
 
 
-def test_an_inconsistent_order_is_caught_and_the_call_run_again(ctx):
-    """Every pb / pre_merge order is replayed on the host before it is returned (greedy.hip, greedy_mean): GLIA_HMT_FAULT_INJECT=n
-    spoils the first n attempts of a call (the last merge names a region that went at merge 0).  One spoiled attempt: the answer
-    is the oracle's and the retry counter moves; three: the call fails with the internal error instead of returning the order."""
+def _dense(order, labels):
+    """keys -> dense ids: leaf i = i-th label ascending, merged key maxKey + 1 + k -> R + k"""
+    lab = np.unique(labels[labels != 0]) if (labels == 0).any() else np.unique(labels)
+    R, top = len(lab), int(lab.max())
+    o = order.astype(np.int64)
+    d = np.where(o > top, o - (top + 1) + R, np.searchsorted(lab, np.minimum(o, top)))
+    return d.astype(np.uint32), R
+
+
+def test_orders_satisfy_the_library_invariant_and_a_spoiled_one_does_not(ctx):
+    """glia_hmt_check_merge_order is the replay the pb / pre_merge loops run on every order before they return it (a violation is
+    GLIA_HMT_ERR_INTERNAL, never a second run): the device's orders pass it, an order whose last merge names a region that went at
+    merge 0 does not, and neither raised the process's internal-error count."""
     import torch
     from glia_amd import hmt
     from oracle import pyoracle as O
     labels, pb = O.synth((40, 40, 24), 5, 10)
     d_lab, d_pb = torch.from_numpy(labels.view(np.int32)).cuda(), torch.from_numpy(pb).cuda()
-    ro, rs = O.Rag(labels, only_contour=True).merge_order_pb(pb, type=2)
-    po, ps = O.Rag(labels).pre_merge(pb, [100, 300], 0.3)
-    before = hmt.Context.merge_loop_retries()
+    before = hmt.Context.internal_errors()
     o, s = _order(ctx, d_lab, d_pb)
-    assert (o == ro).all() and (s == rs).all() and hmt.Context.merge_loop_retries() == before
-    o, s = _order(ctx, d_lab, d_pb, GLIA_HMT_FAULT_INJECT=1)
-    assert (o == ro).all() and (s == rs).all() and hmt.Context.merge_loop_retries() == before + 1
-    os.environ["GLIA_HMT_FAULT_INJECT"] = "2"
-    try:
-        rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, only_contour=False)
-        o, s = rm.pre_merge([100, 300], 0.3)
-        rm.close()
-        assert o.shape == po.shape and (o == po).all() and (s == ps).all() and hmt.Context.merge_loop_retries() == before + 3
-        os.environ["GLIA_HMT_FAULT_INJECT"] = "3"
-        rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, only_contour=True)
-        with pytest.raises(hmt.HmtError, match="consistency check"):
-            rm.merge_order_pb(type=2)
-        rm.close()
-    finally:
-        del os.environ["GLIA_HMT_FAULT_INJECT"]
+    rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, only_contour=False)
+    po, ps = rm.pre_merge([100, 300], 0.3)
+    rm.close()
+    for order in (o, po):
+        d, R = _dense(order, labels)
+        assert len(d) > 10 and hmt.check_merge_order(d, R) == -1
+        bad = d.copy()
+        bad[-1, 0] = bad[0, 0]
+        assert hmt.check_merge_order(bad, R) == len(bad) - 1
+        bad = d.copy()
+        bad[5, 2] += 1
+        assert hmt.check_merge_order(bad, R) == 5
+    assert hmt.Context.internal_errors() == before

@@ -68,6 +68,52 @@ def test_watershed_feeds_the_merge_path(ctx):
     assert (o == ro).all() and (s == rs).all()
 
 
+def test_watershed_at_128_cubed_matches_oracle(ctx):
+    """the largest size the oracle's sequential flood finishes in seconds: 2.1 M voxels of smooth noise, thousands of basins"""
+    import torch
+    from oracle import pyoracle as O
+    img = _smooth((128, 128, 128), seed=7, passes=3)
+    ref, n_ref = O.watershed(img, 0.01)
+    lab, n, _ = ctx.watershed(torch.from_numpy(img).cuda(), 0.01)
+    got = lab.cpu().numpy().view(np.uint32)
+    assert n == n_ref and n > 500 and (got == ref).all()
+
+
+def test_config2_chain_at_256_cubed(ctx):
+    """BASELINE config 2 at its own size, label bit-exact vs the CPU: 256^3 pb volume -> watershed supervoxels -> RAG -> full
+    pb-mean merge tree on the device = the same chain through the oracle (its sequential flood takes ~15 s here); the classifier
+    linkage (255-tree forest), which the oracle cannot finish at this size, is held to the invariant of
+    util/struct_merge.hxx:19-31 (glia_hmt_check_merge_order)."""
+    import torch
+    from glia_amd import hmt
+    from oracle import pyoracle as O
+    from test_gpu_headline import _forest
+    size, S = 256, 16
+    _, pb = O.synth((size,) * 3, S, 8 * S)
+    img = pb.astype(np.float64)                       # two box passes per axis: basins larger than single voxels
+    for _ in range(2):
+        for ax in range(3):
+            img = (img + np.roll(img, 1, ax) + np.roll(img, -1, ax)) / 3.0
+    img = img.astype(np.float32)
+    ref, n_ref = O.watershed(img, 0.02)
+    d_pb = torch.from_numpy(pb).cuda()
+    lab, n, _ = ctx.watershed(torch.from_numpy(img).cuda(), 0.02)
+    got = lab.cpu().numpy().view(np.uint32)
+    assert n == n_ref and n > 1000 and (got == ref).all()
+    sizes = np.bincount(got.reshape(-1), minlength=n + 1)
+    assert sizes[0] == 0 and (sizes[1:] > 0).all()                                   # every voxel labelled, labels 1..n all used
+    rm = hmt.RegionMap(ctx, lab, pb=d_pb, cfg=hmt.make_config(d_pb, rb=[(d_pb, 8, 0.0, 1.0)]))
+    assert rm.num_regions == n
+    o, s = rm.merge_order_pb(type=2)
+    ro, rs = O.Rag(ref, only_contour=True).merge_order_pb(pb, type=2)
+    assert o.shape == ro.shape and (o == ro).all() and (s == rs).all()
+    ob, sb = rm.merge_order_bc(_forest(ctx))
+    rm.close()
+    d = (ob.astype(np.int64) - 1).astype(np.uint32)              # labels 1..n -> dense 0..n-1, merged key n + 1 + k -> n + k
+    assert len(ob) == len(o) and hmt.check_merge_order(d, n) == -1
+    assert ((sb >= 0) & (sb <= 1)).all()
+
+
 def test_watershed_cli(tmp_path):
     from oracle import pyoracle as O
     from test_gpu_cli import write_mha, read_mha
