@@ -78,6 +78,34 @@ def cpu_baseline(size, S, bc_size, curve_sizes=(), target_regions=0):
     return out
 
 
+def openmp_bc_feat_baseline(size, S):
+    """The GLIA_MT OpenMP baseline the north star names.  bc_feat is the only OpenMP user on the path (hmt/main_bc_feat.cxx:59-101):
+    oracle/_ref/ref_parfor_st / _mt are the reference's own util/mp.hxx (parfor) compiled in place without / with -DGLIA_MT -fopenmp,
+    driving the oracle's feature functions over the pb-mean order of a size^3 sample of the same synthetic workload.  One D_f vector
+    per merge: edge-features/s = merges / seconds of the two parfor loops + serialisation (the region map's set-up excluded)."""
+    import subprocess
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    st = os.path.join(ROOT, "oracle", "_ref", "ref_parfor_st"); mt = os.path.join(ROOT, "oracle", "_ref", "ref_parfor_mt")
+    if not (os.path.exists(st) and os.path.exists(mt)):
+        return None
+    out = {"sample": "%d^3 synthetic volume, S=%d, --rbi pb --rbb 8 --bt 0.2 0.5 0.8 (D_f=104), given pb-mean merge order; "
+                     "reference parfor (util/mp.hxx built in place) over the oracle's RegionFeats / BoundaryFeats restatement" % (size, S),
+           "cores_available": ncpu, "kind": "reference parfor + port features", "threads": [], "seconds": [], "edge_features_per_sec": []}
+    fnv = set()
+    for exe, threads in ((st, 1), (mt, ncpu)):
+        try:
+            res = subprocess.run([exe, str(size), str(S)], capture_output=True, text=True, check=True, timeout=600,
+                                 env=dict(os.environ, OMP_NUM_THREADS=str(threads)))
+        except Exception:      # noqa: BLE001
+            return None
+        w = res.stdout.split(); kv = dict(zip(w[0::2], w[1::2]))
+        secs = float(kv["seconds_regions"]) + float(kv["seconds_boundaries"]) + float(kv["seconds_serialize"])
+        out["threads"].append(int(kv["threads"])); out["seconds"].append(secs); out["edge_features_per_sec"].append(int(kv["merges"]) / secs)
+        out["regions"] = int(kv["regions"]); out["merges"] = int(kv["merges"]); fnv.add(kv["rows_fnv"])
+    out["rows_identical_across_builds"] = len(fnv) == 1
+    return out
+
+
 def reference_curve(sizes, S, ref, target_regions):
     """The reference's own merge engine (oracle/_ref/ref_engine) at several region counts of the same synthetic workload:
     its boundary-table update scans a std::map prefix per merge (type/boundary_table.hxx:127-128), so the rate falls with
@@ -209,6 +237,7 @@ def main():
     ap.add_argument("--S", type=int, default=16)
     ap.add_argument("--cpu-size", type=int, default=256)
     ap.add_argument("--cpu-bc-size", type=int, default=40)
+    ap.add_argument("--cpu-bcfeat-size", type=int, default=128, help="sample of the OpenMP bc_feat baseline (S/2 supervoxels: 4096 regions at 128)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-curve", type=str, default="128,256,384", help="volume sizes for the reference engine's scaling curve ('' = none)")
     ap.add_argument("--no-bc", action="store_true", help="skip the classifier-linkage merge tree (timed once, outside the steps)")
@@ -374,6 +403,24 @@ def main():
         if not args.no_cpu:
             curve = tuple(int(x) for x in args.cpu_curve.split(",") if x)
             out["cpu_baseline"] = cpu_baseline(args.cpu_size, args.S, args.cpu_bc_size, curve, infos[0]["R"])
+            # the OpenMP leg, and the SAME sample through the library's bc_feat (given order, no queue) for a like-for-like ratio
+            omp = openmp_bc_feat_baseline(args.cpu_bcfeat_size, args.S // 2)
+            if omp is not None:
+                l2, p2 = ctx.synth((args.cpu_bcfeat_size,) * 3, args.S // 2, 4 * args.S)
+                c2 = hmt.make_config(p2, rb=[(p2, 8, 0.0, 1.0)], thresholds=(0.2, 0.5, 0.8))
+                rm2 = hmt.RegionMap(ctx, l2, pb=p2, only_contour=False, cfg=c2)
+                o2, _ = rm2.merge_order_pb(type=2)
+                rm2.bc_feat(o2)                                    # warm-up
+                torch.cuda.synchronize(); ctx.sync()
+                tq = time.time()
+                f2 = rm2.bc_feat(o2)
+                tq = time.time() - tq
+                rm2.close()
+                omp["gpu_same_sample"] = {"merges": len(o2), "seconds": tq, "edge_features_per_sec": len(o2) / tq, "dim": int(f2.shape[1]),
+                                          "ratio_vs_openmp": (len(o2) / tq) / omp["edge_features_per_sec"][-1],
+                                          "ratio_vs_1_thread": (len(o2) / tq) / omp["edge_features_per_sec"][0]}
+                out["cpu_baseline"]["bc_feat"] = omp
+                out["cpu_baseline"]["cores_note"] = "value / curve: 1 thread (GLIA's merge loop is single-threaded); bc_feat: %d OpenMP threads" % omp["threads"][-1]
 
     def emit(slab_info):
         if rank == 0:

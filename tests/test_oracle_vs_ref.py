@@ -266,3 +266,28 @@ def test_stats_match_reference(seed):
         assert (got == ref).all(), (i, got, ref)
         rs = np.array([float(x) for x in out[2 * i + 1].split()])
         assert (O.rescale(a, np.minimum(a, b), np.maximum(a, b)) == rs).all()
+
+
+def test_bc_feat_under_the_reference_parfor_equals_the_serial_oracle(tmp_path):
+    """oracle/_ref/ref_parfor_{st,mt}: the reference's util/mp.hxx (parfor, compiled in place without / with -DGLIA_MT -fopenmp) drives
+    the oracle's feature functions over a merge order the way hmt/main_bc_feat.cxx:57-101 does (shuffled indices, two loops).  Both
+    builds, and the OpenMP one on 1 and 4 threads, must write the rows of the oracle's own serial bc_feat byte for byte: the baseline
+    bench.py times (cpu_baseline.bc_feat) computes what the checker computes."""
+    _ensure_ref()
+    st = os.path.join(os.path.dirname(REF), "ref_parfor_st")
+    mt = os.path.join(os.path.dirname(REF), "ref_parfor_mt")
+    if not (os.path.exists(st) and os.path.exists(mt)):
+        pytest.skip("oracle/_ref/ref_parfor_* not built")
+    size, S = 40, 8
+    labels, pb = O.synth((size,) * 3, S, 8 * S)
+    order, _ = O.Rag(labels, only_contour=True).merge_order_pb(pb, type=2)
+    cfg = O.make_cfg(pb, rb=[(pb, 8, 0.0, 1.0)])
+    want = O.Rag(labels).bc_feat(cfg, order)
+    for exe, threads in ((st, 1), (mt, 1), (mt, 4)):
+        out = str(tmp_path / "rows.bin")
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads))
+        line = subprocess.run([exe, str(size), str(S), out], capture_output=True, text=True, check=True, env=env).stdout.split()
+        kv = dict(zip(line[0::2], line[1::2]))
+        assert int(kv["threads"]) == threads and int(kv["merges"]) == len(order) and int(kv["dim"]) == want.shape[1]
+        got = np.fromfile(out, np.float64).reshape(want.shape)
+        assert (got.view(np.uint64) == want.view(np.uint64)).all(), (exe, threads)
