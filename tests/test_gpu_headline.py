@@ -76,8 +76,8 @@ def test_classifier_order_at_headline_size(ctx, size, expect):
 # ---- BASELINE config 5: 2048 x 2048 x 512, RF-scored, label volume -> final segmentation, on one MI355X ----------------------
 # recorded by this test's first run on the round-4 library (profiles/r04_config5.txt); the order / saliency digests of the same
 # volume were also printed by tools/e2e_bench.py
-C5_ORDER, C5_SAL = None, None
-C5_SEGMENTS, C5_SIZES_SHA, C5_CHECKSUM = None, None, None
+C5_ORDER, C5_SAL = "15f7edfbc88e5b32aff621cd07c148e4bac66c35", "b4617f3fc80c24543b9b8374e4e30cf3a984ebe6"
+C5_SEGMENTS, C5_SIZES_SHA, C5_CHECKSUM = 167593, "515ee46de3020d101d323cec4004bba1b9668850", 10347935045297336445
 
 
 def _forest(ctx):
