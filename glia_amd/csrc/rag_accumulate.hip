@@ -28,10 +28,18 @@
 //     masks).  After the march the workgroup folds its LDS tables into the global hash tables.
 //   * All reductions are integer adds, ORs, unsigned max, or f64 adds: exact, hence order-independent and
 //     bit-reproducible, whenever the image is a multiple of 2^-k (Q8 pb); otherwise within ~1e-15 relative.
+#include <tuple>
 #include <type_traits>
+#include <utility>
 
 #include "hmt_internal.hpp"
 #include "skew.hpp"
+
+// the pass's own cycle counters (ring waits of the marching waves, busy cycles of the drainers): profiling build, or make accvar
+// ACCFLAGS=-DGLIA_ACC_STATS (printed by rag_build when GLIA_HMT_DEBUG has bit 32)
+#if defined(GLIA_HMT_PROFILE) || defined(GLIA_ACC_STATS)
+#define GLIA_ACC_COUNTERS 1
+#endif
 
 namespace glia {
 
@@ -61,12 +69,15 @@ template <int BINS> struct Geo {
   static_assert(kPasses * kMarchers == kTileY, "rows of a tile = marching waves x passes");
 };
 #ifndef GLIA_ACC_DRAINAT
-#define GLIA_ACC_DRAINAT 32
+#define GLIA_ACC_DRAINAT 48          // (round 4, with the combining drain: 16 -> 9.02 ms, 32 -> 8.81, 48 -> 8.78)
 #endif
 constexpr int kDrainAt = GLIA_ACC_DRAINAT;            // a drainer gathers at least this many entries unless a wave of its waits or is done
 constexpr int kLdsProbes = 32;
 constexpr int kGlobalProbes = 512;
-constexpr int kAhead = 4;             // planes the loads run ahead of the arithmetic (= buffers per stream)
+#ifndef GLIA_ACC_AHEAD
+#define GLIA_ACC_AHEAD 4
+#endif
+constexpr int kAhead = GLIA_ACC_AHEAD;   // planes the loads run ahead of the arithmetic (= buffers per stream); a power of two
 
 // ---- LDS record layouts (words); all-zero = empty.  Histogram / threshold counters are 16 bits wide, two per word: a tile
 // has fewer than 65536 voxels, and a 64-bit LDS atomic then adds four of them at once.
@@ -160,6 +171,9 @@ __device__ __forceinline__ int global_pair_slot(const P& p, unsigned long long k
 //  2 region: x | y<<6 | zfirst<<11 | zlast<<16 | border<<21 (tile-relative)     pair: cnt
 //  3 region: cnt (only read with a mask: without one cnt = zlast - zfirst + 1)  pair: 4 x 8-bit threshold counters
 //  4,5 sum (f64)   6,7 sq (f64)   8 min (float)   9 max (float)   10,11 hist bins 0-7 (8-bit packed)  [12,13 bins 8-15]
+// (0 .. kAhead-1 as a tuple of integral constants: the plane buffers are indexed at compile time)
+template <int... I> constexpr auto ahead_seq(std::integer_sequence<int, I...>) { return std::tuple<std::integral_constant<int, I>...>{}; }
+using kAheadSeq = decltype(ahead_seq(std::make_integer_sequence<int, kAhead>{}));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 __attribute__((address_space(3))) lds_u32x4;
 typedef lds_u32x4* lds_u4_ptr;
@@ -183,23 +197,100 @@ __device__ __forceinline__ uint32_t hist_byte(const u32x4& c, const u32x4& d, in
   return (w >> ((k & 3) * 8)) & 0xFF;
 }
 
+// ---- combining a batch before it touches the tables (round 4) --------------------------------------------------------------
+// Lanes of a marching wave that sit in the same supervoxel finish their runs together: a batch (lane = entry) holds RUNS of adjacent
+// lanes with one key -- thirteen on average -- and every LDS atomic on one address is serialised by the hardware (f64 adds worst).
+// With the prefetch pipeline repaired the drainers became the pass's critical path (ablations of round 4: march alone 2.9 ms,
+// + ring writes 4.6 ms, + drain 8.4 ms, + fold 9.7 ms; drain without same-address conflicts 6.5 ms).  So a batch is first reduced by
+// key inside the wave: a segmented inclusive scan over each row of sixteen lanes (DPP row_shr 1, 2, 4, 8; a segment = adjacent
+// lanes with equal keys), after which only the LAST lane of every segment goes to the tables -- a fifth of the lookups and atomics,
+// nearly all of them on distinct addresses.  Every field of an entry reduces by an integer add, an OR, an unsigned max or an f64 add
+// (exact for Q8 images, 1e-15 otherwise, like the table atomics they replace), and zero is the identity of all of them, which is what a
+// lane without a source in its row receives.
+template <int D> __device__ __forceinline__ uint32_t row_shr(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + D, 0xf, 0xf, true); }
+__device__ __forceinline__ uint32_t row_shl1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true); }
+struct SegAdd { __device__ __forceinline__ uint32_t operator()(uint32_t a, uint32_t b) const { return a + b; } };
+struct SegOr { __device__ __forceinline__ uint32_t operator()(uint32_t a, uint32_t b) const { return a | b; } };
+struct SegMax { __device__ __forceinline__ uint32_t operator()(uint32_t a, uint32_t b) const { return a > b ? a : b; } };
+template <int D, class Op> __device__ __forceinline__ void seg_u32(uint32_t& v, const uint32_t m, Op op) { v = op(v, m & row_shr<D>(v)); }
+template <int D> __device__ __forceinline__ void seg_f64(double& v, const uint32_t m) {
+  const uint32_t lo = m & row_shr<D>((uint32_t)__double2loint(v)), hi = m & row_shr<D>((uint32_t)__double2hiint(v));
+  v += __hiloint2double((int)hi, (int)lo);            // (a masked-out contribution is +0.0)
+}
+#ifndef GLIA_ACC_COMBINE
+#define GLIA_ACC_COMBINE 2       // (swept in round 4 at 1024^3: none 9.78 ms, 1 level 9.24, 2 levels 8.81, 3 levels 8.96, 4 levels 9.14)
+#endif
+constexpr int kCombineLevels = GLIA_ACC_COMBINE;
+// head flags of a batch: 1 where a segment starts (first lane of a row, inactive lane, key differs from the lane before)
+__device__ __forceinline__ uint32_t seg_heads(const uint32_t klo, const uint32_t khi, const bool act, const int lane) {
+  const uint32_t plo = row_shr<1>(klo), phi = row_shr<1>(khi);
+  return (!act || (lane & ((1 << kCombineLevels) - 1)) == 0 || plo != klo || phi != khi) ? 1u : 0u;
+}
+// ... and whether a lane is the LAST of its segment (the lane that goes to the tables).  LEVELS scan steps combine groups of
+// 2^LEVELS lanes: a segment is cut at every multiple of that.
+template <int LEVELS>
+__device__ __forceinline__ bool seg_tail(const uint32_t head, const bool act, const int lane) {
+  constexpr int G = (1 << LEVELS) - 1;
+  const uint32_t next_head = row_shl1(head);      // (fetched by EVERY lane, in front of the test: a DPP move under a divergent condition cannot read the lanes the condition switched off)
+  return act && ((lane & G) == G || next_head != 0u);      // (an inactive lane is a head; no lane behind the row's last: handled by the first test)
+}
+
 // One batch of finished REGION runs (lane = entry) goes into the workgroup's tables
-template <int BINS, bool MASK>
-__device__ __forceinline__ void drain_regions(Lds<BINS>& s, const uint32_t entryAddr, const bool act) {
+template <int BINS, bool MASK, class Release>
+__device__ __forceinline__ void drain_regions(Lds<BINS>& s, const uint32_t entryAddr, const bool act, const int lane, Release release) {
   using G = Geo<BINS>;
-  if (!act) return;
   const lds_u4_ptr e = (lds_u4_ptr)(uintptr_t)entryAddr;
-  const u32x4 a = e[0], b = e[1], c = e[2];
-  u32x4 d = {0, 0, 0, 0};
-  if (BINS > 8) d = e[3];
-  const double sum = __hiloint2double((int)b.y, (int)b.x), sq = __hiloint2double((int)b.w, (int)b.z);
+  u32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0}, c = {0, 0, 0, 0}, d = {0, 0, 0, 0};
+  if (act) { a = e[0]; b = e[1]; c = e[2]; if (BINS > 8) d = e[3]; }
+  // the entries are in registers: their ring slots are free from here on (the heads move BEFORE the tables are touched -- a
+  // marching wave that waits for room waits a few hundred cycles less per batch)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  release();
+  double sum = __hiloint2double((int)b.y, (int)b.x), sq = __hiloint2double((int)b.w, (int)b.z);
   const uint32_t cmn = c.x, cmx = c.y;      // (__builtin_bit_cast of a vector ELEMENT reads element 0 whatever the index)
-  const uint32_t omin = ~float_ord(__builtin_bit_cast(float, cmn)), omax = float_ord(__builtin_bit_cast(float, cmx));
+  uint32_t omin = act ? ~float_ord(__builtin_bit_cast(float, cmn)) : 0u, omax = act ? float_ord(__builtin_bit_cast(float, cmx)) : 0u;
   const uint32_t meta = a.z;
-  const uint32_t rx = meta & 63, ry = (meta >> 6) & 31, zs = (meta >> 11) & 31, zl = (meta >> 16) & 31, border = (meta >> 21) & 63;
-  const uint32_t rcnt = MASK ? a.w : zl - zs + 1u;
-  const uint32_t zmask = (2u << zl) - (1u << zs);      // planes zs..zl (2u << 31 wraps to 0: the subtraction still gives the bits)
+  const uint32_t rx = meta & 63, ry = (meta >> 6) & 31, zs = (meta >> 11) & 31, zl = (meta >> 16) & 31;
+  uint32_t border = (meta >> 21) & 63;
+  uint32_t rcnt = act ? (MASK ? a.w : zl - zs + 1u) : 0u;
+  uint32_t zmask = act ? (2u << zl) - (1u << zs) : 0u;      // planes zs..zl (2u << 31 wraps to 0: the subtraction still gives the bits)
+  uint32_t xlo = act ? (rx < 32u ? 1u << rx : 0u) : 0u, xhi = act ? (rx >= 32u ? 1u << (rx - 32u) : 0u) : 0u, ymask = act ? 1u << ry : 0u;
+  uint32_t first = act ? 0xFFFFFu - ((zs << 11) | (meta & 0x7FFu)) : 0u;
+  unsigned long long hw[BINS / 4];
+  hw[0] = widen4(c.z); hw[1] = widen4(c.w);
+  if (BINS > 8) { hw[BINS / 4 - 2] = widen4(d.x); hw[BINS / 4 - 1] = widen4(d.y); }
+  uint32_t h[BINS / 2];
+#pragma unroll
+  for (int k = 0; k < BINS / 4; ++k) { h[2 * k] = (uint32_t)hw[k]; h[2 * k + 1] = (uint32_t)(hw[k] >> 32); }
+#ifndef GLIA_ACC_NOCOMBINE
+  const uint32_t head = seg_heads(a.x, 0u, act, lane);
+  uint32_t f = head;
+  auto level = [&](auto DT) __attribute__((always_inline)) {
+    constexpr int D = decltype(DT)::value;
+    const uint32_t m = f ? 0u : 0xFFFFFFFFu;
+    seg_u32<D>(rcnt, m, SegAdd{}); seg_u32<D>(border, m, SegAdd{});
+    seg_u32<D>(xlo, m, SegOr{}); seg_u32<D>(xhi, m, SegOr{}); seg_u32<D>(ymask, m, SegOr{}); seg_u32<D>(zmask, m, SegOr{});
+    seg_u32<D>(first, m, SegMax{}); seg_u32<D>(omin, m, SegMax{}); seg_u32<D>(omax, m, SegMax{});
+    seg_f64<D>(sum, m); seg_f64<D>(sq, m);
+#pragma unroll
+    for (int k = 0; k < BINS / 2; ++k) seg_u32<D>(h[k], m, SegAdd{});
+    f |= row_shr<D>(f);
+  };
+  level(std::integral_constant<int, 1>{}); level(std::integral_constant<int, 2>{});
+  if (kCombineLevels > 2) level(std::integral_constant<int, 4>{});
+  if (kCombineLevels > 3) level(std::integral_constant<int, 8>{});
+  if (!seg_tail<kCombineLevels>(head, act, lane)) return;
+#else
+  if (!act) return;
+#endif
+#ifdef GLIA_ACC_NOLOOKUP
+  int slot = (int)((a.x * 2654435761u) >> 24);
+#else
   int slot = lds_slot(s.rkey, G::kRegSlots, (unsigned long long)a.x);
+#endif
+#ifdef GLIA_ACC_NOATOM
+  if (slot >= 0) { if (rcnt == 0xFFFFFFFFu) s.rrec[slot] = rcnt + first + omin + omax + xlo + xhi + ymask + zmask + h[0] + h[1] + h[2] + h[3] + (uint32_t)sum + (uint32_t)sq; return; }
+#endif
 #ifdef GLIA_ACC_NOCONFLICT
   if (slot >= 0) slot = (int)((entryAddr / 48u) % (uint32_t)G::kRegSlots);
 #endif
@@ -210,15 +301,11 @@ __device__ __forceinline__ void drain_regions(Lds<BINS>& s, const uint32_t entry
     atomicAdd((double*)&rec[LR_SQ], sq);
     atomicMax(&rec[LR_MIN], omin);
     atomicMax(&rec[LR_MAX], omax);
-    atomicAdd((unsigned long long*)&rec[LR_HIST], widen4(c.z));
-    atomicAdd((unsigned long long*)&rec[LR_HIST + 2], widen4(c.w));
-    if (BINS > 8) {
-      atomicAdd((unsigned long long*)&rec[LR_HIST + 4], widen4(d.x));
-      atomicAdd((unsigned long long*)&rec[LR_HIST + 6], widen4(d.y));
-    }
-    atomicOr((unsigned long long*)&rec[LR_XMASK], 1ull << rx);
-    atomicOr((unsigned long long*)&rec[LR_YMASK], (unsigned long long)(1u << ry) | ((unsigned long long)zmask << 32));
-    atomicMax(&rec[LR_FIRST], 0xFFFFFu - ((zs << 11) | (meta & 0x7FFu)));
+#pragma unroll
+    for (int k = 0; k < BINS / 4; ++k) atomicAdd((unsigned long long*)&rec[LR_HIST + 2 * k], (unsigned long long)h[2 * k] | ((unsigned long long)h[2 * k + 1] << 32));
+    atomicOr((unsigned long long*)&rec[LR_XMASK], (unsigned long long)xlo | ((unsigned long long)xhi << 32));
+    atomicOr((unsigned long long*)&rec[LR_YMASK], (unsigned long long)ymask | ((unsigned long long)zmask << 32));
+    atomicMax(&rec[LR_FIRST], first);
     return;
   }
   // LDS table saturated (tile with very many tiny supervoxels): straight to the global tables (slow, exact).  The host
@@ -232,50 +319,91 @@ __device__ __forceinline__ void drain_regions(Lds<BINS>& s, const uint32_t entry
   if (border) atomicAdd(&r[R_BORDER], border);
   atomicAdd((double*)&r[R_SUM], sum); atomicAdd((double*)&r[R_SQ], sq);
   atomicMax(&r[R_MIN], omin); atomicMax(&r[R_MAX], omax);
-  const uint32_t gx = (uint32_t)p.x0 + rx, gy = (uint32_t)p.y0 + ry;
-  atomicMax(&r[R_LO + 0], 0x7fffffffu - gx); atomicMax(&r[R_HI + 0], gx + 1u);
-  atomicMax(&r[R_LO + 1], 0x7fffffffu - gy); atomicMax(&r[R_HI + 1], gy + 1u);
-  atomicMax(&r[R_LO + 2], 0x7fffffffu - ((uint32_t)p.z0 + zs)); atomicMax(&r[R_HI + 2], (uint32_t)p.z0 + zl + 1u);
-  const unsigned long long fidx = (unsigned long long)((p.z0 + zs) * p.ny * p.nx + (p.y0 + ry) * p.nx + (p.x0 + rx));
-  atomicMax((unsigned long long*)&r[R_FIRST], ~fidx);
+  {
+    // the combined run's extent from its occupancy masks (tile-relative), its first voxel from `first`
+    const unsigned long long xm = (unsigned long long)xlo | ((unsigned long long)xhi << 32);
+    const uint32_t gx0 = (uint32_t)p.x0 + (uint32_t)__builtin_ctzll(xm), gx1 = (uint32_t)p.x0 + 63u - (uint32_t)__builtin_clzll(xm);
+    const uint32_t gy0 = (uint32_t)p.y0 + (uint32_t)__builtin_ctz(ymask), gy1 = (uint32_t)p.y0 + 31u - (uint32_t)__builtin_clz(ymask);
+    const uint32_t gz0 = (uint32_t)p.z0 + (uint32_t)__builtin_ctz(zmask), gz1 = (uint32_t)p.z0 + 31u - (uint32_t)__builtin_clz(zmask);
+    atomicMax(&r[R_LO + 0], 0x7fffffffu - gx0); atomicMax(&r[R_HI + 0], gx1 + 1u);
+    atomicMax(&r[R_LO + 1], 0x7fffffffu - gy0); atomicMax(&r[R_HI + 1], gy1 + 1u);
+    atomicMax(&r[R_LO + 2], 0x7fffffffu - gz0); atomicMax(&r[R_HI + 2], gz1 + 1u);
+    const uint32_t fv = 0xFFFFFu - first;
+    const unsigned long long fidx = (unsigned long long)((p.z0 + (fv >> 11)) * p.ny * p.nx + (p.y0 + ((fv >> 6) & 31)) * p.nx + (p.x0 + (fv & 63)));
+    atomicMax((unsigned long long*)&r[R_FIRST], ~fidx);
+  }
 #pragma unroll
   for (int k = 0; k < BINS; ++k) {
-    const uint32_t h = hist_byte(c, d, k);
-    if (h) atomicAdd(&r[R_HIST + k], h);
+    const uint32_t hk = (h[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+    if (hk) atomicAdd(&r[R_HIST + k], hk);
   }
 }
 
 // One batch of finished PAIR runs
-template <int BINS>
-__device__ __forceinline__ void drain_pairs(Lds<BINS>& s, const uint32_t entryAddr, const bool act) {
+template <int BINS, class Release>
+__device__ __forceinline__ void drain_pairs(Lds<BINS>& s, const uint32_t entryAddr, const bool act, const int lane, Release release) {
   using G = Geo<BINS>;
-  if (!act) return;
   const lds_u4_ptr e = (lds_u4_ptr)(uintptr_t)entryAddr;
-  const u32x4 a = e[0], b = e[1], c = e[2];
-  u32x4 d = {0, 0, 0, 0};
-  if (BINS > 8) d = e[3];
-  const double sum = __hiloint2double((int)b.y, (int)b.x), sq = __hiloint2double((int)b.w, (int)b.z);
+  u32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0}, c = {0, 0, 0, 0}, d = {0, 0, 0, 0};
+  if (act) { a = e[0]; b = e[1]; c = e[2]; if (BINS > 8) d = e[3]; }
+  // the entries are in registers: their ring slots are free from here on (the heads move BEFORE the tables are touched -- a
+  // marching wave that waits for room waits a few hundred cycles less per batch)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  release();
+  double sum = __hiloint2double((int)b.y, (int)b.x), sq = __hiloint2double((int)b.w, (int)b.z);
   const uint32_t cmn = c.x, cmx = c.y;      // (__builtin_bit_cast of a vector ELEMENT reads element 0 whatever the index)
-  const uint32_t omin = ~float_ord(__builtin_bit_cast(float, cmn)), omax = float_ord(__builtin_bit_cast(float, cmx));
+  uint32_t omin = act ? ~float_ord(__builtin_bit_cast(float, cmn)) : 0u, omax = act ? float_ord(__builtin_bit_cast(float, cmx)) : 0u;
   const unsigned long long key = ((unsigned long long)a.y << 32) | a.x;
+  uint32_t cnt = a.z;
+  const unsigned long long tw = widen4(a.w);
+  uint32_t t0 = (uint32_t)tw, t1 = (uint32_t)(tw >> 32);
+  unsigned long long hw[BINS / 4];
+  hw[0] = widen4(c.z); hw[1] = widen4(c.w);
+  if (BINS > 8) { hw[BINS / 4 - 2] = widen4(d.x); hw[BINS / 4 - 1] = widen4(d.y); }
+  uint32_t h[BINS / 2];
+#pragma unroll
+  for (int k = 0; k < BINS / 4; ++k) { h[2 * k] = (uint32_t)hw[k]; h[2 * k + 1] = (uint32_t)(hw[k] >> 32); }
+#ifndef GLIA_ACC_NOCOMBINE
+  const uint32_t head = seg_heads(a.x, a.y, act, lane);
+  uint32_t f = head;
+  auto level = [&](auto DT) __attribute__((always_inline)) {
+    constexpr int D = decltype(DT)::value;
+    const uint32_t m = f ? 0u : 0xFFFFFFFFu;
+    seg_u32<D>(cnt, m, SegAdd{}); seg_u32<D>(t0, m, SegAdd{}); seg_u32<D>(t1, m, SegAdd{});
+    seg_u32<D>(omin, m, SegMax{}); seg_u32<D>(omax, m, SegMax{});
+    seg_f64<D>(sum, m); seg_f64<D>(sq, m);
+#pragma unroll
+    for (int k = 0; k < BINS / 2; ++k) seg_u32<D>(h[k], m, SegAdd{});
+    f |= row_shr<D>(f);
+  };
+  level(std::integral_constant<int, 1>{}); level(std::integral_constant<int, 2>{});
+  if (kCombineLevels > 2) level(std::integral_constant<int, 4>{});
+  if (kCombineLevels > 3) level(std::integral_constant<int, 8>{});
+  if (!seg_tail<kCombineLevels>(head, act, lane)) return;
+#else
+  if (!act) return;
+#endif
+#ifdef GLIA_ACC_NOLOOKUP
+  int slot = (int)(((a.x ^ (a.y * 0x9E3779B1u)) * 2654435761u) >> 22);
+#else
   int slot = lds_slot(s.pkey, G::kPairSlots, key);
+#endif
+#ifdef GLIA_ACC_NOATOM
+  if (slot >= 0) { if (cnt == 0xFFFFFFFFu) s.prec[slot] = cnt + t0 + t1 + omin + omax + h[0] + h[1] + h[2] + h[3] + (uint32_t)sum + (uint32_t)sq; return; }
+#endif
 #ifdef GLIA_ACC_NOCONFLICT
   if (slot >= 0) slot = (int)((entryAddr / 48u) % (uint32_t)G::kPairSlots);
 #endif
   if (slot >= 0) {
     uint32_t* rec = &s.prec[slot * Lds<BINS>::kPairWordsL];
-    atomicAdd(&rec[LP_CNT], a.z);
-    atomicAdd((unsigned long long*)&rec[LP_THR], widen4(a.w));
+    atomicAdd(&rec[LP_CNT], cnt);
+    atomicAdd((unsigned long long*)&rec[LP_THR], (unsigned long long)t0 | ((unsigned long long)t1 << 32));
     atomicAdd((double*)&rec[LP_SUM], sum);
     atomicAdd((double*)&rec[LP_SQ], sq);
     atomicMax(&rec[LP_MIN], omin);
     atomicMax(&rec[LP_MAX], omax);
-    atomicAdd((unsigned long long*)&rec[LP_HIST], widen4(c.z));
-    atomicAdd((unsigned long long*)&rec[LP_HIST + 2], widen4(c.w));
-    if (BINS > 8) {
-      atomicAdd((unsigned long long*)&rec[LP_HIST + 4], widen4(d.x));
-      atomicAdd((unsigned long long*)&rec[LP_HIST + 6], widen4(d.y));
-    }
+#pragma unroll
+    for (int k = 0; k < BINS / 4; ++k) atomicAdd((unsigned long long*)&rec[LP_HIST + 2 * k], (unsigned long long)h[2 * k] | ((unsigned long long)h[2 * k + 1] << 32));
     return;
   }
   const TableParams& p = s.tp;
@@ -283,18 +411,18 @@ __device__ __forceinline__ void drain_pairs(Lds<BINS>& s, const uint32_t entryAd
   const int g = global_pair_slot(p, key);
   if (g < 0) return;
   uint32_t* r = &p.prec[(size_t)g * kPairWords];
-  atomicAdd(&r[P_CNT], a.z);
+  atomicAdd(&r[P_CNT], cnt);
   atomicAdd((double*)&r[P_SUM], sum); atomicAdd((double*)&r[P_SQ], sq);
   atomicMax(&r[P_MIN], omin); atomicMax(&r[P_MAX], omax);
 #pragma unroll
   for (int k = 0; k < GLIA_HMT_MAX_THRESH; ++k) {
-    const uint32_t h = (a.w >> (8 * k)) & 0xFF;
-    if (h) atomicAdd(&r[P_THR + k], h);
+    const uint32_t tk = ((k < 2 ? t0 : t1) >> ((k & 1) * 16)) & 0xFFFFu;
+    if (tk) atomicAdd(&r[P_THR + k], tk);
   }
 #pragma unroll
   for (int k = 0; k < BINS; ++k) {
-    const uint32_t h = hist_byte(c, d, k);
-    if (h) atomicAdd(&r[P_HIST + k], h);
+    const uint32_t hk = (h[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+    if (hk) atomicAdd(&r[P_HIST + k], hk);
   }
 }
 
@@ -313,7 +441,7 @@ __device__ __forceinline__ void drainer_loop(Lds<BINS>& s, const int d, const in
 #define GLIA_ACC_DPRIO 3
 #endif
   __builtin_amdgcn_s_setprio(GLIA_ACC_DPRIO);     // the marching waves of this SIMD always have work: without priority the drainer starves
-#ifdef GLIA_HMT_PROFILE
+#ifdef GLIA_ACC_COUNTERS
   unsigned long long pc[6] = {0, 0, 0, 0, 0, 0};     // region batches, entries, cycles; pair batches, entries, cycles
   uint32_t polls = 0;
   const unsigned long long tstart = __builtin_readcyclecounter();
@@ -354,12 +482,13 @@ __device__ __forceinline__ void drainer_loop(Lds<BINS>& s, const int d, const in
         const uint32_t base = in0 ? bR0 : in1 ? bR1 : bR2;
         const uint32_t idx = in0 ? hR0 + j : in1 ? hR1 + (j - c0) : hR2 + (j - c0 - c1);
         DPROF(const unsigned long long tq = __builtin_readcyclecounter();)
-        drain_regions<BINS, MASK>(s, base + (idx & (uint32_t)(kRingR - 1)) * EB, j < c0 + c1 + c2);
-        DPROF(asm volatile("s_waitcnt lgkmcnt(0)"); pc[0] += 1; pc[1] += c0 + c1 + c2; pc[2] += __builtin_readcyclecounter() - tq;)
         hR0 += c0; hR1 += c1; hR2 += c2;
-        if (c0) ctl_store(&s.ctl[w0][C_HEAD_R], hR0);
-        if (c1) ctl_store(&s.ctl[w1][C_HEAD_R], hR1);
-        if (c2) ctl_store(&s.ctl[w2][C_HEAD_R], hR2);
+        drain_regions<BINS, MASK>(s, base + (idx & (uint32_t)(kRingR - 1)) * EB, j < c0 + c1 + c2, lane, [&]() __attribute__((always_inline)) {
+          if (c0) ctl_store(&s.ctl[w0][C_HEAD_R], hR0);
+          if (c1) ctl_store(&s.ctl[w1][C_HEAD_R], hR1);
+          if (c2) ctl_store(&s.ctl[w2][C_HEAD_R], hR2);
+        });
+        DPROF(asm volatile("s_waitcnt lgkmcnt(0)"); pc[0] += 1; pc[1] += c0 + c1 + c2; pc[2] += __builtin_readcyclecounter() - tq;)
         left = total - (c0 + c1 + c2);
         any = true;
       }
@@ -383,12 +512,13 @@ __device__ __forceinline__ void drainer_loop(Lds<BINS>& s, const int d, const in
         const uint32_t base = in0 ? bP0 : in1 ? bP1 : bP2;
         const uint32_t idx = in0 ? hP0 + j : in1 ? hP1 + (j - c0) : hP2 + (j - c0 - c1);
         DPROF(const unsigned long long tq = __builtin_readcyclecounter();)
-        drain_pairs<BINS>(s, base + (idx & (uint32_t)(kRingP - 1)) * EB, j < c0 + c1 + c2);
-        DPROF(asm volatile("s_waitcnt lgkmcnt(0)"); pc[3] += 1; pc[4] += c0 + c1 + c2; pc[5] += __builtin_readcyclecounter() - tq;)
         hP0 += c0; hP1 += c1; hP2 += c2;
-        if (c0) ctl_store(&s.ctl[w0][C_HEAD_P], hP0);
-        if (c1) ctl_store(&s.ctl[w1][C_HEAD_P], hP1);
-        if (c2) ctl_store(&s.ctl[w2][C_HEAD_P], hP2);
+        drain_pairs<BINS>(s, base + (idx & (uint32_t)(kRingP - 1)) * EB, j < c0 + c1 + c2, lane, [&]() __attribute__((always_inline)) {
+          if (c0) ctl_store(&s.ctl[w0][C_HEAD_P], hP0);
+          if (c1) ctl_store(&s.ctl[w1][C_HEAD_P], hP1);
+          if (c2) ctl_store(&s.ctl[w2][C_HEAD_P], hP2);
+        });
+        DPROF(asm volatile("s_waitcnt lgkmcnt(0)"); pc[3] += 1; pc[4] += c0 + c1 + c2; pc[5] += __builtin_readcyclecounter() - tq;)
         left -= c0 + c1 + c2;
         any = true;
       }
@@ -397,7 +527,7 @@ __device__ __forceinline__ void drainer_loop(Lds<BINS>& s, const int d, const in
     DPROF(polls += any ? 0u : 1u;)
     if (!any) __builtin_amdgcn_s_sleep(2);
   }
-#ifdef GLIA_HMT_PROFILE
+#ifdef GLIA_ACC_COUNTERS
   if (lane == 0) {
     unsigned long long* g = reinterpret_cast<unsigned long long*>(s.tp.flags + 16);
     for (int k = 0; k < 6; ++k) atomicAdd(&g[k], pc[k]);
@@ -483,7 +613,10 @@ __global__ __launch_bounds__(Geo<BINS>::kThreadsT) void rag_accumulate_kernel(co
 #ifdef GLIA_HMT_PROFILE
   const uint32_t dbg = p.debug;       // ablation switches (GLIA_HMT_DEBUG), profiling builds only
 #else
-  constexpr uint32_t dbg = 0;
+#ifndef GLIA_ACC_ABL
+#define GLIA_ACC_ABL 0
+#endif
+  constexpr uint32_t dbg = GLIA_ACC_ABL;      // (kernel experiments: the same switches fixed at compile time, make accvar; 0 in the shipped build)
 #endif
   if (tid == 0) {
     TableParams tp;
@@ -524,7 +657,7 @@ __global__ __launch_bounds__(Geo<BINS>::kThreadsT) void rag_accumulate_kernel(co
     e[0] = a; e[1] = b; e[2] = c;
     if (BINS > 8) { u32x4 d; d.x = (uint32_t)r.h[BINS / 8 - 1]; d.y = (uint32_t)(r.h[BINS / 8 - 1] >> 32); d.z = 0; d.w = 0; e[3] = d; }
   };
-#ifdef GLIA_HMT_PROFILE
+#ifdef GLIA_ACC_COUNTERS
   unsigned long long waitCycles = 0; uint32_t waits = 0;
   const unsigned long long tmarch0 = __builtin_readcyclecounter();
 #endif
@@ -545,14 +678,14 @@ __global__ __launch_bounds__(Geo<BINS>::kThreadsT) void rag_accumulate_kernel(co
       if (tail - seen + (uint32_t)n > (uint32_t)cap) {
         publish();                                  // what is written must be seen, or nobody makes room
         ctl_store(&ctl[C_STATE], kRingWaiting);
-#ifdef GLIA_HMT_PROFILE
+#ifdef GLIA_ACC_COUNTERS
         const unsigned long long tw0 = __builtin_readcyclecounter();
 #endif
         do {
           __builtin_amdgcn_s_sleep(1);
           seen = ctl_load(&ctl[headWord]);
         } while (tail - seen + (uint32_t)n > (uint32_t)cap);
-#ifdef GLIA_HMT_PROFILE
+#ifdef GLIA_ACC_COUNTERS
         waitCycles += __builtin_readcyclecounter() - tw0; waits += 1;
 #endif
         ctl_store(&ctl[C_STATE], 0u);
@@ -593,12 +726,15 @@ __global__ __launch_bounds__(Geo<BINS>::kThreadsT) void rag_accumulate_kernel(co
 
   // INNER (a workgroup-uniform compile-time tag): the tile and its one-voxel halo lie inside the volume and there is no mask,
   // so every voxel is valid, every neighbour exists and no voxel is a border voxel -- the validity logic folds away.
-  const bool inner_tile = !MASK && is3d && dbg == 0 && tile.x0 > 0 && tile.x0 + kTileX < nx && tile.y0 > 0 && tile.y0 + kTileY < ny &&
+  const bool inner_tile = !MASK && is3d && (dbg & 4) == 0 && tile.x0 > 0 && tile.x0 + kTileX < nx && tile.y0 > 0 && tile.y0 + kTileY < ny &&
                           tile.z0 + gz0 > 0 && z1 + gz0 < gnz && tile.z0 > 0 && z1 < nz;
 
   // one column: the row yrel of the tile, planes tile.z0 .. z1-1, one voxel per lane and plane
-  auto column = [&](auto INNER_T, const int yrel) __attribute__((always_inline)) {
+  // WHOLE (workgroup-uniform): the tile has a whole number of groups of kAhead planes, at least two -- every request of the
+  // prefetch pipeline is then unconditional and the wait counts are the same on every path (see `step`)
+  auto column = [&](auto INNER_T, auto WHOLE_T, const int yrel) __attribute__((always_inline)) {
     constexpr bool INNER = decltype(INNER_T)::value;
+    constexpr bool WHOLE = decltype(WHOLE_T)::value;
     const int64_t y = tile.y0 + yrel;
     if (!INNER && y >= ny) return;                                  // wave-uniform
     const bool laneOk = INNER || x < nx;
@@ -611,10 +747,16 @@ __global__ __launch_bounds__(Geo<BINS>::kThreadsT) void rag_accumulate_kernel(co
     const uint32_t oc0 = szb + nxb + 4u;                                    // byte offset of (x0, y, plane 0 of the current base)
     // per-lane byte offsets.  The halo load reads relative to x0-1: lane 0 fetches x0-1, lane 63 fetches x0+64, the others
     // their own voxel again (the same cache lines).
-    const uint32_t lx4 = (uint32_t)lane * 4u;
-    uint32_t hx4 = (uint32_t)lane * 4u + 4u;
+    // Lanes beyond the volume's last column (edge tiles) read the last valid voxel of the row instead: every load of the pipeline is
+    // then UNCONDITIONAL -- no branch, no exec mask around it -- and what an invalid lane or an invalid neighbour row delivers is
+    // ignored by the validity flags of `step`.  (A skipped load is a path with fewer loads in flight: the wait-count pass then
+    // waits for everything on every path.)
+    const uint32_t lc = INNER ? (uint32_t)lane : (uint32_t)(x < nx ? lane : (int)(nx - 1 - tile.x0));
+    const uint32_t lx4 = lc * 4u;
+    uint32_t hx4 = lc * 4u + 4u;
     if (lane == 0 && xmv) hx4 = 0u;
     if (lane == 63 && xpv) hx4 = 65u * 4u;
+    const uint32_t upb = ymv ? nxb : 0u, dnb = ypv ? nxb : 0u;         // a row that does not exist: the centre row again
     const uint32_t yx = ((uint32_t)yrel << 6) | (uint32_t)lane;
 
     uint32_t bLn[kAhead], bUp[kAhead], bDn[kAhead], bH[kAhead], bC[kAhead];
@@ -630,29 +772,22 @@ __global__ __launch_bounds__(Geo<BINS>::kThreadsT) void rag_accumulate_kernel(co
         bH[j] = bload(rL, hx4, oc - 4u);
         bV[j] = __builtin_bit_cast(float, bload(rV, lx4, oc));
       } else {
-        bLn[j] = 0u; bUp[j] = 0u; bDn[j] = 0u; bH[j] = 0u; bV[j] = 0.f;
-        if (MASK) bC[j] = 0u;
-        if (laneOk) {
-          if (tile.z0 + t + 1 < nz) bLn[j] = bload(rL, lx4, oc + szb);
-          if (ymv) bUp[j] = bload(rL, lx4, oc - nxb);
-          if (ypv) bDn[j] = bload(rL, lx4, oc + nxb);
-          bH[j] = bload(rL, hx4, oc - 4u);
-          bV[j] = __builtin_bit_cast(float, bload(rV, lx4, oc));
-          if (MASK && sepCentre) bC[j] = bload(rC, lx4, oc);
-        }
+        const uint32_t dz = (tile.z0 + t + 1 < nz) ? szb : 0u;         // the plane above the volume's last: this plane again
+        bLn[j] = bload(rL, lx4, oc + dz); bUp[j] = bload(rL, lx4, oc - upb); bDn[j] = bload(rL, lx4, oc + dnb);
+        bH[j] = bload(rL, hx4, oc - 4u);
+        bV[j] = __builtin_bit_cast(float, bload(rV, lx4, oc));
+        if (MASK) bC[j] = bload(rC, lx4, oc);
       }
     };
     uint32_t Lp = 0u, Lc = 0u;
     {
       const rsrc_t rL = make_rsrc(p.lab + rowoff), rV = make_rsrc(p.img + rowoff), rC = make_rsrc(p.lab_c + rowoff);
-      if (laneOk) {
-        if (INNER || tile.z0 > 0) Lp = bload(rL, lx4, oc0 - szb);
-        Lc = bload(rL, lx4, oc0);
-      }
-      issue(0, oc0, rL, rV, rC, std::integral_constant<int, 0>{});
-      if (1 < n) issue(1, oc0 + szb, rL, rV, rC, std::integral_constant<int, 1>{});
-      if (2 < n) issue(2, oc0 + 2u * szb, rL, rV, rC, std::integral_constant<int, 2>{});
-      if (3 < n) issue(3, oc0 + 3u * szb, rL, rV, rC, std::integral_constant<int, 3>{});
+      Lp = bload(rL, lx4, oc0 - ((INNER || tile.z0 > 0) ? szb : 0u));
+      Lc = bload(rL, lx4, oc0);
+      auto first = [&](auto... J) __attribute__((always_inline)) {
+        ((void)((WHOLE || decltype(J)::value < n) ? (issue(decltype(J)::value, oc0 + (uint32_t)decltype(J)::value * szb, rL, rV, rC, J), 0) : 0), ...);
+      };
+      std::apply(first, kAheadSeq{});
     }
     if (INNER) {     // every voxel is valid: the region run of the column's first voxel starts here, `rhas` is constant
       rr.k0 = Lc; rr.pos = yx; rr.cnt = 0; rr.aux = 0; rr.sum = 0.0; rr.sq = 0.0; rr.mn = __builtin_inff(); rr.mx = -__builtin_inff();
@@ -662,8 +797,14 @@ __global__ __launch_bounds__(Geo<BINS>::kThreadsT) void rag_accumulate_kernel(co
     }
 
     // one voxel per lane: neighbour rule, run bookkeeping, accumulation
-    auto step = [&](const int t, const int tb, const rsrc_t rL, const rsrc_t rV, const rsrc_t rC, auto J) __attribute__((always_inline)) {
+    // ISSUE: 1 = the rows of plane t + kAhead are requested unconditionally, 2 = never, 0 = if that plane exists.  The conditional
+    // form costs the prefetch: where the two paths meet the compiler's wait-count pass must assume the path WITHOUT the newer
+    // loads, so every step waited for the loads it had just issued (s_waitcnt vmcnt(4) right behind five buffer loads, vmcnt(0)
+    // at the top of every group -- a full memory round trip per plane, found in the ISA in round 4).  The main loop below
+    // issues always, its last group never; only ragged columns take the conditional form.
+    auto step = [&](const int t, const int tb, const rsrc_t rL, const rsrc_t rV, const rsrc_t rC, auto J, auto ISSUE_T) __attribute__((always_inline)) {
       constexpr int j = decltype(J)::value;
+      constexpr int ISSUE = decltype(ISSUE_T)::value;
       const uint32_t Ln = bLn[j], Up = bUp[j], Dn = bDn[j], Hh = bH[j];
       const float v = bV[j];
       const uint32_t xm = from_left(Hh, Lc), xp = from_right(Hh, Lc);
@@ -736,25 +877,45 @@ __global__ __launch_bounds__(Geo<BINS>::kThreadsT) void rag_accumulate_kernel(co
         if (BINS <= 8) pr.h[0] += hinc;
         else { pr.h[0] += (bin < 8) ? hinc : 0ull; pr.h[BINS / 8 - 1] += (bin < 8) ? 0ull : hinc; }
       }
-      Lp = Lc; Lc = Ln;
-      if (t + kAhead < n) issue(t + kAhead, oc0 + (uint32_t)(t + kAhead - tb) * szb, rL, rV, rC, J);
+      // Lc takes Ln's VALUE through an opaque move: left to coalesce Lc with the load's destination register, the compiler gives the
+      // NEXT load of this buffer another register and copies it back at the loop's back edge -- a wait for loads just issued
+      Lp = Lc;
+      asm("v_mov_b32 %0, %1" : "=v"(Lc) : "v"(Ln));
+      if (ISSUE == 1 || (ISSUE == 0 && t + kAhead < n)) issue(t + kAhead, oc0 + (uint32_t)(t + kAhead - tb) * szb, rL, rV, rC, J);
     };
 
     const uint32_t* baseL = p.lab + rowoff; const float* baseV = p.img + rowoff; const uint32_t* baseC = p.lab_c + rowoff;
     const int64_t stride4 = (int64_t)kAhead * sz;
-    for (int tb = 0; tb < n; tb += kAhead) {
+    // a group of kAhead planes from base plane tb
+    auto group = [&](const int tb, auto ISSUE_T) __attribute__((always_inline)) {
+      constexpr int ISSUE = decltype(ISSUE_T)::value;
       // (through an empty asm: otherwise the 64-bit products that form the bases are recomputed in every plane)
       asm volatile("" : "+s"(baseL), "+s"(baseV));
       if (MASK) asm volatile("" : "+s"(baseC));
       const rsrc_t rL = make_rsrc(baseL), rV = make_rsrc(baseV), rC = make_rsrc(baseC);
       baseL += stride4; baseV += stride4; baseC += stride4;
-      step(tb, tb, rL, rV, rC, std::integral_constant<int, 0>{});
-      if (tb + 1 < n) step(tb + 1, tb, rL, rV, rC, std::integral_constant<int, 1>{});
-      if (tb + 2 < n) step(tb + 2, tb, rL, rV, rC, std::integral_constant<int, 2>{});
-      if (tb + 3 < n) step(tb + 3, tb, rL, rV, rC, std::integral_constant<int, 3>{});
+      auto steps = [&](auto... J) __attribute__((always_inline)) {
+        ((void)((ISSUE != 0 || tb + decltype(J)::value < n) ? (step(tb + decltype(J)::value, tb, rL, rV, rC, J, ISSUE_T), 0) : 0), ...);
+      };
+      std::apply(steps, kAheadSeq{});
+    };
+    if (WHOLE) {
+      int tb = 0;
+#pragma unroll 1
+      for (; tb + 2 * kAhead <= n; tb += kAhead) group(tb, std::integral_constant<int, 1>{});
+      group(tb, std::integral_constant<int, 2>{});
+    } else {
+#pragma unroll 1
+      for (int tb = 0; tb < n; tb += kAhead) group(tb, std::integral_constant<int, 0>{});
     }
     // the column ends: every lane hands in what it holds
+#ifndef GLIA_ACC_WHOLEFLUSH
+    // in two halves: all 64 lanes at once need an EMPTY region ring, i.e. a full round trip through the drainer
+    enqueue(((dbg & 1) ? false : rhas) && lane < 32, ((dbg & 2) ? false : phas) && lane < 32, (uint32_t)(n - 1));
+    enqueue(((dbg & 1) ? false : rhas) && lane >= 32, ((dbg & 2) ? false : phas) && lane >= 32, (uint32_t)(n - 1));
+#else
     enqueue((dbg & 1) ? false : rhas, (dbg & 2) ? false : phas, (uint32_t)(n - 1));
+#endif
     publish();
     rhas = false; phas = false;
   };
@@ -764,15 +925,15 @@ __global__ __launch_bounds__(Geo<BINS>::kThreadsT) void rag_accumulate_kernel(co
     drainer_loop<BINS, MASK>(s, wave - G::kMarchers, lane);
 #endif
   } else {
-    if (inner_tile) {
+    const bool whole = n >= 2 * kAhead && (n & (kAhead - 1)) == 0;
+    auto passes = [&](auto INNER_T, auto WHOLE_T) __attribute__((always_inline)) {
 #pragma unroll 1
-      for (int pass = 0; pass < G::kPasses; ++pass) column(std::true_type{}, wave + pass * G::kMarchers);
-    } else {
-#pragma unroll 1
-      for (int pass = 0; pass < G::kPasses; ++pass) column(std::false_type{}, wave + pass * G::kMarchers);
-    }
+      for (int pass = 0; pass < G::kPasses; ++pass) column(INNER_T, WHOLE_T, wave + pass * G::kMarchers);
+    };
+    if (inner_tile) { if (whole) passes(std::true_type{}, std::true_type{}); else passes(std::true_type{}, std::false_type{}); }
+    else { if (whole) passes(std::false_type{}, std::true_type{}); else passes(std::false_type{}, std::false_type{}); }
     ctl_store(&ctl[C_STATE], kRingDone);
-#ifdef GLIA_HMT_PROFILE
+#ifdef GLIA_ACC_COUNTERS
     if (lane == 0) {
       unsigned long long* g = reinterpret_cast<unsigned long long*>(s.tp.flags + 16);
       atomicAdd(&g[8], waitCycles); atomicAdd(&g[9], (unsigned long long)waits); atomicAdd(&g[10], __builtin_readcyclecounter() - tmarch0);
