@@ -28,7 +28,10 @@ bool merge_order_is_consistent(const uint32_t* dense_order, int64_t n, uint32_t 
 
 // ---- accumulation tile geometry -------------------------------------------------------------
 constexpr int kTileX = 64;         // one wave = one row of 64 voxels, one voxel per lane
-constexpr int kTileY = 24;         // rows of a tile: 12 marching waves x 2 rows (8-bin records) or 6 x 4 (16-bin records)
+#ifndef GLIA_ACC_TILEY
+#define GLIA_ACC_TILEY 24
+#endif
+constexpr int kTileY = GLIA_ACC_TILEY;   // rows of a tile = marching waves x rows per wave (rag_accumulate.hip, Geo)
 constexpr int kTZ = 32;            // planes a workgroup marches through (a run of a lane has at most kTZ voxels: 8-bit counters)
 
 // ---- record layouts (32-bit words).  All zero == "empty": minima / lower bounds are stored

@@ -54,19 +54,28 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
   return x;
 }
 
-static_assert(kTileX == 64 && kTileY == 24 && kTZ == 32, "the pass assumes 64 x 24 x 32 tiles");
+static_assert(kTileX == 64 && kTileY <= 32 && kTZ == 32 && kTileX * kTileY * kTZ < 65536, "64 x (<= 32) x 32 tiles: y occupancy in 32 bits, 16-bit counters");
 
 // ---- geometry ----------------------------------------------------------------------------------------
+// marching : draining waves.  Round 4 (prefetch repaired, combining drain): the marching waves alone need 4.6 ms at 12 waves, the
+// four drainers could not keep up (8.7 ms); the split is a build parameter of the experiments (make accvar) -- see DESIGN 3.1.
+#ifndef GLIA_ACC_MARCHERS
+#define GLIA_ACC_MARCHERS 12
+#endif
+#ifndef GLIA_ACC_DRAINERS
+#define GLIA_ACC_DRAINERS 4
+#endif
 template <int BINS> struct Geo {
-  static constexpr int kWaves = BINS <= 8 ? 16 : 8;         // 16-bin records need the LDS for tables: half the waves
+  static constexpr int kMarchers = BINS <= 8 ? GLIA_ACC_MARCHERS : GLIA_ACC_MARCHERS / 2;     // waves that march columns (16-bin records need the LDS for tables: half the waves)
+  static constexpr int kDrainers = BINS <= 8 ? GLIA_ACC_DRAINERS : (GLIA_ACC_DRAINERS + 1) / 2;   // waves that only empty the rings of the others
+  static constexpr int kWaves = kMarchers + kDrainers;
   static constexpr int kThreadsT = kWaves * 64;
-  static constexpr int kDrainers = BINS <= 8 ? 4 : 2;       // waves that only empty the rings of the others
-  static constexpr int kMarchers = kWaves - kDrainers;      // waves that march columns: 12 / 6
-  static constexpr int kPasses = kTileY / kMarchers;        // rows a wave marches one after the other: 2 / 4
+  static constexpr int kPasses = kTileY / kMarchers;        // rows a wave marches one after the other
   static constexpr int kRegSlots = 256;
   static constexpr int kPairSlots = 1024;
   static constexpr int kEntryWords = BINS <= 8 ? 12 : 16;   // ring entry
   static_assert(kPasses * kMarchers == kTileY, "rows of a tile = marching waves x passes");
+  static_assert(kWaves <= 16 && kMarchers <= 3 * kDrainers, "at most 1024 threads; a drainer serves at most three rings");
 };
 #ifndef GLIA_ACC_DRAINAT
 #define GLIA_ACC_DRAINAT 48          // (round 4, with the combining drain: 16 -> 9.02 ms, 32 -> 8.81, 48 -> 8.78)
@@ -431,11 +440,14 @@ __device__ __forceinline__ void drain_pairs(Lds<BINS>& s, const uint32_t entryAd
 template <int BINS, bool MASK>
 __device__ __forceinline__ void drainer_loop(Lds<BINS>& s, const int d, const int lane) {
   using G = Geo<BINS>;
-  static_assert(G::kMarchers == 3 * G::kDrainers, "three marching waves per drainer");
   constexpr uint32_t EB = G::kEntryWords * 4;
+  // the rings of the marching waves d, d + kDrainers, d + 2 kDrainers (those that exist: one to three)
   const int w0 = d, w1 = d + G::kDrainers, w2 = d + 2 * G::kDrainers;
-  const uint32_t bR0 = (uint32_t)(uintptr_t)s.ringR[w0], bR1 = (uint32_t)(uintptr_t)s.ringR[w1], bR2 = (uint32_t)(uintptr_t)s.ringR[w2];
-  const uint32_t bP0 = (uint32_t)(uintptr_t)s.ringP[w0], bP1 = (uint32_t)(uintptr_t)s.ringP[w1], bP2 = (uint32_t)(uintptr_t)s.ringP[w2];
+  const bool v1 = w1 < G::kMarchers, v2 = w2 < G::kMarchers;                        // (wave-uniform)
+  const int x1 = v1 ? w1 : w0, x2 = v2 ? w2 : w0;                                   // (a ring that does not exist: ring 0's words, never taken from)
+  const uint32_t share = v2 ? 21u : v1 ? 32u : 64u;                                 // a balanced take
+  const uint32_t bR0 = (uint32_t)(uintptr_t)s.ringR[w0], bR1 = (uint32_t)(uintptr_t)s.ringR[x1], bR2 = (uint32_t)(uintptr_t)s.ringR[x2];
+  const uint32_t bP0 = (uint32_t)(uintptr_t)s.ringP[w0], bP1 = (uint32_t)(uintptr_t)s.ringP[x1], bP2 = (uint32_t)(uintptr_t)s.ringP[x2];
   uint32_t hR0 = 0, hR1 = 0, hR2 = 0, hP0 = 0, hP1 = 0, hP2 = 0;      // entries consumed (wave-uniform)
 #ifndef GLIA_ACC_DPRIO
 #define GLIA_ACC_DPRIO 3
@@ -452,15 +464,15 @@ __device__ __forceinline__ void drainer_loop(Lds<BINS>& s, const int d, const in
   for (;;) {
     // tails and state of a wave in one 16-byte read ("done" is stored after the last tails, and the LDS keeps a wave's order)
     u32x4 q0 = *(const volatile lds_u32x4*)(uintptr_t)(uint32_t)(uintptr_t)&s.ctl[w0][0];
-    u32x4 q1 = *(const volatile lds_u32x4*)(uintptr_t)(uint32_t)(uintptr_t)&s.ctl[w1][0];
-    u32x4 q2 = *(const volatile lds_u32x4*)(uintptr_t)(uint32_t)(uintptr_t)&s.ctl[w2][0];
-    const uint32_t st0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q0.z), st1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q1.z),
-                   st2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q2.z);
-    const uint32_t tR0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q0.x), tR1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q1.x),
-                   tR2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q2.x);
-    const uint32_t tP0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q0.y), tP1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q1.y),
-                   tP2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q2.y);
-    const bool urgent = (st0 | st1 | st2) != 0u;
+    u32x4 q1 = *(const volatile lds_u32x4*)(uintptr_t)(uint32_t)(uintptr_t)&s.ctl[x1][0];
+    u32x4 q2 = *(const volatile lds_u32x4*)(uintptr_t)(uint32_t)(uintptr_t)&s.ctl[x2][0];
+    const uint32_t st0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q0.z), st1 = v1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)q1.z) : kRingDone,
+                   st2 = v2 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)q2.z) : kRingDone;
+    const uint32_t tR0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q0.x), tR1 = v1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)q1.x) : hR1,
+                   tR2 = v2 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)q2.x) : hR2;
+    const uint32_t tP0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q0.y), tP1 = v1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)q1.y) : hP1,
+                   tP2 = v2 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)q2.y) : hP2;
+    const bool urgent = ((st0 | st1 | st2) & kRingWaiting) != 0u || st0 == kRingDone || (v1 && st1 == kRingDone) || (v2 && st2 == kRingDone);
     bool any = false;
     uint32_t left;
     {
@@ -470,7 +482,7 @@ __device__ __forceinline__ void drainer_loop(Lds<BINS>& s, const int d, const in
       if (total >= (uint32_t)kDrainAt || (urgent && total)) {
         // a balanced take: entries of one wave repeat few keys (LDS atomics on one address serialise), those of three waves
         // rows apart do not
-        uint32_t c0 = a0 < 21u ? a0 : 21u, c1 = a1 < 21u ? a1 : 21u, c2 = a2 < 21u ? a2 : 21u;
+        uint32_t c0 = a0 < share ? a0 : share, c1 = a1 < share ? a1 : share, c2 = a2 < share ? a2 : share;
         {
           uint32_t room = 64u - (c0 + c1 + c2);
           const uint32_t e0 = a0 - c0 < room ? a0 - c0 : room; c0 += e0; room -= e0;
@@ -485,8 +497,8 @@ __device__ __forceinline__ void drainer_loop(Lds<BINS>& s, const int d, const in
         hR0 += c0; hR1 += c1; hR2 += c2;
         drain_regions<BINS, MASK>(s, base + (idx & (uint32_t)(kRingR - 1)) * EB, j < c0 + c1 + c2, lane, [&]() __attribute__((always_inline)) {
           if (c0) ctl_store(&s.ctl[w0][C_HEAD_R], hR0);
-          if (c1) ctl_store(&s.ctl[w1][C_HEAD_R], hR1);
-          if (c2) ctl_store(&s.ctl[w2][C_HEAD_R], hR2);
+          if (c1) ctl_store(&s.ctl[x1][C_HEAD_R], hR1);
+          if (c2) ctl_store(&s.ctl[x2][C_HEAD_R], hR2);
         });
         DPROF(asm volatile("s_waitcnt lgkmcnt(0)"); pc[0] += 1; pc[1] += c0 + c1 + c2; pc[2] += __builtin_readcyclecounter() - tq;)
         left = total - (c0 + c1 + c2);
@@ -500,7 +512,7 @@ __device__ __forceinline__ void drainer_loop(Lds<BINS>& s, const int d, const in
       if (total >= (uint32_t)kDrainAt || (urgent && total)) {
         // a balanced take: entries of one wave repeat few keys (LDS atomics on one address serialise), those of three waves
         // rows apart do not
-        uint32_t c0 = a0 < 21u ? a0 : 21u, c1 = a1 < 21u ? a1 : 21u, c2 = a2 < 21u ? a2 : 21u;
+        uint32_t c0 = a0 < share ? a0 : share, c1 = a1 < share ? a1 : share, c2 = a2 < share ? a2 : share;
         {
           uint32_t room = 64u - (c0 + c1 + c2);
           const uint32_t e0 = a0 - c0 < room ? a0 - c0 : room; c0 += e0; room -= e0;
@@ -515,8 +527,8 @@ __device__ __forceinline__ void drainer_loop(Lds<BINS>& s, const int d, const in
         hP0 += c0; hP1 += c1; hP2 += c2;
         drain_pairs<BINS>(s, base + (idx & (uint32_t)(kRingP - 1)) * EB, j < c0 + c1 + c2, lane, [&]() __attribute__((always_inline)) {
           if (c0) ctl_store(&s.ctl[w0][C_HEAD_P], hP0);
-          if (c1) ctl_store(&s.ctl[w1][C_HEAD_P], hP1);
-          if (c2) ctl_store(&s.ctl[w2][C_HEAD_P], hP2);
+          if (c1) ctl_store(&s.ctl[x1][C_HEAD_P], hP1);
+          if (c2) ctl_store(&s.ctl[x2][C_HEAD_P], hP2);
         });
         DPROF(asm volatile("s_waitcnt lgkmcnt(0)"); pc[3] += 1; pc[4] += c0 + c1 + c2; pc[5] += __builtin_readcyclecounter() - tq;)
         left -= c0 + c1 + c2;

@@ -5,7 +5,7 @@
 // (greedy_window_kernel's edge counter).  Such a bug needs adverse timing to show.  This build makes the adverse
 // timing the rule: behind EVERY workgroup barrier of the loop kernels -- full_barrier / lds_barrier / __syncthreads and its
 // _or / _count forms -- every wave but wave 0 (GLIA_HMT_SKEW=1: the writer is early, the readers late) or wave 0 alone
-// (GLIA_HMT_SKEW=2: the writer late) sleeps for tens of thousands of cycles.  A kernel whose barriers separate every such
+// (GLIA_HMT_SKEW=2: the writer late) sleeps for eight thousand cycles.  A kernel whose barriers separate every such
 // read from its rewrite gives the same bytes under both; the GPU tests are run once against each library
 // (tools/skew_tests.sh, record in profiles/).
 #pragma once
@@ -13,7 +13,7 @@
 
 #ifdef GLIA_HMT_SKEW
 #ifndef GLIA_HMT_SKEW_SLEEPS
-#define GLIA_HMT_SKEW_SLEEPS 4          // x s_sleep 127 (8128 cycles each)
+#define GLIA_HMT_SKEW_SLEEPS 1          // x s_sleep 127 (8128 cycles each: ~20 x the barrier-to-barrier distance of the loops)
 #endif
 namespace glia {
 __device__ __forceinline__ void skew_delay() {

@@ -49,9 +49,9 @@ __global__ void ws_shift(const float* f, float* g, long long n, double level) {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p < n) g[p] = (float)((double)f[p] + level);
 }
-__global__ void ws_iota(unsigned long long* c, long long n) {
+__global__ void ws_iota(uint32_t* c, long long n) {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < n) c[p] = (unsigned long long)p;
+  if (p < n) c[p] = (uint32_t)p;
 }
 
 // ---- tiles --------------------------------------------------------------------------------------------------------------------
@@ -153,47 +153,49 @@ __global__ __launch_bounds__(kWsThreads) void ws_hmin_tile(WsGrid G, const float
 // plateau components by union-find: comp(p) -> the smallest linear index of p's face-connected set of equal g.  One pass unites
 // every voxel with its +x / +y / +z neighbour of equal value (the larger root is linked under the smaller with atomicMin), one
 // pass flattens.
-__device__ __forceinline__ unsigned long long ws_root(const unsigned long long* comp, unsigned long long x) {
+__device__ __forceinline__ uint32_t ws_root(const uint32_t* comp, uint32_t x) {
   for (;;) {
-    const unsigned long long p = __hip_atomic_load(&comp[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t p = __hip_atomic_load(&comp[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (p == x) return x;
     x = p;
   }
 }
-__device__ __forceinline__ void ws_unite(unsigned long long* comp, unsigned long long a, unsigned long long b) {
+__device__ __forceinline__ void ws_unite(uint32_t* comp, uint32_t a, uint32_t b) {
   for (;;) {
     a = ws_root(comp, a); b = ws_root(comp, b);
     if (a == b) return;
-    if (a > b) { const unsigned long long t = a; a = b; b = t; }
-    const unsigned long long old = atomicMin(&comp[b], a);       // b was a root: now it points at the smaller root a
+    if (a > b) { const uint32_t t = a; a = b; b = t; }
+    const uint32_t old = atomicMin(&comp[b], a);       // b was a root: now it points at the smaller root a
     if (old == b) return;
-    b = old;                                                     // somebody linked b meanwhile: go on from there
+    b = old;                                           // somebody linked b meanwhile: go on from there
   }
 }
-__global__ void ws_comp_unite(WsGrid G, const float* g, unsigned long long* comp) {
+__global__ void ws_comp_unite(WsGrid G, const float* g, uint32_t* comp) {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= G.n) return;
   const long long x = p % G.nx, y = (p / G.nx) % G.ny, z = p / (G.nx * G.ny);
   const float gp = g[p];
-  if (x + 1 < G.nx && g[p + 1] == gp) ws_unite(comp, (unsigned long long)p, (unsigned long long)(p + 1));
-  if (y + 1 < G.ny && g[p + G.nx] == gp) ws_unite(comp, (unsigned long long)p, (unsigned long long)(p + G.nx));
-  if (G.dim == 3 && z + 1 < G.nz && g[p + G.nx * G.ny] == gp) ws_unite(comp, (unsigned long long)p, (unsigned long long)(p + G.nx * G.ny));
+  if (x + 1 < G.nx && g[p + 1] == gp) ws_unite(comp, (uint32_t)p, (uint32_t)(p + 1));
+  if (y + 1 < G.ny && g[p + G.nx] == gp) ws_unite(comp, (uint32_t)p, (uint32_t)(p + G.nx));
+  if (G.dim == 3 && z + 1 < G.nz && g[p + G.nx * G.ny] == gp) ws_unite(comp, (uint32_t)p, (uint32_t)(p + G.nx * G.ny));
 }
-__global__ void ws_comp_flatten(WsGrid G, unsigned long long* comp) {
+__global__ void ws_comp_flatten(WsGrid G, uint32_t* comp) {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < G.n) comp[p] = ws_root(comp, (unsigned long long)p);
+  if (p < G.n) comp[p] = ws_root(comp, (uint32_t)p);
 }
-__global__ void ws_lower_flag(WsGrid G, const float* g, const unsigned long long* comp, uint32_t* haslower) {
+// "this plateau has a lower neighbour": one BIT per voxel index, set at the plateau's root
+__global__ void ws_lower_flag(WsGrid G, const float* g, const uint32_t* comp, uint32_t* haslower) {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= G.n) return;
   const float gp = g[p];
   bool lower = false;
   ws_neighbours(G, p, [&](long long q) { lower = lower || g[q] < gp; });
-  if (lower) haslower[comp[p]] = 1u;
+  if (lower) { const uint32_t c = comp[p]; atomicOr(&haslower[c >> 5], 1u << (c & 31u)); }
 }
-__global__ void ws_root_flag(WsGrid G, const unsigned long long* comp, const uint32_t* haslower, uint32_t* root) {
+__device__ __forceinline__ bool ws_bit(const uint32_t* bits, uint32_t i) { return (bits[i >> 5] >> (i & 31u)) & 1u; }
+__global__ void ws_root_flag(WsGrid G, const uint32_t* comp, const uint32_t* haslower, uint32_t* root) {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < G.n) root[p] = (comp[p] == (unsigned long long)p && !haslower[p]) ? 1u : 0u;
+  if (p < G.n) root[p] = (comp[p] == (uint32_t)p && !ws_bit(haslower, (uint32_t)p)) ? 1u : 0u;
 }
 // flooding in two fixed points.  A voxel's final state is the lexicographic minimum over its neighbours q of
 // (max(L_q, f_p), L unchanged ? d_q + 1 : 0, label_q), markers fixed.  Its first component alone obeys L_p = max(f_p, min_q L_q)
@@ -201,16 +203,22 @@ __global__ void ws_root_flag(WsGrid G, const unsigned long long* comp, const uin
 // the minimum): ws_hmin_tile computes it in place.  With the levels final, only neighbours that reach p AT its level count:
 // L_q == L_p continues the plateau (d_q + 1), L_q < L_p with f_p == L_p is a rise (distance 0); (d, label) is ONE 64-bit word and
 // its rule a monotone decrease, so it is updated in place -- in LDS and in the volume -- in any order.
-__global__ void ws_init_flood(WsGrid G, const float* f, const unsigned long long* comp, const uint32_t* haslower, const uint32_t* rank, float* L,
-                              unsigned long long* st) {
+// markers: label = raster rank of the plateau's first voxel + 1, everything else 0 -- into the caller's label volume, which then
+// says "fixed or free" for the whole flood (the plateau arrays are dead from here on: their storage becomes the flood's state)
+__global__ void ws_marker_labels(WsGrid G, const uint32_t* comp, const uint32_t* haslower, const uint32_t* rank, uint32_t* lab) {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= G.n) return;
-  const unsigned long long c = comp[p];
-  const bool m = !haslower[c];
-  L[p] = m ? f[p] : __builtin_inff();
-  st[p] = m ? (unsigned long long)(rank[c] + 1u) : ~0ull;       // marker: distance 0, its label; else unreached
+  const uint32_t c = comp[p];
+  lab[p] = ws_bit(haslower, c) ? 0u : rank[c] + 1u;
 }
-__global__ __launch_bounds__(kWsThreads) void ws_label_tile(WsGrid G, const float* f, const float* L, const uint32_t* haslower, const unsigned long long* comp,
+__global__ void ws_init_flood(WsGrid G, const float* f, const uint32_t* lab, float* L, unsigned long long* st) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= G.n) return;
+  const uint32_t m = lab[p];
+  L[p] = m ? f[p] : __builtin_inff();
+  st[p] = m ? (unsigned long long)m : ~0ull;       // marker: distance 0, its label; else unreached
+}
+__global__ __launch_bounds__(kWsThreads) void ws_label_tile(WsGrid G, const float* f, const float* L, const uint32_t* marker,
                                                             unsigned long long* st, uint32_t* changed, uint8_t* dirty_now, uint8_t* dirty_next) {
   if (!ws_tile_take(dirty_now)) return;
   __shared__ float sL[kWsCells];
@@ -232,7 +240,7 @@ __global__ __launch_bounds__(kWsThreads) void ws_label_tile(WsGrid G, const floa
     const long long v = ws_cell_voxel(G, T, c, cx, cy, cz);
     sL[c] = v >= 0 ? L[v] : __builtin_inff();
     ss[c] = v >= 0 ? st[v] : ~0ull;          // outside the volume: unreached for ever
-    if (v >= 0 && ws_interior(G, T, cx, cy, cz) && haslower[comp[v]]) kind[k] = (f[v] == L[v]) ? 3u : 1u;
+    if (v >= 0 && ws_interior(G, T, cx, cy, cz) && marker[v] == 0u) kind[k] = (f[v] == L[v]) ? 3u : 1u;
   }
   __syncthreads();
   const int sy = T.hx, sz = T.hx * T.hy;
@@ -291,13 +299,19 @@ int watershed_labels(int dim, const int64_t dims[3], const float* d_img, double 
   const unsigned blocks = (unsigned)((n + 255) / 256);
   const long long tx = dim == 3 ? 16 : 64, tz = dim == 3 ? 16 : 1;
   const unsigned tiles = (unsigned)(((G.nx + tx - 1) / tx) * ((G.ny + tx - 1) / tx) * ((G.nz + tz - 1) / tz));
-  float *g0 = nullptr, *L0 = nullptr;
-  uint32_t *haslower = nullptr, *root = nullptr, *rank = nullptr, *changed = nullptr;
-  unsigned long long* comp = nullptr;
+  // Scratch: 12.1 bytes per voxel, in two blocks that change roles (round 4; 28 bytes in round 3 -- at 1024^3 that was 28 GB,
+  // more than the block cache parks, and the call's time was the driver's allocator: 0.44 s or 1.11 s).
+  //   A (4 n bytes)  the h-minima image g            -> the flood levels L          (g is dead once the markers are numbered)
+  //   B (8 n bytes)  plateau roots | raster ranks    -> the flood's (distance, label) words
+  //   bits (n / 8)   "plateau has a lower neighbour"
+  // The caller's label volume carries the markers' labels through the flood (0 = free voxel) and receives the result.
+  float* A = nullptr;
+  unsigned long long* B = nullptr;
+  uint32_t *haslower = nullptr, *changed = nullptr;
   char* tmp = nullptr;
   int total_sweeps = 0;
-  // the scratch volumes (28 bytes per voxel in all) come from the process-wide block cache (greedy_common.hpp): hipMalloc / hipFree
-  // of gigabyte blocks cost more than the kernels (measured: 160 ms of a 215 ms call at 512^3)
+  // the scratch blocks come from the process-wide block cache (greedy_common.hpp): hipMalloc / hipFree of gigabyte blocks cost
+  // more than the kernels (measured: 160 ms of a 215 ms call at 512^3)
   DeviceBuffers buf;
   auto fail = [&](int rc) { return rc; };
 #define WS_TRY(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_error(std::string("watershed: ") + hipGetErrorString(_e)); return fail(GLIA_HMT_ERR_HIP); } } while (0)
@@ -309,7 +323,8 @@ int watershed_labels(int dim, const int64_t dims[3], const float* d_img, double 
     (void)hipStreamSynchronize(stream);
     fprintf(stderr, "[trace] watershed: %s at %.2f ms (%d launches so far)\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count(), total_sweeps);
   };
-  WS_GET(g0, n); WS_GET(changed, 4);
+  WS_GET(A, n); WS_GET(changed, 4);
+  float* const g0 = A;
   uint8_t* dirty[2] = {nullptr, nullptr};
   WS_GET(dirty[0], tiles); WS_GET(dirty[1], tiles);
   WS_TRY(hipMemsetAsync(dirty[0], 1, tiles, stream)); WS_TRY(hipMemsetAsync(dirty[1], 0, tiles, stream));
@@ -329,28 +344,34 @@ int watershed_labels(int dim, const int64_t dims[3], const float* d_img, double 
   lap("h-minima done");
   const float* g = g0;
   // 2. plateaus, regional minima, raster-order numbering
-  WS_GET(comp, n); WS_GET(haslower, n); WS_GET(root, n + 1); WS_GET(rank, n + 1);
+  WS_GET(B, n + 1); WS_GET(haslower, (n + 31) / 32);
+  uint32_t* const comp = reinterpret_cast<uint32_t*>(B);
+  uint32_t* const rank = comp + n;                    // [n]
+  uint32_t* const root = d_out;                       // (the output volume is free until the markers are written)
   hipLaunchKernelGGL(ws_iota, dim3(blocks), dim3(256), 0, stream, comp, n);
   hipLaunchKernelGGL(ws_comp_unite, dim3(blocks), dim3(256), 0, stream, G, g, comp);
   hipLaunchKernelGGL(ws_comp_flatten, dim3(blocks), dim3(256), 0, stream, G, comp);
   total_sweeps += 2;
-  WS_TRY(hipMemsetAsync(haslower, 0, 4 * n, stream));
+  WS_TRY(hipMemsetAsync(haslower, 0, 4 * (size_t)((n + 31) / 32), stream));
   hipLaunchKernelGGL(ws_lower_flag, dim3(blocks), dim3(256), 0, stream, G, g, comp, haslower);
   hipLaunchKernelGGL(ws_root_flag, dim3(blocks), dim3(256), 0, stream, G, comp, haslower, root);
-  WS_TRY(hipMemsetAsync(root + n, 0, 4, stream));
   {
     size_t bytes = 0;
-    WS_TRY(rocprim::exclusive_scan(nullptr, bytes, root, rank, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), stream));
+    WS_TRY(rocprim::exclusive_scan(nullptr, bytes, root, rank, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
     WS_GET(tmp, bytes ? bytes : 16);
-    WS_TRY(rocprim::exclusive_scan(tmp, bytes, root, rank, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), stream));
+    WS_TRY(rocprim::exclusive_scan(tmp, bytes, root, rank, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
   }
-  uint32_t nlab = 0;
-  WS_TRY(hipMemcpyAsync(&nlab, rank + n, 4, hipMemcpyDeviceToHost, stream));
+  uint32_t last[2] = {0, 0};                          // markers = rank[n-1] + root[n-1]
+  WS_TRY(hipMemcpyAsync(&last[0], rank + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+  WS_TRY(hipMemcpyAsync(&last[1], root + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+  hipLaunchKernelGGL(ws_marker_labels, dim3(blocks), dim3(256), 0, stream, G, comp, haslower, rank, d_out);
   lap("plateaus + markers done");
+  WS_TRY(hipStreamSynchronize(stream));
+  const uint32_t nlab = last[0] + last[1];
   // 3. flooding: levels (the erosion kernel again, in place), then (distance, label) in place
-  unsigned long long* stw = nullptr;
-  WS_GET(L0, n); WS_GET(stw, n);
-  hipLaunchKernelGGL(ws_init_flood, dim3(blocks), dim3(256), 0, stream, G, d_img, comp, haslower, rank, L0, stw);
+  float* const L0 = A;
+  unsigned long long* const stw = B;
+  hipLaunchKernelGGL(ws_init_flood, dim3(blocks), dim3(256), 0, stream, G, d_img, d_out, L0, stw);
   WS_TRY(hipMemsetAsync(dirty[0], 1, tiles, stream)); WS_TRY(hipMemsetAsync(dirty[1], 0, tiles, stream));
   for (;;) {
     uint32_t h = 0;
@@ -369,7 +390,7 @@ int watershed_labels(int dim, const int64_t dims[3], const float* d_img, double 
     uint32_t h = 0;
     WS_TRY(hipMemsetAsync(changed, 0, 16, stream));
     for (int rep = 0; rep < 2; ++rep) {
-      hipLaunchKernelGGL(ws_label_tile, dim3(tiles), dim3(kWsThreads), 0, stream, G, d_img, L0, haslower, comp, stw, changed, dirty[rep], dirty[rep ^ 1]);
+      hipLaunchKernelGGL(ws_label_tile, dim3(tiles), dim3(kWsThreads), 0, stream, G, d_img, L0, d_out, stw, changed, dirty[rep], dirty[rep ^ 1]);
       ++total_sweeps;
     }
     WS_TRY(hipMemcpyAsync(&h, changed, 4, hipMemcpyDeviceToHost, stream));
