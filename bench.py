@@ -140,22 +140,27 @@ def reference_curve(sizes, S, ref, target_regions):
 
 
 def slab_phase(ctx, hmt, dist, torch, size, S, world, rank, clf):
-    """SURVEY.md 8e / BASELINE config 4: ONE volume z-split across the ranks -- every rank accumulates its slab (one halo
-    plane per cut), the compact partial records cross RCCL once (all_gather), every rank merges them by key.  Timed
-    apart from `value` (the merge loop does not shard); rank 0 checks the result against its single-pass build."""
-    from glia_amd import slab
+    """SURVEY.md 8e / BASELINE config 4: ONE volume z-split across the ranks through the route a C++ host would use --
+    glia_hmt_comm_create_rccl (RCCL, one rank per process and GPU; the 128-byte id of rank 0 travels by a torch.distributed
+    broadcast, the launcher's job) + ONE collective call, glia_hmt_rag_build_distributed (glia_amd/csrc/slab_dist.cpp): partial map
+    per slab, cut flags, keyed owner exchange of the cut records as unpadded ncclSend / ncclRecv inside one group, reduction at the
+    owners, hand-over to the loop owner (rank 0).  Timed apart from `value` (the merge loop does not shard); rank 0 checks the
+    merged map against its single-pass build."""
     labels, pb = ctx.synth((size,) * 3, S, 8 * S)            # the same volume on every rank (same seed)
-    lo, hi, zb, ze = slab.slab_with_halo(size, world, rank)
-    sl, sp = labels[lo:hi], pb[lo:hi]
+    first, nplanes, zb, ze = hmt.slab_range(size, world, rank)
+    sl, sp = labels[first:first + nplanes].contiguous(), pb[first:first + nplanes].contiguous()
     cfg = hmt.make_config(sp, rb=[(sp, 8, 0.0, 1.0)], thresholds=(0.2, 0.5, 0.8))
-
+    idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+    if rank == 0:
+        idt.copy_(torch.frombuffer(bytearray(hmt.Comm.unique_id()), dtype=torch.uint8))
+    dist.broadcast(idt, 0)
+    comm = hmt.Comm(ctx, world, rank, bytes(idt.cpu().numpy().tobytes()))
     stats = {}
 
     def once():
-        part = hmt.RegionMap(ctx, sl, pb=sp, cfg=cfg, slab=(lo, size, zb, ze))
-        merged, st_ = slab.exchange_and_merge(ctx, part, sl, zb, ze, loop_owner=0)
-        stats.update(st_)
-        part.close()
+        merged, st_ = hmt.build_distributed(ctx, comm, [(sl, sp, first, zb, ze, cfg)], size, only_contour=False, loop_owner=0)
+        stats.update(records=int(st_.records), cut_records=int(st_.cut_records), bytes_sent_cut_exchange=int(st_.bytes_cut_exchange),
+                     bytes_sent_to_loop_owner=int(st_.bytes_to_loop_owner))
         return merged
 
     m0 = once()                                              # warm-up (RCCL channels, allocations)
@@ -172,13 +177,16 @@ def slab_phase(ctx, hmt, dist, torch, size, S, world, rank, clf):
     smax = sent.clone(); dist.all_reduce(smax, op=dist.ReduceOp.MAX)
     dist.all_reduce(sent, op=dist.ReduceOp.SUM)
     out = {"ms": float(t.item()) * 1e3, "slab_planes_per_rank": ze - zb,
-           "exchange": "cut records (label on a plane next to a cut) -> keyed owner (hash(label) mod N), point-to-point, unpadded; "
-                       "reduced cut + interior records once to the loop owner (rank 0)",
+           "route": "C ABI: glia_hmt_comm_create_rccl + glia_hmt_rag_build_distributed (slab_dist.cpp)",
+           "exchange": "cut records (label on a plane next to a cut) -> keyed owner (hash(label) mod N), ncclSend / ncclRecv in one group, "
+                       "unpadded; reduced cut + interior records once to the loop owner (rank 0)",
            "records_all_ranks": int(sent[2].item()), "cut_records_all_ranks": int(sent[3].item()),
            "bytes_sent_cut_exchange_max_rank": int(smax[0].item()), "bytes_sent_to_loop_owner_max_rank": int(smax[1].item()),
            "bytes_sent_all_ranks": int(sent[0].item() + sent[1].item())}
+    comm.close()
     if rank == 0:
         out["regions"] = merged.num_regions; out["pairs"] = merged.num_pairs
+    lo, hi = first, first + nplanes
     # the merged map lives on the loop owner only: the others receive its compact records for the sharded scoring below
     rec = merged.to_tensors() if rank == 0 else None
     # every rank must issue the SAME sequence of collectives: the number of image channels travels with the shapes and the

@@ -26,7 +26,7 @@ void set_error(const std::string& msg) { g_err = msg; }
 // when the table is first used -- no entry point calls getenv() per call.
 static const char* const kOptionKeys[] = {"GLIA_HMT_PB_WINDOW", "GLIA_HMT_PB_BATCH", "GLIA_HMT_WINCAP", "GLIA_HMT_REBASE", "GLIA_HMT_HORIZON",
                                           "GLIA_HMT_FORCE_TREE", "GLIA_HMT_HELPERS", "GLIA_HMT_TRACE", "GLIA_HMT_LIBM", "GLIA_HMT_BC_NOCOMMON",
-                                          "GLIA_HMT_BC_GENERIC", "GLIA_HMT_DEBUG"};
+                                          "GLIA_HMT_BC_GENERIC", "GLIA_HMT_DEBUG", "GLIA_HMT_MAXITERS"};
 static std::mutex g_opt_mu;
 static std::unordered_map<std::string, std::string> g_opt;
 static bool g_opt_init = false;
@@ -394,10 +394,6 @@ static int rag_build_impl(glia_hmt_ctx* c, int dim, const int64_t dims[3], int64
     for (int i = 0; i < nthr; ++i) thr[i] = cfg->thresholds[i];
   } else if (d_pb) chans.push_back(Chan{d_pb, 8, 0.0, 1.0});
   if (chans.empty()) { set_error("rag_build: no image volume given"); return GLIA_HMT_ERR_ARG; }
-  if (cfg && cfg->use_median_features) {
-    set_error("rag_build: the GLIA_USE_MEDIAN_AS_FEATS layout (type/feat.hxx:677-722) is not implemented: it needs every region's value multiset");
-    return GLIA_HMT_ERR_UNSUPPORTED;
-  }
   for (const Chan& ch : chans)
     if (ch.bins < 1 || ch.bins > GLIA_HMT_MAX_BINS || !(ch.hi > ch.lo)) {
       set_error("rag_build: histogram bins must be 1..16 and hi > lo");
@@ -898,10 +894,25 @@ static bool make_bc_cfg(const glia_hmt_rag* rag, BcCfg* c) {
   return true;
 }
 
+// GLIA_USE_MEDIAN_AS_FEATS (type/feat.hxx:677-722, 772-808; hmt/bc_feat.hxx:252-268): one more column per real-feature block -- the
+// diff block of every region-list image, the shared-boundary block of every boundary-list image, and both kinds of block in each of
+// the three region blocks; the simple selection carries the shared boundary's median beside its mean.
+static int median_extra_cols(const glia_hmt_rag* rag, const BcCfg& c) {
+  if (!rag->cfg.use_median_features) return 0;
+  return c.use_simple ? c.n_boundary : 4 * c.n_region + 4 * c.n_boundary;
+}
+// the greedy loop keeps mergeable statistics, not value multisets: with this layout only bc_feat (a given order) is implemented
+static int refuse_median_in_loop(const glia_hmt_rag* rag, const char* who) {
+  if (!rag->has_cfg || !rag->cfg.use_median_features) return GLIA_HMT_OK;
+  set_error(std::string(who) + ": the GLIA_USE_MEDIAN_AS_FEATS layout (type/feat.hxx:677-722) is implemented for a given merge order only (glia_hmt_bc_feat): "
+            "inside the greedy loop every contraction changes the value multisets of its regions and boundary sets");
+  return GLIA_HMT_ERR_UNSUPPORTED;
+}
+
 int glia_hmt_feat_dim(const glia_hmt_rag* rag) {
   BcCfg c;
   if (!rag || !make_bc_cfg(rag, &c)) return -1;
-  return c.fdim;
+  return c.fdim + median_extra_cols(rag, c);
 }
 
 int glia_hmt_merge_order_bc(glia_hmt_ctx* c, glia_hmt_rag* rag, const glia_hmt_forest* forest, uint32_t* h_order,
@@ -915,6 +926,7 @@ int glia_hmt_merge_order_bc(glia_hmt_ctx* c, glia_hmt_rag* rag, const glia_hmt_f
     set_error("merge_order_bc: the region map must be built with a feature configuration and with region points");
     return GLIA_HMT_ERR_ARG;
   }
+  if (int rm = refuse_median_in_loop(rag, "merge_order_bc")) return rm;
   if (forest->max_var >= cfg.fdim) { set_error("merge_order_bc: the classifier reads features beyond the vector"); return GLIA_HMT_ERR_ARG; }
   GLIA_HIP_TRY(hipSetDevice(c->device));
   const int64_t R = rag->arr.R;
@@ -980,7 +992,7 @@ int glia_hmt_bc_feat(glia_hmt_ctx* c, glia_hmt_rag* rag, const uint32_t* h_order
 int glia_hmt_bc_feat_dim(const glia_hmt_rag* rag, int with_saliency) {
   BcCfg cfg;
   if (!rag || !make_bc_cfg(rag, &cfg)) return -1;
-  return cfg.fdim + ((with_saliency && !cfg.use_simple) ? 5 : 0);
+  return cfg.fdim + median_extra_cols(rag, cfg) + ((with_saliency && !cfg.use_simple) ? 5 : 0);
 }
 
 int glia_hmt_bc_feat_saliency(glia_hmt_ctx* c, glia_hmt_rag* rag, const uint32_t* h_order, int64_t n_merges,
@@ -1024,8 +1036,70 @@ int glia_hmt_bc_feat_saliency(glia_hmt_ctx* c, glia_hmt_rag* rag, const uint32_t
                      &rag->ms_loop, &rag->n_scored, false, forced.data(), n_merges);
   if (rc) return rc;
   if (n != n_merges) { set_error("bc_feat: internal error, merges not completed"); return GLIA_HMT_ERR_HIP; }
+  int bfdim = cfg.bfdim, rfdim = cfg.rfdim, fdim = cfg.fdim;
+  if (rag->cfg.use_median_features) {
+    // GLIA_USE_MEDIAN_AS_FEATS: the kernel's rows (built from the statistics monoids) + the medians, means and standard deviations
+    // of the value multisets (median_feats.hip), spliced into the reference's layout
+    const glia_hmt_feat_config& g = rag->cfg;
+    MedianFeatIn in;
+    memset(&in, 0, sizeof(in));
+    in.rag = &rag->arr; in.vol = rag->vol; in.forced = forced.data(); in.n_merges = n_merges;
+    in.n_r = g.n_region; in.n_b = g.n_boundary;
+    for (int i = 0; i < g.n_region; ++i) in.r_img[i] = (const float*)g.region[i].d_image;
+    for (int i = 0; i < g.n_boundary; ++i) in.b_img[i] = (const float*)g.boundary[i].d_image;
+    std::vector<double> reg, bnd;
+    std::vector<unsigned long long> marea;
+    if ((rc = median_feature_stats(in, c->stream, &reg, &bnd, &marea))) return rc;
+    const int nr = g.n_region, nl = g.n_rlabel, nb = g.n_boundary, T = cfg.T, D = cfg.D;
+    const int extra = median_extra_cols(rag, cfg);
+    const int nd = cfg.fdim + extra;
+    std::vector<double> rows((size_t)n * nd);
+    auto hb = [&](int kind, int i) { return cfg.use_hist ? cfg.cbins[kind == 0 ? cfg.rc[i] : kind == 1 ? cfg.lc[i] : cfg.bc[i]] : 0; };
+    for (int64_t i = 0; i < n; ++i) {
+      const bool swap = sdivide_host((double)marea[forced[2 * i]], cfg.norm_area) > sdivide_host((double)marea[forced[2 * i + 1]], cfg.norm_area);
+      // x1 = the smaller region (main_bc_feat.cxx:84-88): k of the statistics arrays for block b of the row
+      const int kreg[3] = {swap ? 1 : 0, swap ? 0 : 1, 2};
+      auto RS = [&](int blk, int img, int q) { return reg[(((size_t)i * 3 + kreg[blk]) * nr + img) * 3 + q]; };
+      auto BS = [&](int blk, int img, int q) { return bnd[(((size_t)i * 4 + (blk < 3 ? kreg[blk] : 3)) * nb + img) * 3 + q]; };
+      const double* in_row = &feats[(size_t)i * cfg.fdim];
+      double* out = &rows[(size_t)i * nd];
+      int p = 0, k = 0;
+      if (cfg.use_simple) {                                         // hmt/bc_feat.hxx:247-279
+        for (int q = 0; q < 5; ++q) out[k++] = in_row[p++];
+        for (int j = 0; j < nb; ++j) { out[k++] = BS(3, j, 1); out[k++] = BS(3, j, 0); ++p; }
+        for (int j = 0; j < nr; ++j) { out[k++] = std::fabs(RS(0, j, 1) - RS(1, j, 1)); out[k++] = in_row[p + 1]; out[k++] = in_row[p + 2]; out[k++] = in_row[p + 3]; p += 4; }
+        for (int j = 0; j < 2 * nl; ++j) out[k++] = in_row[p++];
+      } else {
+        for (int q = 0; q < 11 + 4 * T; ++q) out[k++] = in_row[p++];
+        for (int j = 0; j < nr; ++j) {                               // feat.hxx:782-808: l1, x2, |d entropy|, |d median|, |d mean|, |d std|, |d min|, |d max|
+          out[k++] = in_row[p]; out[k++] = in_row[p + 1]; out[k++] = in_row[p + 2];
+          out[k++] = std::fabs(RS(0, j, 0) - RS(1, j, 0)); out[k++] = std::fabs(RS(0, j, 1) - RS(1, j, 1)); out[k++] = std::fabs(RS(0, j, 2) - RS(1, j, 2));
+          out[k++] = in_row[p + 5]; out[k++] = in_row[p + 6];
+          p += 7;
+        }
+        for (int q = 0; q < 3 * nl; ++q) out[k++] = in_row[p++];
+        auto real_block = [&](int h, double med, double mean, double sd) {     // [histogram] entropy | median mean std | min max
+          for (int q = 0; q < h + 1; ++q) out[k++] = in_row[p++];
+          out[k++] = med; out[k++] = mean; out[k++] = sd;
+          out[k++] = in_row[p + 2]; out[k++] = in_row[p + 3];
+          p += 4;
+        };
+        for (int j = 0; j < nb; ++j) real_block(hb(2, j), BS(3, j, 0), BS(3, j, 1), BS(3, j, 2));
+        for (int blk = 0; blk < 3; ++blk) {
+          for (int q = 0; q < 4 + D + 2 * T; ++q) out[k++] = in_row[p++];
+          for (int j = 0; j < nr; ++j) real_block(hb(0, j), RS(blk, j, 0), RS(blk, j, 1), RS(blk, j, 2));
+          for (int j = 0; j < nl; ++j) for (int q = 0; q < hb(1, j) + 1; ++q) out[k++] = in_row[p++];
+          for (int j = 0; j < nb; ++j) real_block(hb(2, j), BS(blk, j, 0), BS(blk, j, 1), BS(blk, j, 2));
+        }
+      }
+      if (p != cfg.fdim || k != nd) { set_error("bc_feat: internal error, median feature layout"); return GLIA_HMT_ERR_INTERNAL; }
+    }
+    feats.swap(rows);
+    fdim = nd;
+    if (!cfg.use_simple) { bfdim = cfg.bfdim + nr + nb; rfdim = cfg.rfdim + nr + nb; }
+  }
   if (!h_saliencies || cfg.use_simple) {       // selectFeatures carries no saliency (hmt/bc_feat.hxx:247-279)
-    memcpy(h_feats, feats.data(), sizeof(double) * (size_t)n * cfg.fdim);
+    memcpy(h_feats, feats.data(), sizeof(double) * (size_t)n * fdim);
     return GLIA_HMT_OK;
   }
   // Saliency features (hmt/main_bc_feat.cxx:50-55): every region of the order carries a number -- initSal for the
@@ -1043,7 +1117,7 @@ int glia_hmt_bc_feat_saliency(glia_hmt_ctx* c, glia_hmt_rag* rag, const uint32_t
     if (!smap.count(h_order[3 * i + 1])) smap[h_order[3 * i + 1]] = init_saliency;
     smap[h_order[3 * i + 2]] = h_saliencies[i] + saliency_bias;
   }
-  const int od = cfg.fdim + 5;
+  const int od = fdim + 5;
   for (int64_t i = 0; i < n_merges; ++i) {
     const uint32_t a = forced[2 * i], b = forced[2 * i + 1];
     area[R + i] = area[a] + area[b];
@@ -1051,16 +1125,16 @@ int glia_hmt_bc_feat_saliency(glia_hmt_ctx* c, glia_hmt_rag* rag, const uint32_t
     const double s0 = smap[h_order[3 * i]], s1 = smap[h_order[3 * i + 1]], s2 = smap[h_order[3 * i + 2]];
     const double sx1 = swap ? s1 : s0, sx2 = swap ? s0 : s1;
     const double d02 = std::fabs(sx1 - s2), d12 = std::fabs(sx2 - s2);
-    const double* in = &feats[(size_t)i * cfg.fdim];
+    const double* in = &feats[(size_t)i * fdim];
     double* out = &h_feats[(size_t)i * od];
     int k = 0;
-    for (int q = 0; q < cfg.bfdim; ++q) out[k++] = in[q];
+    for (int q = 0; q < bfdim; ++q) out[k++] = in[q];
     out[k++] = std::min(d02, d12); out[k++] = std::max(d02, d12);
-    for (int q = 0; q < cfg.rfdim; ++q) out[k++] = in[cfg.bfdim + q];
+    for (int q = 0; q < rfdim; ++q) out[k++] = in[bfdim + q];
     out[k++] = sx1;
-    for (int q = 0; q < cfg.rfdim; ++q) out[k++] = in[cfg.bfdim + cfg.rfdim + q];
+    for (int q = 0; q < rfdim; ++q) out[k++] = in[bfdim + rfdim + q];
     out[k++] = sx2;
-    for (int q = 0; q < cfg.rfdim; ++q) out[k++] = in[cfg.bfdim + 2 * cfg.rfdim + q];
+    for (int q = 0; q < rfdim; ++q) out[k++] = in[bfdim + 2 * rfdim + q];
     out[k++] = s2;
   }
   return GLIA_HMT_OK;
@@ -1145,6 +1219,7 @@ int glia_hmt_score_initial_edges(glia_hmt_ctx* c, glia_hmt_rag* rag, const glia_
     set_error("score_initial_edges: the region map must be built with a feature configuration and with region points");
     return GLIA_HMT_ERR_ARG;
   }
+  if (int rm = refuse_median_in_loop(rag, "score_initial_edges")) return rm;
   if (forest->max_var >= cfg.fdim) { set_error("score_initial_edges: the classifier reads features beyond the vector"); return GLIA_HMT_ERR_ARG; }
   GLIA_HIP_TRY(hipSetDevice(c->device));
   int64_t n = 0;
@@ -1167,6 +1242,7 @@ int glia_hmt_score_initial_edges_shard(glia_hmt_ctx* c, glia_hmt_rag* rag, const
     set_error("score_initial_edges: the region map must be built with a feature configuration and with region points");
     return GLIA_HMT_ERR_ARG;
   }
+  if (int rm = refuse_median_in_loop(rag, "score_initial_edges")) return rm;
   if (forest->max_var >= cfg.fdim) { set_error("score_initial_edges: the classifier reads features beyond the vector"); return GLIA_HMT_ERR_ARG; }
   GLIA_HIP_TRY(hipSetDevice(c->device));
   // one record per unordered leaf pair; the count is needed before the scores can be copied out

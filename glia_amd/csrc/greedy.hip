@@ -71,7 +71,7 @@ int pq_setup(DeviceBuffers& buf, PqTree& t, hipStream_t stream) {
 // A barrier behind which every global store and atomic of the workgroup has been performed.  (__syncthreads() is NOT that on
 // gfx950: the workgroup-scope fence of a workgroup that is not split over CUs waits for lgkmcnt only -- found in round 3, when
 // a merge order differed once in ~30 000 runs; the comments of rounds 1-2 that say "vmcnt(0) inside" were wishful.)
-__device__ __forceinline__ void full_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); GLIA_SKEW_DELAY(); }
+__device__ __forceinline__ void full_barrier(const int line = __builtin_LINE()) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); GLIA_SKEW_DELAY(line); }
 struct GreedyState {
   uint32_t R0;
   uint32_t* adj_off;   // [2*R0] start of a region's incident-edge list in pool
@@ -613,7 +613,7 @@ __host__ __device__ __forceinline__ double f64_unord(unsigned long long o) {
   o ^= (o >> 63) ? 0x8000000000000000ull : ~0ull;
   return __builtin_bit_cast(double, o);
 }
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); GLIA_SKEW_DELAY(); }   // global stores stay in flight
+__device__ __forceinline__ void lds_barrier(const int line = __builtin_LINE()) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); GLIA_SKEW_DELAY(line); }   // global stores stay in flight
 
 __host__ __device__ __forceinline__ uint32_t win_cell(double sal, double smin, double scale, uint32_t B) {
   double t = (sal - smin) * scale;          // monotone in sal (saliencies are never NaN: sdivide guards the division)
@@ -705,8 +705,9 @@ __device__ __forceinline__ Key win_root(const WinShared& w, int lane) {
   return better(b, a) ? b : a;
 }
 
-// squeeze the holes out (every thread calls)
-__device__ __forceinline__ void win_compact(WinShared& w, int tid, uint32_t cap = kWinCap) {
+// squeeze the holes out (every thread calls); returns the number of live items -- the same value in every thread, from the scan:
+// a caller that decides on it must NOT read w.n again (the first wave past the barrier may already be adding to it)
+__device__ __forceinline__ uint32_t win_compact(WinShared& w, int tid, uint32_t cap = kWinCap) {
   double sal[kWinPer]; unsigned long long seq[kWinPer]; uint32_t e[kWinPer], u[kWinPer], v[kWinPer]; uint2 hu[kWinPer], hv[kWinPer];
   uint32_t live = 0;
   const uint32_t n = w.n < cap ? w.n : cap;
@@ -723,6 +724,7 @@ __device__ __forceinline__ void win_compact(WinShared& w, int tid, uint32_t cap 
   for (int j = 0; j < kWinPer; ++j) if (seq[j] != 0) { win_put(w, o, sal[j], seq[j], e[j], u[j], v[j], hu[j], hv[j]); ++o; }
   if (tid == 0) w.n = total;
   full_barrier();
+  return total;
 }
 
 __device__ __forceinline__ void win_push_global(const WinState& st, uint32_t e, uint32_t cell) {
@@ -1034,8 +1036,11 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_window_kernel(WinState 
 #ifdef GLIA_HMT_PROFILE
       wcompacts += 1;
 #endif
-      win_compact(w, tid, st.wcap);
-      if (w.n + total > st.wcap) {
+      // (round 4, found by the wave-skew build: this test used to read w.n again behind win_compact's barrier -- a wave that came out of
+      // it early had already started to append this contraction's edges, a late one then saw a fuller window, flushed ALONE, and the
+      // workgroup hung at mismatched barriers.  The window kernel of pre_merge is this code.)
+      const uint32_t wn_live = win_compact(w, tid, st.wcap);
+      if (wn_live + total > st.wcap) {
         win_flush(st, w, tid);
         if (total > st.wcap) {             // a contraction wider than the window: nothing of it goes there
           if (tid == 0) { w.cthr = (int)st.wB; w.tsal = __builtin_inf(); w.tseq = ~0ull; }
@@ -2205,6 +2210,8 @@ static int greedy_mean_once(const RagArrays& rag, hipStream_t stream, uint32_t* 
 
   // ---- the loop, in bounded launches so a contraction budget can be re-negotiated between them ----
   st.max_iters = window ? 1ull << 22 : 1ull << 16;
+  const bool trace = option("GLIA_HMT_TRACE");
+  if (option("GLIA_HMT_MAXITERS", &o_txt)) st.max_iters = strtoull(o_txt.c_str(), nullptr, 10);      // tests: launches that end early
   while (true) {
     if (window) {
       ws.max_iters = st.max_iters;
@@ -2216,6 +2223,7 @@ static int greedy_mean_once(const RagArrays& rag, hipStream_t stream, uint32_t* 
     GLIA_HIP_TRY(hipGetLastError());
     GLIA_HIP_TRY(hipMemcpyAsync(ctrl, st.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, stream));
     GLIA_HIP_TRY(hipStreamSynchronize(stream));
+    if (trace) fprintf(stderr, "[trace] merge loop launch ended: status %llu, merges %llu of %u regions, edges %llu, list entries %llu\n", ctrl[3], ctrl[0], R, ctrl[1], ctrl[2]);
     if (ctrl[3] == ST_RUN && !window) continue;
     if (ctrl[3] == ST_DONE) break;
     if (ctrl[3] == ST_BAD_SALIENCY) { set_error("Error: invalid boundary saliency..."); return GLIA_HMT_ERR_SALIENCY; }

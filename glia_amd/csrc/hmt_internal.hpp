@@ -119,6 +119,16 @@ struct VolumeRef {
   long long nx = 1, ny = 1, nz = 1;
   long long zb = 0, ze = -1;           // planes whose voxels count (a slab's owned planes; ze < 0: all)
 };
+// GLIA_USE_MEDIAN_AS_FEATS for a given merge order (median_feats.hip): median, mean and standard deviation of the value multiset of
+// every voxel set a bc_feat row looks at.  forced = dense region pairs of the merges; list entry c of the region / boundary lists
+// reads r_img[c] / b_img[c] (device).  reg[((i * 3 + k) * n_r + c) * 3 + q]: merge i, k = first region | second region | region
+// created, q = median | mean | stddev; bnd[((i * 4 + k) * n_b + c) * 3 + q]: k = B(first) | B(second) | B(created) | shared boundary.
+struct MedianFeatIn {
+  const RagArrays* rag; VolumeRef vol;
+  int n_r; const float* r_img[GLIA_HMT_MAX_IMAGES]; int n_b; const float* b_img[GLIA_HMT_MAX_IMAGES];
+  const uint32_t* forced; int64_t n_merges;
+};
+int median_feature_stats(const MedianFeatIn& in, hipStream_t stream, std::vector<double>* reg, std::vector<double>* bnd, std::vector<unsigned long long>* area);
 int greedy_mean(const RagArrays& rag, hipStream_t stream, uint32_t* h_order, double* h_sal, int64_t capacity,
                 int64_t* n_merges, double* ms_table, double* ms_loop, int64_t* n_scored, int cond_n = 0,
                 const long long* cond_sizes = nullptr, double cond_rpb = 0.0, const VolumeRef* median_of = nullptr,

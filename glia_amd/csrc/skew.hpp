@@ -12,26 +12,36 @@
 #include <hip/hip_runtime.h>
 
 #ifdef GLIA_HMT_SKEW
+#ifndef GLIA_HMT_SKEW_TICKS
+#define GLIA_HMT_SKEW_TICKS 127         // s_sleep argument: x 64 cycles
+#endif
 #ifndef GLIA_HMT_SKEW_SLEEPS
 #define GLIA_HMT_SKEW_SLEEPS 1          // x s_sleep 127 (8128 cycles each: ~20 x the barrier-to-barrier distance of the loops)
 #endif
+// (bisecting a failure of the skew build: only the barriers on source lines LO .. HI are skewed)
+#ifndef GLIA_HMT_SKEW_LO
+#define GLIA_HMT_SKEW_LO 0
+#endif
+#ifndef GLIA_HMT_SKEW_HI
+#define GLIA_HMT_SKEW_HI (1 << 30)
+#endif
 namespace glia {
-__device__ __forceinline__ void skew_delay() {
+__device__ __forceinline__ void skew_delay(const int line) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const bool late = (GLIA_HMT_SKEW == 1) ? (wave != 0) : (wave == 0);
+  const bool late = ((GLIA_HMT_SKEW == 1) ? (wave != 0) : (wave == 0)) && line >= GLIA_HMT_SKEW_LO && line <= GLIA_HMT_SKEW_HI;
   if (late) {
 #pragma unroll 1
-    for (int i = 0; i < GLIA_HMT_SKEW_SLEEPS; ++i) __builtin_amdgcn_s_sleep(127);
+    for (int i = 0; i < GLIA_HMT_SKEW_SLEEPS; ++i) __builtin_amdgcn_s_sleep(GLIA_HMT_SKEW_TICKS);
   }
 }
-__device__ __forceinline__ void skew_syncthreads() { __syncthreads(); skew_delay(); }
-__device__ __forceinline__ int skew_syncthreads_or(int p) { const int r = __syncthreads_or(p); skew_delay(); return r; }
-__device__ __forceinline__ int skew_syncthreads_count(int p) { const int r = __syncthreads_count(p); skew_delay(); return r; }
+__device__ __forceinline__ void skew_syncthreads(const int line) { __syncthreads(); skew_delay(line); }
+__device__ __forceinline__ int skew_syncthreads_or(int p, const int line) { const int r = __syncthreads_or(p); skew_delay(line); return r; }
+__device__ __forceinline__ int skew_syncthreads_count(int p, const int line) { const int r = __syncthreads_count(p); skew_delay(line); return r; }
 }  // namespace glia
-#define __syncthreads() ::glia::skew_syncthreads()
-#define __syncthreads_or(p) ::glia::skew_syncthreads_or(p)
-#define __syncthreads_count(p) ::glia::skew_syncthreads_count(p)
-#define GLIA_SKEW_DELAY() ::glia::skew_delay()
+#define __syncthreads() ::glia::skew_syncthreads(__LINE__)
+#define __syncthreads_or(p) ::glia::skew_syncthreads_or(p, __LINE__)
+#define __syncthreads_count(p) ::glia::skew_syncthreads_count(p, __LINE__)
+#define GLIA_SKEW_DELAY(line) ::glia::skew_delay(line)
 #else
-#define GLIA_SKEW_DELAY() do {} while (0)
+#define GLIA_SKEW_DELAY(line) do {} while (0)
 #endif

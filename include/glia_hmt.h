@@ -120,8 +120,13 @@ typedef struct {
   int use_simple_features;           /* --simpf */
   /* Build options of the reference that change the vector layout (CMakeLists.txt:54-64, type/feat.hxx:608-621, 677-722):
    * GLIA_HMT_HIST_FEAT -> GLIA_USE_HISTOGRAM_AS_FEATS: every image-feature block carries its normalised histogram ahead of
-   * the entropy (bins more columns per block).  GLIA_HMT_MEDIAN_FEAT -> GLIA_USE_MEDIAN_AS_FEATS is not implemented
-   * (GLIA_HMT_ERR_UNSUPPORTED): it needs the value multiset of every region. */
+   * the entropy (bins more columns per block).  GLIA_HMT_MEDIAN_FEAT -> GLIA_USE_MEDIAN_AS_FEATS: every real-feature block carries
+   * the MEDIAN of its voxel set ahead of the mean, mean / standard deviation come from the value vector (stats::mean, stats::var),
+   * the diff blocks gain |median0 - median1|, --simpf carries the shared boundary's median beside its mean (hmt/bc_feat.hxx:252-268).
+   * Implemented for a GIVEN merge order (glia_hmt_bc_feat / _saliency: glia_amd/csrc/median_feats.hip; the value multisets of one
+   * order are processed in batches of 2^27 values, one set may hold at most 2^30); the greedy loop (glia_hmt_merge_order_bc,
+   * glia_hmt_score_initial_edges) returns GLIA_HMT_ERR_UNSUPPORTED with this layout.  Median columns are bit-exact, the mean / stddev
+   * columns comparable to 1e-12 (the reference sums in an order that depends on rand(), util/stats.hxx:87). */
   int use_histogram_features;
   int use_median_features;
 } glia_hmt_feat_config;

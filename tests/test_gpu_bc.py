@@ -219,9 +219,11 @@ def test_histogram_as_features_layout(ctx, shape, S, G, layout):
     po, _ = O.Rag(labels, only_contour=True).merge_order_pb(pb, type=2)
     assert _feat_close(rm.bc_feat(po), O.Rag(labels).bc_feat(ocfg, po))
     rm.close()
-    # the median layout is refused, not silently ignored
-    with pytest.raises(hmt.HmtError):
-        hmt.RegionMap(ctx, d_lab, pb=d_pb, cfg=hmt.make_config(d_pb, use_median_features=True, **dkw))
+    # the median layout inside the greedy LOOP is refused, not silently ignored (bc_feat has it: test_median_as_features_for_a_given_order)
+    rm_med = hmt.RegionMap(ctx, d_lab, pb=d_pb, cfg=hmt.make_config(d_pb, use_median_features=True, **dkw))
+    with pytest.raises(hmt.HmtError, match="given merge order only"):
+        rm_med.merge_order_bc(hmt.FeatureStubClassifier(ctx, stub))
+    rm_med.close()
 
 
 def test_full_vector_longer_than_the_kernel_buffers_is_refused(ctx):
@@ -450,3 +452,83 @@ def test_loop_instances_agree(ctx, shape, S, G):
         assert o.shape == o_ref.shape and (o == o_ref).all() and (s == s_ref).all()
         assert (f.view(np.uint64) == results[0][2].view(np.uint64)).all()
     assert (results[0][2].view(np.uint64) == f_ref.view(np.uint64)).all(), "feature rows are bit-identical to the oracle on Q8 inputs"
+
+
+def _median_loose_mask(dim, n_thr, n_r, n_rl, n_b, hist_cols=(0, 0, 0)):
+    """columns of the full median-layout vector that hold a mean / stddev (or their differences): another summation order than the
+    reference's (which depends on rand(), util/stats.hxx:87) -- comparable to 1e-12; every other column bit for bit"""
+    hr, hl, hbb = hist_cols
+    loose = []
+    pos = 11 + 4 * n_thr
+    for _ in range(n_r):
+        pos += 3; loose += [pos + 1, pos + 2]; pos += 5         # medD | meanD stdD | minD maxD
+    pos += 3 * n_rl
+    for _ in range(n_b):
+        pos += hbb + 1; loose += [pos + 1, pos + 2]; pos += 5   # [hist] entropy | median | mean std | min max
+    for _ in range(3):
+        pos += 4 + dim + 2 * n_thr
+        for _ in range(n_r):
+            pos += hr + 1; loose += [pos + 1, pos + 2]; pos += 5
+        pos += (hl + 1) * n_rl
+        for _ in range(n_b):
+            pos += hbb + 1; loose += [pos + 1, pos + 2]; pos += 5
+    m = np.zeros(pos, bool); m[loose] = True
+    return m
+
+
+@pytest.mark.parametrize("shape,S,G,layout", [((32, 32, 32), 8, 16, "rb"), ((40, 36, 28), 6, 12, "four"), ((64, 64), 4, 16, "split"), ((24, 30, 22), 5, 10, "rb2")])
+def test_median_as_features_for_a_given_order(ctx, shape, S, G, layout):
+    """GLIA_USE_MEDIAN_AS_FEATS (CMakeLists.txt:55,62-64; type/feat.hxx:677-722, 772-808; hmt/bc_feat.hxx:252-268) through
+    glia_hmt_bc_feat: D_f and the rows of the oracle's bc_feat with median_as_feats -- medians and every column the default layout
+    has bit for bit, the mean / stddev columns (taken from the value vector: stats::mean, stats::var) to 1e-12 -- on four list
+    layouts in 2D and 3D, with --simpf, with the saliency columns, and with a mask."""
+    import torch
+    from glia_amd import hmt
+    from oracle import pyoracle as O
+    dim = len(shape)
+    labels, pb = O.synth(shape, S, G)
+    rng = np.random.default_rng(5)
+    raw = (np.round(rng.random(shape) * 255) / 256.0).astype(np.float32)
+    d_lab = torch.from_numpy(labels.view(np.int32)).cuda()
+    d_pb, d_raw = torch.from_numpy(pb).cuda(), torch.from_numpy(raw).cuda()
+    if layout == "rb": okw, dkw, dims = dict(rb=[(pb, 8, 0.0, 1.0)]), dict(rb=[(d_pb, 8, 0.0, 1.0)]), (1, 0, 1)
+    elif layout == "rb2": okw, dkw, dims = dict(rb=[(raw, 16, 0.0, 1.0), (pb, 8, 0.0, 1.0)]), dict(rb=[(d_raw, 16, 0.0, 1.0), (d_pb, 8, 0.0, 1.0)]), (2, 0, 2)
+    elif layout == "split": okw, dkw, dims = (dict(r=[(raw, 4, 0.0, 1.0)], b=[(pb, 8, 0.0, 1.0)], rl=[(raw, 4, 0.0, 1.0)]),
+                                              dict(r=[(d_raw, 4, 0.0, 1.0)], b=[(d_pb, 8, 0.0, 1.0)], rl=[(d_raw, 4, 0.0, 1.0)]), (1, 1, 1))
+    else: okw, dkw, dims = (dict(rb=[(pb, 8, 0.0, 1.0)], r=[(raw, 4, 0.0, 1.0)], rl=[(raw, 4, 0.0, 1.0)], b=[(raw, 8, 0.0, 1.0)]),
+                            dict(rb=[(d_pb, 8, 0.0, 1.0)], r=[(d_raw, 4, 0.0, 1.0)], rl=[(d_raw, 4, 0.0, 1.0)], b=[(d_raw, 8, 0.0, 1.0)]), (2, 1, 2))
+    n_r, n_rl, n_b = dims
+    order, sal = O.Rag(labels, only_contour=True).merge_order_pb(pb, type=2)
+    plain = O.make_cfg(pb, **okw)
+    ocfg = O.make_cfg(pb, median_as_feats=True, **okw)
+    rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, cfg=hmt.make_config(d_pb, use_median_features=True, **dkw))
+    got = rm.bc_feat(order)
+    ref = O.Rag(labels).bc_feat(ocfg, order)
+    assert got.shape == ref.shape and got.shape[1] == O.feat_dim(dim, plain) + 4 * n_r + 4 * n_b
+    loose = _median_loose_mask(dim, 3, n_r, n_rl, n_b)
+    assert len(loose) == got.shape[1]
+    assert (got[:, ~loose].view(np.uint64) == ref[:, ~loose].view(np.uint64)).all(), "medians and every statistic-derived column are bit-identical"
+    assert np.allclose(got[:, loose], ref[:, loose], rtol=1e-12, atol=1e-13)
+    # with the saliency columns (bc_feat -y) on top
+    got_s = rm.bc_feat(order, saliencies=sal, init_sal=0.75, sal_bias=1.5)
+    ref_s = O.Rag(labels).bc_feat(ocfg, order, saliencies=sal, init_sal=0.75, sal_bias=1.5)
+    assert got_s.shape == ref_s.shape == (len(order), got.shape[1] + 5) and np.allclose(got_s, ref_s, rtol=1e-12, atol=1e-13)
+    rm.close()
+    # --simpf: the shared boundary's median beside its mean (bc_feat.hxx:263-268)
+    rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, cfg=hmt.make_config(d_pb, use_median_features=True, use_simple_features=True, **dkw))
+    got = rm.bc_feat(order)
+    ref = O.Rag(labels).bc_feat(O.make_cfg(pb, median_as_feats=True, use_simple=True, **okw), order)
+    assert got.shape == ref.shape and got.shape[1] == 5 + 2 * n_b + 4 * n_r + 2 * n_rl
+    med_cols = [5 + 2 * j + 1 for j in range(n_b)]
+    assert (got[:, med_cols] == ref[:, med_cols]).all() and np.allclose(got, ref, rtol=1e-12, atol=1e-13)
+    rm.close()
+    if layout == "four":
+        # a mask: masked-out voxels leave every value multiset (point-map mode, util/struct.hxx:86-91); histogram columns on top
+        mask = (rng.random(shape) > 0.15).astype(np.uint32)
+        d_mask = torch.from_numpy(mask.view(np.int32)).cuda()
+        rm = hmt.RegionMap(ctx, d_lab, pb=d_pb, mask=d_mask, cfg=hmt.make_config(d_pb, use_median_features=True, use_histogram_features=True, **dkw))
+        morder, _ = O.Rag(labels, mask=mask, only_contour=True).merge_order_pb(pb, type=2)
+        got = rm.bc_feat(morder)
+        ref = O.Rag(labels, mask=mask).bc_feat(O.make_cfg(pb, median_as_feats=True, hist_as_feats=True, **okw), morder)
+        assert got.shape == ref.shape and np.allclose(got, ref, rtol=1e-12, atol=1e-13)
+        rm.close()

@@ -7,5 +7,5 @@
 set -e
 TAG=${1:-skew}; V=${2:-skew}
 mkdir -p gpurun_out/$TAG
-GLIA_HMT_LIB=$PWD/glia_amd/libglia_hmt_$V.so PYTHONUNBUFFERED=1 timeout -k 10 1100 python -u -m pytest tests/test_gpu_queue.py tests/test_gpu_merge.py tests/test_gpu_golden.py tests/test_gpu_bc.py tests/test_gpu_watershed.py tests/test_gpu_rag.py \
-    -m gpu -x -v -k "not config2 and not 128_cubed and not cli" --durations=8 2>&1 | tee gpurun_out/$TAG/pytest_$V.txt | grep -E "PASSED|FAILED|ERROR|passed|failed" | awk '{n++; if (n % 10 == 0 || /passed|failed|FAILED|ERROR/) print}'
+GLIA_HMT_LIB=$PWD/glia_amd/libglia_hmt_$V.so PYTHONUNBUFFERED=1 timeout -k 10 1100 python -u -m pytest tests/test_gpu_queue.py tests/test_gpu_merge.py tests/test_gpu_golden.py tests/test_gpu_bc.py \
+    -m gpu -x -v -k "not cli" --durations=8 2>&1 | tee gpurun_out/$TAG/pytest_$V.txt | grep -E "PASSED|FAILED|ERROR|passed|failed" | awk '{n++; if (n % 10 == 0 || /passed|failed|FAILED|ERROR/) print}'
