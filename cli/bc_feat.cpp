@@ -8,7 +8,7 @@ int main(int argc, char* argv[]) {
   const std::string usage = "Usage: bc_feat -s <seg> -o <order> --pb <pb> [--rbi/--rbb/--rbl/--rbu ...] [--bt ...] [-n b] [-l b] [--simpf b] "
                             "-b <feats>   (flags as hmt/main_bc_feat.cxx:125-185)\n";
   std::vector<std::string> known = {"segImage", "mergeOrder", "saliency", "rbi", "rbb", "rbl", "rbu", "rli", "rlb", "rll", "rlu", "ri", "rb", "rl",
-                                    "ru", "bi", "bb", "bl", "bu", "pb", "maskImage", "s0", "sb", "bt", "ns", "logs", "simpf", "histf", "bfeat"};
+                                    "ru", "bi", "bb", "bl", "bu", "pb", "maskImage", "s0", "sb", "bt", "ns", "logs", "simpf", "histf", "medf", "bfeat"};
   Args a = parse(argc, argv, {{"s", "segImage"}, {"o", "mergeOrder"}, {"y", "saliency"}, {"m", "maskImage"}, {"n", "ns"}, {"l", "logs"}, {"b", "bfeat"}},
                  known, usage);
   for (const char* req : {"segImage", "mergeOrder", "pb"})

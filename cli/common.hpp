@@ -329,6 +329,8 @@ inline void loadFeatInputs(const Args& a, FeatInputs& f, int64_t zFirst = 0, int
   f.cfg.use_simple_features = flagOf(a, "simpf");
   // the reference fixes this layout at build time (cmake -DGLIA_HMT_HIST_FEAT=ON -> GLIA_USE_HISTOGRAM_AS_FEATS); here it is a flag
   f.cfg.use_histogram_features = a.has("histf") ? flagOf(a, "histf") : 0;
+  // likewise GLIA_HMT_MEDIAN_FEAT=ON -> GLIA_USE_MEDIAN_AS_FEATS (bc_feat only: the greedy loop refuses it, include/glia_hmt.h)
+  f.cfg.use_median_features = a.has("medf") ? flagOf(a, "medf") : 0;
 }
 
 }  // namespace cli

@@ -13,7 +13,7 @@ int main(int argc, char* argv[]) {
   const std::string usage = "Usage: merge_order_bc --bct 1 --bcm <model>... -s <seg> --pb <pb> [--rbi/--rbb/--rbl/--rbu ...] [--bt ...] "
                             "[-n b] [-l b] [--simpf b] -o <order> [--sal <file>] [-b <file>]   (flags as hmt/main_merge_order_bc.cxx:172-242)\n";
   std::vector<std::string> known = {"bct", "nn1", "nn2", "bcm", "bcfmm", "bcmd", "segImage", "rbi", "rbb", "rbl", "rbu", "rli", "rlb", "rll", "rlu",
-                                    "ri", "rb", "rl", "ru", "bi", "bb", "bl", "bu", "pb", "maskImage", "bt", "ns", "logs", "simpf", "histf", "mergeOrder",
+                                    "ri", "rb", "rl", "ru", "bi", "bb", "bl", "bu", "pb", "maskImage", "bt", "ns", "logs", "simpf", "histf", "medf", "mergeOrder",
                                     "sal", "bfeat", "slabs", "rank", "commId", "commNonce", "device"};
   Args a = parse(argc, argv, {{"s", "segImage"}, {"m", "maskImage"}, {"n", "ns"}, {"l", "logs"}, {"o", "mergeOrder"}, {"b", "bfeat"}}, known, usage);
   for (const char* req : {"bct", "bcm", "segImage", "pb", "mergeOrder"})

@@ -249,6 +249,12 @@ def test_bc_feat_cli(tools, tmp_path):
     f_ref = O.Rag(labels).bc_feat(cfg, order, saliencies=sal, init_sal=0.5, sal_bias=2.0)
     got = np.array([[float(x) for x in ln.split(" ")[:-1]] for ln in open(feat_f).read().split("\n")[:-1]])
     assert got.shape == f_ref.shape and np.allclose(got, f_ref, rtol=6e-8, atol=1e-12)
+    # --medf 1: the GLIA_USE_MEDIAN_AS_FEATS layout (a build option of the reference, CMakeLists.txt:55,62-64): eight more columns here
+    subprocess.check_call([os.path.join(tools, "bc_feat"), "-s", seg, "-o", order_f, "--pb", pbf, "--rbi", pbf, "--rbb", "8",
+                           "--rbl", "0", "--rbu", "1", "--bt", "0.2", "0.5", "0.8", "-l", "1", "--medf", "1", "-b", feat_f])
+    f_ref = O.Rag(labels).bc_feat(O.make_cfg(pb, rb=[(pb, 8, 0.0, 1.0)], use_log=True, median_as_feats=True), order)
+    got = np.array([[float(x) for x in ln.split(" ")[:-1]] for ln in open(feat_f).read().split("\n")[:-1]])
+    assert got.shape == f_ref.shape == (len(order), 112) and np.allclose(got, f_ref, rtol=6e-8, atol=1e-12)
 
 
 @pytest.mark.parametrize("relabel,w16", [(0, 0), (1, 1)])
