@@ -100,6 +100,11 @@ struct BcState {
   // list headers.  Region statistics, set extremes, entropies, pool_dir and the merge forest are stored write-through only.
   uint32_t* hctl;                // [kFlagReps * kFlagStride] job sequence number (never 0; 0xFFFFFFFF = quit), replicated: helper h polls copy h % kFlagReps
   unsigned long long* hjob;      // [kJobBufs][kJobWords] job descriptors, slot = sequence % kJobBufs
+  // Round 4: a job goes out in TWO parts.  Part 1 (hjob + hctl) as soon as the contraction's records are built -- the helpers stage
+  // rows and region statistics, form the shared sets and the entropies (S0-S3) while the loop's workgroup is still finding the top two
+  // of r2's extremes; part 2 (hjob2 + hctl2: those extremes and min / max of B(r2)) is what the vector assembly (S4) waits for.
+  uint32_t* hctl2;               // [kFlagReps * kFlagStride] sequence number of the newest job whose part 2 is out
+  unsigned long long* hjob2;     // [kJobBufs][kJob2Words] sequence | per channel: best_mn, best_mx, second_mn, second_mx, (Bmn | Bmx << 32) of r2
   unsigned long long* hvotes;    // [kJobMax] sequence << 32 | model << 24 | votes, indexed by the record's position in the job
   unsigned long long* hrec;      // [kJobMax][K][kRowWords] rows of the current job: e_A | e_NA | rs, own slot | table flag, fragile head
   unsigned long long* hadj;      // [2*R0] adj_off | adj_len << 32 for the helpers
@@ -586,7 +591,8 @@ constexpr uint32_t kJobMax = 1u << 14;    // records per job = slots of the vote
 constexpr uint32_t kRowWords = 32;        // 8-byte words of a record's row in hrec
 constexpr uint32_t kFlagReps = 16, kFlagStride = 64;     // copies of the job flag, 256 bytes apart: 255 pollers on ONE word queue up at its memory channel
 constexpr uint32_t kJobBufs = 4;          // job descriptors in flight (slot = sequence % kJobBufs; see bc_helper_loop)
-constexpr uint32_t kJobWords = 4 + 4 * kMaxChannels;
+constexpr uint32_t kJobWords = 4;          // ne0 | cnt << 32, r2 | newcount << 32, sequence, -
+constexpr uint32_t kJob2Words = 1 + 5 * kMaxChannels;
 constexpr uint32_t kHelpChunk = 8;        // records a helper scores per round (two fill one pass of a 255-tree forest)
 struct RecHdr { uint32_t rec, rs, own, on, fhead, off, len; int model; };
 struct BcShared {
@@ -602,6 +608,8 @@ struct BcShared {
   uint32_t nlog;                 // slots of the full vector that take a logarithm
   uint32_t lost;                 // a helper did not answer in time
   uint32_t job_seq, job_ne0, job_cnt, job_r2, job_newcount, job_ok;     // helper side: the job being worked on
+  uint32_t job2_ok;              // helper side: part 2 of the job has arrived (0 = gave up waiting)
+  float r2bm[kMaxChannels][2];   // helper side: min / max of B(r2) from part 2 (patched into every staged copy of r2)
   // loop side: what the contraction keeps of the region it creates (its statistics are stored write-through for the helpers;
   // reading them back would go to memory): histograms and counts of pts[r2] / Bt[r2], extremes of Bn[r2]
   uint32_t r2hist[kMaxChannels][2][GLIA_HMT_MAX_BINS]; uint32_t r2n[kMaxChannels][2]; float r2bn[kMaxChannels][2];
@@ -757,8 +765,9 @@ __device__ __forceinline__ void stage_regions(const BcState& st, const ScoreWs& 
 //   S2 shared boundary sets (one lane per record and channel) and the neighbours' "all but this record" extremes (16 lanes per
 //   record)   S3 entropies and histogram distances (one lane per bin)   S4 the vector, one of its four blocks per wave
 //   S5 logarithms, selection, model
-template <bool AG>
-__device__ __forceinline__ void score_chunk(const BcState& st, BcShared& s, const ScoreWs& W, uint32_t n, uint32_t newcount, bool prof = false) {
+// mid(): called by every thread between S3 and S4 (a helper waits there for part 2 of its job); returns false to abandon the round
+template <bool AG, class Mid>
+__device__ __forceinline__ bool score_chunk(const BcState& st, BcShared& s, const ScoreWs& W, uint32_t n, uint32_t newcount, Mid mid, bool prof = false) {
   const int tid = threadIdx.x;
   const int K = BC_K(st.cfg);
   const BcCfg& cf = st.cfg;
@@ -879,6 +888,7 @@ __device__ __forceinline__ void score_chunk(const BcState& st, BcShared& s, cons
   }
   __syncthreads();
   SPH(3);
+  if (!mid()) return false;
   // ---- S4 ----
   {
     // one block of the vector per wave: waves 4g..4g+3 write the four blocks of the records 64g..64g+63
@@ -919,6 +929,7 @@ __device__ __forceinline__ void score_chunk(const BcState& st, BcShared& s, cons
   }
   __syncthreads();
   SPH(5);
+  return true;
 }
 
 // the forest's votes for the n vectors of a scoring round into s.votes (every thread calls; ends with a barrier)
@@ -977,15 +988,11 @@ __device__ __forceinline__ void bc_helper_loop(const BcState& st, BcShared& s) {
     // in the same round trip, before the job's size is known: the rows of this helper's first records (waves 1..)
     stage_rows(st, W, cap, h, H, 0u, 0u, 64);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the descriptor has arrived before the flag is read again (all its lanes are in wave 0)
-    if (tid == 0) { s.job_ne0 = (uint32_t)wv; s.job_cnt = (uint32_t)(wv >> 32); }
+    if (tid == 0) { s.job_ne0 = (uint32_t)wv; s.job_cnt = (uint32_t)(wv >> 32); s.job2_ok = 0u; }
     if (tid == 1) { s.job_r2 = (uint32_t)wv; s.job_newcount = (uint32_t)(wv >> 32); }
     if (tid == 2) {
       const uint32_t f2 = ld_relaxed(&st.hctl[(h % kFlagReps) * kFlagStride]);
       s.job_ok = ((uint32_t)wv == v && f2 != 0xFFFFFFFFu && f2 - v < kJobBufs - 1u) ? 1u : 0u;
-    }
-    if ((uint32_t)tid >= 4u && (uint32_t)tid < kJobWords) {
-      const int c = (tid - 4) >> 2, q = (tid - 4) & 3;
-      (q == 0 ? s.best_mn : q == 1 ? s.best_mx : q == 2 ? s.second_mn : s.second_mx)[c] = wv;
     }
     __syncthreads();
     last = v;
@@ -1002,12 +1009,43 @@ __device__ __forceinline__ void bc_helper_loop(const BcState& st, BcShared& s) {
       SPH(0);
       stage_regions(st, W, n, r2);
       SPH(1);
+      // S4 needs part 2 of the job: the top two of r2's extremes and min / max of B(r2).  The first round waits for it (bounded), every
+      // round patches the staged copy of r2 with it.
+      auto mid = [&]() __attribute__((always_inline)) -> bool {
+        if (!s.job2_ok) {                                   // (uniform: written behind the barrier below)
+          if (tid == 0) {
+            uint32_t ok = 0u;
+            for (unsigned long long spins = 0; spins < kHelperSpinLimit; ++spins) {
+              const uint32_t f2 = ld_relaxed(&st.hctl2[(h % kFlagReps) * kFlagStride]);
+              if (f2 == v) { ok = 1u; break; }
+              if (ld_relaxed(&st.hctl[(h % kFlagReps) * kFlagStride]) == 0xFFFFFFFFu) break;      // the loop is over
+              __builtin_amdgcn_s_sleep(1);
+            }
+            s.job2_ok = ok;
+          }
+          __syncthreads();
+          if (!s.job2_ok) return false;
+          after_flag();
+          const unsigned long long* jb2 = st.hjob2 + (size_t)(v % kJobBufs) * kJob2Words;
+          if ((uint32_t)tid >= 1u && (uint32_t)tid < kJob2Words) {
+            const unsigned long long w2 = ld_agent(jb2 + tid);
+            const int c = (tid - 1) / 5, q = (tid - 1) % 5;
+            if (q == 4) { s.r2bm[c][0] = __uint_as_float((uint32_t)w2); s.r2bm[c][1] = __uint_as_float((uint32_t)(w2 >> 32)); }
+            else (q == 0 ? s.best_mn : q == 1 ? s.best_mx : q == 2 ? s.second_mn : s.second_mx)[c] = w2;
+          }
+          __syncthreads();
+        }
+        if (tid < BC_K(st.cfg)) { W.r2[tid].bmn = s.r2bm[tid][0]; W.r2[tid].bmx = s.r2bm[tid][1]; }
+        __syncthreads();
+        return true;
+      };
 #ifdef GLIA_HMT_PROFILE
-      score_chunk<true>(st, s, W, n, newcount, prof);
+      const bool went = score_chunk<true>(st, s, W, n, newcount, mid, prof);
       tsp = __builtin_readcyclecounter();
 #else
-      score_chunk<true>(st, s, W, n, newcount);
+      const bool went = score_chunk<true>(st, s, W, n, newcount, mid);
 #endif
+      if (!went) return;                                    // part 2 never came: the loop's workgroup notices the missing answers
       forest_chunk(st, s, W, n);
       SPH(7);
       if ((uint32_t)tid < n && W.hdr[tid].on)
@@ -1354,6 +1392,19 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState st)
     __syncthreads();
     PH(2);
     const uint32_t newcount = s.newcount;
+    const bool job = rows && newcount != 0u;
+    if (job) {
+      // Part 1 of the job -- records ne .. ne + newcount of region r2 -- goes out NOW: the helpers' first stages (rows, region
+      // statistics, shared sets, entropies) need nothing of the top-two pass below and run beside it.
+      hseq += 1u;
+      unsigned long long* jb = st.hjob + (size_t)(hseq % kJobBufs) * kJobWords;
+      if (tid == 0) st_agent(jb + 0, (unsigned long long)(uint32_t)ne | ((unsigned long long)newcount << 32));
+      if (tid == 1) st_agent(jb + 1, (unsigned long long)r2 | ((unsigned long long)newcount << 32));
+      if (tid == 2) st_agent(jb + 2, (unsigned long long)hseq);
+    }
+    stores_done();          // every wave: the records, rows and statistics of this contraction are acknowledged ...
+    __syncthreads();        // ... before the flag
+    if (job && (uint32_t)tid < kFlagReps) st_agent(&st.hctl[(uint32_t)tid * kFlagStride], hseq);
     // the last thread publishes r2's list header and boundary extremes after the pass below; it requests what it needs
     // from global memory now (Bn(r2) was written two barriers ago), not behind its own stores
     float pre_mn[kMaxChannels], pre_mx[kMaxChannels];
@@ -1409,31 +1460,31 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState st)
       st_agent(&st.hadj[r2], (unsigned long long)r2off | ((unsigned long long)newcount << 32));
 #pragma unroll
       for (int c = 0; c < kMaxChannels; ++c)
-        if (c < K) { float mn, mx; r2_extremes_of(s, newcount, c, kNone, pre_mn[c], pre_mx[c], mn, mx); st_agent(&chan_of(st, c).Bmn[r2], mn); st_agent(&chan_of(st, c).Bmx[r2], mx); }
+        if (c < K) {
+          float mn, mx;
+          r2_extremes_of(s, newcount, c, kNone, pre_mn[c], pre_mx[c], mn, mx);
+          st_agent(&chan_of(st, c).Bmn[r2], mn); st_agent(&chan_of(st, c).Bmx[r2], mx);
+          if (job) st_agent(st.hjob2 + (size_t)(hseq % kJobBufs) * kJob2Words + 1 + 5 * c + 4, (unsigned long long)__float_as_uint(mn) | ((unsigned long long)__float_as_uint(mx) << 32));
+        }
     }
-    const bool job = rows && newcount != 0u;
     if (job) {
-      // the job's descriptor goes out with the contraction's other stores: one drain for both
-      hseq += 1u;
-      unsigned long long* jb = st.hjob + (size_t)(hseq % kJobBufs) * kJobWords;
-      if ((uint32_t)tid < kJobWords) {
-        unsigned long long w = 0;
-        if (tid == 0) w = (unsigned long long)(uint32_t)ne | ((unsigned long long)newcount << 32);
-        else if (tid == 1) w = (unsigned long long)r2 | ((unsigned long long)newcount << 32);
-        else if (tid == 2) w = (unsigned long long)hseq;
-        else if (tid >= 4) { const int c = (tid - 4) >> 2, q = (tid - 4) & 3; w = (q == 0 ? s.best_mn : q == 1 ? s.best_mx : q == 2 ? s.second_mn : s.second_mx)[c]; }
-        st_agent(jb + tid, w);
+      // part 2 of the job: what the vector assembly needs of the top-two pass (the other words went out before it)
+      unsigned long long* jb2 = st.hjob2 + (size_t)(hseq % kJobBufs) * kJob2Words;
+      if (tid == 0) st_agent(jb2, (unsigned long long)hseq);
+      if ((uint32_t)tid >= 1u && (uint32_t)tid < kJob2Words) {
+        const int c = (tid - 1) / 5, q = (tid - 1) % 5;
+        if (q < 4 && c < K) st_agent(jb2 + tid, (q == 0 ? s.best_mn : q == 1 ? s.best_mx : q == 2 ? s.second_mn : s.second_mx)[c]);
       }
     }
     PH(3);
-    stores_done();          // every wave: what this contraction wrote is acknowledged ...
+    stores_done();          // every wave: what this contraction wrote since part 1 is acknowledged ...
     __syncthreads();        // ... before anybody (this workgroup's staging pass, a helper after the flag) reads it
+    if (job && (uint32_t)tid < kFlagReps) st_agent(&st.hctl2[(uint32_t)tid * kFlagStride], hseq);
 
     PH(8);
     // ---- score the new table edges ----
     if (job) {
       // Helper workgroups score whole records (at most kJobMax: larger contractions take the branch below).
-      if ((uint32_t)tid < kFlagReps) st_agent(&st.hctl[(uint32_t)tid * kFlagStride], hseq);
       PH(5);
       // while the helpers work: the priority tree is brought up to date for the removals of this contraction
       pq_propagate<kBcThreads>(st.pq, s.pq, tid);
@@ -1478,7 +1529,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState st)
         if ((uint32_t)tid < cn) W.hdr[tid].rec = (uint32_t)ne + c0 + (uint32_t)tid;
         __syncthreads();
         stage_local(st, W, cn, r2);
-        score_chunk<false>(st, s, W, cn, newcount);
+        (void)score_chunk<false>(st, s, W, cn, newcount, []() { return true; });
         PH(4);
         if (st.clf.kind == 0) forest_chunk(st, s, W, cn);
         PH(5);
@@ -1661,6 +1712,8 @@ int GLIA_BC_ENTRY(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier
   if ((rc = buf.get(&st.hrec, (size_t)kJobMax * cfg.K * kRowWords, false, stream))) return rc;
   if ((rc = buf.get(&st.hadj, R2, true, stream))) return rc;
   if ((rc = buf.get(&st.hjob, (size_t)kJobBufs * kJobWords, true, stream))) return rc;
+  if ((rc = buf.get(&st.hctl2, (size_t)kFlagReps * kFlagStride, true, stream))) return rc;
+  if ((rc = buf.get(&st.hjob2, (size_t)kJobBufs * kJob2Words, true, stream))) return rc;
   if ((rc = buf.get(&st.hvotes, kJobMax, true, stream))) return rc;
   {
     // helper workgroups that score whole records (only a real forest in a scoring run needs them): one per compute unit
@@ -1740,6 +1793,8 @@ int GLIA_BC_ENTRY(const RagArrays& rag, const BcCfg& cfg, const DeviceClassifier
   while (true) {
     GLIA_HIP_TRY(hipMemsetAsync(st.hctl, 0, (size_t)kFlagReps * kFlagStride * sizeof(uint32_t), stream));
     GLIA_HIP_TRY(hipMemsetAsync(st.hjob, 0, (size_t)kJobBufs * kJobWords * sizeof(unsigned long long), stream));
+    GLIA_HIP_TRY(hipMemsetAsync(st.hctl2, 0, (size_t)kFlagReps * kFlagStride * sizeof(uint32_t), stream));
+    GLIA_HIP_TRY(hipMemsetAsync(st.hjob2, 0, (size_t)kJobBufs * kJob2Words * sizeof(unsigned long long), stream));
     GLIA_HIP_TRY(hipMemsetAsync(st.hvotes, 0, (size_t)kJobMax * sizeof(unsigned long long), stream));
     hipLaunchKernelGGL(greedy_bc_kernel, dim3(1 + st.n_helpers), dim3(kBcThreads), 0, stream, st);
     GLIA_HIP_TRY(hipGetLastError());
