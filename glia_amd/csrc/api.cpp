@@ -796,22 +796,22 @@ static int upload_forest(const HostForest& hf, glia_hmt_forest* f, int slot, hip
   f->allocs.push_back(d_roots);
   GLIA_HIP_TRY(hipMemcpyAsync(d_nodes, nodes.data(), sizeof(PackedNode) * nodes.size(), hipMemcpyHostToDevice, stream));
   GLIA_HIP_TRY(hipMemcpyAsync(d_roots, roots.data(), sizeof(int) * roots.size(), hipMemcpyHostToDevice, stream));
-  std::vector<PackedPair> lines;
+  std::vector<PackedTriple> lines;
   std::vector<int> proots;
-  rc = pack_forest_pairs(hf, &lines, &proots);
+  rc = pack_forest_triples(hf, &lines, &proots);
   if (rc) return rc;
-  PackedPair* d_lines = nullptr;
+  PackedTriple* d_lines = nullptr;
   int* d_proots = nullptr;
-  GLIA_HIP_TRY(hipMalloc(&d_lines, sizeof(PackedPair) * lines.size()));
+  GLIA_HIP_TRY(hipMalloc(&d_lines, sizeof(PackedTriple) * lines.size()));
   f->allocs.push_back(d_lines);
   GLIA_HIP_TRY(hipMalloc(&d_proots, sizeof(int) * proots.size()));
   f->allocs.push_back(d_proots);
-  GLIA_HIP_TRY(hipMemcpyAsync(d_lines, lines.data(), sizeof(PackedPair) * lines.size(), hipMemcpyHostToDevice, stream));
+  GLIA_HIP_TRY(hipMemcpyAsync(d_lines, lines.data(), sizeof(PackedTriple) * lines.size(), hipMemcpyHostToDevice, stream));
   GLIA_HIP_TRY(hipMemcpyAsync(d_proots, proots.data(), sizeof(int) * proots.size(), hipMemcpyHostToDevice, stream));
   GLIA_HIP_TRY(hipStreamSynchronize(stream));
   f->dc.f[slot].ntree = hf.ntree; f->dc.f[slot].nrnodes = hf.nrnodes; f->dc.f[slot].nnodes = (int)nodes.size();
   f->dc.f[slot].nodes = d_nodes; f->dc.f[slot].root = d_roots;
-  f->dc.f[slot].pairs = d_lines; f->dc.f[slot].proot = d_proots;
+  f->dc.f[slot].triples = d_lines; f->dc.f[slot].troot = d_proots;
   if (hf.max_var > f->max_var) f->max_var = hf.max_var;
   return GLIA_HMT_OK;
 }

@@ -242,31 +242,38 @@ __host__ __device__ inline int pre_region(const BcCfg& c, int kind, int i) { ret
 __host__ __device__ inline int pre_boundary(const BcCfg& c, int i) { return 5 * (BC_NR(c) + BC_NL(c)) + 4 * i; }
 __host__ __device__ inline int pre_count(const BcCfg& c) { return 5 * (BC_NR(c) + BC_NL(c)) + 4 * BC_NB(c); }
 
+// half: 0 = the whole block; 1 = its first 4 + D columns (area, perimeter, compactness, bounding box); 2 = the rest (thresholded
+// counts and the image lists) -- the greedy loop's helpers give the halves of a block to two waves (two chains of divisions of about
+// equal length)
 template <class Src>
-__device__ __forceinline__ void region_feats_multi(const BcCfg& c, const ShapeIn& r, Src src, double* out, double& area_o, double& perim_o) {
+__device__ __forceinline__ void region_feats_multi(const BcCfg& c, const ShapeIn& r, Src src, double* out, double& area_o, double& perim_o,
+                                                   int half = 0) {
   const int D = c.D, T = c.T;
-  double area = (double)r.n;
-  double perim = (double)((unsigned long long)r.bn + (unsigned long long)r.border);
-  const double compactness = sdiv(pow_perim(perim, D, c.libm_pow), area, 0.0);
-  area = sdiv(area, c.norm_area, 0.0);
-  perim = sdiv(perim, c.norm_len, 0.0);
-  double bboxArea = 1.0;
-  int k = 4;
+  int k = 4 + D;
+  if (half != 2) {
+    double area = (double)r.n;
+    double perim = (double)((unsigned long long)r.bn + (unsigned long long)r.border);
+    const double compactness = sdiv(pow_perim(perim, D, c.libm_pow), area, 0.0);
+    area = sdiv(area, c.norm_area, 0.0);
+    perim = sdiv(perim, c.norm_len, 0.0);
+    double bboxArea = 1.0;
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    if (i < D) {
-      const double bb = (double)(unsigned long long)(r.hi[i] - r.lo[i]);
-      out[k++] = sdiv(bb, c.norm_len, 0.0);
-      bboxArea *= bb;
+    for (int i = 0; i < 3; ++i) {
+      if (i < D) {
+        const double bb = (double)(unsigned long long)(r.hi[i] - r.lo[i]);
+        out[4 + i] = sdiv(bb, c.norm_len, 0.0);
+        bboxArea *= bb;
+      }
     }
+    out[0] = area; out[1] = perim; out[2] = compactness; out[3] = sdiv(bboxArea, c.norm_area, 0.0);
+    area_o = area; perim_o = perim;
   }
-  out[0] = area; out[1] = perim; out[2] = compactness; out[3] = sdiv(bboxArea, c.norm_area, 0.0);
+  if (half == 1) return;
 #pragma unroll
   for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) if (i < T) out[k + i] = sdiv((double)r.thr[i], c.norm_len, 0.0);
 #pragma unroll
   for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) if (i < T) out[k + T + i] = sdiv((double)r.thr[i], (double)r.bn, 0.0);
   k += 2 * T;
-  area_o = area; perim_o = perim;
   for (int i = 0; i < BC_NR(c); ++i) {
     const ImgSrc s = src(0, i);
     const ImgFeats f = image_feats_src(s, c.cbins[c.rc[i]], c.libm_log2);
@@ -288,27 +295,34 @@ __device__ __forceinline__ void region_feats_multi(const BcCfg& c, const ShapeIn
 
 // shn / shthr: voxel and thresholded counts of the shared boundary; src0 / src1: the area-ordered regions (kinds 0, 1);
 // srcSh(i): the shared boundary on boundary-list image i; pre: precomputed distances (see pre_region) or null
+// half: 0 = the whole block; 1 = the area / perimeter / length columns and the image lists; 2 = the 4 T thresholded-length columns
 template <class Src0, class Src1, class SrcSh>
 __device__ __forceinline__ void boundary_feats_multi(const BcCfg& c, uint32_t shn, const uint32_t* shthr, double a0area, double a0perim,
                                                      double a1area, double a1perim, Src0 src0, Src1 src1, SrcSh srcSh, const double* pre,
-                                                     double* out) {
+                                                     double* out, int half = 0) {
   const int T = c.T;
   int k = 0;
-  const double areaDiff = fabs(a0area - a1area);
-  out[k++] = areaDiff; out[k++] = sdiv(areaDiff, a0area, 0.0); out[k++] = sdiv(areaDiff, a1area, 0.0);
-  const double perimDiff = fabs(a0perim - a1perim);
-  out[k++] = perimDiff; out[k++] = sdiv(perimDiff, a0perim, 0.0); out[k++] = sdiv(perimDiff, a1perim, 0.0);
   const double bl = sdiv(ceil(shn / 2.0), c.norm_len, 0.0);
-  out[k++] = bl; out[k++] = sdiv(bl, a0area, 0.0); out[k++] = sdiv(bl, a1area, 0.0);
-  out[k++] = sdiv(bl, a0perim, 0.0); out[k++] = sdiv(bl, a1perim, 0.0);
+  if (half != 2) {
+    const double areaDiff = fabs(a0area - a1area);
+    out[k++] = areaDiff; out[k++] = sdiv(areaDiff, a0area, 0.0); out[k++] = sdiv(areaDiff, a1area, 0.0);
+    const double perimDiff = fabs(a0perim - a1perim);
+    out[k++] = perimDiff; out[k++] = sdiv(perimDiff, a0perim, 0.0); out[k++] = sdiv(perimDiff, a1perim, 0.0);
+    out[k++] = bl; out[k++] = sdiv(bl, a0area, 0.0); out[k++] = sdiv(bl, a1area, 0.0);
+    out[k++] = sdiv(bl, a0perim, 0.0); out[k++] = sdiv(bl, a1perim, 0.0);
+  }
+  k = 11;
+  if (half != 1) {
 #pragma unroll
-  for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) {
-    if (i < T) {
-      const double vbl = sdiv(ceil(shthr[i] / 2.0), c.norm_len, 0.0);
-      out[k + i] = vbl; out[k + T + i] = sdiv(vbl, bl, 0.0);
-      out[k + 2 * T + i] = sdiv(vbl, a0perim, 0.0); out[k + 3 * T + i] = sdiv(vbl, a1perim, 0.0);
+    for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) {
+      if (i < T) {
+        const double vbl = sdiv(ceil(shthr[i] / 2.0), c.norm_len, 0.0);
+        out[k + i] = vbl; out[k + T + i] = sdiv(vbl, bl, 0.0);
+        out[k + 2 * T + i] = sdiv(vbl, a0perim, 0.0); out[k + 3 * T + i] = sdiv(vbl, a1perim, 0.0);
+      }
     }
   }
+  if (half == 2) return;
   k += 4 * T;
   for (int kind = 0; kind < 2; ++kind) {
     const int cnt = kind ? BC_NL(c) : BC_NR(c);

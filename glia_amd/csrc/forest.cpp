@@ -180,43 +180,35 @@ int pack_forest(const HostForest& hf, std::vector<PackedNode>* nodes, std::vecto
   return GLIA_HMT_OK;
 }
 
-// two levels per 64-byte line (forest.hpp): breadth-first over the nodes of even depth
-int pack_forest_pairs(const HostForest& hf, std::vector<PackedPair>* lines, std::vector<int>* roots) {
+// three levels per 128-byte line (forest.hpp): breadth-first over the nodes of depth 0 mod 3
+int pack_forest_triples(const HostForest& hf, std::vector<PackedTriple>* lines, std::vector<int>* roots) {
   lines->clear();
   roots->assign(hf.ntree, 0);
+  if (hf.max_var > 32767) { set_error("forest: feature index beyond 32767"); return GLIA_HMT_ERR_UNSUPPORTED; }
   std::vector<int> queue;          // original node index of the line with the same position (relative to the tree's first line)
-  auto plain = [&](size_t base, int k) {
-    PackedNode n;
-    const int* m = &hf.meta[(base + k) * 4];
-    n.split = hf.split[base + k];
-    if (m[3] >= 0) { n.var = -1 - m[3]; n.left = 0; } else { n.var = m[0]; n.left = 0; }
-    return n;
-  };
   for (int j = 0; j < hf.ntree; ++j) {
     const size_t base = (size_t)j * hf.nrnodes;
     const int first = (int)lines->size();
     (*roots)[j] = first;
     queue.assign(1, 0);
-    lines->push_back(PackedPair());
+    lines->push_back(PackedTriple());
     for (size_t q = 0; q < queue.size(); ++q) {
       if ((int)queue.size() > hf.nrnodes) { set_error("forest: tree has a cycle"); return GLIA_HMT_ERR_IO; }
-      const int k = queue[q];
-      const int* m = &hf.meta[(base + k) * 4];
-      PackedPair L;
+      PackedTriple L;
       memset(&L, 0, sizeof(L));
-      L.n[0] = plain(base, k);
-      L.n[1] = L.n[0]; L.n[2] = L.n[0];
-      if (m[3] < 0) {
-        for (int side = 0; side < 2; ++side) {
-          const int c = m[1 + side];
-          PackedNode cn = plain(base, c);
-          const int* cm = &hf.meta[(base + c) * 4];
-          if (cm[3] < 0) {                       // internal daughter: the lines of its two daughters follow each other
-            cn.left = (int)lines->size();
-            queue.push_back(cm[1]); queue.push_back(cm[2]);
-            lines->push_back(PackedPair()); lines->push_back(PackedPair());
-          }
-          L.n[1 + side] = cn;
+      int orig[7] = {queue[q], -1, -1, -1, -1, -1, -1};      // original node in each slot (-1: below a terminal node)
+      for (int slot = 0; slot < 7; ++slot) {
+        const int k = orig[slot];
+        if (k < 0) continue;
+        const int* m = &hf.meta[(base + k) * 4];
+        L.split[slot] = hf.split[base + k];
+        if (m[3] >= 0) { L.var[slot] = (short)(-1 - m[3]); continue; }
+        L.var[slot] = (short)m[0];
+        if (slot < 3) { orig[2 * slot + 1] = m[1]; orig[2 * slot + 2] = m[2]; }
+        else {                                                // internal node of the line's last level: its daughters get lines of their own
+          L.next[slot - 3] = (int)lines->size();
+          queue.push_back(m[1]); queue.push_back(m[2]);
+          lines->push_back(PackedTriple()); lines->push_back(PackedTriple());
         }
       }
       (*lines)[first + q] = L;

@@ -18,24 +18,29 @@ struct PackedNode {
   int var;       // >= 0: internal node, feature index;  < 0: terminal, vote = -1 - var
   int left;      // index of the left daughter in the packed array (absolute)
 };
-// The same trees for LATENCY-bound walks (one vector, one tree per lane: the classifier loop's helpers): a node of even depth
-// together with its two daughters in one 64-byte line, so that one trip to the L2 decides two levels.  A daughter's `left`
-// is the index of the line of ITS left daughter (the right one follows it).
-struct PackedPair {
-  PackedNode n[3];             // the node, its left daughter, its right daughter (daughters unused below a terminal node)
-  int pad[4];
+// The same trees for LATENCY-bound walks (one vector, one tree per lane: the classifier loop's helpers; the forest of a large volume
+// does not fit the L2 and every trip goes to the memory-side cache): a node of depth 0 mod 3 together with its daughters and
+// grand-daughters in one 128-byte line (the L2's line size), so that one trip decides three levels.
+//   node 0 = the line's own node; 1, 2 = its left / right daughter; 3, 4 = the daughters of 1; 5, 6 = the daughters of 2
+// var >= 0: internal node (feature index); var < 0: terminal, vote = -1 - var; slots below a terminal node hold var = 0, split = 0
+// (never looked at by a walk).  next[i]: for an internal node 3 + i, the line of ITS left daughter (the right one follows it).
+struct alignas(128) PackedTriple {
+  double split[7];
+  short var[8];
+  int next[4];
+  int pad[10];
 };
-static_assert(sizeof(PackedPair) == 64, "one cache line per pair of levels");
+static_assert(sizeof(PackedTriple) == 128, "one L2 line per three levels");
 struct DeviceForest {
   int ntree, nrnodes;          // nrnodes: depth bound for the walk
   int nnodes;                  // packed nodes of all trees
   const PackedNode* nodes;
   const int* root;             // [ntree] index of each tree's root
-  const PackedPair* pairs;     // two levels per line
-  const int* proot;            // [ntree] line of each tree's root
+  const PackedTriple* triples; // three levels per line
+  const int* troot;            // [ntree] line of each tree's root
 };
 int pack_forest(const HostForest& hf, std::vector<PackedNode>* nodes, std::vector<int>* roots);
-int pack_forest_pairs(const HostForest& hf, std::vector<PackedPair>* lines, std::vector<int>* roots);
+int pack_forest_triples(const HostForest& hf, std::vector<PackedTriple>* lines, std::vector<int>* roots);
 
 // What fBcPred evaluates (hmt/main_merge_order_bc.cxx:127-137): one forest, or three forests behind a
 // ThresholdModelDistributor (type/function.hxx:71-85), or -- diagnostics only -- 1 - x[index].

@@ -283,10 +283,11 @@ struct StagedView {
 // ex: per channel {min, max of first's boundary set without the record's mutual entries, the same for second};
 // pre (optional): values of the lane-parallel pass (feat::pre_region / pre_boundary)
 // parts: which blocks to write (1 first region, 2 second region, 4 merged region, 8 boundary block) -- the greedy loop
-// gives each block to a different wave; finish: apply the log / simple selection (the loop does both lane-parallel)
+// gives each block to a different wave, and with few records each HALF of a block (half = 1 / 2, bc_features.hpp; 0 = whole
+// blocks); finish: apply the log / simple selection (the loop does both lane-parallel)
 template <class V>
 __device__ __forceinline__ void edge_features(const BcCfg& c, const V& v, const float* ex, double* out, const double* pre = nullptr, int parts = 15,
-                                              bool finish = true) {
+                                              bool finish = true, int half = 0) {
   const PStats* P0 = v.P0(0);
   const PStats* P1 = v.P1(0);
   const EStats* B0 = v.B0(0);
@@ -335,14 +336,14 @@ __device__ __forceinline__ void edge_features(const BcCfg& c, const V& v, const 
     r.n = n0; r.border = P0->border; r.bn = B0->n;
     for (int i = 0; i < 3; ++i) { r.lo[i] = P0->lo[i]; r.hi[i] = P0->hi[i]; }
     for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) r.thr[i] = B0->thr[i];
-    feat::region_feats_multi(c, r, src_of(0), o_first, ar_first, pe_first);
+    feat::region_feats_multi(c, r, src_of(0), o_first, ar_first, pe_first, half);
   }
   if (parts & 2) {
     feat::ShapeIn r;
     r.n = n1; r.border = P1->border; r.bn = B1->n;
     for (int i = 0; i < 3; ++i) { r.lo[i] = P1->lo[i]; r.hi[i] = P1->hi[i]; }
     for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) r.thr[i] = B1->thr[i];
-    feat::region_feats_multi(c, r, src_of(1), o_second, ar_second, pe_second);
+    feat::region_feats_multi(c, r, src_of(1), o_second, ar_second, pe_second, half);
   }
   if (parts & 4) {
     // the scratch-merged region (TRegionMap::merge under key 0)
@@ -352,7 +353,7 @@ __device__ __forceinline__ void edge_features(const BcCfg& c, const V& v, const 
     r.bn = B0->n + B1->n;
     for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) r.thr[i] = B0->thr[i] + B1->thr[i];
     if (A0) { r.bn -= A0->n; for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) r.thr[i] -= A0->thr[i]; }
-    feat::region_feats_multi(c, r, src_of(2), o_merged, ar_m, pe_m);
+    feat::region_feats_multi(c, r, src_of(2), o_merged, ar_m, pe_m, half);
   }
   if (parts & 8) {
     // shared boundary: counts from channel 0, image statistics from each boundary-list channel
@@ -361,8 +362,8 @@ __device__ __forceinline__ void edge_features(const BcCfg& c, const V& v, const 
       const EStats* sh = v.sh(c.bc[i]);
       return feat::ImgSrc{sh->hist, nullptr, nullptr, sh->n, sh->sum, sh->sq, sh->mn, sh->mx, pre ? pre + feat::pre_boundary(c, i) + 3 : nullptr};
     };
-    if (swap) feat::boundary_feats_multi(c, sh0->n, sh0->thr, ar_second, pe_second, ar_first, pe_first, src_of(1), src_of(0), srcSh, pre, o_bf);
-    else feat::boundary_feats_multi(c, sh0->n, sh0->thr, ar_first, pe_first, ar_second, pe_second, src_of(0), src_of(1), srcSh, pre, o_bf);
+    if (swap) feat::boundary_feats_multi(c, sh0->n, sh0->thr, ar_second, pe_second, ar_first, pe_first, src_of(1), src_of(0), srcSh, pre, o_bf, half);
+    else feat::boundary_feats_multi(c, sh0->n, sh0->thr, ar_first, pe_first, ar_second, pe_second, src_of(0), src_of(1), srcSh, pre, o_bf, half);
   }
   if (finish) feat::finish_features(c, out);
 }
@@ -383,21 +384,32 @@ __device__ __forceinline__ int forest_vote(const DeviceForest& f, int tree, cons
   }
   return 0;
 }
-// the same walk over the two-levels-per-line layout (forest.hpp): half the trips to the L2, for walks that wait on each of them
-__device__ __forceinline__ int forest_vote_pairs(const DeviceForest& f, int tree, const double* x) {
-  int k = f.proot[tree];
-  for (int step = 0; step < f.nrnodes; step += 2) {
-    const uint4* q = reinterpret_cast<const uint4*>(&f.pairs[k]);
-    const uint4 a = q[0], b = q[1], c = q[2];                       // one line, three 16-byte loads in flight together
-    const int var0 = (int)a.z;
-    if (var0 < 0) return -1 - var0;
-    const double s0 = __hiloint2double((int)a.y, (int)a.x);
-    const bool right = !(x[var0] <= s0);
-    const uint4 d = right ? c : b;
-    const int var1 = (int)d.z;
-    if (var1 < 0) return -1 - var1;
-    const double s1 = __hiloint2double((int)d.y, (int)d.x);
-    k = (int)d.w + ((x[var1] <= s1) ? 0 : 1);
+// The walk over the three-levels-per-line layout (forest.hpp): a third of the trips to the L2 / memory-side cache, for walks that
+// wait on each of them.  The line's seven feature values are requested from LDS together (slots below a terminal node name
+// feature 0), so that a line costs one LDS round trip, not one per level.
+__device__ __forceinline__ int forest_vote_triples(const DeviceForest& f, int tree, const double* x) {
+  int k = f.troot[tree];
+  for (int step = 0; step < f.nrnodes; step += 3) {        // bounded: a malformed tree cannot hang the device
+    const uint4* q = reinterpret_cast<const uint4*>(&f.triples[k]);
+    const uint4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], g = q[5];      // 96 of the line's bytes, six loads in flight together
+    const int v0 = (int)(short)(d.z & 0xFFFFu), v1 = (int)(short)(d.z >> 16), v2 = (int)(short)(d.w & 0xFFFFu), v3 = (int)(short)(d.w >> 16);
+    const int v4 = (int)(short)(e.x & 0xFFFFu), v5 = (int)(short)(e.x >> 16), v6 = (int)(short)(e.y & 0xFFFFu);
+    if (v0 < 0) return -1 - v0;
+    const double x0 = x[v0], x1 = x[v1 < 0 ? 0 : v1], x2 = x[v2 < 0 ? 0 : v2], x3 = x[v3 < 0 ? 0 : v3], x4 = x[v4 < 0 ? 0 : v4],
+                 x5 = x[v5 < 0 ? 0 : v5], x6 = x[v6 < 0 ? 0 : v6];
+    const double s0 = __hiloint2double((int)a.y, (int)a.x), s1 = __hiloint2double((int)a.w, (int)a.z);
+    const double s2 = __hiloint2double((int)b.y, (int)b.x), s3 = __hiloint2double((int)b.w, (int)b.z);
+    const double s4 = __hiloint2double((int)c.y, (int)c.x), s5 = __hiloint2double((int)c.w, (int)c.z);
+    const double s6 = __hiloint2double((int)d.y, (int)d.x);
+    const bool r0 = !(x0 <= s0);                            // left iff x[var] <= split
+    const int va = r0 ? v2 : v1;
+    if (va < 0) return -1 - va;
+    const bool r1 = !((r0 ? x2 : x1) <= (r0 ? s2 : s1));
+    const int vb = r0 ? (r1 ? v6 : v5) : (r1 ? v4 : v3);
+    if (vb < 0) return -1 - vb;
+    const double xb = r0 ? (r1 ? x6 : x5) : (r1 ? x4 : x3), sb = r0 ? (r1 ? s6 : s5) : (r1 ? s4 : s3);
+    const int nx = r0 ? (r1 ? (int)g.y : (int)g.x) : (r1 ? (int)e.w : (int)e.z);
+    k = nx + ((xb <= sb) ? 0 : 1);
   }
   return 0;
 }
@@ -891,9 +903,12 @@ __device__ __forceinline__ bool score_chunk(const BcState& st, BcShared& s, cons
   if (!mid()) return false;
   // ---- S4 ----
   {
-    // one block of the vector per wave: waves 4g..4g+3 write the four blocks of the records 64g..64g+63
+    // one block of the vector per wave: waves 4g..4g+3 write the four blocks of the records 64g..64g+63 -- or, with at most 64
+    // records (every helper round), one HALF of a block per wave: a vector is one lane's serial chain of divisions, and a helper
+    // usually has one record
     const int wave = tid >> 6, part = wave & 3;
-    const uint32_t slot = (uint32_t)(wave >> 2) * 64u + (uint32_t)(tid & 63);
+    const bool halves = n <= 64u;
+    const uint32_t slot = halves ? (uint32_t)(tid & 63) : (uint32_t)(wave >> 2) * 64u + (uint32_t)(tid & 63);
     if (slot < n && W.hdr[slot].on) {
       const uint32_t rec = W.hdr[slot].rec;
       const RecIn* in = &W.in[slot * K];
@@ -905,7 +920,8 @@ __device__ __forceinline__ bool score_chunk(const BcState& st, BcShared& s, cons
         ex[4 * c + 0] = a; ex[4 * c + 1] = b; ex[4 * c + 2] = cm; ex[4 * c + 3] = dm;
       }
       const StagedView v{in, W.r2};
-      edge_features(cf, v, ex, &W.feat[slot * W.fstride], W.fx + (size_t)slot * W.npre, 1 << part, false);   // updateFb passes (rs, r2)
+      edge_features(cf, v, ex, &W.feat[slot * W.fstride], W.fx + (size_t)slot * W.npre, 1 << part, false,      // updateFb passes (rs, r2)
+                    halves ? 1 + (wave >> 2) : 0);
     }
   }
   __syncthreads();
@@ -943,7 +959,7 @@ __device__ __forceinline__ void forest_chunk(const BcState& st, BcShared& s, con
     const uint32_t j = i / (uint32_t)ntree, t = i % (uint32_t)ntree;
     const int m = W.hdr[j].model;
     if (m < 0 || (int)t >= st.clf.f[m].ntree) continue;
-    if (forest_vote_pairs(st.clf.f[m], (int)t, &W.feat[j * W.fstride])) atomicAdd(&s.votes[j], 1);
+    if (forest_vote_triples(st.clf.f[m], (int)t, &W.feat[j * W.fstride])) atomicAdd(&s.votes[j], 1);
   }
   __syncthreads();
 }
@@ -955,7 +971,12 @@ __device__ __forceinline__ void forest_chunk(const BcState& st, BcShared& s, con
 // not publish v + 1 before it has every answer of v.
 __device__ __forceinline__ void bc_helper_loop(const BcState& st, BcShared& s) {
   const int tid = threadIdx.x;
-  const uint32_t H = gridDim.x - 1u, h = blockIdx.x - 1u;
+  // helper number: workgroups go to the eight XCDs round-robin, the loop's own (0) to the first -- the workgroups 8, 16, ... share
+  // its L2 and get the lowest numbers (a job's records go to the helpers 0, 1, ...)
+  // (Measured: keeping a job WITH those 31 -- two to four records each, every stage is lane-parallel over the records -- is slower
+  // than dealing it out across the XCDs one record per helper.)
+  const uint32_t H = gridDim.x - 1u, b = blockIdx.x;
+  const uint32_t h = (b & 7u) == 0u ? (b >> 3) - 1u : (H >> 3) + (b - 1u - (b >> 3));
   uint32_t used = 0;
   const ScoreWs W = ws_layout(st.cfg, s.pool, kHelpChunk, &used);
   const uint32_t cap = W.cap;
@@ -1374,7 +1395,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState st)
       st.pq.leaf_sal[newE] = -__builtin_inf();
       st.pool[offRs + posRs] = newE;
       st.pool[r2off + idx] = newE;
-      st.e_posv[newE] = idx | (cat << 30);
+      st.e_posv[newE] = (rows && idx < ldsCap) ? idx : (idx | (cat << 30));      // (the helper route reads the category from smeta)
     }
     // r2's own histogram entropies (BcChan::entP / entB), worked out once -- every new record needs them -- by the last wave,
     // which like most of the workgroup has little to do in this phase: one lane per bin, 16 lanes per (channel, set)
@@ -1545,7 +1566,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState st)
         __syncthreads();
       }
     }
-    for (uint32_t j = tid; j < newcount; j += kBcThreads) st.e_posv[(uint32_t)ne + j] &= 0x3FFFFFFFu;
+    for (uint32_t j = (rows ? ldsCap : 0u) + (uint32_t)tid; j < newcount; j += kBcThreads) st.e_posv[(uint32_t)ne + j] &= 0x3FFFFFFFu;
     PH(3);
     // the tree is brought up to date here unless the records just inserted can wait for the next contraction's helper round
     // (their best is s.cand; the next pop looks at it)
