@@ -1009,7 +1009,7 @@ __device__ __forceinline__ void bc_helper_loop(const BcState& st, BcShared& s) {
     // in the same round trip, before the job's size is known: the rows of this helper's first records (waves 1..)
     stage_rows(st, W, cap, h, H, 0u, 0u, 64);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the descriptor has arrived before the flag is read again (all its lanes are in wave 0)
-    if (tid == 0) { s.job_ne0 = (uint32_t)wv; s.job_cnt = (uint32_t)(wv >> 32); s.job2_ok = 0u; }
+    if (tid == 0) { s.job_ne0 = (uint32_t)wv; s.job_cnt = (uint32_t)(wv >> 32); }
     if (tid == 1) { s.job_r2 = (uint32_t)wv; s.job_newcount = (uint32_t)(wv >> 32); }
     if (tid == 2) {
       const uint32_t f2 = ld_relaxed(&st.hctl[(h % kFlagReps) * kFlagStride]);
@@ -1022,6 +1022,9 @@ __device__ __forceinline__ void bc_helper_loop(const BcState& st, BcShared& s) {
     const uint32_t cnt = s.job_cnt, ne0 = s.job_ne0, r2 = s.job_r2, newcount = s.job_newcount;
     if (h >= cnt) continue;
     const uint32_t m = (cnt - h + H - 1u) / H;          // records at the job's positions h, h + H, ...
+    bool got2 = false;                                  // part 2 of this job is in LDS (a register, the same in every thread: an LDS
+                                                        // flag read here and rewritten below without a barrier in between would let a
+                                                        // late wave skip the barriers the early ones wait at)
     for (uint32_t i0 = 0; i0 < m; i0 += cap) {
       const uint32_t n = m - i0 < cap ? m - i0 : cap;
       if (i0) { stage_rows(st, W, n, h, H, i0, 0u, 0); __syncthreads(); }
@@ -1033,7 +1036,7 @@ __device__ __forceinline__ void bc_helper_loop(const BcState& st, BcShared& s) {
       // S4 needs part 2 of the job: the top two of r2's extremes and min / max of B(r2).  The first round waits for it (bounded), every
       // round patches the staged copy of r2 with it.
       auto mid = [&]() __attribute__((always_inline)) -> bool {
-        if (!s.job2_ok) {                                   // (uniform: written behind the barrier below)
+        if (!got2) {
           if (tid == 0) {
             uint32_t ok = 0u;
             for (unsigned long long spins = 0; spins < kHelperSpinLimit; ++spins) {
@@ -1045,7 +1048,7 @@ __device__ __forceinline__ void bc_helper_loop(const BcState& st, BcShared& s) {
             s.job2_ok = ok;
           }
           __syncthreads();
-          if (!s.job2_ok) return false;
+          if (!s.job2_ok) return false;                      // (read by every thread behind the barrier; rewritten by the next job's wait, barriers later)
           after_flag();
           const unsigned long long* jb2 = st.hjob2 + (size_t)(v % kJobBufs) * kJob2Words;
           if ((uint32_t)tid >= 1u && (uint32_t)tid < kJob2Words) {
@@ -1055,6 +1058,7 @@ __device__ __forceinline__ void bc_helper_loop(const BcState& st, BcShared& s) {
             else (q == 0 ? s.best_mn : q == 1 ? s.best_mx : q == 2 ? s.second_mn : s.second_mx)[c] = w2;
           }
           __syncthreads();
+          got2 = true;
         }
         if (tid < BC_K(st.cfg)) { W.r2[tid].bmn = s.r2bm[tid][0]; W.r2[tid].bmx = s.r2bm[tid][1]; }
         __syncthreads();
