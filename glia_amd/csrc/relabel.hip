@@ -195,6 +195,13 @@ int transform_image(uint32_t* d_lab, int64_t n, const uint32_t* h_src, const uin
   }
   hipEvent_t e0, e1;
   GLIA_HIP_TRY(hipEventCreate(&e0)); GLIA_HIP_TRY(hipEventCreate(&e1));
+  // The first launch of a kernel of this translation unit loads its code object (this file's holds rocPRIM's sorts since the sparse
+  // relabelling path of round 3: several milliseconds) -- on the host, between the two events.  Asking for the kernel's attributes loads it
+  // here, so that the reported time is the kernel's (round 3's closing set reported 12.0 ms for a 4 ms kernel; tools/transform_bench.py).
+  {
+    hipFuncAttributes fa;
+    (void)hipFuncGetAttributes(&fa, dense ? reinterpret_cast<const void*>(&transform_kernel<true>) : reinterpret_cast<const void*>(&transform_kernel<false>));
+  }
   const long long threads = (n + 3) / 4;
   const unsigned blocks = (unsigned)((threads + 255) / 256);
   GLIA_HIP_TRY(hipEventRecord(e0, stream));

@@ -89,6 +89,34 @@ def _forest(ctx):
         return hmt.RandomForest(ctx, path)
 
 
+def test_the_256_cubed_digests_are_the_oracles(ctx):
+    """Anchors the digest chain of this file in the ORACLE: 256^3 (S = 16, 4 096 regions) is the largest headline-shaped volume the CPU
+    restatement finishes in seconds.  The device's pb-mean order and its classifier order (the 255-tree forest of the gates above) are
+    compared with the oracle's byte for byte, and the classifier digest recorded above for 256^3 -- produced by the same kernels, the
+    same forest and the same generator as the 512^3 / 1024^3 ones -- must be the ORACLE's digest."""
+    from glia_amd import hmt
+    from glia_amd.synth_forest import synthetic_forest
+    from oracle import pyoracle as O
+    labels, pb = ctx.synth((256,) * 3, 16, 128)
+    lab_h, pb_h = labels.cpu().numpy(), pb.cpu().numpy()
+    # pb-mean (contour-only map, as the gate above builds it)
+    rm = hmt.RegionMap(ctx, labels, pb=pb, only_contour=True)
+    order, sal = rm.merge_order_pb(type=2)
+    rm.close()
+    o_ref, s_ref = O.Rag(lab_h, only_contour=True).merge_order_pb(pb_h, type=2)
+    assert order.shape == o_ref.shape and (order == o_ref).all() and (sal == s_ref).all()
+    # classifier linkage
+    cfg = hmt.make_config(pb, rb=[(pb, 8, 0.0, 1.0)])
+    clf = _forest(ctx)
+    rm = hmt.RegionMap(ctx, labels, pb=pb, cfg=cfg)
+    order, sal = rm.merge_order_bc(clf)
+    rm.close()
+    ocfg = O.make_cfg(pb_h, rb=[(pb_h, 8, 0.0, 1.0)])
+    o_ref, s_ref = O.Rag(lab_h).merge_order_bc(ocfg, O.make_forest(synthetic_forest(ntree=255, dim=3), -1))[:2]
+    assert order.shape == o_ref.shape and (order == o_ref).all() and (sal == s_ref).all()
+    assert (_sha(o_ref), _sha(s_ref)) == BC_256
+
+
 def _position_checksum(torch, lab):
     """sum over voxels of label * (1 + index mod 1000003), in wrapping int64, slab by slab on the device: depends on WHERE every
     label sits, costs one pass"""
