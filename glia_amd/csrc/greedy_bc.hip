@@ -1201,7 +1201,14 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState st)
         }
       }
       __syncthreads();
-      if (tid == 0) {
+      // The vector, as the scoring rounds build it: the shared boundary sets one lane per channel, then every HALF of a block
+      // (bc_features.hpp) by the first lane of one wave, straight into the idle scoring workspace -- one thread with the vector in a
+      // private array (scratch memory) took 40 of the 70 microseconds a bc_feat row cost.
+      EStats* shv = reinterpret_cast<EStats*>(W.in);                 // [K] (a RecIn holds four of them)
+      static_assert(sizeof(RecIn) >= kMaxChannels * sizeof(EStats), "shared sets fit the first staging slot");
+      if (tid < K) shared_boundary(st, tid, e, shv[tid]);
+      __syncthreads();
+      if ((tid & 63) == 0) {
         const bool keep = forced || st.e_orient[e];        // bc_feat: (x0, x1) as given
         float ex[4 * kMaxChannels];
 #pragma unroll
@@ -1213,11 +1220,14 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState st)
           }
           ex[4 * c + 0] = keep ? m0 : m1; ex[4 * c + 1] = keep ? x0 : x1; ex[4 * c + 2] = keep ? m1 : m0; ex[4 * c + 3] = keep ? x1 : x0;
         }
-        double x[kMaxFeat];
-        if (keep) edge_features_global(st, r0, r1, e, ex, x);
-        else edge_features_global(st, r1, r0, e, ex, x);
-        for (int i = 0; i < fdim; ++i) st.feats_out[(size_t)k * fdim + i] = x[i];
+        const int wave = tid >> 6;
+        const GlobalView v{&st, keep ? r0 : r1, keep ? r1 : r0, e, shv};
+        edge_features(st.cfg, v, ex, W.feat, nullptr, 1 << (wave & 3), false, 1 + (wave >> 2));
       }
+      __syncthreads();
+      if (tid == 0) feat::finish_features(st.cfg, W.feat);
+      __syncthreads();
+      for (int i = tid; i < fdim; i += kBcThreads) st.feats_out[(size_t)k * fdim + i] = W.feat[i];
       __syncthreads();
     }
 
