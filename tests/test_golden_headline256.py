@@ -1,4 +1,4 @@
-"""tests/golden/headline256_oracle.npz -- the ORACLE's merge orders of the 256^3 headline-shaped volume (tests/golden/gen_headline256.py) --
+"""tests/golden/headline/headline256_oracle.npz -- the ORACLE's merge orders of the 256^3 headline-shaped volume (tests/golden/gen_headline256.py) --
 against the invariants of util/struct_merge.hxx:19-31 and against the classifier digest that tests/test_gpu_headline.py records for that
 size: the digest chain of the headline gates (256^3 -> 512^3 -> 1024^3, same kernels, same forest, same generator) starts at an array the
 CPU restatement produced.  The oracle's own synth must still produce the fixture's volume."""
@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-PATH = os.path.join(HERE, "golden", "headline256_oracle.npz")
+PATH = os.path.join(HERE, "golden", "headline", "headline256_oracle.npz")
 BC_256 = ("51b7b5316e0d8fd648ab2b444527633d8eaf65c5", "5eadbd683d6a042f7bf950aa2352ef93bdc12956")      # = test_gpu_headline.BC_256
 
 

@@ -91,14 +91,14 @@ def _forest(ctx):
 
 def test_the_256_cubed_orders_are_the_oracles(ctx):
     """Anchors the digest chain of this file in the ORACLE.  256^3 (S = 16, 4 096 regions) is the largest headline-shaped volume the CPU
-    restatement finishes (49 minutes of one core: tests/golden/gen_headline256.py wrote tests/golden/headline256_oracle.npz once).  The device's
+    restatement finishes (49 minutes of one core: tests/golden/gen_headline256.py wrote tests/golden/headline/headline256_oracle.npz once).  The device's
     pb-mean order and its classifier order (the 255-tree forest of the gates above) are compared with the oracle's byte for byte, and
     the digest recorded above for the 256^3 classifier run -- same kernels, forest and generator as the 512^3 / 1024^3 ones -- is the
     digest of the ORACLE's arrays."""
     from glia_amd import hmt
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "headline256_oracle.npz")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "headline", "headline256_oracle.npz")
     if not os.path.exists(path):
-        pytest.skip("tests/golden/headline256_oracle.npz has not been generated (python tests/golden/gen_headline256.py, 49 minutes of CPU)")
+        pytest.skip("tests/golden/headline/headline256_oracle.npz has not been generated (python tests/golden/gen_headline256.py, 49 minutes of CPU)")
     g = np.load(path)
     labels, pb = ctx.synth((256,) * 3, 16, 128)
     assert _sha(labels.cpu().numpy()) == str(g["labels_sha1"]) and _sha(pb.cpu().numpy()) == str(g["pb_sha1"])     # the fixture's volume
