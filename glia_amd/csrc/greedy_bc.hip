@@ -772,6 +772,33 @@ __device__ __forceinline__ void stage_regions(const BcState& st, const ScoreWs& 
   __syncthreads();
 }
 
+// ---- fragile entries of a record's shared boundary, helper side ----------------------------------------------------------------
+// A record's fragile entries are a linked list, and each needs leaf_alive(): a merge-forest find plus a look at the leaf's mutual
+// entries -- four to six DEPENDENT loads.  One lane per (record, channel) doing both is ~4 k cycles per entry; profiles/r04z_*:
+// at 1024^3 a job nearly always holds a record with 4 .. 15 entries (+15 .. 60 k cycles on the answer the loop waits for), and a
+// few thousand records late in the run hold hundreds to thousands (millions of cycles each).  Helpers therefore split the work:
+// the (record, channel) lane only WALKS its list (one load per entry) into an LDS segment, then every lane of the workgroup takes
+// (segment, entry) pairs, decides aliveness and adds the entry's statistics to the segment's accumulator with LDS atomics; long
+// lists go round in batches of kFragSeg.  The helpers' copy of the mark table's LDS (never used by a helper) holds all of it.
+constexpr uint32_t kFragSeg = 128;         // list entries per (record, channel) and batch
+constexpr uint32_t kFragItems = kHelpChunk * kMaxChannels;
+struct FragAcc { uint32_t n, thr[GLIA_HMT_MAX_THRESH], mn_ord, mx_ord; double sum, sq; uint32_t hist[GLIA_HMT_MAX_BINS]; };
+static_assert(sizeof(FragAcc) == sizeof(EStats), "same fields, extremes as ordered integers");
+struct FragWs { uint32_t* ids; FragAcc* acc; uint32_t* cnt; };
+static_assert(kFragItems * kFragSeg * 4u + kFragItems * sizeof(FragAcc) + kFragItems * 4u <= kMarkBytes, "fits the mark table's LDS");
+__device__ __forceinline__ FragWs frag_ws(unsigned char* pool) {
+  FragWs f;
+  f.acc = reinterpret_cast<FragAcc*>(pool + kWsBytes);
+  f.ids = reinterpret_cast<uint32_t*>(f.acc + kFragItems);
+  f.cnt = f.ids + kFragItems * kFragSeg;
+  return f;
+}
+__device__ __forceinline__ void frag_clear(FragAcc& a) {
+  a.n = 0; a.mn_ord = 0xFFFFFFFFu; a.mx_ord = 0u; a.sum = 0.0; a.sq = 0.0;
+  for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) a.thr[i] = 0;
+  for (int i = 0; i < GLIA_HMT_MAX_BINS; ++i) a.hist[i] = 0;
+}
+
 // Every thread of the workgroup calls, after a staging step.  AG: the caller is a helper workgroup -- what is still read from
 // global memory (incident lists, fragile-entry chains, the merge forest) is read with agent-scope loads.
 //   S2 shared boundary sets (one lane per record and channel) and the neighbours' "all but this record" extremes (16 lanes per
@@ -796,8 +823,8 @@ __device__ __forceinline__ bool score_chunk(const BcState& st, BcShared& s, cons
     RecIn& in = W.in[j * K + c];
     EStats sh = in.A;
     estats_add(sh, in.sh);
-    for (uint32_t f = h.fhead; f != kNone; f = ldm<AG>(&st.le_next[f])) if (leaf_alive<AG>(st, st.le_dst[f])) estats_add(sh, chan_of(st, c).le_stats[f]);
-    in.sh = sh;
+    if (!AG) for (uint32_t f = h.fhead; f != kNone; f = ldm<AG>(&st.le_next[f])) if (leaf_alive<AG>(st, st.le_dst[f])) estats_add(sh, chan_of(st, c).le_stats[f]);
+    in.sh = sh;                                              // (a helper adds the fragile entries below)
   }
   {
     // excl_minmax of every record's neighbour region, 16 lanes per record: unconditional, batched loads (a load behind a branch
@@ -839,6 +866,51 @@ __device__ __forceinline__ bool score_chunk(const BcState& st, BcShared& s, cons
           for (int o = 8; o >= 1; o >>= 1) { a = fminf(a, __shfl_xor(a, o, 16)); b = fmaxf(b, __shfl_xor(b, o, 16)); }
           if (l16 == 0 && h.on) { W.in[j * K + c].exmn = a; W.in[j * K + c].exmx = b; }
         }
+      }
+    }
+  }
+  if (AG) {
+    // the fragile entries (see FragWs): the LAST wave walks the lists -- lane i the list of (record, channel) pair i -- while the
+    // first waves are busy with the neighbour lists above; then everybody evaluates
+    const FragWs F = frag_ws(s.pool);
+    const uint32_t items = n * (uint32_t)K;
+    const uint32_t it = (uint32_t)tid - (kBcThreads - 64u);          // (< items only in the last wave)
+    uint32_t f = kNone;
+    if (it < items && W.hdr[it / (uint32_t)K].on) f = W.hdr[it / (uint32_t)K].fhead;
+    for (;;) {
+      if (it < items) {
+        uint32_t cnt = 0;
+        while (f != kNone && cnt < kFragSeg) { F.ids[it * kFragSeg + cnt++] = f; f = ldm<AG>(&st.le_next[f]); }
+        F.cnt[it] = cnt;
+      }
+      const int more = __syncthreads_or(it < items && f != kNone);   // (uniform; the segments and their counts are written)
+      for (uint32_t slot = tid; slot < items * kFragSeg; slot += kBcThreads) {
+        const uint32_t q = slot / kFragSeg, idx = slot % kFragSeg;
+        if (idx >= F.cnt[q]) continue;
+        const uint32_t e = F.ids[slot];
+        if (!leaf_alive<AG>(st, st.le_dst[e])) continue;
+        const EStats es = chan_of(st, (int)(q % (uint32_t)K)).le_stats[e];
+        FragAcc& a = F.acc[q];
+        atomicAdd(&a.n, es.n);
+#pragma unroll
+        for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) if (es.thr[i]) atomicAdd(&a.thr[i], es.thr[i]);
+        atomicMin(&a.mn_ord, float_ord(es.mn)); atomicMax(&a.mx_ord, float_ord(es.mx));
+        atomicAdd(&a.sum, es.sum); atomicAdd(&a.sq, es.sq);
+#pragma unroll
+        for (int i = 0; i < GLIA_HMT_MAX_BINS; ++i) if (es.hist[i]) atomicAdd(&a.hist[i], es.hist[i]);
+      }
+      __syncthreads();                                               // (the accumulators are complete; the segments may be rewritten)
+      if (!more) break;
+    }
+    if (it < items) {
+      FragAcc& a = F.acc[it];
+      if (a.n) {
+        EStats& sh = W.in[it].sh;                                    // (W.in is indexed [record * K + channel], as the pairs are)
+        sh.n += a.n; sh.sum += a.sum; sh.sq += a.sq;
+        sh.mn = fminf(sh.mn, ord_float(a.mn_ord)); sh.mx = fmaxf(sh.mx, ord_float(a.mx_ord));
+        for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) sh.thr[i] += a.thr[i];
+        for (int i = 0; i < GLIA_HMT_MAX_BINS; ++i) sh.hist[i] += a.hist[i];
+        frag_clear(a);
       }
     }
   }
@@ -981,6 +1053,7 @@ __device__ __forceinline__ void bc_helper_loop(const BcState& st, BcShared& s) {
   const ScoreWs W = ws_layout(st.cfg, s.pool, kHelpChunk, &used);
   const uint32_t cap = W.cap;
   if (tid == 0) s.nlog = (uint32_t)feat::log_slots(st.cfg, s.logpos);
+  if ((uint32_t)tid < kFragItems) frag_clear(frag_ws(s.pool).acc[tid]);
   for (int i = tid; i < glibc::kLog2TabWords; i += kBcThreads) s.log2tab[i] = i < 18 ? glibc::kLog2Head[i] : i < 18 + 128 ? glibc::kLog2Tab[i - 18] : glibc::kLog2Tab2[i - 18 - 128];
   uint32_t last = 0;
   for (;;) {

@@ -77,7 +77,7 @@ template <int MODE> int run(const char* name, uint32_t partner) {
 }
 
 int main() {
-  for (uint32_t partner : {8u, 16u, 1u, 3u}) {
+  for (uint32_t partner : {8u, 16u, 1u, 2u, 3u, 4u, 5u, 6u, 7u}) {
     run<0>("agent-scope atomic load/store", partner);
     run<4>("agent-scope atomic RMW", partner);
     run<3>("workgroup-scope atomic RMW", partner);
