@@ -774,23 +774,26 @@ __device__ __forceinline__ void stage_regions(const BcState& st, const ScoreWs& 
 
 // ---- fragile entries of a record's shared boundary, helper side ----------------------------------------------------------------
 // A record's fragile entries are a linked list, and each needs leaf_alive(): a merge-forest find plus a look at the leaf's mutual
-// entries -- four to six DEPENDENT loads.  One lane per (record, channel) doing both is ~4 k cycles per entry; profiles/r04z_*:
-// at 1024^3 a job nearly always holds a record with 4 .. 15 entries (+15 .. 60 k cycles on the answer the loop waits for), and a
-// few thousand records late in the run hold hundreds to thousands (millions of cycles each).  Helpers therefore split the work:
-// the (record, channel) lane only WALKS its list (one load per entry) into an LDS segment, then every lane of the workgroup takes
-// (segment, entry) pairs, decides aliveness and adds the entry's statistics to the segment's accumulator with LDS atomics; long
-// lists go round in batches of kFragSeg.  The helpers' copy of the mark table's LDS (never used by a helper) holds all of it.
-constexpr uint32_t kFragSeg = 128;         // list entries per (record, channel) and batch
+// entries -- four to six DEPENDENT loads.  One lane per (record, channel) doing both is ~4 k cycles per entry; at 1024^3 a job nearly
+// always holds a record with 4 .. 15 entries (+15 .. 60 k cycles on the answer the loop waits for), and a few thousand records late
+// in the run hold hundreds to thousands (millions of cycles each: profiles/r04z_bc1024_fragile.txt).  A helper's LAST WAVE therefore
+// owns the shared sets: lane i only WALKS the list of (record, channel) pair i (one load per entry), appending to ONE work list in
+// LDS; then the wave's 64 lanes take the list's entries, decide aliveness and add the statistics to the pair's accumulator with LDS
+// atomics; long lists go round in batches of kFragCap.  All of it inside one wave -- no workgroup barrier -- while the other waves
+// scan the neighbour lists.  The helpers' copy of the mark table's LDS (never used by a helper) holds the lists.
+constexpr uint32_t kFragCap = 4096;        // work-list entries per batch
 constexpr uint32_t kFragItems = kHelpChunk * kMaxChannels;
 struct FragAcc { uint32_t n, thr[GLIA_HMT_MAX_THRESH], mn_ord, mx_ord; double sum, sq; uint32_t hist[GLIA_HMT_MAX_BINS]; };
 static_assert(sizeof(FragAcc) == sizeof(EStats), "same fields, extremes as ordered integers");
-struct FragWs { uint32_t* ids; FragAcc* acc; uint32_t* cnt; };
-static_assert(kFragItems * kFragSeg * 4u + kFragItems * sizeof(FragAcc) + kFragItems * 4u <= kMarkBytes, "fits the mark table's LDS");
+struct FragWs { FragAcc* acc; uint32_t* ids; unsigned char* tag; uint32_t* total; };
+static_assert(kFragItems * sizeof(FragAcc) + kFragCap * 5u + 16u <= kMarkBytes, "fits the mark table's LDS");
+static_assert(kFragItems <= 64u, "one lane per (record, channel) pair");
 __device__ __forceinline__ FragWs frag_ws(unsigned char* pool) {
   FragWs f;
   f.acc = reinterpret_cast<FragAcc*>(pool + kWsBytes);
   f.ids = reinterpret_cast<uint32_t*>(f.acc + kFragItems);
-  f.cnt = f.ids + kFragItems * kFragSeg;
+  f.total = f.ids + kFragCap;
+  f.tag = reinterpret_cast<unsigned char*>(f.total + 4);
   return f;
 }
 __device__ __forceinline__ void frag_clear(FragAcc& a) {
@@ -798,6 +801,8 @@ __device__ __forceinline__ void frag_clear(FragAcc& a) {
   for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) a.thr[i] = 0;
   for (int i = 0; i < GLIA_HMT_MAX_BINS; ++i) a.hist[i] = 0;
 }
+// LDS traffic between lanes of ONE wave: the LDS keeps a wave's operations in order; the compiler must not move them across this
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // Every thread of the workgroup calls, after a staging step.  AG: the caller is a helper workgroup -- what is still read from
 // global memory (incident lists, fragile-entry chains, the merge forest) is read with agent-scope loads.
@@ -814,7 +819,7 @@ __device__ __forceinline__ bool score_chunk(const BcState& st, BcShared& s, cons
   unsigned long long tsp = __builtin_readcyclecounter();
 #endif
   // ---- S2 ----
-  for (uint32_t w = tid; w < n * (uint32_t)K; w += kBcThreads) {
+  for (uint32_t w = tid; w < (AG ? 0u : n * (uint32_t)K); w += kBcThreads) {       // (a helper: its last wave, below)
     // shared boundary (getBoundary / boundaryWith): mutual entries + always-alive non-mutual ones + the fragile ones whose target
     // leaf still owns an un-cancelled entry
     const uint32_t j = w / (uint32_t)K; const int c = (int)(w % (uint32_t)K);
@@ -823,8 +828,8 @@ __device__ __forceinline__ bool score_chunk(const BcState& st, BcShared& s, cons
     RecIn& in = W.in[j * K + c];
     EStats sh = in.A;
     estats_add(sh, in.sh);
-    if (!AG) for (uint32_t f = h.fhead; f != kNone; f = ldm<AG>(&st.le_next[f])) if (leaf_alive<AG>(st, st.le_dst[f])) estats_add(sh, chan_of(st, c).le_stats[f]);
-    in.sh = sh;                                              // (a helper adds the fragile entries below)
+    for (uint32_t f = h.fhead; f != kNone; f = ldm<AG>(&st.le_next[f])) if (leaf_alive<AG>(st, st.le_dst[f])) estats_add(sh, chan_of(st, c).le_stats[f]);
+    in.sh = sh;
   }
   {
     // excl_minmax of every record's neighbour region, 16 lanes per record: unconditional, batched loads (a load behind a branch
@@ -869,25 +874,24 @@ __device__ __forceinline__ bool score_chunk(const BcState& st, BcShared& s, cons
       }
     }
   }
-  if (AG) {
-    // the fragile entries (see FragWs): the LAST wave walks the lists -- lane i the list of (record, channel) pair i -- while the
-    // first waves are busy with the neighbour lists above; then everybody evaluates
+  if (AG && tid >= (int)kBcThreads - 64) {
+    // the shared sets, by the last wave alone (see FragWs)
     const FragWs F = frag_ws(s.pool);
-    const uint32_t items = n * (uint32_t)K;
-    const uint32_t it = (uint32_t)tid - (kBcThreads - 64u);          // (< items only in the last wave)
-    uint32_t f = kNone;
-    if (it < items && W.hdr[it / (uint32_t)K].on) f = W.hdr[it / (uint32_t)K].fhead;
+    const uint32_t lane = (uint32_t)tid & 63u, items = n * (uint32_t)K;
+    const bool mine = lane < items && W.hdr[lane / (uint32_t)K].on != 0u;
+    uint32_t f = mine ? W.hdr[lane / (uint32_t)K].fhead : kNone;
     for (;;) {
-      if (it < items) {
-        uint32_t cnt = 0;
-        while (f != kNone && cnt < kFragSeg) { F.ids[it * kFragSeg + cnt++] = f; f = ldm<AG>(&st.le_next[f]); }
-        F.cnt[it] = cnt;
+      while (f != kNone) {
+        const uint32_t pos = atomicAdd(F.total, 1u);
+        if (pos >= kFragCap) break;                       // the list is full: this entry opens the next batch
+        F.ids[pos] = f; F.tag[pos] = (unsigned char)lane;
+        f = ldm<AG>(&st.le_next[f]);
       }
-      const int more = __syncthreads_or(it < items && f != kNone);   // (uniform; the segments and their counts are written)
-      for (uint32_t slot = tid; slot < items * kFragSeg; slot += kBcThreads) {
-        const uint32_t q = slot / kFragSeg, idx = slot % kFragSeg;
-        if (idx >= F.cnt[q]) continue;
-        const uint32_t e = F.ids[slot];
+      wave_lds_fence();
+      const uint32_t tot = *F.total < kFragCap ? *F.total : kFragCap;
+      const bool more = __ballot(f != kNone) != 0ull;
+      for (uint32_t k = lane; k < tot; k += 64u) {
+        const uint32_t e = F.ids[k], q = F.tag[k];
         if (!leaf_alive<AG>(st, st.le_dst[e])) continue;
         const EStats es = chan_of(st, (int)(q % (uint32_t)K)).le_stats[e];
         FragAcc& a = F.acc[q];
@@ -899,19 +903,24 @@ __device__ __forceinline__ bool score_chunk(const BcState& st, BcShared& s, cons
 #pragma unroll
         for (int i = 0; i < GLIA_HMT_MAX_BINS; ++i) if (es.hist[i]) atomicAdd(&a.hist[i], es.hist[i]);
       }
-      __syncthreads();                                               // (the accumulators are complete; the segments may be rewritten)
+      wave_lds_fence();
+      if (lane == 0u) *F.total = 0u;
+      wave_lds_fence();
       if (!more) break;
     }
-    if (it < items) {
-      FragAcc& a = F.acc[it];
+    if (mine) {
+      RecIn& in = W.in[lane];                              // (W.in is indexed [record * K + channel], as the pairs are)
+      EStats sh = in.A;
+      estats_add(sh, in.sh);
+      FragAcc& a = F.acc[lane];
       if (a.n) {
-        EStats& sh = W.in[it].sh;                                    // (W.in is indexed [record * K + channel], as the pairs are)
         sh.n += a.n; sh.sum += a.sum; sh.sq += a.sq;
         sh.mn = fminf(sh.mn, ord_float(a.mn_ord)); sh.mx = fmaxf(sh.mx, ord_float(a.mx_ord));
         for (int i = 0; i < GLIA_HMT_MAX_THRESH; ++i) sh.thr[i] += a.thr[i];
         for (int i = 0; i < GLIA_HMT_MAX_BINS; ++i) sh.hist[i] += a.hist[i];
         frag_clear(a);
       }
+      in.sh = sh;
     }
   }
   __syncthreads();
@@ -1054,6 +1063,7 @@ __device__ __forceinline__ void bc_helper_loop(const BcState& st, BcShared& s) {
   const uint32_t cap = W.cap;
   if (tid == 0) s.nlog = (uint32_t)feat::log_slots(st.cfg, s.logpos);
   if ((uint32_t)tid < kFragItems) frag_clear(frag_ws(s.pool).acc[tid]);
+  if (tid == 0) *frag_ws(s.pool).total = 0u;
   for (int i = tid; i < glibc::kLog2TabWords; i += kBcThreads) s.log2tab[i] = i < 18 ? glibc::kLog2Head[i] : i < 18 + 128 ? glibc::kLog2Tab[i - 18] : glibc::kLog2Tab2[i - 18 - 128];
   uint32_t last = 0;
   for (;;) {
