@@ -818,6 +818,58 @@ __device__ __forceinline__ bool score_chunk(const BcState& st, BcShared& s, cons
 #ifdef GLIA_HMT_PROFILE
   unsigned long long tsp = __builtin_readcyclecounter();
 #endif
+  // ---- S3, as a function of the task (called from the places below) ----
+  // entropies and histogram distances, one lane per bin: the log2 and divisions of a vector are by far its longest serial
+  // stretch.  A TASK = 16 lanes on one group of sums of one record -- region / label list entry i: entropy of the merged voxel
+  // set + L1 + chi-square; boundary list entry i: entropy of the merged boundary set; the same entry: entropy of the shared
+  // boundary -- so the (usually three) logarithm passes of a record run side by side.  The bins' terms are added IN BIN ORDER, as
+  // the reference does (bin_chain).
+  // (consecutive tasks go to different WAVES: sixteen-lane groups of one wave would run their logarithms one after the other)
+  const uint32_t l16 = (uint32_t)tid & 15u;
+  const uint32_t nrl = (uint32_t)(BC_NR(cf) + BC_NL(cf)), NBq = (uint32_t)BC_NB(cf), G = nrl + 2u * NBq;
+  auto s3_task = [&](const uint32_t task) __attribute__((always_inline)) {
+      const uint32_t j = task / G, g = task - j * G;
+      const bool on = W.hdr[j].on != 0;              // uniform over the 16 lanes
+      const RecIn* in = &W.in[j * K];
+      double* fx = W.fx + (size_t)j * W.npre;
+      if (g < nrl) {
+        const int kind = g < (uint32_t)BC_NR(cf) ? 0 : 1;
+        const int i = kind ? (int)g - BC_NR(cf) : (int)g;
+        const int cc = kind ? cf.lc[i] : cf.rc[i];
+        const int bins = cf.cbins[cc];
+        double t2 = 0.0, tl = 0.0, tx = 0.0;
+        const PStats* P0 = &in[cc].P; const PStats* P1 = &W.r2[cc].P;
+        const uint32_t h0 = P0->hist[l16], h1 = P1->hist[l16], pn0 = P0->n, pn1 = P1->n;
+        const double e0 = in[cc].entP;                  // filed when rs was created (BcChan::entP)
+        const double e1 = W.r2[cc].entP;                // r2's: worked out once per contraction
+        if (on && (int)l16 < bins) {
+          t2 = feat::entropy_term(h0 + h1, pn0 + pn1, cf.libm_log2, s.log2tab);
+          feat::dist_terms(h0, pn0, h1, pn1, tl, tx);
+        }
+        const double e2 = bin_chain(t2, bins, true);
+        const double dl = bin_chain(tl, bins, false), dx = bin_chain(tx, bins, false);
+        if (on && (int)l16 == bins - 1) { double* q = fx + feat::pre_region(cf, kind, i); q[0] = e0; q[1] = e1; q[2] = e2; q[3] = dl; q[4] = dx; }
+      } else {
+        const uint32_t gb = g - nrl;
+        const int i = (int)(gb >> 1); const bool shared = (gb & 1u) != 0u;
+        const int cc = cf.bc[i];
+        const int bins = cf.cbins[cc];
+        const EStats* B0 = &in[cc].B; const EStats* B1 = &W.r2[cc].B;
+        const EStats* A = &in[cc].A;
+        const EStats* sh = &in[cc].sh;
+        const uint32_t g0 = B0->hist[l16], g1 = B1->hist[l16], ga = A->hist[l16], bn0 = B0->n, bn1 = B1->n, an = A->n;
+        const uint32_t gs = sh->hist[l16], sn = sh->n;
+        const uint32_t cq = shared ? gs : g0 + g1 - ga, nq = shared ? sn : bn0 + bn1 - an;
+        double t = 0.0;
+        if (on && (int)l16 < bins) t = feat::entropy_term(cq, nq, cf.libm_log2, s.log2tab);
+        const double en = bin_chain(t, bins, true);
+        if (on && (int)l16 == bins - 1) {
+          double* q = fx + feat::pre_boundary(cf, i);
+          if (shared) q[3] = en;
+          else { q[0] = in[cc].entB; q[1] = W.r2[cc].entB; q[2] = en; }
+        }
+      }
+  };
   // ---- S2 ----
   for (uint32_t w = tid; w < (AG ? 0u : n * (uint32_t)K); w += kBcThreads) {       // (a helper: its last wave, below)
     // shared boundary (getBoundary / boundaryWith): mutual entries + always-alive non-mutual ones + the fragile ones whose target
@@ -922,62 +974,24 @@ __device__ __forceinline__ bool score_chunk(const BcState& st, BcShared& s, cons
       }
       in.sh = sh;
     }
+    // ... and the entropies of the shared sets (S3's tasks that need them), four at a time
+    wave_lds_fence();
+    for (uint32_t t3 = lane >> 4; t3 < n * NBq; t3 += 4u) { const uint32_t j = t3 / NBq, i = t3 - j * NBq; s3_task(j * G + nrl + 2u * i + 1u); }
+  } else if (AG && tid >= 128) {
+    // S3's other tasks need nothing of this stage: the waves 2 .. 6 run them now, beside the list scans of the waves 0 and 1 and the
+    // last wave's shared sets (consecutive tasks on different waves)
+    const uint32_t G2 = nrl + NBq, sub2 = (((uint32_t)tid >> 6) - 2u) + 5u * (((uint32_t)tid & 63u) >> 4);
+    for (uint32_t t2 = sub2; t2 < n * G2; t2 += 20u) {
+      const uint32_t j = t2 / G2, g2 = t2 - j * G2;
+      s3_task(j * G + (g2 < nrl ? g2 : nrl + 2u * (g2 - nrl)));
+    }
   }
-  __syncthreads();
+  if (!AG) __syncthreads();       // (a helper's S4 lies behind the barrier that ends S3)
   SPH(2);
   // ---- S3 ----
-  {
-    // entropies and histogram distances, one lane per bin: the log2 and divisions of a vector are by far its longest serial
-    // stretch.  A TASK = 16 lanes on one group of sums of one record -- region / label list entry i: entropy of the merged voxel
-    // set + L1 + chi-square; boundary list entry i: entropy of the merged boundary set; the same entry: entropy of the shared
-    // boundary -- so the (usually three) logarithm passes of a record run side by side.  The bins' terms are added IN BIN ORDER, as
-    // the reference does (bin_chain).
-    // (consecutive tasks go to different WAVES: sixteen-lane groups of one wave would run their logarithms one after the other)
-    const uint32_t sub = ((uint32_t)tid >> 6) + (kBcThreads / 64) * (((uint32_t)tid & 63u) >> 4), l16 = (uint32_t)tid & 15u;
-    const uint32_t nrl = (uint32_t)(BC_NR(cf) + BC_NL(cf)), G = nrl + 2u * (uint32_t)BC_NB(cf);
-    for (uint32_t task = sub; task < n * G; task += kBcThreads / 16) {
-      const uint32_t j = task / G, g = task - j * G;
-      const bool on = W.hdr[j].on != 0;              // uniform over the 16 lanes
-      const RecIn* in = &W.in[j * K];
-      double* fx = W.fx + (size_t)j * W.npre;
-      if (g < nrl) {
-        const int kind = g < (uint32_t)BC_NR(cf) ? 0 : 1;
-        const int i = kind ? (int)g - BC_NR(cf) : (int)g;
-        const int cc = kind ? cf.lc[i] : cf.rc[i];
-        const int bins = cf.cbins[cc];
-        double t2 = 0.0, tl = 0.0, tx = 0.0;
-        const PStats* P0 = &in[cc].P; const PStats* P1 = &W.r2[cc].P;
-        const uint32_t h0 = P0->hist[l16], h1 = P1->hist[l16], pn0 = P0->n, pn1 = P1->n;
-        const double e0 = in[cc].entP;                  // filed when rs was created (BcChan::entP)
-        const double e1 = W.r2[cc].entP;                // r2's: worked out once per contraction
-        if (on && (int)l16 < bins) {
-          t2 = feat::entropy_term(h0 + h1, pn0 + pn1, cf.libm_log2, s.log2tab);
-          feat::dist_terms(h0, pn0, h1, pn1, tl, tx);
-        }
-        const double e2 = bin_chain(t2, bins, true);
-        const double dl = bin_chain(tl, bins, false), dx = bin_chain(tx, bins, false);
-        if (on && (int)l16 == bins - 1) { double* q = fx + feat::pre_region(cf, kind, i); q[0] = e0; q[1] = e1; q[2] = e2; q[3] = dl; q[4] = dx; }
-      } else {
-        const uint32_t gb = g - nrl;
-        const int i = (int)(gb >> 1); const bool shared = (gb & 1u) != 0u;
-        const int cc = cf.bc[i];
-        const int bins = cf.cbins[cc];
-        const EStats* B0 = &in[cc].B; const EStats* B1 = &W.r2[cc].B;
-        const EStats* A = &in[cc].A;
-        const EStats* sh = &in[cc].sh;
-        const uint32_t g0 = B0->hist[l16], g1 = B1->hist[l16], ga = A->hist[l16], bn0 = B0->n, bn1 = B1->n, an = A->n;
-        const uint32_t gs = sh->hist[l16], sn = sh->n;
-        const uint32_t cq = shared ? gs : g0 + g1 - ga, nq = shared ? sn : bn0 + bn1 - an;
-        double t = 0.0;
-        if (on && (int)l16 < bins) t = feat::entropy_term(cq, nq, cf.libm_log2, s.log2tab);
-        const double en = bin_chain(t, bins, true);
-        if (on && (int)l16 == bins - 1) {
-          double* q = fx + feat::pre_boundary(cf, i);
-          if (shared) q[3] = en;
-          else { q[0] = in[cc].entB; q[1] = W.r2[cc].entB; q[2] = en; }
-        }
-      }
-    }
+  if (!AG) {
+    const uint32_t sub = ((uint32_t)tid >> 6) + (kBcThreads / 64) * (((uint32_t)tid & 63u) >> 4);
+    for (uint32_t task = sub; task < n * G; task += kBcThreads / 16) s3_task(task);
   }
   __syncthreads();
   SPH(3);
