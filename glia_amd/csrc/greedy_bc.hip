@@ -1368,11 +1368,15 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState st)
     const bool small = total <= kMarkMax;                 // neighbour table in LDS
     uint32_t* mk = reinterpret_cast<uint32_t*>(s.pool + kWsBytes);
     uint32_t* mv0 = mk + kMarkSlots; uint32_t* mv1 = mv0 + kMarkSlots;
+    // (what the first pass of this loop reads about its list entry, phase B's first pass needs again: kept in registers, two round
+    // trips less in front of the new records)
+    uint32_t k_eid = kNone, k_u = 0, k_v = 0, k_pu = 0, k_pv = 0;
     for (uint32_t i = tid; i < total; i += kBcThreads) {
       const bool side1 = i >= len0;
       const uint32_t eid = st.pool[side1 ? off1 + (i - len0) : off0 + i];
       const uint8_t alive = st.e_alive[eid];           // unconditional loads: one round trip (see greedy_common.hpp)
       const uint32_t u = st.e_u[eid], v = st.e_v[eid];
+      if (i == (uint32_t)tid) { k_eid = eid; k_u = u; k_v = v; k_pu = st.e_posu[eid]; k_pv = st.e_posv[eid]; }
       if (eid == e || !alive) continue;
       const uint32_t r = side1 ? r1 : r0;
       const uint32_t rs = (u == r) ? v : u;
@@ -1400,9 +1404,12 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState st)
     // (without one they are the record's own: a cache hit).
     for (uint32_t i = tid; i < total; i += kBcThreads) {
       const bool side1 = i >= len0;
-      const uint32_t eid = st.pool[side1 ? off1 + (i - len0) : off0 + i];
+      uint32_t eid = k_eid, u = k_u, v = k_v, pu = k_pu, pv = k_pv;
+      if (i != (uint32_t)tid) {                          // (a list of more than 512 entries: the later passes read again)
+        eid = st.pool[side1 ? off1 + (i - len0) : off0 + i];
+        u = st.e_u[eid]; v = st.e_v[eid]; pu = st.e_posu[eid]; pv = st.e_posv[eid];
+      }
       if (eid == e) continue;
-      const uint32_t u = st.e_u[eid], v = st.e_v[eid], pu = st.e_posu[eid], pv = st.e_posv[eid];
       const uint32_t r = side1 ? r1 : r0;
       if (u != r && v != r) continue;
       const uint32_t rs = (u == r) ? v : u;
