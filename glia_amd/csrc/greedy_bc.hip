@@ -619,6 +619,8 @@ struct BcShared {
   unsigned long long t2[kBcThreads / 64][kMaxChannels][4];      // per wave: (best, second) of the min keys, of the complemented max keys
   uint32_t nlog;                 // slots of the full vector that take a logarithm
   uint32_t lost;                 // a helper did not answer in time
+  // what the next pop will need if the tree's root stays the best edge: fetched by an idle thread while the helpers score (kNone = nothing)
+  uint32_t pre_e, pre_r0, pre_r1, pre_len0, pre_len1, pre_off0, pre_off1;
   uint32_t job_seq, job_ne0, job_cnt, job_r2, job_newcount, job_ok;     // helper side: the job being worked on
   uint32_t job2_ok;              // helper side: part 2 of the job has arrived (0 = gave up waiting)
   float r2bm[kMaxChannels][2];   // helper side: min / max of B(r2) from part 2 (patched into every staged copy of r2)
@@ -1222,7 +1224,7 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState st)
   const int fdim = st.cfg.fdim;
   const int K = BC_K(st.cfg);
   const ScoreWs W = ws_layout(st.cfg, s.pool);
-  if (tid == 0) { s.pq.wln[0] = s.pq.wln[1] = 0; s.pq.ovf = 0; s.pq.spill = 0; s.lost = 0; s.nlog = (uint32_t)feat::log_slots(st.cfg, s.logpos); s.cand.sal = -__builtin_inf(); s.cand.seq = 0; s.cand.arg = 0; }
+  if (tid == 0) { s.pq.wln[0] = s.pq.wln[1] = 0; s.pq.ovf = 0; s.pq.spill = 0; s.lost = 0; s.pre_e = kNone; s.nlog = (uint32_t)feat::log_slots(st.cfg, s.logpos); s.cand.sal = -__builtin_inf(); s.cand.seq = 0; s.cand.arg = 0; }
   bool deferred = false;         // inserts of the last contraction are waiting in the worklist (uniform)
   for (int i = tid; i < glibc::kLog2TabWords; i += blockDim.x) s.log2tab[i] = i < 18 ? glibc::kLog2Head[i] : i < 18 + 128 ? glibc::kLog2Tab[i - 18] : glibc::kLog2Tab2[i - 18 - 128];
   for (int i = tid; i < kSetSlots; i += blockDim.x) { s.pq.set[0][i] = 0; s.pq.set[1][i] = 0; }
@@ -1253,10 +1255,15 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState st)
       else {
         const uint32_t e = forced ? kNone : root.arg;
         s.e = e;
-        if (forced) { s.r0 = st.forced[2 * k]; s.r1 = st.forced[2 * k + 1]; }
-        else { s.r0 = st.e_u[e]; s.r1 = st.e_v[e]; }
-        s.len0 = st.adj_len[s.r0]; s.len1 = st.adj_len[s.r1];
-        s.off0 = st.adj_off[s.r0]; s.off1 = st.adj_off[s.r1];
+        if (!forced && s.pre_e == e) {                   // (two dependent round trips of one thread, already made)
+          s.r0 = s.pre_r0; s.r1 = s.pre_r1; s.len0 = s.pre_len0; s.len1 = s.pre_len1; s.off0 = s.pre_off0; s.off1 = s.pre_off1;
+        } else {
+          if (forced) { s.r0 = st.forced[2 * k]; s.r1 = st.forced[2 * k + 1]; }
+          else { s.r0 = st.e_u[e]; s.r1 = st.e_v[e]; }
+          s.len0 = st.adj_len[s.r0]; s.len1 = st.adj_len[s.r1];
+          s.off0 = st.adj_off[s.r0]; s.off1 = st.adj_off[s.r1];
+        }
+        s.pre_e = kNone;
         const unsigned long long tot = (unsigned long long)s.len0 + s.len1;
         if (ne + tot > st.Ecap) s.stop = ST_NEED_EDGES;
         else if (pool_used + tot > st.pool_cap) s.stop = ST_NEED_POOL;
@@ -1628,6 +1635,16 @@ __global__ __launch_bounds__(kBcThreads) void greedy_bc_kernel(const BcState st)
       // while the helpers work: the priority tree is brought up to date for the removals of this contraction
       pq_propagate<kBcThreads>(st.pq, s.pq, tid);
       PH(6);
+      // the tree's root is final now (this contraction's own records are the candidate `s.cand`): if it stays the best edge, the next
+      // pop needs its regions and their lists -- the last thread, idle here, fetches them (read by thread 0 behind the next barrier)
+      if (tid == kBcThreads - 1) {
+        const Key rt = pq_root<kBcThreads>(s.pq);
+        if (rt.seq != 0) {
+          const uint32_t pe = rt.arg, pu = st.e_u[pe], pv = st.e_v[pe];
+          s.pre_r0 = pu; s.pre_r1 = pv; s.pre_len0 = st.adj_len[pu]; s.pre_len1 = st.adj_len[pv]; s.pre_off0 = st.adj_off[pu]; s.pre_off1 = st.adj_off[pv];
+          s.pre_e = pe;
+        }
+      }
       Key mine; mine.sal = -__builtin_inf(); mine.seq = 0; mine.arg = 0;
       for (uint32_t j = tid; j < newcount; j += kBcThreads) {
         const uint32_t rec = (uint32_t)ne + j;
