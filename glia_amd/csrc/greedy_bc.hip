@@ -1072,8 +1072,20 @@ __device__ __forceinline__ void bc_helper_loop(const BcState& st, BcShared& s) {
   // its L2 and get the lowest numbers (a job's records go to the helpers 0, 1, ...)
   // (Measured: keeping a job WITH those 31 -- two to four records each, every stage is lane-parallel over the records -- is slower
   // than dealing it out across the XCDs one record per helper.)
+  // The helpers of the OTHER XCDs are numbered XCD by XCD (1, 2, ... 7: the ping-pong latency from XCD 0 grows in that order,
+  // tools/micro/xcd_pingpong), not round-robin: a job of ~94 records then stays on three XCDs, whose L2s keep the forest's lines --
+  // spread over seven, each XCD walks too rarely to hold the deep ones.
   const uint32_t H = gridDim.x - 1u, b = blockIdx.x;
-  const uint32_t h = (b & 7u) == 0u ? (b >> 3) - 1u : (H >> 3) + (b - 1u - (b >> 3));
+  uint32_t h;
+  {
+    const uint32_t x = b & 7u, q = b >> 3;                        // XCD, position among the XCD's workgroups
+    if (x == 0u) h = q - 1u;                                      // (workgroup 0 is the loop's own)
+    else {
+      h = H >> 3;                                                 // the helpers of XCD 0
+      for (uint32_t y = 1; y < x; ++y) h += y <= H ? (H - y) / 8u + 1u : 0u;      // workgroups y, y + 8, ... <= H
+      h += q;
+    }
+  }
   uint32_t used = 0;
   const ScoreWs W = ws_layout(st.cfg, s.pool, kHelpChunk, &used);
   const uint32_t cap = W.cap;
