@@ -384,14 +384,21 @@ __device__ __forceinline__ int forest_vote(const DeviceForest& f, int tree, cons
   }
   return 0;
 }
-// The walk over the three-levels-per-line layout (forest.hpp): a third of the trips to the L2 / memory-side cache, for walks that
-// wait on each of them.  The line's seven feature values are requested from LDS together (slots below a terminal node name
-// feature 0), so that a line costs one LDS round trip, not one per level.
-__device__ __forceinline__ int forest_vote_triples(const DeviceForest& f, int tree, const double* x) {
+// The walk over the three-levels-per-line layout (forest.hpp) -- a third of the dependent trips of a node-per-load walk; the line's seven
+// feature values are requested from LDS together (slots below a terminal node name feature 0) -- by a PAIR of lanes (2 i, 2 i + 1):
+// each loads half of the line's 96 bytes and the halves are swapped inside the quad
+// (DPP), so a wave asks the texture path for 3 x 32 lines per step instead of 6 x 64 -- the walk of 255 trees on one compute unit is
+// bound by that address rate, not by the trips.  Both lanes then decide (no divergence inside the pair) and end in the same state.
+__device__ __forceinline__ uint4 swap_pair(const uint4 v) {
+  return make_uint4(dpp_u32<0xB1, 0xf>(v.x), dpp_u32<0xB1, 0xf>(v.y), dpp_u32<0xB1, 0xf>(v.z), dpp_u32<0xB1, 0xf>(v.w));
+}
+__device__ __forceinline__ int forest_vote_triples_pair(const DeviceForest& f, int tree, const double* x, const bool odd) {
   int k = f.troot[tree];
   for (int step = 0; step < f.nrnodes; step += 3) {        // bounded: a malformed tree cannot hang the device
-    const uint4* q = reinterpret_cast<const uint4*>(&f.triples[k]);
-    const uint4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], g = q[5];      // 96 of the line's bytes, six loads in flight together
+    const uint4* q = reinterpret_cast<const uint4*>(&f.triples[k]) + (odd ? 3 : 0);
+    const uint4 m0 = q[0], m1 = q[1], m2 = q[2];
+    const uint4 o0 = swap_pair(m0), o1 = swap_pair(m1), o2 = swap_pair(m2);
+    const uint4 a = odd ? o0 : m0, b = odd ? o1 : m1, c = odd ? o2 : m2, d = odd ? m0 : o0, e = odd ? m1 : o1, g = odd ? m2 : o2;
     const int v0 = (int)(short)(d.z & 0xFFFFu), v1 = (int)(short)(d.z >> 16), v2 = (int)(short)(d.w & 0xFFFFu), v3 = (int)(short)(d.w >> 16);
     const int v4 = (int)(short)(e.x & 0xFFFFu), v5 = (int)(short)(e.x >> 16), v6 = (int)(short)(e.y & 0xFFFFu);
     if (v0 < 0) return -1 - v0;
@@ -1052,11 +1059,13 @@ __device__ __forceinline__ void forest_chunk(const BcState& st, BcShared& s, con
   __syncthreads();
   int ntree = st.clf.f[0].ntree;          // ensemble members may differ in size: iterate over the largest
   for (int m = 1; m < st.clf.n_models; ++m) ntree = st.clf.f[m].ntree > ntree ? st.clf.f[m].ntree : ntree;
-  for (uint32_t i = tid; i < n * (uint32_t)ntree; i += kBcThreads) {
+  // a pair of lanes per (vector, tree) walk (forest_vote_triples_pair); both lanes of a pair take every branch together
+  for (uint32_t i = (uint32_t)tid >> 1; i < n * (uint32_t)ntree; i += kBcThreads / 2) {
     const uint32_t j = i / (uint32_t)ntree, t = i % (uint32_t)ntree;
     const int m = W.hdr[j].model;
     if (m < 0 || (int)t >= st.clf.f[m].ntree) continue;
-    if (forest_vote_triples(st.clf.f[m], (int)t, &W.feat[j * W.fstride])) atomicAdd(&s.votes[j], 1);
+    const int vote = forest_vote_triples_pair(st.clf.f[m], (int)t, &W.feat[j * W.fstride], (tid & 1) != 0);
+    if (vote && (tid & 1) == 0) atomicAdd(&s.votes[j], 1);
   }
   __syncthreads();
 }
